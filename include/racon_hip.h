@@ -1,0 +1,134 @@
+/*
+ * racon_hip.h — C ABI of the MI355X-native window-consensus engine.
+ *
+ * This is the drop-in boundary for ONE path of lbcb-sci/racon: the per-window
+ * POA consensus, i.e. what `racon::Window::generate_consensus`
+ * (reference src/window.cpp:65-149) computes through spoa, batched the way the
+ * reference's own accelerator seam batches it (`CUDABatchProcessor`,
+ * reference src/cuda/cudabatch.hpp:27-122 and src/cuda/cudabatch.cpp:77-270).
+ *
+ * Plain pointers and sizes only; no C++ / torch types cross this boundary.
+ * All functions return 0 on success, >0 for "soft" conditions documented per
+ * function, <0 for errors (see rcn_strerror).
+ */
+#ifndef RACON_HIP_H_
+#define RACON_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------
+ * Packed window batch: the information a racon::Window holds
+ * (reference src/window.hpp:64-73: id_, rank_, type_, sequences_, qualities_,
+ * positions_) for many windows, flattened.  Sequence 0 of every window is the
+ * backbone (positions (0,0), reference src/window.cpp:29-37); the others are
+ * the layers in add_layer() arrival order (reference src/window.cpp:42-63).
+ * The engine does the begin-ordered `std::sort` of window.cpp:79-86 itself.
+ * ------------------------------------------------------------------------- */
+typedef struct rcn_batch {
+    uint32_t n_windows;
+    uint32_t n_seqs;               /* == win_seq_off[n_windows]                        */
+    const uint32_t* win_seq_off;   /* [n_windows+1] first sequence of each window      */
+    const uint8_t*  win_type;      /* [n_windows]  0 = kNGS, 1 = kTGS (window.hpp:21)   */
+    const uint64_t* seq_off;       /* [n_seqs+1]   byte offset of each sequence         */
+    const uint8_t*  seq_has_qual;  /* [n_seqs]     0 => quality pointer was nullptr     */
+    const uint32_t* seq_begin;     /* [n_seqs]     positions_.first  (backbone: 0)      */
+    const uint32_t* seq_end;       /* [n_seqs]     positions_.second (backbone: 0)      */
+    const uint8_t*  bases;         /* [seq_off[n_seqs]] upper-case ASCII as in Sequence */
+    const uint8_t*  quals;         /* [seq_off[n_seqs]] phred+33; ignored if !has_qual  */
+} rcn_batch;
+
+/* Result of one batch.  Pointers are owned by the producer (engine handle or
+ * oracle result object) and stay valid until the next run/reset/destroy. */
+typedef struct rcn_result {
+    uint32_t n_windows;
+    const uint64_t* cons_off;      /* [n_windows+1] */
+    const uint8_t*  cons;          /* consensus bytes (after TGS trimming)             */
+    const uint8_t*  polished;      /* [n_windows] return value of generate_consensus   */
+    const uint8_t*  chimeric;      /* [n_windows] 1 => the "might be chimeric" warning
+                                      of window.cpp:139-142 applies                    */
+} rcn_result;
+
+/* Engine configuration; mirrors the arguments of createCUDABatch
+ * (reference src/cuda/cudabatch.hpp:25) and spoa::AlignmentEngine::Create
+ * (reference src/polisher.cpp:180-182). */
+typedef struct rcn_engine_config {
+    int32_t device;        /* HIP device ordinal                                        */
+    int8_t  match;         /* -m */
+    int8_t  mismatch;      /* -x */
+    int8_t  gap;           /* -g (linear)                                               */
+    uint8_t trim;          /* Polisher trim_ flag (main.cpp:87-89: --no-trimming -> 0)  */
+    uint64_t arena_bytes;  /* device scratch budget; 0 = pick from free memory          */
+    uint32_t max_slots;    /* resident windows (wavefronts) in flight; 0 = auto         */
+    uint32_t flags;        /* RCN_FLAG_*                                                */
+} rcn_engine_config;
+
+#define RCN_FLAG_NONE        0u
+#define RCN_FLAG_PROFILE     1u   /* record per-launch HIP event timings               */
+
+typedef struct rcn_engine rcn_engine;
+
+/* Per-run timing / work counters (for bench.py's roofline line). */
+typedef struct rcn_run_stats {
+    double   kernel_ms;        /* HIP-event time of the consensus kernel launches       */
+    double   h2d_ms, d2h_ms;   /* staging copies (0 when inputs are device resident)    */
+    uint32_t n_launches;
+    uint32_t n_retried;        /* windows re-run with worst-case capacities             */
+    uint64_t dp_cells;         /* sum over alignments of (V'+1)(l+1), counted on device */
+    uint64_t dp_pred_cells;    /* sum of cells * (#in-edge rows read), on device        */
+    uint64_t bytes_in, bytes_out;
+} rcn_run_stats;
+
+/* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */
+int  rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out);
+void rcn_engine_destroy(rcn_engine* e);
+
+/* --- whole-batch form: upload (H2D) / run / fetch ------------------------- */
+/* rcn_engine_upload packs and copies a batch into HBM (may be called once and
+ * followed by many rcn_engine_run calls: inputs stay resident).               */
+int  rcn_engine_upload(rcn_engine* e, const rcn_batch* b);
+/* Runs the consensus kernel(s) over the resident batch and brings results back. */
+int  rcn_engine_run(rcn_engine* e);
+int  rcn_engine_result(rcn_engine* e, rcn_result* out);
+int  rcn_engine_stats(rcn_engine* e, rcn_run_stats* out);
+
+/* --- incremental form (replaces CUDABatchProcessor::addWindow / hasWindows /
+ *     generateConsensus / reset, cudabatch.hpp:39-64) ----------------------- */
+typedef struct rcn_window_desc {
+    uint8_t  type;                 /* 0 kNGS / 1 kTGS                                   */
+    uint32_t n_seqs;               /* backbone + layers                                 */
+    const char* const* seq;        /* [n_seqs] borrowed pointers, copied at add time    */
+    const uint32_t* seq_len;       /* [n_seqs]                                          */
+    const char* const* qual;       /* [n_seqs] NULL => no quality                       */
+    const uint32_t* begin;         /* [n_seqs]                                          */
+    const uint32_t* end;           /* [n_seqs]                                          */
+} rcn_window_desc;
+/* 0 = added; 1 = batch full (window NOT consumed), like addWindow()==false.    */
+int  rcn_engine_add_window(rcn_engine* e, const rcn_window_desc* w);
+int  rcn_engine_has_windows(rcn_engine* e);
+/* upload+run over the windows added so far */
+int  rcn_engine_generate_consensus(rcn_engine* e);
+int  rcn_engine_reset(rcn_engine* e);
+
+/* --- misc ------------------------------------------------------------------ */
+int  rcn_device_count(void);
+const char* rcn_strerror(int code);
+const char* rcn_version(void);
+
+#define RCN_OK              0
+#define RCN_BATCH_FULL      1
+#define RCN_E_NO_DEVICE   (-1)
+#define RCN_E_HIP         (-2)
+#define RCN_E_ARG         (-3)
+#define RCN_E_NOMEM       (-4)
+#define RCN_E_STATE       (-5)
+#define RCN_E_CAPACITY    (-6)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RACON_HIP_H_ */

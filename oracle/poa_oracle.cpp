@@ -1,0 +1,560 @@
+// poa_oracle.cpp — CPU ORACLE (test infrastructure, NOT product code).
+//
+// A scalar restatement of the per-window consensus of lbcb-sci/racon:
+//   racon::Window::generate_consensus            reference src/window.cpp:65-149
+// over the parts of rvaser/spoa 4.0.8 it calls (pinned in the reference's
+// CMakeLists.txt:60-65; the spoa sources are NOT in /root/reference — vendor/spoa
+// is an empty submodule — so what follows restates spoa's published algorithm
+// and is pinned through racon's own end-to-end goldens, test/racon_test.cpp:86-295;
+// see tests/test_oracle_goldens.py):
+//   spoa::Graph::AddAlignment / AddSequence / AddEdge / TopologicalSort /
+//               Subgraph / UpdateAlignment / GenerateConsensus (+ heaviest bundle,
+//               branch completion, Node::Coverage)
+//   spoa::AlignmentEngine::Align  (kNW, linear gap; SISD semantics)
+// call sites: reference src/window.cpp:73-77, 95-97, 100-107, 111-118, 123 and
+// src/polisher.cpp:180-182.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library.  The product (racon_amd/csrc) never links it.
+//
+// Deliberately simple: std::vector graph, int32 full DP matrix, serial traceback.
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../include/racon_hip.h"
+
+namespace {
+
+using Alignment = std::vector<std::pair<int32_t, int32_t>>;
+
+struct Graph {
+    struct Node {
+        int32_t code;
+        std::vector<int32_t> in, out;      // edge ids, creation order
+        std::vector<int32_t> aligned;      // node ids, insertion order
+    };
+    struct Edge {
+        int32_t tail, head;
+        int64_t weight;
+        std::vector<uint32_t> labels;
+    };
+    int32_t num_codes = 0;
+    int32_t coder[256];
+    uint8_t decoder[256];
+    uint32_t num_sequences = 0;
+    std::vector<Node> nodes;
+    std::vector<Edge> edges;
+    std::vector<int32_t> rank_to_node;
+
+    Graph() { for (auto& c : coder) c = -1; std::memset(decoder, 0, sizeof(decoder)); }
+
+    int32_t AddNode(int32_t code) {
+        nodes.push_back(Node{code, {}, {}, {}});
+        return static_cast<int32_t>(nodes.size()) - 1;
+    }
+
+    void AddEdge(int32_t tail, int32_t head, int64_t w) {
+        for (int32_t e : nodes[tail].out) {
+            if (edges[e].head == head) {
+                edges[e].labels.push_back(num_sequences);
+                edges[e].weight += w;
+                return;
+            }
+        }
+        int32_t id = static_cast<int32_t>(edges.size());
+        edges.push_back(Edge{tail, head, w, {num_sequences}});
+        nodes[tail].out.push_back(id);
+        nodes[head].in.push_back(id);
+    }
+
+    // chain of new nodes for seq[b, e); returns first node id or -1
+    int32_t AddSequence(const uint8_t* seq, const std::vector<uint32_t>& w, uint32_t b, uint32_t e) {
+        if (b == e) return -1;
+        int32_t first = -1, prev = -1;
+        for (uint32_t i = b; i < e; ++i) {
+            int32_t c = AddNode(coder[seq[i]]);
+            if (first < 0) first = c;
+            if (prev >= 0) AddEdge(prev, c, static_cast<int64_t>(static_cast<uint32_t>(w[i - 1] + w[i])));   // uint32 sum, as spoa
+            prev = c;
+        }
+        return first;
+    }
+
+    void AddAlignment(const Alignment& al, const uint8_t* seq, uint32_t len,
+                      const std::vector<uint32_t>& w) {
+        if (len == 0) return;
+        for (uint32_t i = 0; i < len; ++i) {
+            if (coder[seq[i]] == -1) {
+                coder[seq[i]] = num_codes;
+                decoder[num_codes] = seq[i];
+                ++num_codes;
+            }
+        }
+        if (al.empty()) {
+            AddSequence(seq, w, 0, len);
+            ++num_sequences;
+            TopologicalSort();
+            return;
+        }
+        std::vector<uint32_t> valid;
+        for (const auto& p : al) if (p.second != -1) valid.push_back(p.second);
+        if (valid.empty()) { fprintf(stderr, "[oracle] invalid alignment\n"); exit(1); }
+
+        int32_t begin = AddSequence(seq, w, 0, valid.front());
+        int32_t prev = begin < 0 ? -1 : static_cast<int32_t>(nodes.size()) - 1;
+        int32_t last = AddSequence(seq, w, valid.back() + 1, len);
+
+        for (const auto& p : al) {
+            if (p.second == -1) continue;
+            int32_t code = coder[seq[p.second]];
+            int32_t curr = -1;
+            if (p.first == -1) {
+                curr = AddNode(code);
+            } else {
+                int32_t t = p.first;
+                if (nodes[t].code == code) {
+                    curr = t;
+                } else {
+                    for (int32_t a : nodes[t].aligned) {
+                        if (nodes[a].code == code) { curr = a; break; }
+                    }
+                    if (curr < 0) {
+                        curr = AddNode(code);
+                        // copy: nodes may have reallocated, and we mutate lists while iterating
+                        std::vector<int32_t> ring = nodes[t].aligned;
+                        for (int32_t a : ring) {
+                            nodes[a].aligned.push_back(curr);
+                            nodes[curr].aligned.push_back(a);
+                        }
+                        nodes[t].aligned.push_back(curr);
+                        nodes[curr].aligned.push_back(t);
+                    }
+                }
+            }
+            if (begin < 0) begin = curr;
+            if (prev >= 0) {
+                AddEdge(prev, curr, static_cast<int64_t>(static_cast<uint32_t>(w[p.second - 1] + w[p.second])));
+            }
+            prev = curr;
+        }
+        if (last >= 0) {
+            AddEdge(prev, last, static_cast<int64_t>(static_cast<uint32_t>(w[valid.back()] + w[valid.back() + 1])));
+        }
+        ++num_sequences;
+        TopologicalSort();
+    }
+
+    void TopologicalSort() {
+        const size_t n = nodes.size();
+        rank_to_node.clear();
+        std::vector<uint8_t> marks(n, 0), ignored(n, 0);
+        std::vector<int32_t> st;
+        for (size_t s = 0; s < n; ++s) {
+            if (marks[s] != 0) continue;
+            st.push_back(static_cast<int32_t>(s));
+            while (!st.empty()) {
+                int32_t c = st.back();
+                bool valid = true;
+                if (marks[c] != 2) {
+                    for (int32_t e : nodes[c].in) {
+                        int32_t t = edges[e].tail;
+                        if (marks[t] != 2) { st.push_back(t); valid = false; }
+                    }
+                    if (!ignored[c]) {
+                        for (int32_t a : nodes[c].aligned) {
+                            if (marks[a] != 2) { st.push_back(a); ignored[a] = 1; valid = false; }
+                        }
+                    }
+                    if (valid) {
+                        marks[c] = 2;
+                        if (!ignored[c]) {
+                            rank_to_node.push_back(c);
+                            for (int32_t a : nodes[c].aligned) rank_to_node.push_back(a);
+                        }
+                    } else {
+                        marks[c] = 1;
+                    }
+                }
+                if (valid) st.pop_back();
+            }
+        }
+        if (rank_to_node.size() != n) { fprintf(stderr, "[oracle] graph is not a DAG\n"); exit(1); }
+    }
+
+    // Subgraph(begin, end, &mapping): backward reachability from node `end`
+    // restricted to ids >= begin; fresh graph in ascending original id.
+    Graph Subgraph(uint32_t begin, uint32_t end, std::vector<int32_t>* mapping) const {
+        const size_t n = nodes.size();
+        std::vector<uint8_t> inc(n, 0);
+        std::vector<int32_t> st{static_cast<int32_t>(end)};
+        while (!st.empty()) {
+            int32_t c = st.back(); st.pop_back();
+            if (!inc[c] && static_cast<uint32_t>(c) >= begin) {
+                for (int32_t e : nodes[c].in) st.push_back(edges[e].tail);
+                for (int32_t a : nodes[c].aligned) st.push_back(a);
+                inc[c] = 1;
+            }
+        }
+        Graph g;
+        g.num_codes = num_codes;
+        std::memcpy(g.coder, coder, sizeof(coder));
+        std::memcpy(g.decoder, decoder, sizeof(decoder));
+        std::vector<int32_t> g2s(n, -1);
+        mapping->clear();
+        for (size_t i = 0; i < n; ++i) {
+            if (inc[i]) { g2s[i] = g.AddNode(nodes[i].code); mapping->push_back(static_cast<int32_t>(i)); }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (!inc[i]) continue;
+            int32_t j = g2s[i];
+            for (int32_t e : nodes[i].in) {
+                int32_t t = g2s[edges[e].tail];
+                if (t >= 0) g.AddEdge(t, j, edges[e].weight);
+            }
+            for (int32_t a : nodes[i].aligned) {
+                if (g2s[a] >= 0) g.nodes[j].aligned.push_back(g2s[a]);
+            }
+        }
+        g.TopologicalSort();
+        return g;
+    }
+
+    uint32_t Coverage(int32_t v) const {
+        std::vector<uint32_t> lab;
+        for (int32_t e : nodes[v].in) lab.insert(lab.end(), edges[e].labels.begin(), edges[e].labels.end());
+        for (int32_t e : nodes[v].out) lab.insert(lab.end(), edges[e].labels.begin(), edges[e].labels.end());
+        std::sort(lab.begin(), lab.end());
+        return static_cast<uint32_t>(std::unique(lab.begin(), lab.end()) - lab.begin());
+    }
+
+    std::string GenerateConsensus(std::vector<uint32_t>* coverages) const {
+        const int32_t n = static_cast<int32_t>(nodes.size());
+        std::vector<int32_t> pred(n, -1);
+        std::vector<int64_t> sc(n, -1);
+        int32_t mx = -1;
+        auto relax = [&](int32_t it, bool skip) {
+            for (int32_t e : nodes[it].in) {
+                int32_t t = edges[e].tail;
+                if (skip && sc[t] == -1) continue;
+                int64_t w = edges[e].weight;
+                if (sc[it] < w || (sc[it] == w && sc[pred[it]] <= sc[t])) {
+                    sc[it] = w; pred[it] = t;
+                }
+            }
+            if (pred[it] >= 0) sc[it] += sc[pred[it]];
+        };
+        for (int32_t it : rank_to_node) {
+            relax(it, false);
+            if (mx < 0 || sc[mx] < sc[it]) mx = it;
+        }
+        if (!nodes[mx].out.empty()) {
+            std::vector<int32_t> n2r(n, 0);
+            for (int32_t i = 0; i < n; ++i) n2r[rank_to_node[i]] = i;
+            while (!nodes[mx].out.empty()) {
+                int32_t start = mx;
+                for (int32_t e : nodes[start].out) {
+                    for (int32_t f : nodes[edges[e].head].in) {
+                        if (edges[f].tail != start) sc[edges[f].tail] = -1;
+                    }
+                }
+                int32_t m2 = -1;
+                for (int32_t i = n2r[start] + 1; i < n; ++i) {
+                    int32_t it = rank_to_node[i];
+                    sc[it] = -1; pred[it] = -1;
+                    relax(it, true);
+                    if (m2 < 0 || sc[m2] < sc[it]) m2 = it;
+                }
+                mx = m2;
+            }
+        }
+        std::vector<int32_t> cons;
+        while (pred[mx] >= 0) { cons.push_back(mx); mx = pred[mx]; }
+        cons.push_back(mx);
+        std::reverse(cons.begin(), cons.end());
+        std::string s;
+        coverages->clear();
+        for (int32_t v : cons) {
+            s += static_cast<char>(decoder[nodes[v].code]);
+            uint32_t c = Coverage(v);
+            for (int32_t a : nodes[v].aligned) c += Coverage(a);
+            coverages->push_back(c);
+        }
+        return s;
+    }
+};
+
+struct Engine {
+    int32_t m, x, g;
+    std::vector<int32_t> H;              // (V+1) x (L+1)
+    std::vector<int32_t> profile;        // num_codes x (L+1)
+    uint64_t cells = 0;                  // Σ (V+1)(L+1)
+    double   cells_x_pred = 0;           // Σ cells * (1 + E/V)
+
+    Alignment Align(const uint8_t* seq, uint32_t L, const Graph& g_) {
+        const int32_t V = static_cast<int32_t>(g_.nodes.size());
+        if (V == 0 || L == 0) return {};
+        const size_t W = static_cast<size_t>(L) + 1;
+        H.resize(static_cast<size_t>(V + 1) * W);
+        profile.resize(static_cast<size_t>(g_.num_codes) * W);
+        for (int32_t c = 0; c < g_.num_codes; ++c) {
+            int32_t* P = &profile[c * W];
+            P[0] = 0;
+            for (uint32_t j = 1; j <= L; ++j) P[j] = (g_.decoder[c] == seq[j - 1]) ? m : x;
+        }
+        cells += static_cast<uint64_t>(V + 1) * W;
+        cells_x_pred += static_cast<double>(V + 1) * W *
+            (1.0 + static_cast<double>(g_.edges.size()) / V);
+
+        std::vector<int32_t> n2r(V);
+        for (int32_t r = 0; r < V; ++r) n2r[g_.rank_to_node[r]] = r;
+        for (uint32_t j = 0; j <= L; ++j) H[j] = static_cast<int32_t>(j) * g;
+
+        bool have_best = false; int32_t best = 0, bi = 0;
+        std::vector<int32_t> ps;
+        for (int32_t r = 0; r < V; ++r) {
+            const int32_t v = g_.rank_to_node[r];
+            const auto& node = g_.nodes[v];
+            int32_t* row = &H[static_cast<size_t>(r + 1) * W];
+            const int32_t* P = &profile[node.code * W];
+            ps.clear();
+            for (int32_t e : node.in) ps.push_back(n2r[g_.edges[e].tail] + 1);
+            if (ps.empty()) ps.push_back(0);
+            {
+                const int32_t* Hp = &H[static_cast<size_t>(ps[0]) * W];
+                int32_t h0 = Hp[0];
+                for (uint32_t j = 1; j <= L; ++j) row[j] = std::max(Hp[j - 1] + P[j], Hp[j] + g);
+                for (size_t k = 1; k < ps.size(); ++k) {
+                    Hp = &H[static_cast<size_t>(ps[k]) * W];
+                    h0 = std::max(h0, Hp[0]);
+                    for (uint32_t j = 1; j <= L; ++j)
+                        row[j] = std::max(row[j], std::max(Hp[j - 1] + P[j], Hp[j] + g));
+                }
+                row[0] = (node.in.empty() ? 0 : h0) + g;
+            }
+            for (uint32_t j = 1; j <= L; ++j) row[j] = std::max(row[j - 1] + g, row[j]);
+            if (node.out.empty()) {
+                if (!have_best || best < row[L]) { have_best = true; best = row[L]; bi = r + 1; }
+            }
+        }
+
+        Alignment al;
+        int32_t i = bi, j = static_cast<int32_t>(L);
+        while (!(i == 0 && j == 0)) {
+            const int32_t hij = H[static_cast<size_t>(i) * W + j];
+            int32_t pi = 0, pj = 0; bool found = false;
+            if (i != 0) {
+                const int32_t v = g_.rank_to_node[i - 1];
+                const auto& node = g_.nodes[v];
+                if (j != 0) {
+                    const int32_t mc = profile[node.code * W + j];
+                    if (node.in.empty()) {
+                        if (hij == H[j - 1] + mc) { pi = 0; pj = j - 1; found = true; }
+                    } else {
+                        for (int32_t e : node.in) {
+                            int32_t p = n2r[g_.edges[e].tail] + 1;
+                            if (hij == H[static_cast<size_t>(p) * W + j - 1] + mc) {
+                                pi = p; pj = j - 1; found = true; break;
+                            }
+                        }
+                    }
+                }
+                if (!found) {
+                    if (node.in.empty()) {
+                        if (hij == H[j] + g) { pi = 0; pj = j; found = true; }
+                    } else {
+                        for (int32_t e : node.in) {
+                            int32_t p = n2r[g_.edges[e].tail] + 1;
+                            if (hij == H[static_cast<size_t>(p) * W + j] + g) {
+                                pi = p; pj = j; found = true; break;
+                            }
+                        }
+                    }
+                }
+            }
+            if (!found && j != 0 && hij == H[static_cast<size_t>(i) * W + j - 1] + g) {
+                pi = i; pj = j - 1; found = true;
+            }
+            if (!found) { fprintf(stderr, "[oracle] traceback stuck at (%d,%d)\n", i, j); exit(1); }
+            al.emplace_back(i == pi ? -1 : g_.rank_to_node[i - 1], j == pj ? -1 : j - 1);
+            i = pi; j = pj;
+        }
+        std::reverse(al.begin(), al.end());
+        return al;
+    }
+};
+
+struct WindowOut {
+    std::string consensus;
+    bool polished = false;
+    bool chimeric = false;
+};
+
+// racon::Window::generate_consensus — reference src/window.cpp:65-149
+WindowOut window_consensus(const rcn_batch* b, uint32_t w, Engine& eng, bool trim) {
+    WindowOut out;
+    const uint32_t s0 = b->win_seq_off[w], s1 = b->win_seq_off[w + 1];
+    const uint32_t nseq = s1 - s0;
+    auto seq_ptr = [&](uint32_t i) { return b->bases + b->seq_off[s0 + i]; };
+    auto seq_len = [&](uint32_t i) { return static_cast<uint32_t>(b->seq_off[s0 + i + 1] - b->seq_off[s0 + i]); };
+    auto weights = [&](uint32_t i) {
+        const uint32_t len = seq_len(i);
+        std::vector<uint32_t> wv(len, 1u);               // no-quality overload: weight 1 per base
+        if (b->seq_has_qual[s0 + i]) {
+            const uint8_t* q = b->quals + b->seq_off[s0 + i];
+            // char -> uint32_t(quality[i] - 33); racon passes `const char*`
+            for (uint32_t k = 0; k < len; ++k)
+                wv[k] = static_cast<uint32_t>(static_cast<int32_t>(static_cast<signed char>(q[k])) - 33);
+        }
+        return wv;
+    };
+
+    const uint32_t L = seq_len(0);
+    if (nseq < 3) {                                        // window.cpp:68-71
+        out.consensus.assign(reinterpret_cast<const char*>(seq_ptr(0)), L);
+        return out;
+    }
+
+    Graph graph;
+    graph.AddAlignment(Alignment(), seq_ptr(0), L, weights(0));   // window.cpp:73-77
+
+    std::vector<uint32_t> rank(nseq);
+    for (uint32_t i = 0; i < nseq; ++i) rank[i] = i;
+    std::sort(rank.begin() + 1, rank.end(), [&](uint32_t lhs, uint32_t rhs) {   // window.cpp:85-86
+        return b->seq_begin[s0 + lhs] < b->seq_begin[s0 + rhs]; });
+
+    const uint32_t offset = static_cast<uint32_t>(0.01 * L);     // window.cpp:88
+    for (uint32_t j = 1; j < nseq; ++j) {
+        const uint32_t i = rank[j];
+        const uint32_t bg = b->seq_begin[s0 + i], en = b->seq_end[s0 + i];
+        Alignment al;
+        if (bg < offset && en > L - offset) {
+            al = eng.Align(seq_ptr(i), seq_len(i), graph);
+        } else {
+            std::vector<int32_t> mapping;
+            Graph sub = graph.Subgraph(bg, en, &mapping);
+            al = eng.Align(seq_ptr(i), seq_len(i), sub);
+            for (auto& p : al) if (p.first != -1) p.first = mapping[p.first];
+        }
+        graph.AddAlignment(al, seq_ptr(i), seq_len(i), weights(i));
+    }
+
+    std::vector<uint32_t> cov;
+    out.consensus = graph.GenerateConsensus(&cov);
+    out.polished = true;
+
+    if (b->win_type[w] == 1 && trim) {                        // window.cpp:125-146
+        const uint32_t avg = (nseq - 1) / 2;
+        int32_t begin = 0, end = static_cast<int32_t>(out.consensus.size()) - 1;
+        for (; begin < static_cast<int32_t>(out.consensus.size()); ++begin)
+            if (cov[begin] >= avg) break;
+        for (; end >= 0; --end)
+            if (cov[end] >= avg) break;
+        if (begin >= end) out.chimeric = true;
+        else out.consensus = out.consensus.substr(begin, end - begin + 1);
+    }
+    return out;
+}
+
+struct OracleResult {
+    std::vector<uint64_t> cons_off;
+    std::vector<uint8_t> cons, polished, chimeric;
+    std::vector<uint64_t> cells;
+    std::vector<double> cells_x_pred;
+};
+
+}  // namespace
+
+extern "C" {
+
+// Runs the oracle over a batch with `nthreads` host threads (windows are
+// independent, reference src/polisher.cpp:496-503).  *handle must be released
+// with rcn_oracle_free.  cells / cells_x_pred (each [n_windows], may be NULL)
+// receive Σ(V'+1)(l+1) and Σ(V'+1)(l+1)(1+E'/V') per window.
+int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int nthreads,
+                         rcn_result* out, void** handle, uint64_t* cells, double* cells_x_pred) {
+    if (!b || !out || !handle) return RCN_E_ARG;
+    const uint32_t n = b->n_windows;
+    std::vector<WindowOut> res(n);
+    std::vector<uint64_t> cl(n); std::vector<double> cx(n);
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        Engine eng; eng.m = m; eng.x = x; eng.g = g;
+        for (;;) {
+            uint32_t w = next.fetch_add(1);
+            if (w >= n) break;
+            eng.cells = 0; eng.cells_x_pred = 0;
+            res[w] = window_consensus(b, w, eng, trim != 0);
+            cl[w] = eng.cells; cx[w] = eng.cells_x_pred;
+        }
+    };
+    if (nthreads <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+    }
+    auto* r = new OracleResult();
+    r->cons_off.resize(n + 1, 0); r->polished.resize(n); r->chimeric.resize(n);
+    for (uint32_t w = 0; w < n; ++w) {
+        r->cons_off[w + 1] = r->cons_off[w] + res[w].consensus.size();
+        r->polished[w] = res[w].polished; r->chimeric[w] = res[w].chimeric;
+    }
+    r->cons.resize(r->cons_off[n] + 1);
+    for (uint32_t w = 0; w < n; ++w)
+        std::memcpy(r->cons.data() + r->cons_off[w], res[w].consensus.data(), res[w].consensus.size());
+    out->n_windows = n; out->cons_off = r->cons_off.data(); out->cons = r->cons.data();
+    out->polished = r->polished.data(); out->chimeric = r->chimeric.data();
+    if (cells) std::memcpy(cells, cl.data(), n * sizeof(uint64_t));
+    if (cells_x_pred) std::memcpy(cells_x_pred, cx.data(), n * sizeof(double));
+    *handle = r;
+    return RCN_OK;
+}
+
+void rcn_oracle_free(void* handle) { delete static_cast<OracleResult*>(handle); }
+
+// Exact global (NW) unit-cost edit distance, Myers 1999 bit-vector, block based.
+// Stand-in for edlibAlign(..., edlibDefaultAlignConfig()) in the reference's test
+// helper calculateEditDistance (reference test/racon_test.cpp:14-23).
+uint64_t rcn_oracle_edit_distance(const uint8_t* q, uint64_t m, const uint8_t* t, uint64_t n) {
+    if (m == 0) return n;
+    if (n == 0) return m;
+    const uint64_t nb = (m + 63) / 64;
+    std::vector<uint64_t> peq(256 * nb, 0), Pv(nb, ~0ull), Mv(nb, 0);
+    for (uint64_t i = 0; i < m; ++i) peq[q[i] * nb + i / 64] |= 1ull << (i % 64);
+    uint64_t score = m;
+    const uint64_t last_bit = 1ull << ((m - 1) % 64);
+    for (uint64_t j = 0; j < n; ++j) {
+        const uint64_t* eqc = &peq[t[j] * nb];
+        int hin = 1;   // global: row 0 increases by 1 per column
+        for (uint64_t k = 0; k < nb; ++k) {
+            uint64_t Eq = eqc[k], pv = Pv[k], mv = Mv[k];
+            uint64_t hinNeg = hin < 0 ? 1ull : 0ull;
+            uint64_t Xv = Eq | mv;
+            Eq |= hinNeg;
+            uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+            uint64_t Ph = mv | ~(Xh | pv);
+            uint64_t Mh = pv & Xh;
+            int hout = 0;
+            const uint64_t top = (k == nb - 1) ? last_bit : (1ull << 63);
+            if (Ph & top) hout = 1; else if (Mh & top) hout = -1;
+            Ph <<= 1; Mh <<= 1;
+            if (hin < 0) Mh |= 1; else if (hin > 0) Ph |= 1;
+            Pv[k] = Mh | ~(Xv | Ph);
+            Mv[k] = Ph & Xv;
+            hin = hout;
+        }
+        score += hin;
+    }
+    return score;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+"""Seeded synthetic window sets for the configurations of BASELINE.json
+(SURVEY.md §8(d)): a random contig, error-bearing reads laid over it, cut into
+racon windows exactly as reference src/overlap.cpp:226-292 (CIGAR -> breaking
+points) + src/polisher.cpp:405-458 (length / mean-quality filters, add_layer
+coordinates) would cut them when the overlaps carry the simulator's true
+alignment.  Output is a WindowBatch; there is no file I/O on this path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .batch import WindowBatch
+
+_ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def simulate_windows(contig_len: int, window_len: int = 500, coverage: float = 30.0, read_len: int = 10000,
+                     sub: float = 0.03, ins: float = 0.03, dele: float = 0.04, seed: int = 20260921,
+                     phred_mean: float = 15.0, phred_sd: float = 4.0, phred_lo: int = 5, phred_hi: int = 30,
+                     with_quality: bool = True, quality_threshold: float = 10.0, tgs: bool | None = None,
+                     backbone_errors: float = 0.0) -> WindowBatch:
+    rng = np.random.default_rng(seed)
+    contig = _ACGT[rng.integers(0, 4, contig_len)]
+    # the backbone (draft assembly) may itself carry substitution errors
+    backbone = contig.copy()
+    if backbone_errors > 0:
+        e = rng.random(contig_len) < backbone_errors
+        backbone[e] = _ACGT[(np.searchsorted(_ACGT, backbone[e]) + rng.integers(1, 4, int(e.sum()))) % 4]
+
+    n_win = (contig_len + window_len - 1) // window_len
+    layers = [[] for _ in range(n_win)]          # (bases, qual|None, begin, end) in read (overlap-file) order
+    n_reads = int(round(coverage * contig_len / read_len))
+    total_read_len = 0
+    for _ in range(n_reads):
+        ts = int(rng.integers(0, max(1, contig_len - read_len // 4)))
+        te = min(contig_len, ts + read_len)
+        n = te - ts
+        tgt = contig[ts:te]
+        deleted = rng.random(n) < dele
+        deleted[0] = deleted[-1] = False
+        subst = rng.random(n) < sub
+        base = tgt.copy()
+        base[subst] = _ACGT[(np.searchsorted(_ACGT, tgt[subst]) + rng.integers(1, 4, int(subst.sum()))) % 4]
+        has_ins = rng.random(n) < ins
+        has_ins[-1] = False
+        emit = (~deleted).astype(np.int64) + has_ins.astype(np.int64)      # bases emitted per target column
+        qpos = np.concatenate([[0], np.cumsum(emit)])                        # query index of column's M base
+        qlen = int(qpos[-1])
+        total_read_len += qlen
+        read = np.empty(qlen, np.uint8)
+        mcols = np.nonzero(~deleted)[0]
+        read[qpos[mcols]] = base[mcols]
+        icols = np.nonzero(has_ins)[0]
+        read[qpos[icols] + (~deleted[icols]).astype(np.int64)] = _ACGT[rng.integers(0, 4, icols.size)]
+        if with_quality:
+            q = np.clip(np.rint(rng.normal(phred_mean, phred_sd, qlen)), phred_lo, phred_hi).astype(np.uint8) + 33
+        # cut at window boundaries: first / last MATCH column inside each window
+        w0, w1 = ts // window_len, (te - 1) // window_len
+        for w in range(w0, w1 + 1):
+            a = max(ts, w * window_len) - ts
+            b = min(te, (w + 1) * window_len) - ts
+            m = mcols[(mcols >= a) & (mcols < b)]
+            if m.size == 0:
+                continue
+            first_t, last_t = int(m[0]), int(m[-1])
+            q0, q1 = int(qpos[first_t]), int(qpos[last_t]) + 1
+            if (q1 - q0) < 0.02 * window_len:                      # polisher.cpp:415
+                continue
+            if with_quality:
+                if float(np.mean(q[q0:q1].astype(np.float64) - 33.0)) < quality_threshold:   # polisher.cpp:419-433
+                    continue
+            begin = ts + first_t - w * window_len
+            end = ts + last_t + 1 - w * window_len - 1             # polisher.cpp:454-457
+            if begin == end:                                        # window.cpp:45-47
+                continue
+            layers[w].append((read[q0:q1].tobytes(), q[q0:q1].tobytes() if with_quality else None, begin, end))
+    if tgs is None:
+        tgs = (total_read_len / max(1, n_reads)) > 1000               # polisher.cpp:277-278
+    windows = []
+    for w in range(n_win):
+        bb = backbone[w * window_len:min(contig_len, (w + 1) * window_len)].tobytes()
+        windows.append({"type": 1 if tgs else 0, "seqs": [(bb, b"!" * len(bb), 0, 0)] + layers[w]})
+    return WindowBatch.from_windows(windows)
+
+
+def config_windows(name: str, scale: float = 1.0) -> WindowBatch:
+    """The named synthetic configurations of SURVEY.md §8(d).  `scale` shrinks the
+    contig (tests use small scales; bench.py uses 1.0)."""
+    if name == "cfg2":      # 1 Mbp contig, 30x ONT-like reads, -w 500  (2000 windows at scale 1)
+        return simulate_windows(int(1_000_000 * scale), 500, 30.0, 10000, seed=20260921)
+    if name == "cfg3":      # 50 Mbp contig (8 GPUs)
+        return simulate_windows(int(50_000_000 * scale), 500, 30.0, 10000, seed=20260922)
+    if name == "cfg4":      # short reads: 150 bp at 60x, -w 200, kNGS
+        return simulate_windows(int(1_000_000 * scale), 200, 60.0, 150, sub=0.003, ins=0.0005, dele=0.0005,
+                                seed=20260923, phred_mean=30.0, phred_sd=0.0, phred_lo=30, phred_hi=30)
+    if name == "w1000":     # larger window (int32 score range)
+        return simulate_windows(int(1_000_000 * scale), 1000, 30.0, 10000, seed=20260925)
+    raise ValueError(name)
