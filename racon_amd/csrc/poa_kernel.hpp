@@ -1,0 +1,288 @@
+// poa_kernel.hpp — the MI355X (gfx950) window-consensus kernel.
+//
+// One 64-lane wavefront owns one window (one partial-order graph) at a time and
+// loops over a device-side work queue (persistent slots).  Per window it runs
+// racon's Window::generate_consensus (reference src/window.cpp:65-149):
+//
+//   backbone -> graph                         (wave-parallel)
+//   for every layer, in the host-sorted order of window.cpp:79-86:
+//       [subgraph mask + exact DFS order]     (lane 0;  window.cpp:99-103)
+//       row descriptors                       (wave-parallel, 64 rows at a time)
+//       NW sequence-to-graph DP               (wave-parallel: each lane owns CT
+//                                              adjacent columns of a row; the
+//                                              horizontal gap is a wave-wide
+//                                              prefix-max; window.cpp:95-97,104-106)
+//       traceback                             (lane 0)
+//       AddAlignment + exact DFS toposort     (lane 0;  window.cpp:110-119)
+//   heaviest-bundle consensus, coverage, trim (lane 0;  window.cpp:122-146)
+//
+// Integer DP on an irregular DAG: no MFMA.  Scores are int32 in HBM scratch;
+// the previous row is kept in registers (the common predecessor).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "poa_core.hpp"
+
+namespace rcn {
+
+struct KParams {
+    // resident batch (rcn_batch, device copies)
+    const uint32_t* win_seq_off; const uint8_t* win_type; const uint64_t* seq_off;
+    const uint8_t* seq_has_qual; const uint32_t* seq_begin; const uint32_t* seq_end;
+    const uint8_t* bases; const uint8_t* quals;
+    const uint32_t* order;        // [n_seqs] processing order inside each window (std::sort on host)
+    const uint8_t*  seq_full;     // [n_seqs] 1 = full-span layer (window.cpp:93-94), else Subgraph
+    const uint32_t* win_ids;      // [n_work] indirection (retry pass) or nullptr
+    uint32_t n_work;
+    int32_t m, x, g, trim;
+    // per-slot scratch
+    uint8_t* scratch; uint64_t slot_bytes; int32_t ncap, ecap, ring, lmax, hstride;
+    // outputs
+    uint8_t* out_cons; uint64_t out_stride; uint32_t* out_len; uint8_t* out_flags;
+    // queue + counters
+    unsigned int* next; unsigned long long* stats;   // stats[0]=cells, [1]=pred cells
+};
+
+enum : uint8_t { kFlagPolished = 1, kFlagChimeric = 2, kFlagOverflow = 4, kFlagError = 8 };
+
+__device__ __forceinline__ int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int wave_excl_scan_max(int z, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(z, d);
+        if (lane >= d) z = max(z, t);
+    }
+    int ex = __shfl_up(z, 1);
+    return lane == 0 ? kNeg : ex;
+}
+
+// One column tile [t0, t0 + 64*CT) of the DP matrix, all rows.
+constexpr int kMaxCT = 12;   // widest column tile: 64 * 12 = 768 columns per pass
+struct DpState { int best, best_row, have_best; unsigned int pred_rows; };
+
+template <int CT>
+__device__ __forceinline__ DpState dp_tile(const Win& g, int V, bool sub, const uint8_t* __restrict__ seq, int len,
+                                        int t0, bool last_tile, int m, int x, int gp, DpState st) {
+    int best = st.best, best_row = st.best_row, have_best = st.have_best;
+    unsigned int pred_rows = 0;
+    const int lane = threadIdx.x;
+    const int j0 = t0 + lane * CT;
+    const int64_t hs = g.hstride;
+    int32_t* __restrict__ H = g.H.ptr();
+
+    uint8_t sq[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { const int j = j0 + c; sq[c] = (j >= 1 && j <= len) ? seq[j - 1] : 0; }
+
+    int last[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) last[c] = (j0 + c) * gp;      // row 0
+    int last_row = 0;
+    const int own_lane = (len - t0) / CT;                       // lane owning column `len` (last tile only)
+
+    RowDesc dl; dl.p0 = 0; dl.p1 = -1; dl.erest = -1; dl.meta = 0;
+    for (int r = 0; r < V; ++r) {
+        if ((r & 63) == 0) { if (r + lane < V) dl = g.desc[r + lane]; }
+        const int k = r & 63;
+        const int p0 = __builtin_amdgcn_readlane(dl.p0, k);
+        const int p1 = __builtin_amdgcn_readlane(dl.p1, k);
+        const int er = __builtin_amdgcn_readlane(dl.erest, k);
+        const int meta = __builtin_amdgcn_readlane(dl.meta, k);
+        const uint8_t sym = meta & 255;
+        const int i = r + 1;
+
+        int acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = kNeg;
+
+        auto accumulate = [&](int p) {
+            int hp[CT];
+            if (p == last_row) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) hp[c] = last[c];
+            } else {
+                const int2* src = reinterpret_cast<const int2*>(H + p * hs + j0);
+#pragma unroll
+                for (int c = 0; c < CT; c += 2) { int2 v = src[c >> 1]; hp[c] = v.x; hp[c + 1] = v.y; }
+            }
+            int left = __shfl_up(hp[CT - 1], 1);
+            if (lane == 0) left = (t0 > 0) ? H[p * hs + t0 - 1] : kNeg;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int dg = (c == 0 ? left : hp[c - 1]) + (sq[c] == sym ? m : x);
+                const int up = hp[c] + gp;
+                acc[c] = max(acc[c], max(dg, up));
+            }
+            ++pred_rows;
+        };
+        accumulate(p0);
+        if (p1 >= 0) accumulate(p1);
+        for (int e = er; e >= 0; e = g.e_nin[e]) {
+            const int t = g.e_tail[e];
+            if (sub && !g.inc[t]) continue;
+            accumulate(g.n2r[t] + 1);
+        }
+        // horizontal gap: in-lane pass, then wave-wide prefix max of the transformed lane tails
+#pragma unroll
+        for (int c = 1; c < CT; ++c) acc[c] = max(acc[c], acc[c - 1] + gp);
+        int z = acc[CT - 1] - (j0 + CT - 1) * gp;
+        int zex = wave_excl_scan_max(z, lane);
+        if (t0 > 0) zex = max(zex, H[i * hs + t0 - 1] - (t0 - 1) * gp);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = max(acc[c], zex + (j0 + c) * gp);
+
+        int2* dst = reinterpret_cast<int2*>(H + i * hs + j0);
+#pragma unroll
+        for (int c = 0; c < CT; c += 2) dst[c >> 1] = make_int2(acc[c], acc[c + 1]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) last[c] = acc[c];
+        last_row = i;
+
+        if (last_tile && (meta & 256)) {
+            int cand = kNeg;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) if (j0 + c == len) cand = acc[c];
+            const int val = __builtin_amdgcn_readlane(cand, own_lane);
+            if (!have_best || best < val) { have_best = 1; best = val; best_row = i; }
+        }
+    }
+    DpState o; o.best = best; o.best_row = best_row; o.have_best = have_best;
+    o.pred_rows = (t0 == 0) ? pred_rows : st.pred_rows;
+    return o;
+}
+
+__device__ __forceinline__ void wave_sync() { __threadfence_block(); __syncthreads(); }
+
+__global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
+    const int lane = threadIdx.x;
+    Win g;
+    win_bind(g, P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes, P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
+    unsigned long long st_cells = 0, st_pred = 0;
+
+    for (;;) {
+        unsigned int wi = 0;
+        if (lane == 0) wi = atomicAdd(P.next, 1u);
+        wi = bcast0(wi);
+        if (wi >= P.n_work) break;
+        const uint32_t w = P.win_ids ? P.win_ids[wi] : wi;
+        const uint32_t s0 = P.win_seq_off[w];
+        const int ns = static_cast<int>(P.win_seq_off[w + 1] - s0);
+        const uint8_t* bb = P.bases + P.seq_off[s0];
+        const int L = static_cast<int>(P.seq_off[s0 + 1] - P.seq_off[s0]);
+        uint8_t* out = P.out_cons + static_cast<uint64_t>(wi) * P.out_stride;   // outputs are indexed by work item
+
+        if (ns < 3) {                                          // window.cpp:68-71
+            for (int i = lane; i < L; i += 64) out[i] = bb[i];
+            if (lane == 0) { P.out_len[wi] = L; P.out_flags[wi] = 0; }
+            continue;
+        }
+        // ---- backbone -> graph (window.cpp:73-77) ----
+        g.n_nodes = L; g.n_edges = L - 1; g.overflow = 0;
+        {
+            const uint8_t* q0 = P.seq_has_qual[s0] ? P.quals + P.seq_off[s0] : nullptr;
+            for (int i = lane; i < L; i += 64) {
+                g.code[i] = bb[i]; g.al_cnt[i] = 0;
+                g.in_head[i] = g.in_tail[i] = (i > 0) ? i - 1 : -1;
+                g.out_head[i] = g.out_tail[i] = (i < L - 1) ? i : -1;
+                g.cov[i] = L >= 2 ? 1u : 0u;
+                g.rank_full[i] = i;
+                if (i < L - 1) {
+                    g.e_tail[i] = i; g.e_head[i] = i + 1; g.e_nin[i] = -1; g.e_nout[i] = -1;
+                    g.e_w[i] = pair_weight(q0, i + 1);
+                }
+            }
+        }
+        wave_sync();
+
+        for (int jl = 1; jl < ns && !g.overflow; ++jl) {
+            const uint32_t si = s0 + P.order[s0 + jl];
+            const uint8_t* seq = P.bases + P.seq_off[si];
+            const uint8_t* qual = P.seq_has_qual[si] ? P.quals + P.seq_off[si] : nullptr;
+            const int len = static_cast<int>(P.seq_off[si + 1] - P.seq_off[si]);
+            const bool sub = P.seq_full[si] == 0;
+            int V = g.n_nodes;
+            const int32_t* rank = g.rank_full.ptr();
+            if (sub) {
+                int nv = 0;
+                if (lane == 0) {
+                    graph_subgraph_mask(g, static_cast<int32_t>(P.seq_begin[si]), static_cast<int32_t>(P.seq_end[si]), g.H.ptr());
+                    nv = graph_toposort(g, g.rank_sub.ptr(), true, g.H.ptr());
+                }
+                V = bcast0(nv);
+                rank = g.rank_sub.ptr();
+                wave_sync();
+            }
+            // ---- row descriptors ----
+            for (int r = lane; r < V; r += 64) g.n2r[rank[r]] = r;
+            wave_sync();
+            for (int r = lane; r < V; r += 64) g.desc[r] = make_row_desc(g, rank[r], sub);
+            for (int j = lane; j < g.hstride; j += 64) g.H[j] = j * P.g;
+            wave_sync();
+            // ---- DP ----
+            DpState ds; ds.best = 0; ds.best_row = 0; ds.have_best = 0; ds.pred_rows = 0;
+            const int W = len + 1;
+            for (int t0 = 0; t0 < W;) {
+                const int need = (W - t0 + 63) / 64;
+                int ct = (need + 1) & ~1;
+                if (ct > kMaxCT) ct = kMaxCT;
+                const bool lastt = t0 + 64 * ct >= W;
+                switch (ct) {
+#define RCN_CASE(C) case C: ds = dp_tile<C>(g, V, sub, seq, len, t0, lastt, P.m, P.x, P.g, ds); break;
+                    RCN_CASE(2) RCN_CASE(4) RCN_CASE(6) RCN_CASE(8) RCN_CASE(10)
+                    RCN_CASE(12)
+#undef RCN_CASE
+                }
+                t0 += 64 * ct;
+                wave_sync();
+            }
+            st_cells += static_cast<unsigned long long>(V + 1) * W;
+            st_pred += static_cast<unsigned long long>(ds.pred_rows) * W;
+            const int best_row = ds.best_row;
+            // ---- traceback + AddAlignment + toposort (serial) ----
+            if (lane == 0) {
+                const int plen = nw_traceback(g, rank, sub, seq, len, best_row, P.m, P.x, P.g);
+                if (!g.overflow) graph_add_alignment(g, plen, seq, qual, len);
+                if (!g.overflow) {
+                    const int nr = graph_toposort(g, g.rank_full.ptr(), false, g.H.ptr());
+                    if (nr != g.n_nodes) g.overflow = 5;
+                }
+            }
+            g.n_nodes = bcast0(g.n_nodes); g.n_edges = bcast0(g.n_edges); g.overflow = bcast0(g.overflow);
+            wave_sync();
+        }
+
+        if (g.overflow) {
+            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (g.overflow == 1 || g.overflow == 3) ? kFlagOverflow : kFlagError; }
+            continue;
+        }
+        // ---- consensus (window.cpp:122-146) ----
+        for (int r = lane; r < g.n_nodes; r += 64) g.n2r[g.rank_full[r]] = r;
+        wave_sync();
+        int clen = 0, cb = 0, flags = kFlagPolished;
+        if (lane == 0) {
+            int32_t* cn = g.path_node.ptr();
+            const int k = graph_consensus(g, cn);
+            int bgn = 0, end = k - 1;
+            if (P.win_type[w] == 1 && P.trim) {
+                const uint32_t avg = static_cast<uint32_t>(ns - 1) / 2;
+                for (; bgn < k; ++bgn) if (consensus_coverage(g, cn[bgn]) >= avg) break;
+                for (; end >= 0; --end) if (consensus_coverage(g, cn[end]) >= avg) break;
+                if (bgn >= end) { bgn = 0; end = k - 1; flags |= kFlagChimeric; }
+            }
+            cb = bgn; clen = end - bgn + 1;
+        }
+        clen = bcast0(clen); cb = bcast0(cb); flags = bcast0(flags);
+        wave_sync();
+        if (static_cast<uint64_t>(clen) > P.out_stride) {
+            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = kFlagOverflow; }
+            continue;
+        }
+        for (int t = lane; t < clen; t += 64) out[t] = g.code[g.path_node[cb + t]];
+        if (lane == 0) { P.out_len[wi] = clen; P.out_flags[wi] = static_cast<uint8_t>(flags); }
+        wave_sync();
+    }
+    if (lane == 0) { atomicAdd(&P.stats[0], st_cells); atomicAdd(&P.stats[1], st_pred); }
+}
+
+}  // namespace rcn

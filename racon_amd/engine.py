@@ -1,0 +1,151 @@
+"""ctypes binding of the C ABI in include/racon_hip.h (racon_amd/csrc/libracon_hip.so).
+
+There is no CPU fallback: `HipEngine()` raises if the library is missing or no
+MI355X is visible.  This mirrors how racon's CUDAPolisher uses its batch object
+(reference src/cuda/cudapolisher.cpp:228-333): create per device, feed windows,
+generate consensus, read back per-window status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libracon_hip.so")
+
+
+class RcnEngineConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("match", C.c_int8), ("mismatch", C.c_int8), ("gap", C.c_int8),
+                ("trim", C.c_uint8), ("arena_bytes", C.c_uint64), ("max_slots", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class RcnRunStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("n_launches", C.c_uint32), ("n_retried", C.c_uint32), ("dp_cells", C.c_uint64),
+                ("dp_pred_cells", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64)]
+
+
+class RcnWindowDesc(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("n_seqs", C.c_uint32), ("seq", C.POINTER(C.c_char_p)),
+                ("seq_len", C.POINTER(C.c_uint32)), ("qual", C.POINTER(C.c_char_p)),
+                ("begin", C.POINTER(C.c_uint32)), ("end", C.POINTER(C.c_uint32))]
+
+
+EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_engine_run", "rcn_engine_result",
+           "rcn_engine_stats", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
+           "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version"]
+
+_lib = None
+
+
+def load_library():
+    """Loads libracon_hip.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP engine)")
+    lib = C.CDLL(LIB_PATH)
+    lib.rcn_engine_create.argtypes = [C.POINTER(RcnEngineConfig), C.POINTER(C.c_void_p)]
+    lib.rcn_engine_destroy.argtypes = [C.c_void_p]
+    lib.rcn_engine_destroy.restype = None
+    lib.rcn_engine_upload.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
+    lib.rcn_engine_run.argtypes = [C.c_void_p]
+    lib.rcn_engine_result.argtypes = [C.c_void_p, C.POINTER(RcnResult)]
+    lib.rcn_engine_stats.argtypes = [C.c_void_p, C.POINTER(RcnRunStats)]
+    lib.rcn_engine_add_window.argtypes = [C.c_void_p, C.POINTER(RcnWindowDesc)]
+    lib.rcn_engine_has_windows.argtypes = [C.c_void_p]
+    lib.rcn_engine_generate_consensus.argtypes = [C.c_void_p]
+    lib.rcn_engine_reset.argtypes = [C.c_void_p]
+    lib.rcn_strerror.restype = C.c_char_p
+    lib.rcn_strerror.argtypes = [C.c_int]
+    lib.rcn_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed: {load_library().rcn_strerror(rc).decode()} ({rc})")
+    return rc
+
+
+class HipEngine:
+    """One engine = one device + one stream (like one CUDABatchProcessor)."""
+
+    def __init__(self, match: int = 3, mismatch: int = -5, gap: int = -4, trim: bool = True, device: int = 0,
+                 arena_bytes: int = 0, max_slots: int = 0):
+        self.lib = load_library()
+        if self.lib.rcn_device_count() <= 0:
+            raise RuntimeError("no HIP device visible: the racon_amd engine has no CPU fallback")
+        cfg = RcnEngineConfig(device, match, mismatch, gap, int(trim), arena_bytes, max_slots, 0)
+        self.h = C.c_void_p()
+        _check(self.lib.rcn_engine_create(C.byref(cfg), C.byref(self.h)), "rcn_engine_create")
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rcn_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # whole-batch form ---------------------------------------------------------
+    def upload(self, batch: WindowBatch):
+        cb = batch.as_c()
+        self._keep = (batch, cb)
+        _check(self.lib.rcn_engine_upload(self.h, C.byref(cb)), "rcn_engine_upload")
+
+    def run(self) -> ConsensusResult:
+        _check(self.lib.rcn_engine_run(self.h), "rcn_engine_run")
+        return self.result()
+
+    def run_only(self):
+        _check(self.lib.rcn_engine_run(self.h), "rcn_engine_run")
+
+    def result(self) -> ConsensusResult:
+        r = RcnResult()
+        _check(self.lib.rcn_engine_result(self.h, C.byref(r)), "rcn_engine_result")
+        return ConsensusResult.from_c(r)
+
+    def stats(self) -> dict:
+        s = RcnRunStats()
+        _check(self.lib.rcn_engine_stats(self.h, C.byref(s)), "rcn_engine_stats")
+        return {k: getattr(s, k) for k, _ in RcnRunStats._fields_}
+
+    def consensus(self, batch: WindowBatch) -> ConsensusResult:
+        self.upload(batch)
+        return self.run()
+
+    # incremental form (CUDABatchProcessor::addWindow ...) ------------------------
+    def add_window(self, window: dict) -> bool:
+        seqs = window["seqs"]
+        n = len(seqs)
+        sp = (C.c_char_p * n)(*[bytes(s[0]) for s in seqs])
+        qp = (C.c_char_p * n)(*[(bytes(s[1]) if s[1] is not None else None) for s in seqs])
+        ln = (C.c_uint32 * n)(*[len(s[0]) for s in seqs])
+        bg = (C.c_uint32 * n)(*[s[2] for s in seqs])
+        en = (C.c_uint32 * n)(*[s[3] for s in seqs])
+        d = RcnWindowDesc(int(window.get("type", 1)), n, sp, ln, qp, bg, en)
+        rc = _check(self.lib.rcn_engine_add_window(self.h, C.byref(d)), "rcn_engine_add_window")
+        return rc == 0
+
+    def has_windows(self) -> bool:
+        return bool(self.lib.rcn_engine_has_windows(self.h))
+
+    def generate_consensus(self) -> ConsensusResult:
+        _check(self.lib.rcn_engine_generate_consensus(self.h), "rcn_engine_generate_consensus")
+        return self.result()
+
+    def reset(self):
+        _check(self.lib.rcn_engine_reset(self.h), "rcn_engine_reset")

@@ -1,0 +1,109 @@
+// emul_main.cpp — TEST HARNESS: runs the flat-array graph code of
+// racon_amd/csrc/poa_core.hpp (the code the HIP kernel executes on one lane)
+// on the CPU with a scalar DP, so it can be checked against the oracle without
+// a GPU.  Built by tests/test_core_emulation.py into tests/emul/libemul.so.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/racon_hip.h"
+#include "../../racon_amd/csrc/poa_core.hpp"
+
+using namespace rcn;
+
+static void host_dp(Win& g, const int32_t* rank, int V, bool sub, const uint8_t* seq, int len,
+                    int m, int x, int gp, int& best_row) {
+    const int64_t W = g.hstride;
+    for (int r = 0; r < V; ++r) g.n2r[rank[r]] = r;
+    for (int r = 0; r < V; ++r) g.desc[r] = make_row_desc(g, rank[r], sub);
+    for (int j = 0; j <= len; ++j) g.H[j] = j * gp;
+    bool have = false; int best = 0; best_row = 0;
+    for (int r = 0; r < V; ++r) {
+        const RowDesc d = g.desc[r];
+        int32_t* row = &g.H[(int64_t)(r + 1) * W];
+        const int sym = d.meta & 255;
+        for (int j = 0; j <= len; ++j) row[j] = kNeg;
+        auto acc = [&](int p) {
+            const int32_t* hp = &g.H[p * W];
+            for (int j = 0; j <= len; ++j) {
+                int dg = j > 0 ? hp[j - 1] + (sym == seq[j - 1] ? m : x) : kNeg;
+                row[j] = std::max(row[j], std::max(dg, hp[j] + gp));
+            }
+        };
+        acc(d.p0);
+        if (d.p1 >= 0) acc(d.p1);
+        for (int e = d.erest; e >= 0; e = g.e_nin[e]) {
+            int t = g.e_tail[e];
+            if (sub && !g.inc[t]) continue;
+            acc(g.n2r[t] + 1);
+        }
+        for (int j = 1; j <= len; ++j) row[j] = std::max(row[j], row[j - 1] + gp);
+        if (d.meta & 256) { if (!have || best < row[len]) { have = true; best = row[len]; best_row = r + 1; } }
+    }
+}
+
+extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int trim,
+                                  uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint8_t* polished) {
+    uint64_t out = 0;
+    for (uint32_t w = 0; w < b->n_windows; ++w) {
+        const uint32_t s0 = b->win_seq_off[w], ns = b->win_seq_off[w + 1] - s0;
+        auto sp = [&](uint32_t i) { return b->bases + b->seq_off[s0 + i]; };
+        auto qp = [&](uint32_t i) { return b->seq_has_qual[s0 + i] ? b->quals + b->seq_off[s0 + i] : nullptr; };
+        auto sl = [&](uint32_t i) { return (int)(b->seq_off[s0 + i + 1] - b->seq_off[s0 + i]); };
+        const int L = sl(0);
+        cons_off[w] = out;
+        if (ns < 3) {
+            if (out + L > cons_cap) return -1;
+            memcpy(cons + out, sp(0), L); out += L; polished[w] = 0; continue;
+        }
+        int tot = L, lmax = 0;
+        for (uint32_t i = 1; i < ns; ++i) { tot += sl(i); lmax = std::max(lmax, sl(i)); }
+        const int ncap = tot + 8, ecap = tot + 8, ring = 8, hstride = lmax + 1 + 4;
+        Win g{};
+        uint64_t bytes = win_bind(g, nullptr, ncap, ecap, ring, lmax, hstride);
+        std::vector<uint8_t> mem(bytes + 64);
+        win_bind(g, mem.data(), ncap, ecap, ring, lmax, hstride);
+        // backbone
+        const uint8_t* q0 = qp(0);
+        for (int i = 0; i < L; ++i) { int v = add_node(g, sp(0)[i]); g.cov[v] = L >= 2 ? 1 : 0; if (i) add_edge(g, v - 1, v, pair_weight(q0, i)); g.rank_full[i] = i; }
+        std::vector<uint32_t> rank(ns);
+        for (uint32_t i = 0; i < ns; ++i) rank[i] = i;
+        std::sort(rank.begin() + 1, rank.end(), [&](uint32_t l, uint32_t r) { return b->seq_begin[s0 + l] < b->seq_begin[s0 + r]; });
+        const uint32_t offset = (uint32_t)(0.01 * L);
+        for (uint32_t j = 1; j < ns; ++j) {
+            const uint32_t i = rank[j];
+            const uint32_t bg = b->seq_begin[s0 + i], en = b->seq_end[s0 + i];
+            const bool full = bg < offset && en > (uint32_t)L - offset;
+            const int32_t* rk = g.rank_full.ptr(); int V = g.n_nodes;
+            if (!full) {
+                graph_subgraph_mask(g, bg, en, g.H.ptr());
+                V = graph_toposort(g, g.rank_sub.ptr(), true, g.H.ptr());
+                rk = g.rank_sub.ptr();
+            }
+            int best_row = 0;
+            host_dp(g, rk, V, !full, sp(i), sl(i), m, x, gp, best_row);
+            int plen = nw_traceback(g, rk, !full, sp(i), sl(i), best_row, m, x, gp);
+            graph_add_alignment(g, plen, sp(i), qp(i), sl(i));
+            if (g.overflow) { fprintf(stderr, "emul overflow %d\n", g.overflow); return -2; }
+            int nr = graph_toposort(g, g.rank_full.ptr(), false, g.H.ptr());
+            if (nr != g.n_nodes) return -3;
+        }
+        for (int r = 0; r < g.n_nodes; ++r) g.n2r[g.rank_full[r]] = r;
+        std::vector<int32_t> cn(g.n_nodes);
+        int k = graph_consensus(g, cn.data());
+        int bgn = 0, end = k - 1;
+        if (b->win_type[w] == 1 && trim) {
+            const uint32_t avg = (ns - 1) / 2;
+            for (; bgn < k; ++bgn) if (consensus_coverage(g, cn[bgn]) >= avg) break;
+            for (; end >= 0; --end) if (consensus_coverage(g, cn[end]) >= avg) break;
+            if (bgn >= end) { bgn = 0; end = k - 1; }
+        }
+        if (out + (end - bgn + 1) > cons_cap) return -1;
+        for (int t = bgn; t <= end; ++t) cons[out++] = g.code[cn[t]];
+        polished[w] = 1;
+    }
+    cons_off[b->n_windows] = out;
+    return 0;
+}
