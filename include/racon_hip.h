@@ -81,6 +81,7 @@ typedef struct rcn_run_stats {
     uint64_t dp_cells;         /* sum over alignments of (V'+1)(l+1), counted on device */
     uint64_t dp_pred_cells;    /* sum of cells * (#in-edge rows read), on device        */
     uint64_t bytes_in, bytes_out;
+    uint64_t dp_bytes;         /* algorithmic DP bytes (SURVEY 8(d) yardstick), on device     */
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */

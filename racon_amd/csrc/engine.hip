@@ -341,9 +341,9 @@ int rcn_engine_run(rcn_engine* e) {
     }
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
 
-    unsigned long long st[2] = {0, 0};
-    HIP_TRY(hipMemcpy(st, e->d_ctr.as<uint8_t>() + 16, 16, hipMemcpyDeviceToHost));
-    e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1];
+    unsigned long long st[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(st, e->d_ctr.as<uint8_t>() + 16, 24, hipMemcpyDeviceToHost));
+    e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
 
     for (uint32_t w = 0; w < nw; ++w) e->cons_off[w + 1] = e->cons_off[w] + out_len[w];
     e->cons.resize(e->cons_off[nw] + 1);

@@ -40,7 +40,7 @@ struct KParams {
     // outputs
     uint8_t* out_cons; uint64_t out_stride; uint32_t* out_len; uint8_t* out_flags;
     // queue + counters
-    unsigned int* next; unsigned long long* stats;   // stats[0]=cells, [1]=pred cells
+    unsigned int* next; unsigned long long* stats;   // stats[0]=cells, [1]=pred cells, [2]=algorithmic DP bytes
 };
 
 enum : uint8_t { kFlagPolished = 1, kFlagChimeric = 2, kFlagOverflow = 4, kFlagError = 8 };
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
     const int lane = threadIdx.x;
     Win g;
     win_bind(g, P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes, P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
-    unsigned long long st_cells = 0, st_pred = 0;
+    unsigned long long st_cells = 0, st_pred = 0, st_bytes = 0;
 
     for (;;) {
         unsigned int wi = 0;
@@ -238,6 +238,12 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
             }
             st_cells += static_cast<unsigned long long>(V + 1) * W;
             st_pred += static_cast<unsigned long long>(ds.pred_rows) * W;
+            {   // SURVEY 8(d) yardstick: every cell written once + every predecessor row read once per
+                // in-edge, at 2 B/cell when the worst-case score bound fits int16, else 4 B/cell
+                const int amax = max(max(abs(P.m), abs(P.x)), abs(P.g));
+                const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
+                st_bytes += sbytes * (static_cast<unsigned long long>(V + 1) + ds.pred_rows) * W;
+            }
             const int best_row = ds.best_row;
             // ---- traceback + AddAlignment + toposort (serial) ----
             if (lane == 0) {
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
         if (lane == 0) { P.out_len[wi] = clen; P.out_flags[wi] = static_cast<uint8_t>(flags); }
         wave_sync();
     }
-    if (lane == 0) { atomicAdd(&P.stats[0], st_cells); atomicAdd(&P.stats[1], st_pred); }
+    if (lane == 0) { atomicAdd(&P.stats[0], st_cells); atomicAdd(&P.stats[1], st_pred); atomicAdd(&P.stats[2], st_bytes); }
 }
 
 }  // namespace rcn

@@ -27,7 +27,8 @@ class RcnEngineConfig(C.Structure):
 class RcnRunStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("n_launches", C.c_uint32), ("n_retried", C.c_uint32), ("dp_cells", C.c_uint64),
-                ("dp_pred_cells", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64)]
+                ("dp_pred_cells", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
+                ("dp_bytes", C.c_uint64)]
 
 
 class RcnWindowDesc(C.Structure):

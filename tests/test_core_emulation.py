@@ -1,0 +1,53 @@
+"""The flat-array graph code the HIP kernel runs on one lane
+(racon_amd/csrc/poa_core.hpp), compiled for the CPU with a scalar DP
+(tests/emul/emul_main.cpp), against the oracle.  Catches logic errors in the
+device data structures without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import edge_case_batch, synthetic_sets
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(HERE, "emul", "libemul.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "emul", "emul_main.cpp")])
+    return C.CDLL(so)
+
+
+def run_emul(lib, b, m, x, g, trim=True):
+    cb = b.as_c()
+    n = b.n_windows
+    cap = int(b.bases.size) + 64
+    off = np.zeros(n + 1, np.uint64)
+    cons = np.zeros(cap, np.uint8)
+    pol = np.zeros(n, np.uint8)
+    rc = lib.rcn_emul_consensus(C.byref(cb), m, x, g, int(trim), off.ctypes.data_as(C.c_void_p),
+                                cons.ctypes.data_as(C.c_void_p), C.c_uint64(cap), pol.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    return [cons[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)], pol
+
+
+def test_emul_edge_cases(emul, oracle):
+    b = edge_case_batch()
+    for sc in [(3, -5, -4), (1, -1, -1)]:
+        ref = oracle.consensus(b, *sc, True, 2)
+        got, pol = run_emul(emul, b, *sc)
+        assert got == ref.consensus
+        assert (pol == ref.polished).all()
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_emul_synthetic(emul, oracle, idx):
+    name, b, sc = synthetic_sets()[idx]
+    b = b.select(range(min(b.n_windows, 8)))
+    ref = oracle.consensus(b, *sc, True, 4)
+    got, pol = run_emul(emul, b, *sc)
+    assert got == ref.consensus, name
+    assert (pol == ref.polished).all()

@@ -1,0 +1,64 @@
+"""Oracle (oracle/poa_oracle.cpp) against the independent pure-Python executable
+specification (oracle/spec_py.py) on small cases."""
+import numpy as np
+import pytest
+
+from racon_amd.batch import WindowBatch
+from racon_amd.synth import simulate_windows
+from oracle import spec_py
+from helpers import edge_case_batch, edge_case_windows
+
+
+def spec_consensus(win, m, x, g, trim=True):
+    seqs = [(s.decode("latin1"), (qq.decode("latin1") if qq is not None else None), b, e) for (s, qq, b, e) in win["seqs"]]
+    c, p = spec_py.window_consensus({"seqs": seqs}, m, x, g, tgs=(win["type"] == 1), trim=trim)
+    return c.encode("latin1"), p
+
+
+@pytest.mark.parametrize("scores", [(3, -5, -4), (5, -4, -8), (1, -1, -1)])
+def test_oracle_matches_spec_on_edge_cases(oracle, scores, capsys):
+    b = edge_case_batch()
+    r = oracle.consensus(b, *scores, True, 2)
+    for w, win in enumerate(edge_case_windows()):
+        c, p = spec_consensus(win, *scores)
+        assert c == r.consensus[w], f"window {w}"
+        assert p == bool(r.polished[w])
+
+
+def test_oracle_matches_spec_on_synthetic(oracle):
+    b = simulate_windows(3000, 500, 12, 2000, seed=5)
+    r = oracle.consensus(b, 3, -5, -4, True, 2)
+    for w in range(b.n_windows):
+        c, p = spec_consensus(b.window(w), 3, -5, -4)
+        assert c == r.consensus[w]
+        assert p == bool(r.polished[w])
+
+
+def test_oracle_trim_and_type_semantics(oracle):
+    b = edge_case_batch()
+    r_trim = oracle.consensus(b, 3, -5, -4, True, 1)
+    r_no = oracle.consensus(b, 3, -5, -4, False, 1)
+    bb = edge_case_windows()[0]["seqs"][0][0]
+    assert r_trim.consensus[0] == bb and not r_trim.polished[0]          # < 3 sequences: backbone copy (window.cpp:68-71)
+    assert r_trim.consensus[1] == bb and not r_trim.polished[1]
+    assert r_trim.consensus[2] == bb and r_trim.polished[2]
+    assert r_trim.consensus[5] == r_no.consensus[5]                        # kNGS: never trimmed (window.cpp:125)
+    assert len(r_trim.consensus[6]) < len(r_no.consensus[6])               # kTGS + trim: ends stripped
+    assert r_trim.chimeric[9] == 1 and r_no.chimeric[9] == 0              # warning only on the trim path
+    assert r_trim.consensus[9] == r_no.consensus[9]                        # ... and the consensus is kept untrimmed
+
+
+def test_edit_distance_helper(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        a = bytes(rng.integers(65, 69, rng.integers(1, 200)).astype(np.uint8))
+        b = bytes(rng.integers(65, 69, rng.integers(1, 200)).astype(np.uint8))
+        # reference DP
+        D = list(range(len(b) + 1))
+        for i in range(1, len(a) + 1):
+            prev, D[0] = D[0], i
+            for j in range(1, len(b) + 1):
+                cur = min(D[j] + 1, D[j - 1] + 1, prev + (a[i - 1] != b[j - 1]))
+                prev, D[j] = D[j], cur
+        assert oracle.edit_distance(a, b) == D[-1]
+    assert oracle.edit_distance(b"", b"ACG") == 3
