@@ -82,6 +82,9 @@ typedef struct rcn_run_stats {
     uint64_t dp_pred_cells;    /* sum of cells * (#in-edge rows read), on device        */
     uint64_t bytes_in, bytes_out;
     uint64_t dp_bytes;         /* algorithmic DP bytes (SURVEY 8(d) yardstick), on device     */
+    uint64_t phase_clocks[8];  /* summed wave clocks: subgraph, row-desc, DP, traceback,
+                                  add-alignment, toposort, consensus, queue/other           */
+    uint64_t n_sink_ties;      /* alignments that needed spoa's exact rank order (sink tie)    */
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */

@@ -176,7 +176,7 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
-    int rc = e->d_ctr.reserve(64);
+    int rc = e->d_ctr.reserve(256);
     if (rc) { delete e; return rc; }
     *out = e;
     return RCN_OK;
@@ -290,7 +290,7 @@ int rcn_engine_run(rcn_engine* e) {
     if ((rc = e->d_out_cons.reserve(static_cast<uint64_t>(nw) * c1.out_stride))) return rc;
     if ((rc = e->d_out_len.reserve(4ull * nw))) return rc;
     if ((rc = e->d_out_flags.reserve(nw))) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 64, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 256, e->stream));
     if ((rc = run_pass(e, c1, nullptr, nw, c1.out_stride))) return rc;
 
     std::vector<uint32_t> out_len(nw);
@@ -341,9 +341,11 @@ int rcn_engine_run(rcn_engine* e) {
     }
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
 
-    unsigned long long st[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpy(st, e->d_ctr.as<uint8_t>() + 16, 24, hipMemcpyDeviceToHost));
+    unsigned long long st[12] = {0};
+    HIP_TRY(hipMemcpy(st, e->d_ctr.as<uint8_t>() + 16, sizeof(st), hipMemcpyDeviceToHost));
     e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
+    for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
+    e->stats.n_sink_ties = st[11];
 
     for (uint32_t w = 0; w < nw; ++w) e->cons_off[w + 1] = e->cons_off[w] + out_len[w];
     e->cons.resize(e->cons_off[nw] + 1);

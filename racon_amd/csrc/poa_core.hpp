@@ -57,9 +57,15 @@ struct Win {
     Arr<int32_t> out_head, out_tail;     // [ncap]
     Arr<uint32_t> cov;             // [ncap] #sequences (len>=2) through node == |labels|
     Arr<int32_t> al_nodes;         // [ncap*ring]
-    Arr<int32_t> rank_full;        // [ncap] rank -> node of the whole graph
-    Arr<int32_t> rank_sub;         // [ncap] rank -> node of the current subgraph
-    Arr<int32_t> n2r;              // [ncap] node -> rank for the graph being aligned
+    Arr<int32_t> rank_full;        // [ncap] rank -> node: a VALID topological order of the whole graph
+                                   //        with aligned rings contiguous, maintained incrementally
+    Arr<int32_t> rank_tmp;         // [ncap] merge output (swapped with rank_full)
+    Arr<int32_t> rank_sub;         // [ncap] rank -> node of the current subgraph (rank_full filtered)
+    Arr<int32_t> rank_x;           // [ncap] spoa's EXACT DFS order (computed lazily: sink ties, consensus)
+    Arr<int32_t> n2r;              // [ncap] inverse of rank_full
+    Arr<int32_t> n2r_x;            // [ncap] inverse of rank_sub / rank_x (whichever is in use)
+    Arr<int32_t> new_id;           // [lmax+2] nodes created by the current layer, in sequence order
+    Arr<int32_t> new_anchor;       // [lmax+2] old rank after whose ring block each of them is inserted (-1 = front)
     Arr<int32_t> pred;             // [ncap] consensus predecessor
     Arr<int64_t> score;            // [ncap] consensus score
     // edges
@@ -69,7 +75,8 @@ struct Win {
     Arr<int32_t> path_node, path_pos;    // [ncap + lmax + 2]
     // DP
     Arr<RowDesc> desc;             // [ncap]
-    Arr<int32_t> H;                // [(ncap+1) * hstride]; also DFS stack scratch
+    Arr<int32_t> stack;            // [ecap + ncap*(ring+1) + 64] DFS stack scratch
+    Arr<int32_t> H;                // [(ncap+1) * hstride]
     int64_t  hcap;                 // ints available in H
     int32_t  hstride;
     int32_t  overflow;             // set when a capacity is exceeded
@@ -120,28 +127,47 @@ RCN_HD int32_t add_sequence(Win& g, const uint8_t* seq, const uint8_t* qual, int
     return first;
 }
 
+// Rank (in rank_full) of the last member of the aligned-ring block that holds v.
+RCN_HD int32_t block_end_rank(const Win& g, int32_t v) {
+    int32_t r = g.n2r[v];
+    const int32_t na = g.al_cnt[v];
+    for (int32_t a = 0; a < na; ++a) { const int32_t q = g.n2r[g.al_nodes[v * g.ring + a]]; r = q > r ? q : r; }
+    return r;
+}
+
 // spoa::Graph::AddAlignment for a non-empty alignment given as the REVERSED
-// traceback path (path_node/path_pos[0..plen) from end to start).
-RCN_HD void graph_add_alignment(Win& g, int32_t plen, const uint8_t* seq, const uint8_t* qual, int32_t len) {
-    if (len == 0) return;
+// traceback path (path_node/path_pos[0..plen) from end to start).  Also records,
+// in sequence order, every node it creates and the rank (in the current
+// rank_full) after whose ring block the node has to be inserted to keep
+// rank_full a valid, ring-contiguous topological order (see order_merge).
+// Returns the number of nodes created.
+RCN_HD int32_t graph_add_alignment(Win& g, int32_t plen, const uint8_t* seq, const uint8_t* qual, int32_t len) {
+    if (len == 0) return 0;
     const uint32_t count = len >= 2 ? 1u : 0u;     // a 1-base sequence creates no edge, hence no label
     // first / last valid sequence positions
     int32_t vfront = -1, vback = -1;
     for (int32_t k = plen - 1; k >= 0; --k) if (g.path_pos[k] != -1) { vfront = g.path_pos[k]; break; }
     for (int32_t k = 0; k < plen; ++k) if (g.path_pos[k] != -1) { vback = g.path_pos[k]; break; }
-    if (vfront < 0) { g.overflow = 2; return; }
+    if (vfront < 0) { g.overflow = 2; return 0; }
+    int32_t nn = 0;
+    int32_t anchor = -1;
+    const int32_t pre0 = g.n_nodes;
     int32_t begin = add_sequence(g, seq, qual, 0, vfront, count);
     int32_t prev = begin < 0 ? -1 : g.n_nodes - 1;
+    for (int32_t v = pre0; v < g.n_nodes; ++v) { g.new_id[nn] = v; g.new_anchor[nn] = -1; ++nn; }
+    const int32_t suf0 = g.n_nodes;
     int32_t last = add_sequence(g, seq, qual, vback + 1, len, count);
-    if (g.overflow) return;
+    const int32_t suf1 = g.n_nodes;
+    if (g.overflow) return nn;
     for (int32_t k = plen - 1; k >= 0; --k) {
         const int32_t pos = g.path_pos[k];
         if (pos == -1) continue;
         const int32_t t = g.path_node[k];
         const uint8_t c = seq[pos];
         int32_t curr = -1;
+        bool created = false;
         if (t == -1) {
-            curr = add_node(g, c);
+            curr = add_node(g, c); created = true;
         } else if (g.code[t] == c) {
             curr = t;
         } else {
@@ -151,9 +177,10 @@ RCN_HD void graph_add_alignment(Win& g, int32_t plen, const uint8_t* seq, const 
                 if (g.code[u] == c) { curr = u; break; }
             }
             if (curr < 0) {
-                if (na >= g.ring) { g.overflow = 3; return; }
-                curr = add_node(g, c);
-                if (g.overflow) return;
+                if (na >= g.ring) { g.overflow = 3; return nn; }
+                anchor = block_end_rank(g, t);          // joins t's block: goes right behind it
+                curr = add_node(g, c); created = true;
+                if (g.overflow) return nn;
                 for (int32_t a = 0; a < na; ++a) {
                     int32_t u = g.al_nodes[t * g.ring + a];
                     g.al_nodes[u * g.ring + g.al_cnt[u]++] = curr;
@@ -163,14 +190,31 @@ RCN_HD void graph_add_alignment(Win& g, int32_t plen, const uint8_t* seq, const 
                 g.al_nodes[curr * g.ring + g.al_cnt[curr]++] = t;
             }
         }
-        if (g.overflow) return;
+        if (g.overflow) return nn;
+        if (created) { g.new_id[nn] = curr; g.new_anchor[nn] = anchor; ++nn; }
+        else anchor = block_end_rank(g, curr);
         g.cov[curr] += count;
         if (begin < 0) begin = curr;
         if (prev >= 0) add_edge(g, prev, curr, pair_weight(qual, pos));
         prev = curr;
-        if (g.overflow) return;
+        if (g.overflow) return nn;
     }
     if (last >= 0) add_edge(g, prev, last, pair_weight(qual, vback + 1));
+    for (int32_t v = suf0; v < suf1; ++v) { g.new_id[nn] = v; g.new_anchor[nn] = anchor; ++nn; }
+    return nn;
+}
+
+// Serial reference of the order merge (the kernel does it wave-parallel):
+// rank_tmp = rank_full with the nn new nodes inserted behind their anchors.
+RCN_HD void order_merge_serial(Win& g, int32_t n_old, int32_t nn) {
+    int32_t k = 0, o = 0;
+    while (k < nn && g.new_anchor[k] < 0) g.rank_tmp[o++] = g.new_id[k++];
+    for (int32_t r = 0; r < n_old; ++r) {
+        g.rank_tmp[o++] = g.rank_full[r];
+        while (k < nn && g.new_anchor[k] == r) g.rank_tmp[o++] = g.new_id[k++];
+    }
+    Arr<int32_t> t = g.rank_full; g.rank_full = g.rank_tmp; g.rank_tmp = t;
+    for (int32_t r = 0; r < o; ++r) g.n2r[g.rank_full[r]] = r;
 }
 
 // Exact spoa DFS topological sort.  With `use_mask`, restricted to nodes with
@@ -242,14 +286,14 @@ RCN_HD void graph_subgraph_mask(Win& g, int32_t begin, int32_t end, int32_t* sta
 }
 
 // Row descriptor of rank r (node v) for the (sub)graph being aligned.
-RCN_HD RowDesc make_row_desc(const Win& g, int32_t v, bool use_mask) {
+RCN_HD RowDesc make_row_desc(const Win& g, const Arr<int32_t>& nr, int32_t v, bool use_mask) {
     RowDesc d; d.p0 = 0; d.p1 = -1; d.erest = -1;
     int32_t k = 0;
     for (int32_t e = g.in_head[v]; e >= 0; e = g.e_nin[e]) {
         const int32_t t = g.e_tail[e];
         if (use_mask && !g.inc[t]) continue;
-        if (k == 0) d.p0 = g.n2r[t] + 1;
-        else if (k == 1) d.p1 = g.n2r[t] + 1;
+        if (k == 0) d.p0 = nr[t] + 1;
+        else if (k == 1) d.p1 = nr[t] + 1;
         else { d.erest = e; break; }
         ++k;
     }
@@ -264,7 +308,7 @@ RCN_HD RowDesc make_row_desc(const Win& g, int32_t v, bool use_mask) {
 // Traceback of spoa's linear NW (priority: diagonal, vertical, horizontal;
 // predecessors in in-edge order).  H rows are indexed rank+1, row 0 virtual.
 // Writes the REVERSED path into path_node/path_pos; returns its length.
-RCN_HD int32_t nw_traceback(Win& g, const int32_t* rank, bool use_mask, const uint8_t* seq, int32_t len,
+RCN_HD int32_t nw_traceback(Win& g, const int32_t* rank, const Arr<int32_t>& nr, bool use_mask, const uint8_t* seq, int32_t len,
                             int32_t best_row, int32_t m, int32_t x, int32_t gp) {
     const int64_t W = g.hstride;
     int32_t i = best_row, j = len, n = 0;
@@ -282,7 +326,7 @@ RCN_HD int32_t nw_traceback(Win& g, const int32_t* rank, bool use_mask, const ui
                         for (int32_t e = d.erest; e >= 0 && !found; e = g.e_nin[e]) {
                             const int32_t t = g.e_tail[e];
                             if (use_mask && !g.inc[t]) continue;
-                            const int32_t p = g.n2r[t] + 1;
+                            const int32_t p = nr[t] + 1;
                             if (hij == g.H[p * W + j - 1] + mc) { pi = p; pj = j - 1; found = true; }
                         }
                     }
@@ -296,7 +340,7 @@ RCN_HD int32_t nw_traceback(Win& g, const int32_t* rank, bool use_mask, const ui
                         for (int32_t e = d.erest; e >= 0 && !found; e = g.e_nin[e]) {
                             const int32_t t = g.e_tail[e];
                             if (use_mask && !g.inc[t]) continue;
-                            const int32_t p = g.n2r[t] + 1;
+                            const int32_t p = nr[t] + 1;
                             if (hij == g.H[p * W + j] + gp) { pi = p; pj = j; found = true; }
                         }
                     }
@@ -328,13 +372,14 @@ RCN_HD void consensus_relax(Win& g, int32_t it, bool skip) {
 }
 
 // Heaviest bundle + branch completion over rank_full; writes the consensus node
-// ids (in order) to out_nodes; returns the length.  n2r must be rank_full's inverse.
-RCN_HD int32_t graph_consensus(Win& g, int32_t* out_nodes) {
+// ids (in order) to out_nodes; returns the length.  `rank` must be spoa's exact
+// order (graph_toposort) and `nr` its inverse.
+RCN_HD int32_t graph_consensus(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int32_t* out_nodes) {
     const int32_t n = g.n_nodes;
     for (int32_t i = 0; i < n; ++i) { g.pred[i] = -1; g.score[i] = -1; }
     int32_t mx = -1;
     for (int32_t r = 0; r < n; ++r) {
-        const int32_t it = g.rank_full[r];
+        const int32_t it = rank[r];
         consensus_relax(g, it, false);
         if (mx < 0 || g.score[mx] < g.score[it]) mx = it;
     }
@@ -346,8 +391,8 @@ RCN_HD int32_t graph_consensus(Win& g, int32_t* out_nodes) {
             }
         }
         int32_t m2 = -1;
-        for (int32_t r = g.n2r[start] + 1; r < n; ++r) {
-            const int32_t it = g.rank_full[r];
+        for (int32_t r = nr[start] + 1; r < n; ++r) {
+            const int32_t it = rank[r];
             g.score[it] = -1; g.pred[it] = -1;
             consensus_relax(g, it, true);
             if (m2 < 0 || g.score[m2] < g.score[it]) m2 = it;
@@ -379,15 +424,16 @@ RCN_HD uint64_t win_bind(Win& g, uint8_t* base, int32_t ncap, int32_t ecap, int3
     RCN_TAKE(code, n); RCN_TAKE(al_cnt, n); RCN_TAKE(mark, n); RCN_TAKE(inc, n);
     RCN_TAKE(in_head, 4 * n); RCN_TAKE(in_tail, 4 * n); RCN_TAKE(out_head, 4 * n); RCN_TAKE(out_tail, 4 * n);
     RCN_TAKE(cov, 4 * n); RCN_TAKE(al_nodes, 4 * n * ring);
-    RCN_TAKE(rank_full, 4 * n); RCN_TAKE(rank_sub, 4 * n); RCN_TAKE(n2r, 4 * n); RCN_TAKE(pred, 4 * n);
+    RCN_TAKE(rank_full, 4 * n); RCN_TAKE(rank_tmp, 4 * n); RCN_TAKE(rank_sub, 4 * n); RCN_TAKE(rank_x, 4 * n);
+    RCN_TAKE(n2r, 4 * n); RCN_TAKE(n2r_x, 4 * n); RCN_TAKE(pred, 4 * (n + 1));
+    RCN_TAKE(new_id, 4 * (static_cast<uint64_t>(lmax) + 2)); RCN_TAKE(new_anchor, 4 * (static_cast<uint64_t>(lmax) + 2));
     RCN_TAKE(score, 8 * n);
     RCN_TAKE(e_tail, 4 * e); RCN_TAKE(e_head, 4 * e); RCN_TAKE(e_nin, 4 * e); RCN_TAKE(e_nout, 4 * e);
     RCN_TAKE(e_w, 8 * e);
     RCN_TAKE(path_node, 4 * (n + lmax + 2)); RCN_TAKE(path_pos, 4 * (n + lmax + 2));
     RCN_TAKE(desc, 16 * n);
-    uint64_t hints = (n + 1) * static_cast<uint64_t>(hstride);
-    const uint64_t stack_need = e + n * (ring + 1) + 64;
-    if (hints < stack_need) hints = stack_need;
+    RCN_TAKE(stack, 4 * (e + n * (ring + 1) + 64));
+    const uint64_t hints = (n + 1) * static_cast<uint64_t>(hstride);
     g.hcap = static_cast<int64_t>(hints);
     RCN_TAKE(H, 4 * hints);          // last: the only array that may start beyond 4 GiB is none (offset of H < 4 GiB)
 #undef RCN_TAKE

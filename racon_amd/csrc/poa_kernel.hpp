@@ -40,7 +40,7 @@ struct KParams {
     // outputs
     uint8_t* out_cons; uint64_t out_stride; uint32_t* out_len; uint8_t* out_flags;
     // queue + counters
-    unsigned int* next; unsigned long long* stats;   // stats[0]=cells, [1]=pred cells, [2]=algorithmic DP bytes
+    unsigned int* next; unsigned long long* stats;   // stats[0]=cells, [1]=pred cells, [2]=algorithmic DP bytes, [3..10]=phase clocks, [11]=sink ties
 };
 
 enum : uint8_t { kFlagPolished = 1, kFlagChimeric = 2, kFlagOverflow = 4, kFlagError = 8 };
@@ -59,12 +59,12 @@ __device__ __forceinline__ int wave_excl_scan_max(int z, int lane) {
 
 // One column tile [t0, t0 + 64*CT) of the DP matrix, all rows.
 constexpr int kMaxCT = 12;   // widest column tile: 64 * 12 = 768 columns per pass
-struct DpState { int best, best_row, have_best; unsigned int pred_rows; };
+struct DpState { int best, best_row, have_best, tied; unsigned int pred_rows; };
 
 template <int CT>
-__device__ __forceinline__ DpState dp_tile(const Win& g, int V, bool sub, const uint8_t* __restrict__ seq, int len,
+__device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr, int V, bool sub, const uint8_t* __restrict__ seq, int len,
                                         int t0, bool last_tile, int m, int x, int gp, DpState st) {
-    int best = st.best, best_row = st.best_row, have_best = st.have_best;
+    int best = st.best, best_row = st.best_row, have_best = st.have_best, tied = st.tied;
     unsigned int pred_rows = 0;
     const int lane = threadIdx.x;
     const int j0 = t0 + lane * CT;
@@ -121,7 +121,7 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, int V, bool sub, const 
         for (int e = er; e >= 0; e = g.e_nin[e]) {
             const int t = g.e_tail[e];
             if (sub && !g.inc[t]) continue;
-            accumulate(g.n2r[t] + 1);
+            accumulate(nr[t] + 1);
         }
         // horizontal gap: in-lane pass, then wave-wide prefix max of the transformed lane tails
 #pragma unroll
@@ -144,10 +144,11 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, int V, bool sub, const 
 #pragma unroll
             for (int c = 0; c < CT; ++c) if (j0 + c == len) cand = acc[c];
             const int val = __builtin_amdgcn_readlane(cand, own_lane);
-            if (!have_best || best < val) { have_best = 1; best = val; best_row = i; }
+            if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
+            else if (best == val) ++tied;
         }
     }
-    DpState o; o.best = best; o.best_row = best_row; o.have_best = have_best;
+    DpState o; o.best = best; o.best_row = best_row; o.have_best = have_best; o.tied = tied;
     o.pred_rows = (t0 == 0) ? pred_rows : st.pred_rows;
     return o;
 }
@@ -158,9 +159,13 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
     const int lane = threadIdx.x;
     Win g;
     win_bind(g, P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes, P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
-    unsigned long long st_cells = 0, st_pred = 0, st_bytes = 0;
+    unsigned long long st_cells = 0, st_pred = 0, st_bytes = 0, st_ties = 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub, desc, dp, traceback, add, toposort, consensus, other
+    long long tck = clock64();
+#define RCN_PHASE(k) do { long long now__ = clock64(); ph[k] += now__ - tck; tck = now__; } while (0)
 
     for (;;) {
+        RCN_PHASE(7);
         unsigned int wi = 0;
         if (lane == 0) wi = atomicAdd(P.next, 1u);
         wi = bcast0(wi);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                 g.in_head[i] = g.in_tail[i] = (i > 0) ? i - 1 : -1;
                 g.out_head[i] = g.out_tail[i] = (i < L - 1) ? i : -1;
                 g.cov[i] = L >= 2 ? 1u : 0u;
-                g.rank_full[i] = i;
+                g.rank_full[i] = i; g.n2r[i] = i;
                 if (i < L - 1) {
                     g.e_tail[i] = i; g.e_head[i] = i + 1; g.e_nin[i] = -1; g.e_nout[i] = -1;
                     g.e_w[i] = pair_weight(q0, i + 1);
@@ -203,24 +208,36 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
             const bool sub = P.seq_full[si] == 0;
             int V = g.n_nodes;
             const int32_t* rank = g.rank_full.ptr();
+            Arr<int32_t> nr = g.n2r;
             if (sub) {
+                // Subgraph (window.cpp:99-103): reachability mask on lane 0, then the sub order is
+                // rank_full filtered by the mask (any valid order restricted to a subset stays valid)
+                if (lane == 0) graph_subgraph_mask(g, static_cast<int32_t>(P.seq_begin[si]), static_cast<int32_t>(P.seq_end[si]), g.stack.ptr());
+                wave_sync();
                 int nv = 0;
-                if (lane == 0) {
-                    graph_subgraph_mask(g, static_cast<int32_t>(P.seq_begin[si]), static_cast<int32_t>(P.seq_end[si]), g.H.ptr());
-                    nv = graph_toposort(g, g.rank_sub.ptr(), true, g.H.ptr());
+                for (int base = 0; base < g.n_nodes; base += 64) {
+                    const int r = base + lane;
+                    const int v = r < g.n_nodes ? g.rank_full[r] : -1;
+                    const bool in = v >= 0 && g.inc[v] != 0;
+                    const unsigned long long mk = __ballot(in);
+                    if (in) {
+                        const int pos = nv + __popcll(mk & ((1ull << lane) - 1ull));
+                        g.rank_sub[pos] = v; g.n2r_x[v] = pos;
+                    }
+                    nv += __popcll(mk);
                 }
-                V = bcast0(nv);
-                rank = g.rank_sub.ptr();
+                V = nv;
+                rank = g.rank_sub.ptr(); nr = g.n2r_x;
                 wave_sync();
             }
+            RCN_PHASE(0);
             // ---- row descriptors ----
-            for (int r = lane; r < V; r += 64) g.n2r[rank[r]] = r;
-            wave_sync();
-            for (int r = lane; r < V; r += 64) g.desc[r] = make_row_desc(g, rank[r], sub);
+            for (int r = lane; r < V; r += 64) g.desc[r] = make_row_desc(g, nr, rank[r], sub);
             for (int j = lane; j < g.hstride; j += 64) g.H[j] = j * P.g;
             wave_sync();
+            RCN_PHASE(1);
             // ---- DP ----
-            DpState ds; ds.best = 0; ds.best_row = 0; ds.have_best = 0; ds.pred_rows = 0;
+            DpState ds; ds.best = 0; ds.best_row = 0; ds.have_best = 0; ds.tied = 0; ds.pred_rows = 0;
             const int W = len + 1;
             for (int t0 = 0; t0 < W;) {
                 const int need = (W - t0 + 63) / 64;
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                 if (ct > kMaxCT) ct = kMaxCT;
                 const bool lastt = t0 + 64 * ct >= W;
                 switch (ct) {
-#define RCN_CASE(C) case C: ds = dp_tile<C>(g, V, sub, seq, len, t0, lastt, P.m, P.x, P.g, ds); break;
+#define RCN_CASE(C) case C: ds = dp_tile<C>(g, nr, V, sub, seq, len, t0, lastt, P.m, P.x, P.g, ds); break;
                     RCN_CASE(2) RCN_CASE(4) RCN_CASE(6) RCN_CASE(8) RCN_CASE(10)
                     RCN_CASE(12)
 #undef RCN_CASE
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                 t0 += 64 * ct;
                 wave_sync();
             }
+            RCN_PHASE(2);
             st_cells += static_cast<unsigned long long>(V + 1) * W;
             st_pred += static_cast<unsigned long long>(ds.pred_rows) * W;
             {   // SURVEY 8(d) yardstick: every cell written once + every predecessor row read once per
@@ -244,31 +262,75 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                 const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
                 st_bytes += sbytes * (static_cast<unsigned long long>(V + 1) + ds.pred_rows) * W;
             }
-            const int best_row = ds.best_row;
-            // ---- traceback + AddAlignment + toposort (serial) ----
+            // ---- traceback + AddAlignment (serial) ----
+            const int n_old = g.n_nodes;
+            int nn = 0;
             if (lane == 0) {
-                const int plen = nw_traceback(g, rank, sub, seq, len, best_row, P.m, P.x, P.g);
-                if (!g.overflow) graph_add_alignment(g, plen, seq, qual, len);
-                if (!g.overflow) {
-                    const int nr = graph_toposort(g, g.rank_full.ptr(), false, g.H.ptr());
-                    if (nr != g.n_nodes) g.overflow = 5;
+                int best_row = ds.best_row;
+                if (ds.tied > 1) {
+                    // several sinks share the best score: spoa takes the first one in ITS rank order
+                    // (exact DFS order), so compute that order now (rare: <1% of alignments)
+                    const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
+                    for (int r = 0; r < nx; ++r) {
+                        const int row = nr[g.rank_x[r]] + 1;
+                        if ((g.desc[row - 1].meta & 256) && g.H[static_cast<int64_t>(row) * g.hstride + len] == ds.best) { best_row = row; break; }
+                    }
+                    ++st_ties;
                 }
+                const int plen = nw_traceback(g, rank, nr, sub, seq, len, best_row, P.m, P.x, P.g);
+                RCN_PHASE(3);
+                if (!g.overflow) nn = graph_add_alignment(g, plen, seq, qual, len);
+                RCN_PHASE(4);
             }
+            nn = bcast0(nn);
             g.n_nodes = bcast0(g.n_nodes); g.n_edges = bcast0(g.n_edges); g.overflow = bcast0(g.overflow);
             wave_sync();
+            // ---- order merge: insert the nn new nodes behind their anchors (wave-parallel) ----
+            if (!g.overflow) {
+                int32_t* delta = g.pred.ptr();                      // [n_old + 1] scratch (pred is consensus-only)
+                for (int r = lane; r <= n_old; r += 64) delta[r] = 0;
+                wave_sync();
+                for (int k = lane; k < nn; k += 64) {
+                    const int a = g.new_anchor[k] + 1;
+                    atomicAdd(&delta[a], 1);
+                    const int v = g.new_id[k];
+                    g.rank_tmp[a + k] = v; g.n2r[v] = a + k;
+                }
+                wave_sync();
+                int carry = 0;
+                for (int base = 0; base < n_old; base += 64) {
+                    const int r = base + lane;
+                    int sc = r < n_old ? delta[r] : 0;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(sc, d); if (lane >= d) sc += t; }
+                    if (r < n_old) { const int v = g.rank_full[r]; const int pos = r + carry + sc; g.rank_tmp[pos] = v; g.n2r[v] = pos; }
+                    carry += __shfl(sc, 63);
+                }
+                { const Arr<int32_t> t = g.rank_full; g.rank_full = g.rank_tmp; g.rank_tmp = t; }
+                wave_sync();
+            }
+            RCN_PHASE(5);
         }
 
         if (g.overflow) {
             if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (g.overflow == 1 || g.overflow == 3) ? kFlagOverflow : kFlagError; }
             continue;
         }
-        // ---- consensus (window.cpp:122-146) ----
-        for (int r = lane; r < g.n_nodes; r += 64) g.n2r[g.rank_full[r]] = r;
+        // ---- consensus (window.cpp:122-146): needs spoa's exact rank order once ----
+        int nx = 0;
+        if (lane == 0) nx = graph_toposort(g, g.rank_x.ptr(), false, g.stack.ptr());
+        nx = bcast0(nx);
+        wave_sync();
+        if (nx != g.n_nodes) {
+            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = kFlagError; }
+            continue;
+        }
+        for (int r = lane; r < g.n_nodes; r += 64) g.n2r_x[g.rank_x[r]] = r;
         wave_sync();
         int clen = 0, cb = 0, flags = kFlagPolished;
         if (lane == 0) {
             int32_t* cn = g.path_node.ptr();
-            const int k = graph_consensus(g, cn);
+            const int k = graph_consensus(g, g.rank_x.ptr(), g.n2r_x, cn);
             int bgn = 0, end = k - 1;
             if (P.win_type[w] == 1 && P.trim) {
                 const uint32_t avg = static_cast<uint32_t>(ns - 1) / 2;
@@ -287,8 +349,11 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
         for (int t = lane; t < clen; t += 64) out[t] = g.code[g.path_node[cb + t]];
         if (lane == 0) { P.out_len[wi] = clen; P.out_flags[wi] = static_cast<uint8_t>(flags); }
         wave_sync();
+        RCN_PHASE(6);
     }
-    if (lane == 0) { atomicAdd(&P.stats[0], st_cells); atomicAdd(&P.stats[1], st_pred); atomicAdd(&P.stats[2], st_bytes); }
+    if (lane == 0) { atomicAdd(&P.stats[0], st_cells); atomicAdd(&P.stats[1], st_pred); atomicAdd(&P.stats[2], st_bytes);
+                     for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[3 + k], ph[k]);
+                     atomicAdd(&P.stats[11], st_ties); }
 }
 
 }  // namespace rcn

@@ -28,7 +28,7 @@ class RcnRunStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("n_launches", C.c_uint32), ("n_retried", C.c_uint32), ("dp_cells", C.c_uint64),
                 ("dp_pred_cells", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
-                ("dp_bytes", C.c_uint64)]
+                ("dp_bytes", C.c_uint64), ("phase_clocks", C.c_uint64 * 8), ("n_sink_ties", C.c_uint64)]
 
 
 class RcnWindowDesc(C.Structure):
@@ -122,7 +122,9 @@ class HipEngine:
     def stats(self) -> dict:
         s = RcnRunStats()
         _check(self.lib.rcn_engine_stats(self.h, C.byref(s)), "rcn_engine_stats")
-        return {k: getattr(s, k) for k, _ in RcnRunStats._fields_}
+        d = {k: getattr(s, k) for k, _ in RcnRunStats._fields_}
+        d["phase_clocks"] = list(s.phase_clocks)
+        return d
 
     def consensus(self, batch: WindowBatch) -> ConsensusResult:
         self.upload(batch)

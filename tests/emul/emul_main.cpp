@@ -13,13 +13,16 @@
 
 using namespace rcn;
 
-static void host_dp(Win& g, const int32_t* rank, int V, bool sub, const uint8_t* seq, int len,
-                    int m, int x, int gp, int& best_row) {
+static int g_ties = 0, g_aligns = 0;
+
+// scalar DP over `rank` (any valid topological order); returns the row of the best sink
+// and how many sinks tie at the best score.
+static void host_dp(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int V, bool sub, const uint8_t* seq, int len,
+                    int m, int x, int gp, int& best_row, int& best, int& tied) {
     const int64_t W = g.hstride;
-    for (int r = 0; r < V; ++r) g.n2r[rank[r]] = r;
-    for (int r = 0; r < V; ++r) g.desc[r] = make_row_desc(g, rank[r], sub);
+    for (int r = 0; r < V; ++r) g.desc[r] = make_row_desc(g, nr, rank[r], sub);
     for (int j = 0; j <= len; ++j) g.H[j] = j * gp;
-    bool have = false; int best = 0; best_row = 0;
+    bool have = false; best = 0; best_row = 0; tied = 0;
     for (int r = 0; r < V; ++r) {
         const RowDesc d = g.desc[r];
         int32_t* row = &g.H[(int64_t)(r + 1) * W];
@@ -37,10 +40,13 @@ static void host_dp(Win& g, const int32_t* rank, int V, bool sub, const uint8_t*
         for (int e = d.erest; e >= 0; e = g.e_nin[e]) {
             int t = g.e_tail[e];
             if (sub && !g.inc[t]) continue;
-            acc(g.n2r[t] + 1);
+            acc(nr[t] + 1);
         }
         for (int j = 1; j <= len; ++j) row[j] = std::max(row[j], row[j - 1] + gp);
-        if (d.meta & 256) { if (!have || best < row[len]) { have = true; best = row[len]; best_row = r + 1; } }
+        if (d.meta & 256) {
+            if (!have || best < row[len]) { have = true; best = row[len]; best_row = r + 1; tied = 1; }
+            else if (best == row[len]) ++tied;
+        }
     }
 }
 
@@ -67,7 +73,7 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
         win_bind(g, mem.data(), ncap, ecap, ring, lmax, hstride);
         // backbone
         const uint8_t* q0 = qp(0);
-        for (int i = 0; i < L; ++i) { int v = add_node(g, sp(0)[i]); g.cov[v] = L >= 2 ? 1 : 0; if (i) add_edge(g, v - 1, v, pair_weight(q0, i)); g.rank_full[i] = i; }
+        for (int i = 0; i < L; ++i) { int v = add_node(g, sp(0)[i]); g.cov[v] = L >= 2 ? 1 : 0; if (i) add_edge(g, v - 1, v, pair_weight(q0, i)); g.rank_full[i] = i; g.n2r[i] = i; }
         std::vector<uint32_t> rank(ns);
         for (uint32_t i = 0; i < ns; ++i) rank[i] = i;
         std::sort(rank.begin() + 1, rank.end(), [&](uint32_t l, uint32_t r) { return b->seq_begin[s0 + l] < b->seq_begin[s0 + r]; });
@@ -77,22 +83,37 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
             const uint32_t bg = b->seq_begin[s0 + i], en = b->seq_end[s0 + i];
             const bool full = bg < offset && en > (uint32_t)L - offset;
             const int32_t* rk = g.rank_full.ptr(); int V = g.n_nodes;
+            const Arr<int32_t>* nr = &g.n2r;
             if (!full) {
-                graph_subgraph_mask(g, bg, en, g.H.ptr());
-                V = graph_toposort(g, g.rank_sub.ptr(), true, g.H.ptr());
-                rk = g.rank_sub.ptr();
+                graph_subgraph_mask(g, bg, en, g.stack.ptr());
+                V = 0;
+                for (int r = 0; r < g.n_nodes; ++r) { int v = g.rank_full[r]; if (g.inc[v]) { g.rank_sub[V] = v; g.n2r_x[v] = V; ++V; } }
+                rk = g.rank_sub.ptr(); nr = &g.n2r_x;
             }
-            int best_row = 0;
-            host_dp(g, rk, V, !full, sp(i), sl(i), m, x, gp, best_row);
-            int plen = nw_traceback(g, rk, !full, sp(i), sl(i), best_row, m, x, gp);
-            graph_add_alignment(g, plen, sp(i), qp(i), sl(i));
+            int best_row = 0, best = 0, tied = 0;
+            host_dp(g, rk, *nr, V, !full, sp(i), sl(i), m, x, gp, best_row, best, tied);
+            ++g_aligns;
+            if (tied > 1) {       // spoa picks the first best sink in ITS rank order: run the exact DFS
+                ++g_ties;
+                int nx = graph_toposort(g, g.rank_x.ptr(), !full, g.stack.ptr());
+                for (int r = 0; r < nx; ++r) {
+                    int v = g.rank_x[r]; int row = (*nr)[v] + 1;
+                    if ((g.desc[row - 1].meta & 256) && g.H[(int64_t)row * g.hstride + sl(i)] == best) { best_row = row; break; }
+                }
+            }
+            int plen = nw_traceback(g, rk, *nr, !full, sp(i), sl(i), best_row, m, x, gp);
+            const int n_old = g.n_nodes;
+            int nn = graph_add_alignment(g, plen, sp(i), qp(i), sl(i));
             if (g.overflow) { fprintf(stderr, "emul overflow %d\n", g.overflow); return -2; }
-            int nr = graph_toposort(g, g.rank_full.ptr(), false, g.H.ptr());
-            if (nr != g.n_nodes) return -3;
+            order_merge_serial(g, n_old, nn);
         }
-        for (int r = 0; r < g.n_nodes; ++r) g.n2r[g.rank_full[r]] = r;
+        {
+            int nr_ = graph_toposort(g, g.rank_x.ptr(), false, g.stack.ptr());
+            if (nr_ != g.n_nodes) return -3;
+        }
+        for (int r = 0; r < g.n_nodes; ++r) g.n2r_x[g.rank_x[r]] = r;
         std::vector<int32_t> cn(g.n_nodes);
-        int k = graph_consensus(g, cn.data());
+        int k = graph_consensus(g, g.rank_x.ptr(), g.n2r_x, cn.data());
         int bgn = 0, end = k - 1;
         if (b->win_type[w] == 1 && trim) {
             const uint32_t avg = (ns - 1) / 2;
@@ -105,5 +126,6 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
         polished[w] = 1;
     }
     cons_off[b->n_windows] = out;
+    if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] alignments %d, sink ties %d\n", g_aligns, g_ties);
     return 0;
 }

@@ -30,6 +30,9 @@ for rep in range(a.reps):
     print("run %d: wall %.3fs kernel %.1f ms  %.1f windows/s  GCUPS %.2f  retried %d" % (
         rep, dt, st["kernel_ms"], b.n_windows / (st["kernel_ms"] / 1e3), st["dp_cells"] / st["kernel_ms"] / 1e6, st["n_retried"]), flush=True)
 print(json.dumps(st))
+names = ["sub", "desc", "dp", "traceback", "add", "toposort", "consensus", "other"]
+tot = sum(st["phase_clocks"]) or 1
+print("phases:", ", ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, st["phase_clocks"])))
 if not a.no_oracle:
     t = time.time(); o, cells, cx = oracle_lib.consensus(b, m, x, g, True, 0, with_stats=True); dt = time.time() - t
     print("oracle %.2fs (%d threads) %.1f windows/s; cells %d (device %d)" % (dt, os.cpu_count(), b.n_windows / dt, cells.sum(), st["dp_cells"]))
