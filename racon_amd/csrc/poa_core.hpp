@@ -66,6 +66,10 @@ struct Win {
     Arr<int32_t> n2r_x;            // [ncap] inverse of rank_sub / rank_x (whichever is in use)
     Arr<int32_t> new_id;           // [lmax+2] nodes created by the current layer, in sequence order
     Arr<int32_t> new_anchor;       // [lmax+2] old rank after whose ring block each of them is inserted (-1 = front)
+    // per-sequence-position scratch of the wave-parallel AddAlignment
+    Arr<int32_t> pos_t;            // [lmax+2] aligned node (-1 = none)
+    Arr<int32_t> pos_curr;         // [lmax+2] node that carries the base (existing or new)
+    Arr<int32_t> pos_a;            // [lmax+2] order anchor contributed by / inherited at this position
     Arr<int32_t> pred;             // [ncap] consensus predecessor
     Arr<int64_t> score;            // [ncap] consensus score
     // edges
@@ -202,6 +206,70 @@ RCN_HD int32_t graph_add_alignment(Win& g, int32_t plen, const uint8_t* seq, con
     if (last >= 0) add_edge(g, prev, last, pair_weight(qual, vback + 1));
     for (int32_t v = suf0; v < suf1; ++v) { g.new_id[nn] = v; g.new_anchor[nn] = anchor; ++nn; }
     return nn;
+}
+
+// ---- wave-parallel AddAlignment: per-position phase bodies -------------------
+// A global (NW) alignment consumes every sequence position exactly once, so there
+// is no unaligned prefix/suffix chain and every position is independent except
+// for (a) the node-id / edge-id numbering (prefix sums over "creates a node" /
+// "creates an edge" flags, done by the caller) and (b) the order anchors (prefix
+// max).  Distinct positions touch distinct nodes, rings and adjacency-list tails.
+
+// phase 2: resolve position `pos`.  Returns 0 = existing node (pos_curr set),
+// 1 = new node, unaligned (insertion), 2 = new node that joins the ring of pos_t.
+RCN_HD int32_t addp_classify(Win& g, const uint8_t* seq, int32_t pos) {
+    const int32_t t = g.pos_t[pos];
+    const uint8_t c = seq[pos];
+    if (t == -1) { g.pos_curr[pos] = -1; g.pos_a[pos] = -1; return 1; }
+    if (g.code[t] == c) { g.pos_curr[pos] = t; g.pos_a[pos] = block_end_rank(g, t); return 0; }
+    const int32_t na = g.al_cnt[t];
+    for (int32_t a = 0; a < na; ++a) {
+        const int32_t u = g.al_nodes[t * g.ring + a];
+        if (g.code[u] == c) { g.pos_curr[pos] = u; g.pos_a[pos] = block_end_rank(g, u); return 0; }
+    }
+    g.pos_curr[pos] = -1; g.pos_a[pos] = block_end_rank(g, t);
+    return 2;
+}
+
+// phase 4: materialise the new node `id` for position pos (kind 1 or 2).
+RCN_HD void addp_create(Win& g, const uint8_t* seq, int32_t pos, int32_t kind, int32_t id, uint32_t count) {
+    g.code[id] = seq[pos]; g.al_cnt[id] = 0;
+    g.in_head[id] = g.in_tail[id] = g.out_head[id] = g.out_tail[id] = -1;
+    g.cov[id] = 0;
+    (void)count;
+    if (kind == 2) {
+        const int32_t t = g.pos_t[pos];
+        const int32_t na = g.al_cnt[t];
+        for (int32_t a = 0; a < na; ++a) {
+            const int32_t u = g.al_nodes[t * g.ring + a];
+            g.al_nodes[u * g.ring + g.al_cnt[u]] = id; g.al_cnt[u] = g.al_cnt[u] + 1;
+            g.al_nodes[id * g.ring + a] = u;
+        }
+        g.al_nodes[t * g.ring + na] = id; g.al_cnt[t] = static_cast<uint8_t>(na + 1);
+        g.al_nodes[id * g.ring + na] = t;
+        g.al_cnt[id] = static_cast<uint8_t>(na + 1);
+    }
+    g.pos_curr[pos] = id;
+}
+
+// phase 5: edge pos_curr[pos-1] -> pos_curr[pos]: reinforce it if present (returns 0)
+// or report that it must be created (returns 1).
+RCN_HD int32_t addp_edge_find(Win& g, const uint8_t* qual, int32_t pos) {
+    const int32_t tail = g.pos_curr[pos - 1], head = g.pos_curr[pos];
+    for (int32_t e = g.out_head[tail]; e >= 0; e = g.e_nout[e]) {
+        if (g.e_head[e] == head) { g.e_w[e] += pair_weight(qual, pos); return 0; }
+    }
+    return 1;
+}
+
+// phase 7: create edge `e` for position pos and append it to both adjacency lists.
+RCN_HD void addp_edge_create(Win& g, const uint8_t* qual, int32_t pos, int32_t e) {
+    const int32_t tail = g.pos_curr[pos - 1], head = g.pos_curr[pos];
+    g.e_tail[e] = tail; g.e_head[e] = head; g.e_w[e] = pair_weight(qual, pos); g.e_nin[e] = -1; g.e_nout[e] = -1;
+    if (g.out_tail[tail] < 0) g.out_head[tail] = e; else g.e_nout[g.out_tail[tail]] = e;
+    g.out_tail[tail] = e;
+    if (g.in_tail[head] < 0) g.in_head[head] = e; else g.e_nin[g.in_tail[head]] = e;
+    g.in_tail[head] = e;
 }
 
 // Serial reference of the order merge (the kernel does it wave-parallel):
@@ -427,6 +495,8 @@ RCN_HD uint64_t win_bind(Win& g, uint8_t* base, int32_t ncap, int32_t ecap, int3
     RCN_TAKE(rank_full, 4 * n); RCN_TAKE(rank_tmp, 4 * n); RCN_TAKE(rank_sub, 4 * n); RCN_TAKE(rank_x, 4 * n);
     RCN_TAKE(n2r, 4 * n); RCN_TAKE(n2r_x, 4 * n); RCN_TAKE(pred, 4 * (n + 1));
     RCN_TAKE(new_id, 4 * (static_cast<uint64_t>(lmax) + 2)); RCN_TAKE(new_anchor, 4 * (static_cast<uint64_t>(lmax) + 2));
+    RCN_TAKE(pos_t, 4 * (static_cast<uint64_t>(lmax) + 2)); RCN_TAKE(pos_curr, 4 * (static_cast<uint64_t>(lmax) + 2));
+    RCN_TAKE(pos_a, 4 * (static_cast<uint64_t>(lmax) + 2));
     RCN_TAKE(score, 8 * n);
     RCN_TAKE(e_tail, 4 * e); RCN_TAKE(e_head, 4 * e); RCN_TAKE(e_nin, 4 * e); RCN_TAKE(e_nout, 4 * e);
     RCN_TAKE(e_w, 8 * e);

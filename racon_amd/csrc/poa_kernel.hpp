@@ -262,14 +262,14 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                 const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
                 st_bytes += sbytes * (static_cast<unsigned long long>(V + 1) + ds.pred_rows) * W;
             }
-            // ---- traceback + AddAlignment (serial) ----
+            // ---- traceback (serial, lane 0) ----
             const int n_old = g.n_nodes;
-            int nn = 0;
+            int nn = 0, plen = 0;
             if (lane == 0) {
                 int best_row = ds.best_row;
                 if (ds.tied > 1) {
                     // several sinks share the best score: spoa takes the first one in ITS rank order
-                    // (exact DFS order), so compute that order now (rare: <1% of alignments)
+                    // (exact DFS order), so compute that order now (rare: ~2% of alignments)
                     const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
                     for (int r = 0; r < nx; ++r) {
                         const int row = nr[g.rank_x[r]] + 1;
@@ -277,14 +277,64 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                     }
                     ++st_ties;
                 }
-                const int plen = nw_traceback(g, rank, nr, sub, seq, len, best_row, P.m, P.x, P.g);
-                RCN_PHASE(3);
-                if (!g.overflow) nn = graph_add_alignment(g, plen, seq, qual, len);
-                RCN_PHASE(4);
+                plen = nw_traceback(g, rank, nr, sub, seq, len, best_row, P.m, P.x, P.g);
             }
-            nn = bcast0(nn);
-            g.n_nodes = bcast0(g.n_nodes); g.n_edges = bcast0(g.n_edges); g.overflow = bcast0(g.overflow);
+            plen = bcast0(plen); g.overflow = bcast0(g.overflow);
             wave_sync();
+            RCN_PHASE(3);
+            // ---- AddAlignment, wave-parallel over sequence positions (window.cpp:110-119) ----
+            if (!g.overflow) {
+                const uint32_t count = len >= 2 ? 1u : 0u;
+                for (int k = lane; k < plen; k += 64) { const int pp = g.path_pos[k]; if (pp != -1) g.pos_t[pp] = g.path_node[k]; }
+                wave_sync();
+                // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)
+                int32_t* kindv = g.path_pos.ptr();           // path arrays are free from here on
+                int32_t* idxv = g.path_node.ptr();
+                int anchor = -1;
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                for (int base = 0; base < len; base += 64) {
+                    const int pos = base + lane;
+                    int kind = 0, a = -1;
+                    if (pos < len) { kind = addp_classify(g, seq, pos); a = g.pos_a[pos]; }
+                    const unsigned long long mk = __ballot(kind != 0);
+                    const int idx = nn + __popcll(mk & lt);
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(a, d); if (lane >= d) a = max(a, t); }
+                    a = max(a, anchor);
+                    if (pos < len) { kindv[pos] = kind; idxv[pos] = idx; g.pos_a[pos] = a; }
+                    nn += __popcll(mk);
+                    anchor = __shfl(a, 63);
+                }
+                if (n_old + nn > g.ncap) g.overflow = 1;
+                wave_sync();
+                if (!g.overflow) {
+                    for (int pos = lane; pos < len; pos += 64) {
+                        const int kind = kindv[pos];
+                        if (kind) {
+                            const int idx = idxv[pos];
+                            addp_create(g, seq, pos, kind, n_old + idx, count);
+                            g.new_id[idx] = n_old + idx; g.new_anchor[idx] = g.pos_a[pos];
+                        }
+                    }
+                    g.n_nodes = n_old + nn;
+                    wave_sync();
+                    int ne = 0, ovf = 0;
+                    for (int base = 0; base < len; base += 64) {
+                        const int pos = base + lane;
+                        int f = 0;
+                        if (pos >= 1 && pos < len) f = addp_edge_find(g, qual, pos);
+                        const unsigned long long mk = __ballot(f != 0);
+                        const int e = g.n_edges + ne + __popcll(mk & lt);
+                        if (f) { if (e < g.ecap) addp_edge_create(g, qual, pos, e); else ovf = 1; }
+                        ne += __popcll(mk);
+                    }
+                    g.n_edges += ne;
+                    if (__ballot(ovf != 0)) g.overflow = 1;
+                    for (int pos = lane; pos < len; pos += 64) g.cov[g.pos_curr[pos]] += count;
+                }
+            }
+            wave_sync();
+            RCN_PHASE(4);
             // ---- order merge: insert the nn new nodes behind their anchors (wave-parallel) ----
             if (!g.overflow) {
                 int32_t* delta = g.pred.ptr();                      // [n_old + 1] scratch (pred is consensus-only)

@@ -14,6 +14,8 @@
 using namespace rcn;
 
 static int g_ties = 0, g_aligns = 0;
+static long long g_hist[8] = {0};   // pred distance: 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, >64
+static long long g_rows = 0, g_row0 = 0;
 
 // scalar DP over `rank` (any valid topological order); returns the row of the best sink
 // and how many sinks tie at the best score.
@@ -35,6 +37,8 @@ static void host_dp(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int V, 
                 row[j] = std::max(row[j], std::max(dg, hp[j] + gp));
             }
         };
+        auto dist = [&](int p) { if (p == 0) { ++g_row0; return; } int dd = (r + 1) - p; int b = dd <= 1 ? 0 : dd <= 2 ? 1 : dd <= 4 ? 2 : dd <= 8 ? 3 : dd <= 16 ? 4 : dd <= 32 ? 5 : dd <= 64 ? 6 : 7; ++g_hist[b]; };
+        ++g_rows; dist(d.p0); if (d.p1 >= 0) dist(d.p1);
         acc(d.p0);
         if (d.p1 >= 0) acc(d.p1);
         for (int e = d.erest; e >= 0; e = g.e_nin[e]) {
@@ -48,6 +52,36 @@ static void host_dp(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int V, 
             else if (best == row[len]) ++tied;
         }
     }
+}
+
+// The wave-parallel AddAlignment of the kernel, emulated: every phase is a loop whose
+// iterations are independent (run here in REVERSE order to expose any hidden
+// order dependence); the scans between phases are what the wave does with shuffles.
+static int emul_parallel_add(Win& g, int plen, const uint8_t* seq, const uint8_t* qual, int len) {
+    const uint32_t count = len >= 2 ? 1u : 0u;
+    for (int k = 0; k < plen; ++k) if (g.path_pos[k] != -1) g.pos_t[g.path_pos[k]] = g.path_node[k];
+    std::vector<int> kind(len), idx(len), eflag(len, 0), eidx(len, 0);
+    for (int pos = len - 1; pos >= 0; --pos) kind[pos] = addp_classify(g, seq, pos);
+    int nn = 0, anchor = -1;
+    for (int pos = 0; pos < len; ++pos) {                 // scans: exclusive count of new nodes, inclusive max of anchors
+        idx[pos] = nn; if (kind[pos]) ++nn;
+        anchor = std::max(anchor, (int)g.pos_a[pos]); g.pos_a[pos] = anchor;
+    }
+    const int n_old = g.n_nodes;
+    if (n_old + nn > g.ncap) { g.overflow = 1; return 0; }
+    for (int pos = len - 1; pos >= 0; --pos) if (kind[pos]) {
+        addp_create(g, seq, pos, kind[pos], n_old + idx[pos], count);
+        g.new_id[idx[pos]] = n_old + idx[pos]; g.new_anchor[idx[pos]] = g.pos_a[pos];
+    }
+    g.n_nodes = n_old + nn;
+    for (int pos = len - 1; pos >= 1; --pos) eflag[pos] = addp_edge_find(g, qual, pos);
+    int ne = 0;
+    for (int pos = 1; pos < len; ++pos) { eidx[pos] = ne; ne += eflag[pos]; }
+    if (g.n_edges + ne > g.ecap) { g.overflow = 1; return nn; }
+    for (int pos = len - 1; pos >= 1; --pos) if (eflag[pos]) addp_edge_create(g, qual, pos, g.n_edges + eidx[pos]);
+    g.n_edges += ne;
+    for (int pos = 0; pos < len; ++pos) g.cov[g.pos_curr[pos]] += count;
+    return nn;
 }
 
 extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int trim,
@@ -103,7 +137,9 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
             }
             int plen = nw_traceback(g, rk, *nr, !full, sp(i), sl(i), best_row, m, x, gp);
             const int n_old = g.n_nodes;
-            int nn = graph_add_alignment(g, plen, sp(i), qp(i), sl(i));
+            int nn;
+            if (getenv("RCN_EMUL_SERIAL_ADD")) nn = graph_add_alignment(g, plen, sp(i), qp(i), sl(i));
+            else nn = emul_parallel_add(g, plen, sp(i), qp(i), sl(i));
             if (g.overflow) { fprintf(stderr, "emul overflow %d\n", g.overflow); return -2; }
             order_merge_serial(g, n_old, nn);
         }
@@ -126,6 +162,6 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
         polished[w] = 1;
     }
     cons_off[b->n_windows] = out;
-    if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] alignments %d, sink ties %d\n", g_aligns, g_ties);
+    if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] alignments %d, sink ties %d rows %lld row0 %lld hist", g_aligns, g_ties, g_rows, g_row0); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_hist[i]); fprintf(stderr, "\n"); }
     return 0;
 }
