@@ -28,11 +28,11 @@ namespace rcn {
 constexpr int32_t kNeg = -(1 << 29);
 
 // Row descriptor of the DP matrix (one per graph node in rank order).
+constexpr int kInlinePreds = 6;
 struct RowDesc {
-    int32_t p0;      // first predecessor ROW (0 = virtual start row)
-    int32_t p1;      // second predecessor row or -1
-    int32_t erest;   // edge id from which further in-edges must be walked, or -1
-    int32_t meta;    // bits 0-7 symbol, bit 8 sink, bits 9.. node-id is NOT kept here
+    int32_t p[kInlinePreds];   // predecessor ROWS in in-edge order (p[0] = 0, the virtual start row, if none)
+    int32_t erest;             // edge id from which in-edges beyond the inline ones must be walked, or -1
+    int32_t meta;              // bits 0-7 symbol, bit 8 sink, bits 9-12 number of inline predecessors (>= 1)
 };
 
 // Array inside the slot's scratch block: one shared base pointer + a 32-bit
@@ -355,21 +355,21 @@ RCN_HD void graph_subgraph_mask(Win& g, int32_t begin, int32_t end, int32_t* sta
 
 // Row descriptor of rank r (node v) for the (sub)graph being aligned.
 RCN_HD RowDesc make_row_desc(const Win& g, const Arr<int32_t>& nr, int32_t v, bool use_mask) {
-    RowDesc d; d.p0 = 0; d.p1 = -1; d.erest = -1;
+    RowDesc d; d.erest = -1;
+    for (int32_t q = 0; q < kInlinePreds; ++q) d.p[q] = -1;
     int32_t k = 0;
     for (int32_t e = g.in_head[v]; e >= 0; e = g.e_nin[e]) {
         const int32_t t = g.e_tail[e];
         if (use_mask && !g.inc[t]) continue;
-        if (k == 0) d.p0 = nr[t] + 1;
-        else if (k == 1) d.p1 = nr[t] + 1;
-        else { d.erest = e; break; }
-        ++k;
+        if (k == kInlinePreds) { d.erest = e; break; }
+        d.p[k++] = nr[t] + 1;
     }
+    if (k == 0) { d.p[0] = 0; k = 1; }
     bool sink = true;
     for (int32_t e = g.out_head[v]; e >= 0; e = g.e_nout[e]) {
         if (!use_mask || g.inc[g.e_head[e]]) { sink = false; break; }
     }
-    d.meta = static_cast<int32_t>(g.code[v]) | (sink ? 256 : 0);
+    d.meta = static_cast<int32_t>(g.code[v]) | (sink ? 256 : 0) | (k << 9);
     return d;
 }
 
@@ -385,33 +385,18 @@ RCN_HD int32_t nw_traceback(Win& g, const int32_t* rank, const Arr<int32_t>& nr,
         int32_t pi = 0, pj = 0; bool found = false;
         if (i != 0) {
             const RowDesc d = g.desc[i - 1];
-            if (j != 0) {
-                const int32_t mc = ((d.meta & 255) == seq[j - 1]) ? m : x;
-                if (hij == g.H[d.p0 * W + j - 1] + mc) { pi = d.p0; pj = j - 1; found = true; }
-                else if (d.p1 >= 0) {
-                    if (hij == g.H[d.p1 * W + j - 1] + mc) { pi = d.p1; pj = j - 1; found = true; }
-                    else {
-                        for (int32_t e = d.erest; e >= 0 && !found; e = g.e_nin[e]) {
-                            const int32_t t = g.e_tail[e];
-                            if (use_mask && !g.inc[t]) continue;
-                            const int32_t p = nr[t] + 1;
-                            if (hij == g.H[p * W + j - 1] + mc) { pi = p; pj = j - 1; found = true; }
-                        }
-                    }
+            const int32_t np = (d.meta >> 9) & 15;
+            for (int32_t pass = (j != 0 ? 0 : 1); pass < 2 && !found; ++pass) {     // 0: diagonal, 1: vertical
+                const int32_t col = pass == 0 ? j - 1 : j;
+                const int32_t add = pass == 0 ? (((d.meta & 255) == seq[j - 1]) ? m : x) : gp;
+                for (int32_t q = 0; q < np && !found; ++q) {
+                    if (hij == g.H[d.p[q] * W + col] + add) { pi = d.p[q]; pj = col; found = true; }
                 }
-            }
-            if (!found) {
-                if (hij == g.H[d.p0 * W + j] + gp) { pi = d.p0; pj = j; found = true; }
-                else if (d.p1 >= 0) {
-                    if (hij == g.H[d.p1 * W + j] + gp) { pi = d.p1; pj = j; found = true; }
-                    else {
-                        for (int32_t e = d.erest; e >= 0 && !found; e = g.e_nin[e]) {
-                            const int32_t t = g.e_tail[e];
-                            if (use_mask && !g.inc[t]) continue;
-                            const int32_t p = nr[t] + 1;
-                            if (hij == g.H[p * W + j] + gp) { pi = p; pj = j; found = true; }
-                        }
-                    }
+                for (int32_t e = d.erest; e >= 0 && !found; e = g.e_nin[e]) {
+                    const int32_t t = g.e_tail[e];
+                    if (use_mask && !g.inc[t]) continue;
+                    const int32_t p = nr[t] + 1;
+                    if (hij == g.H[p * W + col] + add) { pi = p; pj = col; found = true; }
                 }
             }
         }
@@ -501,7 +486,7 @@ RCN_HD uint64_t win_bind(Win& g, uint8_t* base, int32_t ncap, int32_t ecap, int3
     RCN_TAKE(e_tail, 4 * e); RCN_TAKE(e_head, 4 * e); RCN_TAKE(e_nin, 4 * e); RCN_TAKE(e_nout, 4 * e);
     RCN_TAKE(e_w, 8 * e);
     RCN_TAKE(path_node, 4 * (n + lmax + 2)); RCN_TAKE(path_pos, 4 * (n + lmax + 2));
-    RCN_TAKE(desc, 16 * n);
+    RCN_TAKE(desc, sizeof(RowDesc) * n);
     RCN_TAKE(stack, 4 * (e + n * (ring + 1) + 64));
     const uint64_t hints = (n + 1) * static_cast<uint64_t>(hstride);
     g.hcap = static_cast<int64_t>(hints);

@@ -47,23 +47,44 @@ enum : uint8_t { kFlagPolished = 1, kFlagChimeric = 2, kFlagOverflow = 4, kFlagE
 
 __device__ __forceinline__ int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ int wave_excl_scan_max(int z, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(z, d);
-        if (lane >= d) z = max(z, t);
-    }
-    int ex = __shfl_up(z, 1);
-    return lane == 0 ? kNeg : ex;
+// DPP cross-lane primitives (gfx9-family encodings, valid on gfx950):
+//   row_shr:n = 0x110+n (shift inside a row of 16 lanes), row_bcast15 = 0x142,
+//   row_bcast31 = 0x143, wave_shr:1 = 0x138 (whole-wave shift by one lane).
+// Lanes without a valid source keep `old` (bound_ctrl = false).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+// value of lane-1 (lane 0 gets `fill`)
+__device__ __forceinline__ int wave_shr1(int v, int fill) { return dpp_or<0x138, 0xf>(fill, v); }
+
+__device__ __forceinline__ int wave_incl_scan_max(int v) {
+    v = max(v, dpp_or<0x111, 0xf>(kNeg, v));
+    v = max(v, dpp_or<0x112, 0xf>(kNeg, v));
+    v = max(v, dpp_or<0x114, 0xf>(kNeg, v));
+    v = max(v, dpp_or<0x118, 0xf>(kNeg, v));
+    v = max(v, dpp_or<0x142, 0xa>(kNeg, v));
+    v = max(v, dpp_or<0x143, 0xc>(kNeg, v));
+    return v;
+}
+__device__ __forceinline__ int wave_excl_scan_max(int z, int /*lane*/) {
+    return wave_shr1(wave_incl_scan_max(z), kNeg);
 }
 
 // One column tile [t0, t0 + 64*CT) of the DP matrix, all rows.
-constexpr int kMaxCT = 12;   // widest column tile: 64 * 12 = 768 columns per pass
+constexpr int kMaxCT = 10;   // widest column tile: 64 * 12 = 768 columns per pass
+constexpr int kLdsBytes = 20480;               // per wave (one wave per workgroup): 8 waves / CU
+constexpr int kRingInts = kLdsBytes / 4;
 struct DpState { int best, best_row, have_best, tied; unsigned int pred_rows; };
 
-template <int CT>
+template <int CT, bool FIRST>      // FIRST: the tile starts at column 0 (no global loads in the row loop)
 __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr, int V, bool sub, const uint8_t* __restrict__ seq, int len,
-                                        int t0, bool last_tile, int m, int x, int gp, DpState st) {
+                                        int t0, bool last_tile, int m, int x, int gp, DpState st, int2* __restrict__ ring) {
+    // LDS ring of the last K score rows (predecessors are almost always < 16 rows back in the
+    // incrementally maintained order).  Layout: slot s, column pair q of lane l at
+    // ring[(s * (CT/2) + q) * 64 + l]: every ds_read/write_b64 is stride-8B, conflict free.
+    constexpr int K = kRingInts / (64 * CT) - 1;                // + one spare slot (index K) for far rows
+    int slot = 0;                                               // ring slot of row i (row 0 is analytic)
     int best = st.best, best_row = st.best_row, have_best = st.have_best, tied = st.tied;
     unsigned int pred_rows = 0;
     const int lane = threadIdx.x;
@@ -81,14 +102,24 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
     int last_row = 0;
     const int own_lane = (len - t0) / CT;                       // lane owning column `len` (last tile only)
 
-    RowDesc dl; dl.p0 = 0; dl.p1 = -1; dl.erest = -1; dl.meta = 0;
-    for (int r = 0; r < V; ++r) {
-        if ((r & 63) == 0) { if (r + lane < V) dl = g.desc[r + lane]; }
-        const int k = r & 63;
-        const int p0 = __builtin_amdgcn_readlane(dl.p0, k);
-        const int p1 = __builtin_amdgcn_readlane(dl.p1, k);
+    // Rows are processed in chunks of 64: one coalesced load brings 64 row descriptors (one per
+    // lane), then the inner loop reads them with v_readlane.  Keeping the load (and its
+    // s_waitcnt) out of the inner loop matters: the only VMEM traffic of the inner loop is the
+    // H-row stores, and nothing there ever waits for them.
+#pragma unroll 1
+    for (int rbase = 0; rbase < V; rbase += 64) {
+    RowDesc dl; dl.erest = -1; dl.meta = 1 << 9;
+#pragma unroll
+    for (int q = 0; q < kInlinePreds; ++q) dl.p[q] = 0;
+    if (rbase + lane < V) dl = g.desc[rbase + lane];
+    const int rend = min(V, rbase + 64);
+#pragma unroll 1
+    for (int r = rbase; r < rend; ++r) {
+        const int k = r - rbase;
+        const int p0 = __builtin_amdgcn_readlane(dl.p[0], k);
         const int er = __builtin_amdgcn_readlane(dl.erest, k);
         const int meta = __builtin_amdgcn_readlane(dl.meta, k);
+        const int np = (meta >> 9) & 15;
         const uint8_t sym = meta & 255;
         const int i = r + 1;
 
@@ -101,13 +132,28 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
             if (p == last_row) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) hp[c] = last[c];
-            } else {
-                const int2* src = reinterpret_cast<const int2*>(H + p * hs + j0);
+            } else if (p == 0) {
 #pragma unroll
-                for (int c = 0; c < CT; c += 2) { int2 v = src[c >> 1]; hp[c] = v.x; hp[c + 1] = v.y; }
+                for (int c = 0; c < CT; ++c) hp[c] = (j0 + c) * gp;
+            } else {
+                int sp;
+                if (i - p < K) {
+                    sp = slot - (i - p); if (sp < 0) sp += K;
+                } else {
+                    // rare (<0.1%): predecessor older than the ring -> stage its row through the spare
+                    // slot, so that the common path never has a global load pending at the join
+                    const int2* gsrc = reinterpret_cast<const int2*>(H + p * hs + j0);
+                    int2* sdst = ring + K * (CT / 2) * 64 + lane;
+#pragma unroll
+                    for (int c = 0; c < CT; c += 2) sdst[(c >> 1) * 64] = gsrc[c >> 1];
+                    sp = K;
+                }
+                const int2* src = ring + sp * (CT / 2) * 64 + lane;
+#pragma unroll
+                for (int c = 0; c < CT; c += 2) { const int2 v = src[(c >> 1) * 64]; hp[c] = v.x; hp[c + 1] = v.y; }
             }
-            int left = __shfl_up(hp[CT - 1], 1);
-            if (lane == 0) left = (t0 > 0) ? H[p * hs + t0 - 1] : kNeg;
+            int left = wave_shr1(hp[CT - 1], kNeg);
+            if (!FIRST) { if (lane == 0) left = H[p * hs + t0 - 1]; }
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const int dg = (c == 0 ? left : hp[c - 1]) + (sq[c] == sym ? m : x);
@@ -117,7 +163,15 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
             ++pred_rows;
         };
         accumulate(p0);
-        if (p1 >= 0) accumulate(p1);
+        if (np > 1) {
+            accumulate(__builtin_amdgcn_readlane(dl.p[1], k));
+            if (np > 2) {
+                accumulate(__builtin_amdgcn_readlane(dl.p[2], k));
+                if (np > 3) accumulate(__builtin_amdgcn_readlane(dl.p[3], k));
+                if (np > 4) accumulate(__builtin_amdgcn_readlane(dl.p[4], k));
+                if (np > 5) accumulate(__builtin_amdgcn_readlane(dl.p[5], k));
+            }
+        }
         for (int e = er; e >= 0; e = g.e_nin[e]) {
             const int t = g.e_tail[e];
             if (sub && !g.inc[t]) continue;
@@ -128,13 +182,15 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
         for (int c = 1; c < CT; ++c) acc[c] = max(acc[c], acc[c - 1] + gp);
         int z = acc[CT - 1] - (j0 + CT - 1) * gp;
         int zex = wave_excl_scan_max(z, lane);
-        if (t0 > 0) zex = max(zex, H[i * hs + t0 - 1] - (t0 - 1) * gp);
+        if (!FIRST) zex = max(zex, H[i * hs + t0 - 1] - (t0 - 1) * gp);
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = max(acc[c], zex + (j0 + c) * gp);
 
         int2* dst = reinterpret_cast<int2*>(H + i * hs + j0);
+        int2* rdst = ring + slot * (CT / 2) * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < CT; c += 2) dst[c >> 1] = make_int2(acc[c], acc[c + 1]);
+        for (int c = 0; c < CT; c += 2) { const int2 v = make_int2(acc[c], acc[c + 1]); dst[c >> 1] = v; rdst[(c >> 1) * 64] = v; }
+        slot = (slot + 1 == K) ? 0 : slot + 1;
 #pragma unroll
         for (int c = 0; c < CT; ++c) last[c] = acc[c];
         last_row = i;
@@ -148,6 +204,7 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
             else if (best == val) ++tied;
         }
     }
+    }
     DpState o; o.best = best; o.best_row = best_row; o.have_best = have_best; o.tied = tied;
     o.pred_rows = (t0 == 0) ? pred_rows : st.pred_rows;
     return o;
@@ -155,11 +212,131 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
 
 __device__ __forceinline__ void wave_sync() { __threadfence_block(); __syncthreads(); }
 
-__global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
+// Traceback of spoa's linear NW (same decisions as rcn::nw_traceback) with the
+// score matrix read through LDS tiles: the whole wave stages a 64-row x 64-col
+// tile of H, the 64 row descriptors and the 64 sequence symbols around the
+// current cell; lane 0 then walks inside the tile with LDS reads only (the fast
+// loop contains no global load, so nothing in it waits on memory) and leaves it
+// when a needed cell falls outside.  If a freshly anchored tile still cannot
+// serve the step (predecessor > 60 rows back, or > 2 in-edges), that single
+// step is done against HBM.  Emits (row | -1, pos | -1) in reverse order; rows
+// are mapped to node ids afterwards, in parallel.
+constexpr int kTileStride = 68;   // ints per tile row: 64 + 4 pad (conflict-free ds_write_b128)
+
+__device__ __forceinline__ void traceback_slow_step(Win& g, const Arr<int32_t>& nr, bool sub, const uint8_t* seq,
+                                                    int m, int x, int gp, int& i, int& j, int& n) {
+    const int64_t hs = g.hstride;
+    const int32_t* H = g.H.ptr();
+    const int hij = H[i * hs + j];
+    int pi = 0, pj = 0; bool found = false;
+    if (i != 0) {
+        const RowDesc d = g.desc[i - 1];
+        const int np = (d.meta >> 9) & 15;
+        for (int pass = (j != 0 ? 0 : 1); pass < 2 && !found; ++pass) {
+            const int col = pass == 0 ? j - 1 : j;
+            const int add = pass == 0 ? (((d.meta & 255) == seq[j - 1]) ? m : x) : gp;
+            for (int q = 0; q < np && !found; ++q) {
+                if (hij == H[d.p[q] * hs + col] + add) { pi = d.p[q]; pj = col; found = true; }
+            }
+            for (int e = d.erest; e >= 0 && !found; e = g.e_nin[e]) {
+                const int t = g.e_tail[e];
+                if (sub && !g.inc[t]) continue;
+                const int p = nr[t] + 1;
+                if (hij == H[p * hs + col] + add) { pi = p; pj = col; found = true; }
+            }
+        }
+    }
+    if (!found) {
+        if (j == 0) { g.overflow = 4; i = 0; j = 0; return; }
+        pi = i; pj = j - 1;
+    }
+    g.path_node[n] = (i == pi) ? -1 : i;
+    g.path_pos[n] = (j == pj) ? -1 : j - 1;
+    ++n; i = pi; j = pj;
+}
+
+__device__ __forceinline__ int traceback_tiled(Win& g, const Arr<int32_t>& nr, bool sub, const uint8_t* __restrict__ seq,
+                                               int len, int best_row, int m, int x, int gp, int* __restrict__ tile, unsigned long long* dbg) {
     const int lane = threadIdx.x;
+    const int64_t hs = g.hstride;
+    const int32_t* __restrict__ H = g.H.ptr();
+    RowDesc* tdesc = reinterpret_cast<RowDesc*>(tile + 64 * kTileStride);
+    uint8_t* tseq = reinterpret_cast<uint8_t*>(tile + 64 * kTileStride + 64 * (sizeof(RowDesc) / 4));     // seq[c0 - 1 + k], k = 0..63
+    int32_t* __restrict__ pnode = g.path_node.ptr();
+    int32_t* __restrict__ ppos = g.path_pos.ptr();
+    int i = best_row, j = len, n = 0;
+    while (!(i == 0 && j == 0)) {
+        // ---- stage the tile: rows [i-63, i], cols [c0, c0+63] ----
+        const int ti0 = i;
+        int c0 = (j - 60) & ~3; if (c0 < 0) c0 = 0;
+        const int rmin = ti0 - 63 > 0 ? ti0 - 63 : 0;
+        {
+            const int r = ti0 - lane;
+            if (r >= 0) {
+                const int4* src = reinterpret_cast<const int4*>(H + r * hs + c0);
+                int4* dst = reinterpret_cast<int4*>(tile + lane * kTileStride);
+#pragma unroll 1
+                for (int q = 0; q < 16; q += 4) { const int4 a = src[q], b = src[q + 1], c = src[q + 2], d = src[q + 3]; dst[q] = a; dst[q + 1] = b; dst[q + 2] = c; dst[q + 3] = d; }
+                if (r >= 1) tdesc[lane] = g.desc[r - 1];
+            }
+            const int sc = c0 - 1 + lane;
+            tseq[lane] = (sc >= 0 && sc < len) ? seq[sc] : 0;
+        }
+        __syncthreads();
+        int steps = 0;
+        if (lane == 0) {
+            int hij = tile[(ti0 - i) * kTileStride + (j - c0)];
+            for (;;) {
+                if (i == 0 && j == 0) break;
+                int pi, pj, hnext;
+                if (i == 0) {                       // only horizontal moves are left on the virtual row
+                    pi = 0; pj = j - 1; hnext = hij - gp;
+                    if (j - 1 < c0) break;
+                } else {
+                    const RowDesc d = tdesc[ti0 - i];
+                    const int np = (d.meta >> 9) & 15;
+                    // everything this step may read must be inside the tile
+                    int pmin = d.p[0];
+#pragma unroll
+                    for (int q = 1; q < kInlinePreds; ++q) if (q < np) pmin = min(pmin, d.p[q]);
+                    if (pmin < rmin || d.erest >= 0 || (j > 0 && j - 1 < c0)) break;
+                    const int mc = ((d.meta & 255) == tseq[j - c0]) ? m : x;      // seq[j-1]
+                    const int* col = tile + ti0 * kTileStride + (j - c0);         // col[-p * stride] = H[p][j]
+                    bool found = false;
+                    pi = i; pj = j - 1; hnext = hij - gp;                         // horizontal unless a predecessor matches
+                    if (j > 0) {
+#pragma unroll
+                        for (int q = 0; q < kInlinePreds; ++q) {
+                            if (q < np && !found) { const int h = col[-d.p[q] * kTileStride - 1]; if (hij == h + mc) { pi = d.p[q]; pj = j - 1; hnext = h; found = true; } }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < kInlinePreds; ++q) {
+                        if (q < np && !found) { const int h = col[-d.p[q] * kTileStride]; if (hij == h + gp) { pi = d.p[q]; pj = j; hnext = h; found = true; } }
+                    }
+                }
+                pnode[n] = (i == pi) ? -1 : i;          // ROW index (mapped to the node id later)
+                ppos[n] = (j == pj) ? -1 : j - 1;
+                ++n; ++steps;
+                i = pi; j = pj; hij = hnext;
+            }
+            dbg[0] += 1; dbg[1] += steps;
+            if (steps == 0 && !(i == 0 && j == 0)) { traceback_slow_step(g, nr, sub, seq, m, x, gp, i, j, n); dbg[2] += 1; }
+        }
+        i = bcast0(i); j = bcast0(j); n = bcast0(n);
+        __syncthreads();
+    }
+    g.overflow = bcast0(g.overflow);
+    return n;
+}
+
+__global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
+    const int lane = threadIdx.x;
+    extern __shared__ int4 lds[];                    // kLdsBytes per wave: DP row ring / traceback tile
     Win g;
     win_bind(g, P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes, P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
     unsigned long long st_cells = 0, st_pred = 0, st_bytes = 0, st_ties = 0;
+    unsigned long long dbg[7] = {0, 0, 0, 0, 0, 0, 0};
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub, desc, dp, traceback, add, toposort, consensus, other
     long long tck = clock64();
 #define RCN_PHASE(k) do { long long now__ = clock64(); ph[k] += now__ - tck; tck = now__; } while (0)
@@ -245,9 +422,9 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                 if (ct > kMaxCT) ct = kMaxCT;
                 const bool lastt = t0 + 64 * ct >= W;
                 switch (ct) {
-#define RCN_CASE(C) case C: ds = dp_tile<C>(g, nr, V, sub, seq, len, t0, lastt, P.m, P.x, P.g, ds); break;
+#define RCN_CASE(C) case C: ds = (t0 == 0) ? dp_tile<C, true>(g, nr, V, sub, seq, len, 0, lastt, P.m, P.x, P.g, ds, reinterpret_cast<int2*>(lds)) \
+                                           : dp_tile<C, false>(g, nr, V, sub, seq, len, t0, lastt, P.m, P.x, P.g, ds, reinterpret_cast<int2*>(lds)); break;
                     RCN_CASE(2) RCN_CASE(4) RCN_CASE(6) RCN_CASE(8) RCN_CASE(10)
-                    RCN_CASE(12)
 #undef RCN_CASE
                 }
                 t0 += 64 * ct;
@@ -265,11 +442,11 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
             // ---- traceback (serial, lane 0) ----
             const int n_old = g.n_nodes;
             int nn = 0, plen = 0;
-            if (lane == 0) {
-                int best_row = ds.best_row;
-                if (ds.tied > 1) {
-                    // several sinks share the best score: spoa takes the first one in ITS rank order
-                    // (exact DFS order), so compute that order now (rare: ~2% of alignments)
+            int best_row = ds.best_row;
+            if (ds.tied > 1) {
+                // several sinks share the best score: spoa takes the first one in ITS rank order
+                // (exact DFS order), so compute that order now (rare: ~2% of alignments)
+                if (lane == 0) {
                     const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
                     for (int r = 0; r < nx; ++r) {
                         const int row = nr[g.rank_x[r]] + 1;
@@ -277,15 +454,19 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
                     }
                     ++st_ties;
                 }
-                plen = nw_traceback(g, rank, nr, sub, seq, len, best_row, P.m, P.x, P.g);
+                best_row = bcast0(best_row);
             }
+            plen = traceback_tiled(g, nr, sub, seq, len, best_row, P.m, P.x, P.g, reinterpret_cast<int*>(lds), dbg);
             plen = bcast0(plen); g.overflow = bcast0(g.overflow);
             wave_sync();
             RCN_PHASE(3);
             // ---- AddAlignment, wave-parallel over sequence positions (window.cpp:110-119) ----
             if (!g.overflow) {
                 const uint32_t count = len >= 2 ? 1u : 0u;
-                for (int k = lane; k < plen; k += 64) { const int pp = g.path_pos[k]; if (pp != -1) g.pos_t[pp] = g.path_node[k]; }
+                for (int k = lane; k < plen; k += 64) {
+                    const int pp = g.path_pos[k];
+                    if (pp != -1) { const int row = g.path_node[k]; g.pos_t[pp] = row == -1 ? -1 : rank[row - 1]; }
+                }
                 wave_sync();
                 // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)
                 int32_t* kindv = g.path_pos.ptr();           // path arrays are free from here on
@@ -403,7 +584,8 @@ __global__ __launch_bounds__(64) void poa_window_kernel(KParams P) {
     }
     if (lane == 0) { atomicAdd(&P.stats[0], st_cells); atomicAdd(&P.stats[1], st_pred); atomicAdd(&P.stats[2], st_bytes);
                      for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[3 + k], ph[k]);
-                     atomicAdd(&P.stats[11], st_ties); }
+                     atomicAdd(&P.stats[11], st_ties);
+                     for (int k = 0; k < 7; ++k) atomicAdd(&P.stats[12 + k], dbg[k]); }
 }
 
 }  // namespace rcn

@@ -38,9 +38,9 @@ static void host_dp(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int V, 
             }
         };
         auto dist = [&](int p) { if (p == 0) { ++g_row0; return; } int dd = (r + 1) - p; int b = dd <= 1 ? 0 : dd <= 2 ? 1 : dd <= 4 ? 2 : dd <= 8 ? 3 : dd <= 16 ? 4 : dd <= 32 ? 5 : dd <= 64 ? 6 : 7; ++g_hist[b]; };
-        ++g_rows; dist(d.p0); if (d.p1 >= 0) dist(d.p1);
-        acc(d.p0);
-        if (d.p1 >= 0) acc(d.p1);
+        const int np = (d.meta >> 9) & 15;
+        ++g_rows;
+        for (int q = 0; q < np; ++q) { dist(d.p[q]); acc(d.p[q]); }
         for (int e = d.erest; e >= 0; e = g.e_nin[e]) {
             int t = g.e_tail[e];
             if (sub && !g.inc[t]) continue;
