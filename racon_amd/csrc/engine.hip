@@ -124,7 +124,7 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + 16);
 
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(slots), dim3(64), rcn::kLdsBytes, e->stream, P);
+    hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, e->stream, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
@@ -346,7 +346,7 @@ int rcn_engine_run(rcn_engine* e) {
     e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
     for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
     e->stats.n_sink_ties = st[11];
-    if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] traceback: tiles %llu steps %llu slow %llu | first-step breaks: p0 %llu p1 %llu erest %llu col %llu\n", st[12], st[13], st[14], st[15], st[16], st[17], st[18]);
+    if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] traceback: stage clocks %llu walk clocks %llu tiles %llu steps %llu\n", st[12], st[13], st[14], st[15]);
 
     for (uint32_t w = 0; w < nw; ++w) e->cons_off[w + 1] = e->cons_off[w] + out_len[w];
     e->cons.resize(e->cons_off[nw] + 1);

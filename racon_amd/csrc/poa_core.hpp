@@ -22,6 +22,15 @@
 #else
 #define RCN_HD inline
 #endif
+// Device pointers into the HBM scratch are typed as address space 1 ("global"): the backend then
+// emits global_load/global_store.  A generic pointer that lost its provenance (e.g. after a trip
+// through LDS) would be accessed with FLAT instructions, which are slower and tick lgkmcnt as
+// well as vmcnt (every LDS wait would then also drain the outstanding HBM stores).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RCN_G __attribute__((address_space(1)))
+#else
+#define RCN_G
+#endif
 
 namespace rcn {
 
@@ -39,9 +48,9 @@ struct RowDesc {
 // byte offset (keeps the per-wave scalar-register footprint small on the GPU).
 template <class T>
 struct Arr {
-    uint8_t* base; uint32_t off;
-    RCN_HD T& operator[](int64_t i) const { return reinterpret_cast<T*>(base + off)[i]; }
-    RCN_HD T* ptr() const { return reinterpret_cast<T*>(base + off); }
+    RCN_G uint8_t* base; uint32_t off;
+    RCN_HD RCN_G T& operator[](int64_t i) const { return reinterpret_cast<RCN_G T*>(base + off)[i]; }
+    RCN_HD RCN_G T* ptr() const { return reinterpret_cast<RCN_G T*>(base + off); }
 };
 
 struct Win {
@@ -108,16 +117,16 @@ RCN_HD void add_edge(Win& g, int32_t tail, int32_t head, int64_t w) {
     g.in_tail[head] = e;
 }
 
-RCN_HD uint32_t base_weight(const uint8_t* qual, int32_t i) {
+RCN_HD uint32_t base_weight(RCN_G const uint8_t* qual, int32_t i) {
     // spoa: weights.emplace_back(quality[i] - 33) on `char`; no quality -> 1
     return qual ? static_cast<uint32_t>(static_cast<int32_t>(static_cast<signed char>(qual[i])) - 33) : 1u;
 }
-RCN_HD int64_t pair_weight(const uint8_t* qual, int32_t i) {   // weights[i-1] + weights[i] (uint32 arithmetic)
+RCN_HD int64_t pair_weight(RCN_G const uint8_t* qual, int32_t i) {   // weights[i-1] + weights[i] (uint32 arithmetic)
     return static_cast<int64_t>(static_cast<uint32_t>(base_weight(qual, i - 1) + base_weight(qual, i)));
 }
 
 // chain of new nodes for seq[b,e); returns first node or -1.  `count` = bump coverage.
-RCN_HD int32_t add_sequence(Win& g, const uint8_t* seq, const uint8_t* qual, int32_t b, int32_t e, uint32_t count) {
+RCN_HD int32_t add_sequence(Win& g, RCN_G const uint8_t* seq, RCN_G const uint8_t* qual, int32_t b, int32_t e, uint32_t count) {
     if (b == e) return -1;
     int32_t first = -1, prev = -1;
     for (int32_t i = b; i < e; ++i) {
@@ -145,7 +154,7 @@ RCN_HD int32_t block_end_rank(const Win& g, int32_t v) {
 // rank_full) after whose ring block the node has to be inserted to keep
 // rank_full a valid, ring-contiguous topological order (see order_merge).
 // Returns the number of nodes created.
-RCN_HD int32_t graph_add_alignment(Win& g, int32_t plen, const uint8_t* seq, const uint8_t* qual, int32_t len) {
+RCN_HD int32_t graph_add_alignment(Win& g, int32_t plen, RCN_G const uint8_t* seq, RCN_G const uint8_t* qual, int32_t len) {
     if (len == 0) return 0;
     const uint32_t count = len >= 2 ? 1u : 0u;     // a 1-base sequence creates no edge, hence no label
     // first / last valid sequence positions
@@ -217,7 +226,7 @@ RCN_HD int32_t graph_add_alignment(Win& g, int32_t plen, const uint8_t* seq, con
 
 // phase 2: resolve position `pos`.  Returns 0 = existing node (pos_curr set),
 // 1 = new node, unaligned (insertion), 2 = new node that joins the ring of pos_t.
-RCN_HD int32_t addp_classify(Win& g, const uint8_t* seq, int32_t pos) {
+RCN_HD int32_t addp_classify(Win& g, RCN_G const uint8_t* seq, int32_t pos) {
     const int32_t t = g.pos_t[pos];
     const uint8_t c = seq[pos];
     if (t == -1) { g.pos_curr[pos] = -1; g.pos_a[pos] = -1; return 1; }
@@ -232,7 +241,7 @@ RCN_HD int32_t addp_classify(Win& g, const uint8_t* seq, int32_t pos) {
 }
 
 // phase 4: materialise the new node `id` for position pos (kind 1 or 2).
-RCN_HD void addp_create(Win& g, const uint8_t* seq, int32_t pos, int32_t kind, int32_t id, uint32_t count) {
+RCN_HD void addp_create(Win& g, RCN_G const uint8_t* seq, int32_t pos, int32_t kind, int32_t id, uint32_t count) {
     g.code[id] = seq[pos]; g.al_cnt[id] = 0;
     g.in_head[id] = g.in_tail[id] = g.out_head[id] = g.out_tail[id] = -1;
     g.cov[id] = 0;
@@ -254,7 +263,7 @@ RCN_HD void addp_create(Win& g, const uint8_t* seq, int32_t pos, int32_t kind, i
 
 // phase 5: edge pos_curr[pos-1] -> pos_curr[pos]: reinforce it if present (returns 0)
 // or report that it must be created (returns 1).
-RCN_HD int32_t addp_edge_find(Win& g, const uint8_t* qual, int32_t pos) {
+RCN_HD int32_t addp_edge_find(Win& g, RCN_G const uint8_t* qual, int32_t pos) {
     const int32_t tail = g.pos_curr[pos - 1], head = g.pos_curr[pos];
     for (int32_t e = g.out_head[tail]; e >= 0; e = g.e_nout[e]) {
         if (g.e_head[e] == head) { g.e_w[e] += pair_weight(qual, pos); return 0; }
@@ -263,7 +272,7 @@ RCN_HD int32_t addp_edge_find(Win& g, const uint8_t* qual, int32_t pos) {
 }
 
 // phase 7: create edge `e` for position pos and append it to both adjacency lists.
-RCN_HD void addp_edge_create(Win& g, const uint8_t* qual, int32_t pos, int32_t e) {
+RCN_HD void addp_edge_create(Win& g, RCN_G const uint8_t* qual, int32_t pos, int32_t e) {
     const int32_t tail = g.pos_curr[pos - 1], head = g.pos_curr[pos];
     g.e_tail[e] = tail; g.e_head[e] = head; g.e_w[e] = pair_weight(qual, pos); g.e_nin[e] = -1; g.e_nout[e] = -1;
     if (g.out_tail[tail] < 0) g.out_head[tail] = e; else g.e_nout[g.out_tail[tail]] = e;
@@ -288,7 +297,7 @@ RCN_HD void order_merge_serial(Win& g, int32_t n_old, int32_t nn) {
 // Exact spoa DFS topological sort.  With `use_mask`, restricted to nodes with
 // inc[v] != 0 (== TopologicalSort of the materialised Subgraph).  `stack` needs
 // n_edges + n_nodes*(ring+1) + 1 ints.  Returns the number of ranked nodes.
-RCN_HD int32_t graph_toposort(Win& g, int32_t* rank, bool use_mask, int32_t* stack) {
+RCN_HD int32_t graph_toposort(Win& g, RCN_G int32_t* rank, bool use_mask, RCN_G int32_t* stack) {
     const int32_t n = g.n_nodes;
     for (int32_t i = 0; i < n; ++i) g.mark[i] = 0;
     int32_t nr = 0;
@@ -338,7 +347,7 @@ RCN_HD int32_t graph_toposort(Win& g, int32_t* rank, bool use_mask, int32_t* sta
 
 // spoa::Graph::ExtractSubgraph(end_node, begin_node): backward reachability from
 // node `end` over in-edges and aligned links, keeping ids >= begin.
-RCN_HD void graph_subgraph_mask(Win& g, int32_t begin, int32_t end, int32_t* stack) {
+RCN_HD void graph_subgraph_mask(Win& g, int32_t begin, int32_t end, RCN_G int32_t* stack) {
     for (int32_t i = 0; i < g.n_nodes; ++i) g.inc[i] = 0;
     int32_t sp = 0;
     stack[sp++] = end;
@@ -376,7 +385,7 @@ RCN_HD RowDesc make_row_desc(const Win& g, const Arr<int32_t>& nr, int32_t v, bo
 // Traceback of spoa's linear NW (priority: diagonal, vertical, horizontal;
 // predecessors in in-edge order).  H rows are indexed rank+1, row 0 virtual.
 // Writes the REVERSED path into path_node/path_pos; returns its length.
-RCN_HD int32_t nw_traceback(Win& g, const int32_t* rank, const Arr<int32_t>& nr, bool use_mask, const uint8_t* seq, int32_t len,
+RCN_HD int32_t nw_traceback(Win& g, RCN_G const int32_t* rank, const Arr<int32_t>& nr, bool use_mask, RCN_G const uint8_t* seq, int32_t len,
                             int32_t best_row, int32_t m, int32_t x, int32_t gp) {
     const int64_t W = g.hstride;
     int32_t i = best_row, j = len, n = 0;
@@ -427,7 +436,7 @@ RCN_HD void consensus_relax(Win& g, int32_t it, bool skip) {
 // Heaviest bundle + branch completion over rank_full; writes the consensus node
 // ids (in order) to out_nodes; returns the length.  `rank` must be spoa's exact
 // order (graph_toposort) and `nr` its inverse.
-RCN_HD int32_t graph_consensus(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int32_t* out_nodes) {
+RCN_HD int32_t graph_consensus(Win& g, RCN_G const int32_t* rank, const Arr<int32_t>& nr, RCN_G int32_t* out_nodes) {
     const int32_t n = g.n_nodes;
     for (int32_t i = 0; i < n; ++i) { g.pred[i] = -1; g.score[i] = -1; }
     int32_t mx = -1;
@@ -467,7 +476,7 @@ RCN_HD uint32_t consensus_coverage(const Win& g, int32_t v) {
 }
 
 // Carve a Win out of one slot's scratch block.  Returns bytes used.
-RCN_HD uint64_t win_bind(Win& g, uint8_t* base, int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, int32_t hstride) {
+RCN_HD uint64_t win_bind(Win& g, RCN_G uint8_t* base, int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, int32_t hstride) {
     uint64_t off = 0;
     g.ncap = ncap; g.ecap = ecap; g.ring = ring; g.hstride = hstride;
     g.n_nodes = 0; g.n_edges = 0; g.overflow = 0;

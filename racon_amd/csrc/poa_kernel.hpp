@@ -72,14 +72,46 @@ __device__ __forceinline__ int wave_excl_scan_max(int z, int /*lane*/) {
 }
 
 // One column tile [t0, t0 + 64*CT) of the DP matrix, all rows.
-constexpr int kMaxCT = 10;   // widest column tile: 64 * 12 = 768 columns per pass
-constexpr int kLdsBytes = 20480;               // per wave (one wave per workgroup): 8 waves / CU
+constexpr int kMaxCT = 12;   // widest column tile: 64 * 12 = 768 columns per pass
+constexpr int kLdsBytes = 19968;               // work area per wave (+512 B context = 20 KiB: 8 waves / CU)
 constexpr int kRingInts = kLdsBytes / 4;
 struct DpState { int best, best_row, have_best, tied; unsigned int pred_rows; };
 
+// wave-uniform, global-address-space copy of a pointer that arrived in VGPRs (function arguments
+// do) or came back from LDS
+template <class T>
+__device__ __forceinline__ RCN_G T* uptr(T* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return (RCN_G T*)((static_cast<uint64_t>(hi) << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ RCN_G T* gcast(T* p) { return (RCN_G T*)p; }
+__device__ __forceinline__ int uint_(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Everything dp_tile touches in HBM, passed by value (a reference to the caller's Win would
+// force that struct through scratch memory).
+struct DpMem {
+    int32_t* H; const RowDesc* desc; const int32_t* e_nin; const int32_t* e_tail; const uint8_t* inc; const int32_t* nr;
+    int32_t hstride;
+};
+struct DpMemG {
+    RCN_G int32_t* H; RCN_G const RowDesc* desc; RCN_G const int32_t* e_nin; RCN_G const int32_t* e_tail;
+    RCN_G const uint8_t* inc; RCN_G const int32_t* nr; int32_t hstride;
+};
+
 template <int CT, bool FIRST>      // FIRST: the tile starts at column 0 (no global loads in the row loop)
-__device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr, int V, bool sub, const uint8_t* __restrict__ seq, int len,
+__device__ __noinline__ DpState dp_tile(DpMem mem_in, int V, bool sub, const uint8_t* seq_in, int len,
                                         int t0, bool last_tile, int m, int x, int gp, DpState st, int2* __restrict__ ring) {
+    DpMemG mem;
+    mem.H = uptr(mem_in.H); mem.desc = uptr(mem_in.desc); mem.e_nin = uptr(mem_in.e_nin); mem.e_tail = uptr(mem_in.e_tail);
+    mem.inc = uptr(mem_in.inc); mem.nr = uptr(mem_in.nr); mem.hstride = uint_(mem_in.hstride);
+    RCN_G const uint8_t* seq = uptr(seq_in);
+    V = uint_(V); sub = uint_(sub) != 0; len = uint_(len); t0 = uint_(t0); last_tile = uint_(last_tile) != 0;
+    m = uint_(m); x = uint_(x); gp = uint_(gp);
+    st.best = uint_(st.best); st.best_row = uint_(st.best_row); st.have_best = uint_(st.have_best); st.tied = uint_(st.tied);
+    st.pred_rows = uint_(st.pred_rows);
     // LDS ring of the last K score rows (predecessors are almost always < 16 rows back in the
     // incrementally maintained order).  Layout: slot s, column pair q of lane l at
     // ring[(s * (CT/2) + q) * 64 + l]: every ds_read/write_b64 is stride-8B, conflict free.
@@ -89,8 +121,8 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
     unsigned int pred_rows = 0;
     const int lane = threadIdx.x;
     const int j0 = t0 + lane * CT;
-    const int64_t hs = g.hstride;
-    int32_t* __restrict__ H = g.H.ptr();
+    const int64_t hs = mem.hstride;
+    RCN_G int32_t* __restrict__ H = mem.H;
 
     uint8_t sq[CT];
 #pragma unroll
@@ -111,7 +143,10 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
     RowDesc dl; dl.erest = -1; dl.meta = 1 << 9;
 #pragma unroll
     for (int q = 0; q < kInlinePreds; ++q) dl.p[q] = 0;
-    if (rbase + lane < V) dl = g.desc[rbase + lane];
+    if (rbase + lane < V) dl = mem.desc[rbase + lane];
+    // retire the descriptor load HERE: otherwise the compiler parks its s_waitcnt vmcnt(0) at the first
+    // v_readlane inside the row loop, where it also waits for every outstanding H-row store, every row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int rend = min(V, rbase + 64);
 #pragma unroll 1
     for (int r = rbase; r < rend; ++r) {
@@ -142,7 +177,7 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
                 } else {
                     // rare (<0.1%): predecessor older than the ring -> stage its row through the spare
                     // slot, so that the common path never has a global load pending at the join
-                    const int2* gsrc = reinterpret_cast<const int2*>(H + p * hs + j0);
+                    RCN_G const int2* gsrc = reinterpret_cast<RCN_G const int2*>(H + p * hs + j0);
                     int2* sdst = ring + K * (CT / 2) * 64 + lane;
 #pragma unroll
                     for (int c = 0; c < CT; c += 2) sdst[(c >> 1) * 64] = gsrc[c >> 1];
@@ -164,18 +199,18 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
         };
         accumulate(p0);
         if (np > 1) {
-            accumulate(__builtin_amdgcn_readlane(dl.p[1], k));
-            if (np > 2) {
-                accumulate(__builtin_amdgcn_readlane(dl.p[2], k));
-                if (np > 3) accumulate(__builtin_amdgcn_readlane(dl.p[3], k));
-                if (np > 4) accumulate(__builtin_amdgcn_readlane(dl.p[4], k));
-                if (np > 5) accumulate(__builtin_amdgcn_readlane(dl.p[5], k));
-            }
+            // further inline predecessors: one call site in a uniform loop (keeps the code and the
+            // register footprint of the row loop small)
+            const int q1 = __builtin_amdgcn_readlane(dl.p[1], k), q2 = __builtin_amdgcn_readlane(dl.p[2], k);
+            const int q3 = __builtin_amdgcn_readlane(dl.p[3], k), q4 = __builtin_amdgcn_readlane(dl.p[4], k);
+            const int q5 = __builtin_amdgcn_readlane(dl.p[5], k);
+#pragma unroll 1
+            for (int q = 1; q < np; ++q) accumulate(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
         }
-        for (int e = er; e >= 0; e = g.e_nin[e]) {
-            const int t = g.e_tail[e];
-            if (sub && !g.inc[t]) continue;
-            accumulate(nr[t] + 1);
+        for (int e = er; e >= 0; e = mem.e_nin[e]) {
+            const int t = mem.e_tail[e];
+            if (sub && !mem.inc[t]) continue;
+            accumulate(mem.nr[t] + 1);
         }
         // horizontal gap: in-lane pass, then wave-wide prefix max of the transformed lane tails
 #pragma unroll
@@ -186,7 +221,7 @@ __device__ __forceinline__ DpState dp_tile(const Win& g, const Arr<int32_t>& nr,
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = max(acc[c], zex + (j0 + c) * gp);
 
-        int2* dst = reinterpret_cast<int2*>(H + i * hs + j0);
+        RCN_G int2* dst = reinterpret_cast<RCN_G int2*>(H + i * hs + j0);
         int2* rdst = ring + slot * (CT / 2) * 64 + lane;
 #pragma unroll
         for (int c = 0; c < CT; c += 2) { const int2 v = make_int2(acc[c], acc[c + 1]); dst[c >> 1] = v; rdst[(c >> 1) * 64] = v; }
@@ -221,12 +256,12 @@ __device__ __forceinline__ void wave_sync() { __threadfence_block(); __syncthrea
 // serve the step (predecessor > 60 rows back, or > 2 in-edges), that single
 // step is done against HBM.  Emits (row | -1, pos | -1) in reverse order; rows
 // are mapped to node ids afterwards, in parallel.
-constexpr int kTileStride = 68;   // ints per tile row: 64 + 4 pad (conflict-free ds_write_b128)
+constexpr int kTileStride = 64;   // ints per tile row (rows are filled by direct global->LDS loads, 1 KiB = 4 rows each)
 
-__device__ __forceinline__ void traceback_slow_step(Win& g, const Arr<int32_t>& nr, bool sub, const uint8_t* seq,
+__device__ __forceinline__ void traceback_slow_step(Win& g, const Arr<int32_t>& nr, bool sub, RCN_G const uint8_t* seq,
                                                     int m, int x, int gp, int& i, int& j, int& n) {
     const int64_t hs = g.hstride;
-    const int32_t* H = g.H.ptr();
+    RCN_G const int32_t* H = g.H.ptr();
     const int hij = H[i * hs + j];
     int pi = 0, pj = 0; bool found = false;
     if (i != 0) {
@@ -255,91 +290,375 @@ __device__ __forceinline__ void traceback_slow_step(Win& g, const Arr<int32_t>& 
     ++n; i = pi; j = pj;
 }
 
-__device__ __forceinline__ int traceback_tiled(Win& g, const Arr<int32_t>& nr, bool sub, const uint8_t* __restrict__ seq,
-                                               int len, int best_row, int m, int x, int gp, int* __restrict__ tile, unsigned long long* dbg) {
+__device__ __forceinline__ int traceback_tiled(Win& g, const Arr<int32_t>& nr, bool sub, RCN_G const uint8_t* __restrict__ seq,
+                                               int len, int best_row, int m, int x, int gp, int* __restrict__ tile) {
     const int lane = threadIdx.x;
     const int64_t hs = g.hstride;
-    const int32_t* __restrict__ H = g.H.ptr();
-    RowDesc* tdesc = reinterpret_cast<RowDesc*>(tile + 64 * kTileStride);
-    uint8_t* tseq = reinterpret_cast<uint8_t*>(tile + 64 * kTileStride + 64 * (sizeof(RowDesc) / 4));     // seq[c0 - 1 + k], k = 0..63
-    int32_t* __restrict__ pnode = g.path_node.ptr();
-    int32_t* __restrict__ ppos = g.path_pos.ptr();
-    int i = best_row, j = len, n = 0;
+    RCN_G const int32_t* __restrict__ H = g.H.ptr();
+    int* tdesc = tile + 64 * kTileStride;                                   // 64 x RowDesc (8 ints each)
+    uint8_t* tseq = reinterpret_cast<uint8_t*>(tile + 64 * kTileStride + 64 * (sizeof(RowDesc) / 4));   // seq[c0 - 1 + k]
+    RCN_G int32_t* __restrict__ pnode = g.path_node.ptr();
+    RCN_G int32_t* __restrict__ ppos = g.path_pos.ptr();
+    int i = best_row, j = len, n = 0;               // wave-uniform walk state
     while (!(i == 0 && j == 0)) {
-        // ---- stage the tile: rows [i-63, i], cols [c0, c0+63] ----
+        // ---- stage the tile: rows [i-63, i], cols [c0, c0+63]; all 16 row loads of a lane in flight ----
         const int ti0 = i;
         int c0 = (j - 60) & ~3; if (c0 < 0) c0 = 0;
         const int rmin = ti0 - 63 > 0 ? ti0 - 63 : 0;
         {
-            const int r = ti0 - lane;
-            if (r >= 0) {
-                const int4* src = reinterpret_cast<const int4*>(H + r * hs + c0);
-                int4* dst = reinterpret_cast<int4*>(tile + lane * kTileStride);
-#pragma unroll 1
-                for (int q = 0; q < 16; q += 4) { const int4 a = src[q], b = src[q + 1], c = src[q + 2], d = src[q + 3]; dst[q] = a; dst[q + 1] = b; dst[q + 2] = c; dst[q + 3] = d; }
-                if (r >= 1) tdesc[lane] = g.desc[r - 1];
+            // H tile: 16 direct global->LDS loads (global_load_lds_dwordx4: lane l deposits its 16 B at
+            // LDS base + 16*l, no VGPR round trip), all in flight together; instruction k fills tile
+            // rows 4k..4k+3 (tile row t holds matrix row ti0 - t).
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            const int sub_row = lane >> 4, chunk = lane & 15;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                int r = ti0 - (4 * k + sub_row); if (r < 0) r = 0;
+                RCN_G const int32_t* src = H + r * hs + c0 + chunk * 4;
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(tile + k * 256), 16, 0, 0);
             }
+            const int r = ti0 - lane;
+            int4 d0 = make_int4(0, -1, -1, -1), d1 = make_int4(-1, -1, -1, 1 << 9);
+            if (r >= 1) { RCN_G const int4* dsrc = reinterpret_cast<RCN_G const int4*>(g.desc.ptr() + (r - 1)); d0 = dsrc[0]; d1 = dsrc[1]; }
+            int4* ddst = reinterpret_cast<int4*>(tdesc + lane * 8);
+            ddst[0] = d0; ddst[1] = d1;
             const int sc = c0 - 1 + lane;
             tseq[lane] = (sc >= 0 && sc < len) ? seq[sc] : 0;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int steps = 0;
-        if (lane == 0) {
-            int hij = tile[(ti0 - i) * kTileStride + (j - c0)];
-            for (;;) {
-                if (i == 0 && j == 0) break;
-                int pi, pj, hnext;
-                if (i == 0) {                       // only horizontal moves are left on the virtual row
-                    pi = 0; pj = j - 1; hnext = hij - gp;
-                    if (j - 1 < c0) break;
-                } else {
-                    const RowDesc d = tdesc[ti0 - i];
-                    const int np = (d.meta >> 9) & 15;
-                    // everything this step may read must be inside the tile
-                    int pmin = d.p[0];
-#pragma unroll
-                    for (int q = 1; q < kInlinePreds; ++q) if (q < np) pmin = min(pmin, d.p[q]);
-                    if (pmin < rmin || d.erest >= 0 || (j > 0 && j - 1 < c0)) break;
-                    const int mc = ((d.meta & 255) == tseq[j - c0]) ? m : x;      // seq[j-1]
-                    const int* col = tile + ti0 * kTileStride + (j - c0);         // col[-p * stride] = H[p][j]
-                    bool found = false;
-                    pi = i; pj = j - 1; hnext = hij - gp;                         // horizontal unless a predecessor matches
-                    if (j > 0) {
-#pragma unroll
-                        for (int q = 0; q < kInlinePreds; ++q) {
-                            if (q < np && !found) { const int h = col[-d.p[q] * kTileStride - 1]; if (hij == h + mc) { pi = d.p[q]; pj = j - 1; hnext = h; found = true; } }
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < kInlinePreds; ++q) {
-                        if (q < np && !found) { const int h = col[-d.p[q] * kTileStride]; if (hij == h + gp) { pi = d.p[q]; pj = j; hnext = h; found = true; } }
-                    }
-                }
-                pnode[n] = (i == pi) ? -1 : i;          // ROW index (mapped to the node id later)
-                ppos[n] = (j == pj) ? -1 : j - 1;
-                ++n; ++steps;
-                i = pi; j = pj; hij = hnext;
+        // ---- walk inside the tile: wave-uniform control flow; lane q looks at predecessor q ----
+        int steps = 0, bn = 0, bp = 0, n0 = n;      // up to 64 path entries buffered one per lane
+        int hij = tile[j - c0];                      // row ti0 is tile row 0
+        for (;;) {
+            if (i == 0 && j == 0) break;
+            int pi, pj, hnext;
+            if (i == 0) {                            // only horizontal moves are left on the virtual row
+                if (j - 1 < c0) break;
+                pi = 0; pj = j - 1; hnext = hij - gp;
+            } else {
+                const int* dr = tdesc + (ti0 - i) * 8;
+                const int pq = dr[lane < kInlinePreds ? lane : 0];
+                const int erest = dr[6], meta = dr[7];
+                const int symc = tseq[j - c0];                               // seq[j-1]
+                const int np = (meta >> 9) & 15;
+                const bool valid = lane < np;
+                if (__ballot(valid && pq < rmin) != 0ull || erest >= 0 || (j > 0 && j - 1 < c0)) break;   // leaves the tile
+                const int mc = ((meta & 255) == symc) ? m : x;
+                const int* cp = tile + (ti0 - (valid ? pq : ti0)) * kTileStride + (j - c0);
+                const int hd = cp[j > 0 ? -1 : 0], hu = cp[0];
+                const unsigned long long dmask = __ballot(valid && j > 0 && hij == hd + mc);
+                const unsigned long long umask = __ballot(valid && hij == hu + gp);
+                if (dmask) { const int q = __builtin_ctzll(dmask); pi = __builtin_amdgcn_readlane(pq, q); pj = j - 1; hnext = __builtin_amdgcn_readlane(hd, q); }
+                else if (umask) { const int q = __builtin_ctzll(umask); pi = __builtin_amdgcn_readlane(pq, q); pj = j; hnext = __builtin_amdgcn_readlane(hu, q); }
+                else { if (j == 0) { g.overflow = 4; i = 0; j = 0; break; } pi = i; pj = j - 1; hnext = hij - gp; }
             }
-            dbg[0] += 1; dbg[1] += steps;
-            if (steps == 0 && !(i == 0 && j == 0)) { traceback_slow_step(g, nr, sub, seq, m, x, gp, i, j, n); dbg[2] += 1; }
+            if (lane == steps) { bn = (i == pi) ? -1 : i; bp = (j == pj) ? -1 : j - 1; }   // ROW index (node id later)
+            ++steps;
+            i = pi; j = pj; hij = hnext;
+            if (steps == 64) { pnode[n0 + lane] = bn; ppos[n0 + lane] = bp; n0 += 64; steps = 0; }
         }
-        i = bcast0(i); j = bcast0(j); n = bcast0(n);
+        if (lane < steps) { pnode[n0 + lane] = bn; ppos[n0 + lane] = bp; }
+        const bool progressed = (n0 + steps) != n;
+        n = n0 + steps;
+        if (!progressed && !(i == 0 && j == 0)) {
+            if (lane == 0) traceback_slow_step(g, nr, sub, seq, m, x, gp, i, j, n);
+            i = bcast0(i); j = bcast0(j); n = bcast0(n); g.overflow = bcast0(g.overflow);
+        }
         __syncthreads();
     }
-    g.overflow = bcast0(g.overflow);
     return n;
+}
+
+// ---------------------------------------------------------------------------
+// Per-slot context.  It lives in LDS behind the kLdsBytes work area, so that each
+// phase below can be its own NON-inlined device function with its own register
+// budget: a phase re-derives the scratch layout (win_bind is pure arithmetic on a
+// handful of uniform values) instead of inheriting ~50 live pointers from one
+// giant kernel body.  All fields are wave-uniform.
+// ---------------------------------------------------------------------------
+struct Ctx {
+    // window constants
+    uint8_t* scratch; int32_t ncap, ecap, ring, lmax, hstride;
+    int32_t m, x, gp, trim, pad0;
+    // window state
+    int32_t n_nodes, n_edges, overflow, swapped;
+    // layer
+    const uint8_t* seq; const uint8_t* qual;
+    int32_t len, sub, begin, end;
+    int32_t V, best, best_row, tied;
+    int32_t plen, nn, n_old; uint32_t pred_rows;
+    // statistics
+    unsigned long long cells, pred, bytes, ties;
+};
+static_assert(sizeof(Ctx) % 4 == 0 && sizeof(Ctx) <= 512, "Ctx must fit its LDS slot");
+constexpr int kCtxBytes = 512;
+
+__device__ __forceinline__ int* lds_words() { extern __shared__ int4 lds_dyn[]; return reinterpret_cast<int*>(lds_dyn); }
+__device__ __forceinline__ Ctx* ctx_lds() { return reinterpret_cast<Ctx*>(lds_words() + kLdsBytes / 4); }
+
+// Loads the context from LDS and makes every dword provably wave-uniform (SGPR).
+__device__ __forceinline__ Ctx ctx_load() {
+    Ctx c;
+    const int* src = reinterpret_cast<const int*>(ctx_lds());
+    int* dst = reinterpret_cast<int*>(&c);
+#pragma unroll
+    for (int k = 0; k < static_cast<int>(sizeof(Ctx) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
+    return c;
+}
+__device__ __forceinline__ Win ctx_win(const Ctx& c) {
+    Win g;
+    win_bind(g, gcast(c.scratch), c.ncap, c.ecap, c.ring, c.lmax, c.hstride);
+    g.n_nodes = c.n_nodes; g.n_edges = c.n_edges; g.overflow = c.overflow;
+    if (c.swapped) { const Arr<int32_t> t = g.rank_full; g.rank_full = g.rank_tmp; g.rank_tmp = t; }
+    return g;
+}
+
+// ---- phase: Subgraph mask + filtered order (window.cpp:99-103) ----
+__device__ __noinline__ void phase_subgraph() {
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load();
+    Win g = ctx_win(c);
+    if (lane == 0) graph_subgraph_mask(g, c.begin, c.end, g.stack.ptr());
+    wave_sync();
+    int nv = 0;
+    for (int base = 0; base < g.n_nodes; base += 64) {
+        const int r = base + lane;
+        const int v = r < g.n_nodes ? g.rank_full[r] : -1;
+        const bool in = v >= 0 && g.inc[v] != 0;
+        const unsigned long long mk = __ballot(in);
+        if (in) {
+            const int pos = nv + __popcll(mk & ((1ull << lane) - 1ull));
+            g.rank_sub[pos] = v; g.n2r_x[v] = pos;
+        }
+        nv += __popcll(mk);
+    }
+    if (lane == 0) ctx_lds()->V = nv;
+    wave_sync();
+}
+
+// ---- phase: row descriptors + row 0 ----
+__device__ __noinline__ void phase_desc() {
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load();
+    Win g = ctx_win(c);
+    RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
+    const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
+    for (int r = lane; r < c.V; r += 64) g.desc[r] = make_row_desc(g, nr, rank[r], c.sub != 0);
+    for (int j = lane; j < g.hstride; j += 64) g.H[j] = j * c.gp;
+    wave_sync();
+}
+
+// ---- phase: NW sequence-to-graph DP (window.cpp:95-97, 104-106) ----
+__device__ __noinline__ void phase_dp() {
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load();
+    Win g = ctx_win(c);
+    const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
+    DpState ds; ds.best = 0; ds.best_row = 0; ds.have_best = 0; ds.tied = 0; ds.pred_rows = 0;
+    const int W = c.len + 1;
+    int2* ring = reinterpret_cast<int2*>(lds_words());
+    DpMem mem; mem.H = (int32_t*)g.H.ptr(); mem.desc = (const RowDesc*)g.desc.ptr(); mem.e_nin = (const int32_t*)g.e_nin.ptr();
+    mem.e_tail = (const int32_t*)g.e_tail.ptr(); mem.inc = (const uint8_t*)g.inc.ptr(); mem.nr = (const int32_t*)nr.ptr(); mem.hstride = g.hstride;
+    for (int t0 = 0; t0 < W;) {
+        const int need = (W - t0 + 63) / 64;
+        int ct = (need + 1) & ~1;
+        if (ct > kMaxCT) ct = kMaxCT;
+        const bool lastt = t0 + 64 * ct >= W;
+        switch (ct) {
+#define RCN_CASE(C) case C: ds = (t0 == 0) ? dp_tile<C, true>(mem, c.V, c.sub != 0, c.seq, c.len, 0, lastt, c.m, c.x, c.gp, ds, ring) \
+                                           : dp_tile<C, false>(mem, c.V, c.sub != 0, c.seq, c.len, t0, lastt, c.m, c.x, c.gp, ds, ring); break;
+            RCN_CASE(2) RCN_CASE(4) RCN_CASE(6) RCN_CASE(8) RCN_CASE(10) RCN_CASE(12)
+#undef RCN_CASE
+        }
+        t0 += 64 * ct;
+        wave_sync();
+    }
+    if (lane == 0) {
+        Ctx* o = ctx_lds();
+        o->best = ds.best; o->best_row = ds.best_row; o->tied = ds.tied; o->pred_rows = ds.pred_rows;
+        o->cells += static_cast<unsigned long long>(c.V + 1) * W;
+        o->pred += static_cast<unsigned long long>(ds.pred_rows) * W;
+        // SURVEY 8(d) yardstick: every cell written once + every predecessor row read once per
+        // in-edge, at 2 B/cell when the worst-case score bound fits int16, else 4 B/cell
+        const int amax = max(max(abs(c.m), abs(c.x)), abs(c.gp));
+        const unsigned long long sbytes = (static_cast<long long>(amax) * (c.V + W) < 32767) ? 2ull : 4ull;
+        o->bytes += sbytes * (static_cast<unsigned long long>(c.V + 1) + ds.pred_rows) * W;
+    }
+    wave_sync();
+}
+
+// ---- phase: sink tie-break (rare) + traceback ----
+__device__ __noinline__ void phase_traceback() {
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load();
+    Win g = ctx_win(c);
+    const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
+    int best_row = c.best_row;
+    if (c.tied > 1) {
+        // several sinks share the best score: spoa takes the first one in ITS rank order
+        // (exact DFS order), so compute that order now (rare: ~2% of alignments)
+        if (lane == 0) {
+            const int nx = graph_toposort(g, g.rank_x.ptr(), c.sub != 0, g.stack.ptr());
+            for (int r = 0; r < nx; ++r) {
+                const int row = nr[g.rank_x[r]] + 1;
+                if ((g.desc[row - 1].meta & 256) && g.H[static_cast<int64_t>(row) * g.hstride + c.len] == c.best) { best_row = row; break; }
+            }
+        }
+        best_row = bcast0(best_row);
+    }
+    const int plen = traceback_tiled(g, nr, c.sub != 0, gcast(c.seq), c.len, best_row, c.m, c.x, c.gp, lds_words());
+    if (lane == 0) {
+        Ctx* o = ctx_lds();
+        o->plen = plen; o->overflow = g.overflow;
+        if (c.tied > 1) o->ties += 1;
+    }
+    wave_sync();
+}
+
+// ---- phase: AddAlignment, wave-parallel over sequence positions (window.cpp:110-119) ----
+__device__ __noinline__ void phase_add() {
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load();
+    Win g = ctx_win(c);
+    RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
+    RCN_G const uint8_t* seq = gcast(c.seq); RCN_G const uint8_t* qual = gcast(c.qual);
+    const int len = c.len, plen = c.plen, n_old = g.n_nodes;
+    const uint32_t count = len >= 2 ? 1u : 0u;
+    int nn = 0;
+    for (int k = lane; k < plen; k += 64) {
+        const int pp = g.path_pos[k];
+        if (pp != -1) { const int row = g.path_node[k]; g.pos_t[pp] = row == -1 ? -1 : rank[row - 1]; }
+    }
+    wave_sync();
+    // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)
+    RCN_G int32_t* kindv = g.path_pos.ptr();     // path arrays are free from here on
+    RCN_G int32_t* idxv = g.path_node.ptr();
+    int anchor = -1;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = 0; base < len; base += 64) {
+        const int pos = base + lane;
+        int kind = 0, a = -1;
+        if (pos < len) { kind = addp_classify(g, seq, pos); a = g.pos_a[pos]; }
+        const unsigned long long mk = __ballot(kind != 0);
+        const int idx = nn + __popcll(mk & lt);
+        a = max(wave_incl_scan_max(a), anchor);
+        if (pos < len) { kindv[pos] = kind; idxv[pos] = idx; g.pos_a[pos] = a; }
+        nn += __popcll(mk);
+        anchor = __builtin_amdgcn_readlane(a, 63);
+    }
+    if (n_old + nn > g.ncap) g.overflow = 1;
+    wave_sync();
+    if (!g.overflow) {
+        for (int pos = lane; pos < len; pos += 64) {
+            const int kind = kindv[pos];
+            if (kind) {
+                const int idx = idxv[pos];
+                addp_create(g, seq, pos, kind, n_old + idx, count);
+                g.new_id[idx] = n_old + idx; g.new_anchor[idx] = g.pos_a[pos];
+            }
+        }
+        g.n_nodes = n_old + nn;
+        wave_sync();
+        int ne = 0, ovf = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int pos = base + lane;
+            int f = 0;
+            if (pos >= 1 && pos < len) f = addp_edge_find(g, qual, pos);
+            const unsigned long long mk = __ballot(f != 0);
+            const int e = g.n_edges + ne + __popcll(mk & lt);
+            if (f) { if (e < g.ecap) addp_edge_create(g, qual, pos, e); else ovf = 1; }
+            ne += __popcll(mk);
+        }
+        g.n_edges += ne;
+        if (__ballot(ovf != 0)) g.overflow = 1;
+        for (int pos = lane; pos < len; pos += 64) g.cov[g.pos_curr[pos]] += count;
+    }
+    if (lane == 0) {
+        Ctx* o = ctx_lds();
+        o->n_old = n_old; o->nn = nn; o->n_nodes = g.n_nodes; o->n_edges = g.n_edges; o->overflow = g.overflow;
+    }
+    wave_sync();
+}
+
+// ---- phase: order merge: insert the nn new nodes behind their anchors ----
+__device__ __noinline__ void phase_merge() {
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load();
+    Win g = ctx_win(c);
+    const int n_old = c.n_old, nn = c.nn;
+    RCN_G int32_t* delta = g.pred.ptr();                // [n_old + 1] scratch (pred is consensus-only)
+    for (int r = lane; r <= n_old; r += 64) delta[r] = 0;
+    wave_sync();
+    for (int k = lane; k < nn; k += 64) {
+        const int a = g.new_anchor[k] + 1;
+        atomicAdd((int*)&delta[a], 1);
+        const int v = g.new_id[k];
+        g.rank_tmp[a + k] = v; g.n2r[v] = a + k;
+    }
+    wave_sync();
+    int carry = 0;
+    for (int base = 0; base < n_old; base += 64) {
+        const int r = base + lane;
+        int sc = r < n_old ? delta[r] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(sc, d); if (lane >= d) sc += t; }
+        if (r < n_old) { const int v = g.rank_full[r]; const int pos = r + carry + sc; g.rank_tmp[pos] = v; g.n2r[v] = pos; }
+        carry += __shfl(sc, 63);
+    }
+    if (lane == 0) ctx_lds()->swapped = c.swapped ^ 1;
+    wave_sync();
+}
+
+// ---- phase: consensus + coverage + trim (window.cpp:122-146); returns via out arrays ----
+__device__ __noinline__ void phase_consensus(uint8_t* out_in, uint64_t out_cap, uint32_t* out_len_in, uint8_t* out_flags_in, int ns, int tgs) {
+    RCN_G uint8_t* out = uptr(out_in); RCN_G uint32_t* out_len = uptr(out_len_in); RCN_G uint8_t* out_flags = uptr(out_flags_in);
+    out_cap = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(out_cap >> 32))) << 32) | __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(out_cap));
+    ns = uint_(ns); tgs = uint_(tgs);
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load();
+    Win g = ctx_win(c);
+    int nx = 0;
+    if (lane == 0) nx = graph_toposort(g, g.rank_x.ptr(), false, g.stack.ptr());   // spoa's exact rank order, once
+    nx = bcast0(nx);
+    wave_sync();
+    if (nx != g.n_nodes) { if (lane == 0) { *out_len = 0; *out_flags = kFlagError; } return; }
+    for (int r = lane; r < g.n_nodes; r += 64) g.n2r_x[g.rank_x[r]] = r;
+    wave_sync();
+    int clen = 0, cb = 0, flags = kFlagPolished;
+    if (lane == 0) {
+        RCN_G int32_t* cn = g.path_node.ptr();
+        const int k = graph_consensus(g, g.rank_x.ptr(), g.n2r_x, cn);
+        int bgn = 0, end = k - 1;
+        if (tgs && c.trim) {
+            const uint32_t avg = static_cast<uint32_t>(ns - 1) / 2;
+            for (; bgn < k; ++bgn) if (consensus_coverage(g, cn[bgn]) >= avg) break;
+            for (; end >= 0; --end) if (consensus_coverage(g, cn[end]) >= avg) break;
+            if (bgn >= end) { bgn = 0; end = k - 1; flags |= kFlagChimeric; }
+        }
+        cb = bgn; clen = end - bgn + 1;
+    }
+    clen = bcast0(clen); cb = bcast0(cb); flags = bcast0(flags);
+    wave_sync();
+    if (static_cast<uint64_t>(clen) > out_cap) { if (lane == 0) { *out_len = 0; *out_flags = kFlagOverflow; } return; }
+    for (int t = lane; t < clen; t += 64) out[t] = g.code[g.path_node[cb + t]];
+    if (lane == 0) { *out_len = clen; *out_flags = static_cast<uint8_t>(flags); }
+    wave_sync();
 }
 
 __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
     const int lane = threadIdx.x;
-    extern __shared__ int4 lds[];                    // kLdsBytes per wave: DP row ring / traceback tile
-    Win g;
-    win_bind(g, P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes, P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
-    unsigned long long st_cells = 0, st_pred = 0, st_bytes = 0, st_ties = 0;
-    unsigned long long dbg[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub, desc, dp, traceback, add, toposort, consensus, other
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub, desc, dp, traceback, add, merge, consensus, other
     long long tck = clock64();
 #define RCN_PHASE(k) do { long long now__ = clock64(); ph[k] += now__ - tck; tck = now__; } while (0)
+    Ctx* ctx = ctx_lds();
+    if (lane == 0) {
+        ctx->scratch = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
+        ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride;
+        ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
+        ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
+    }
+    wave_sync();
 
     for (;;) {
         RCN_PHASE(7);
@@ -360,9 +679,10 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
             continue;
         }
         // ---- backbone -> graph (window.cpp:73-77) ----
-        g.n_nodes = L; g.n_edges = L - 1; g.overflow = 0;
         {
-            const uint8_t* q0 = P.seq_has_qual[s0] ? P.quals + P.seq_off[s0] : nullptr;
+            Win g;
+            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
+            RCN_G const uint8_t* q0 = P.seq_has_qual[s0] ? gcast(P.quals + P.seq_off[s0]) : nullptr;
             for (int i = lane; i < L; i += 64) {
                 g.code[i] = bb[i]; g.al_cnt[i] = 0;
                 g.in_head[i] = g.in_tail[i] = (i > 0) ? i - 1 : -1;
@@ -374,218 +694,51 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
                     g.e_w[i] = pair_weight(q0, i + 1);
                 }
             }
+            if (lane == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = 0; ctx->swapped = 0; }
         }
         wave_sync();
 
-        for (int jl = 1; jl < ns && !g.overflow; ++jl) {
+        int overflow = 0;
+        for (int jl = 1; jl < ns && !overflow; ++jl) {
             const uint32_t si = s0 + P.order[s0 + jl];
-            const uint8_t* seq = P.bases + P.seq_off[si];
-            const uint8_t* qual = P.seq_has_qual[si] ? P.quals + P.seq_off[si] : nullptr;
-            const int len = static_cast<int>(P.seq_off[si + 1] - P.seq_off[si]);
-            const bool sub = P.seq_full[si] == 0;
-            int V = g.n_nodes;
-            const int32_t* rank = g.rank_full.ptr();
-            Arr<int32_t> nr = g.n2r;
-            if (sub) {
-                // Subgraph (window.cpp:99-103): reachability mask on lane 0, then the sub order is
-                // rank_full filtered by the mask (any valid order restricted to a subset stays valid)
-                if (lane == 0) graph_subgraph_mask(g, static_cast<int32_t>(P.seq_begin[si]), static_cast<int32_t>(P.seq_end[si]), g.stack.ptr());
-                wave_sync();
-                int nv = 0;
-                for (int base = 0; base < g.n_nodes; base += 64) {
-                    const int r = base + lane;
-                    const int v = r < g.n_nodes ? g.rank_full[r] : -1;
-                    const bool in = v >= 0 && g.inc[v] != 0;
-                    const unsigned long long mk = __ballot(in);
-                    if (in) {
-                        const int pos = nv + __popcll(mk & ((1ull << lane) - 1ull));
-                        g.rank_sub[pos] = v; g.n2r_x[v] = pos;
-                    }
-                    nv += __popcll(mk);
-                }
-                V = nv;
-                rank = g.rank_sub.ptr(); nr = g.n2r_x;
-                wave_sync();
+            if (lane == 0) {
+                ctx->seq = P.bases + P.seq_off[si];
+                ctx->qual = P.seq_has_qual[si] ? P.quals + P.seq_off[si] : nullptr;
+                ctx->len = static_cast<int>(P.seq_off[si + 1] - P.seq_off[si]);
+                ctx->sub = P.seq_full[si] == 0;
+                ctx->begin = static_cast<int32_t>(P.seq_begin[si]); ctx->end = static_cast<int32_t>(P.seq_end[si]);
+                ctx->V = ctx->n_nodes;
             }
+            wave_sync();
+            if (P.seq_full[si] == 0) phase_subgraph();
             RCN_PHASE(0);
-            // ---- row descriptors ----
-            for (int r = lane; r < V; r += 64) g.desc[r] = make_row_desc(g, nr, rank[r], sub);
-            for (int j = lane; j < g.hstride; j += 64) g.H[j] = j * P.g;
-            wave_sync();
+            phase_desc();
             RCN_PHASE(1);
-            // ---- DP ----
-            DpState ds; ds.best = 0; ds.best_row = 0; ds.have_best = 0; ds.tied = 0; ds.pred_rows = 0;
-            const int W = len + 1;
-            for (int t0 = 0; t0 < W;) {
-                const int need = (W - t0 + 63) / 64;
-                int ct = (need + 1) & ~1;
-                if (ct > kMaxCT) ct = kMaxCT;
-                const bool lastt = t0 + 64 * ct >= W;
-                switch (ct) {
-#define RCN_CASE(C) case C: ds = (t0 == 0) ? dp_tile<C, true>(g, nr, V, sub, seq, len, 0, lastt, P.m, P.x, P.g, ds, reinterpret_cast<int2*>(lds)) \
-                                           : dp_tile<C, false>(g, nr, V, sub, seq, len, t0, lastt, P.m, P.x, P.g, ds, reinterpret_cast<int2*>(lds)); break;
-                    RCN_CASE(2) RCN_CASE(4) RCN_CASE(6) RCN_CASE(8) RCN_CASE(10)
-#undef RCN_CASE
-                }
-                t0 += 64 * ct;
-                wave_sync();
-            }
+            phase_dp();
             RCN_PHASE(2);
-            st_cells += static_cast<unsigned long long>(V + 1) * W;
-            st_pred += static_cast<unsigned long long>(ds.pred_rows) * W;
-            {   // SURVEY 8(d) yardstick: every cell written once + every predecessor row read once per
-                // in-edge, at 2 B/cell when the worst-case score bound fits int16, else 4 B/cell
-                const int amax = max(max(abs(P.m), abs(P.x)), abs(P.g));
-                const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
-                st_bytes += sbytes * (static_cast<unsigned long long>(V + 1) + ds.pred_rows) * W;
-            }
-            // ---- traceback (serial, lane 0) ----
-            const int n_old = g.n_nodes;
-            int nn = 0, plen = 0;
-            int best_row = ds.best_row;
-            if (ds.tied > 1) {
-                // several sinks share the best score: spoa takes the first one in ITS rank order
-                // (exact DFS order), so compute that order now (rare: ~2% of alignments)
-                if (lane == 0) {
-                    const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
-                    for (int r = 0; r < nx; ++r) {
-                        const int row = nr[g.rank_x[r]] + 1;
-                        if ((g.desc[row - 1].meta & 256) && g.H[static_cast<int64_t>(row) * g.hstride + len] == ds.best) { best_row = row; break; }
-                    }
-                    ++st_ties;
-                }
-                best_row = bcast0(best_row);
-            }
-            plen = traceback_tiled(g, nr, sub, seq, len, best_row, P.m, P.x, P.g, reinterpret_cast<int*>(lds), dbg);
-            plen = bcast0(plen); g.overflow = bcast0(g.overflow);
-            wave_sync();
+            phase_traceback();
             RCN_PHASE(3);
-            // ---- AddAlignment, wave-parallel over sequence positions (window.cpp:110-119) ----
-            if (!g.overflow) {
-                const uint32_t count = len >= 2 ? 1u : 0u;
-                for (int k = lane; k < plen; k += 64) {
-                    const int pp = g.path_pos[k];
-                    if (pp != -1) { const int row = g.path_node[k]; g.pos_t[pp] = row == -1 ? -1 : rank[row - 1]; }
-                }
-                wave_sync();
-                // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)
-                int32_t* kindv = g.path_pos.ptr();           // path arrays are free from here on
-                int32_t* idxv = g.path_node.ptr();
-                int anchor = -1;
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                for (int base = 0; base < len; base += 64) {
-                    const int pos = base + lane;
-                    int kind = 0, a = -1;
-                    if (pos < len) { kind = addp_classify(g, seq, pos); a = g.pos_a[pos]; }
-                    const unsigned long long mk = __ballot(kind != 0);
-                    const int idx = nn + __popcll(mk & lt);
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(a, d); if (lane >= d) a = max(a, t); }
-                    a = max(a, anchor);
-                    if (pos < len) { kindv[pos] = kind; idxv[pos] = idx; g.pos_a[pos] = a; }
-                    nn += __popcll(mk);
-                    anchor = __shfl(a, 63);
-                }
-                if (n_old + nn > g.ncap) g.overflow = 1;
-                wave_sync();
-                if (!g.overflow) {
-                    for (int pos = lane; pos < len; pos += 64) {
-                        const int kind = kindv[pos];
-                        if (kind) {
-                            const int idx = idxv[pos];
-                            addp_create(g, seq, pos, kind, n_old + idx, count);
-                            g.new_id[idx] = n_old + idx; g.new_anchor[idx] = g.pos_a[pos];
-                        }
-                    }
-                    g.n_nodes = n_old + nn;
-                    wave_sync();
-                    int ne = 0, ovf = 0;
-                    for (int base = 0; base < len; base += 64) {
-                        const int pos = base + lane;
-                        int f = 0;
-                        if (pos >= 1 && pos < len) f = addp_edge_find(g, qual, pos);
-                        const unsigned long long mk = __ballot(f != 0);
-                        const int e = g.n_edges + ne + __popcll(mk & lt);
-                        if (f) { if (e < g.ecap) addp_edge_create(g, qual, pos, e); else ovf = 1; }
-                        ne += __popcll(mk);
-                    }
-                    g.n_edges += ne;
-                    if (__ballot(ovf != 0)) g.overflow = 1;
-                    for (int pos = lane; pos < len; pos += 64) g.cov[g.pos_curr[pos]] += count;
-                }
+            overflow = bcast0(ctx->overflow);
+            if (!overflow) {
+                phase_add();
+                RCN_PHASE(4);
+                overflow = bcast0(ctx->overflow);
+                if (!overflow) phase_merge();
+                RCN_PHASE(5);
             }
-            wave_sync();
-            RCN_PHASE(4);
-            // ---- order merge: insert the nn new nodes behind their anchors (wave-parallel) ----
-            if (!g.overflow) {
-                int32_t* delta = g.pred.ptr();                      // [n_old + 1] scratch (pred is consensus-only)
-                for (int r = lane; r <= n_old; r += 64) delta[r] = 0;
-                wave_sync();
-                for (int k = lane; k < nn; k += 64) {
-                    const int a = g.new_anchor[k] + 1;
-                    atomicAdd(&delta[a], 1);
-                    const int v = g.new_id[k];
-                    g.rank_tmp[a + k] = v; g.n2r[v] = a + k;
-                }
-                wave_sync();
-                int carry = 0;
-                for (int base = 0; base < n_old; base += 64) {
-                    const int r = base + lane;
-                    int sc = r < n_old ? delta[r] : 0;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(sc, d); if (lane >= d) sc += t; }
-                    if (r < n_old) { const int v = g.rank_full[r]; const int pos = r + carry + sc; g.rank_tmp[pos] = v; g.n2r[v] = pos; }
-                    carry += __shfl(sc, 63);
-                }
-                { const Arr<int32_t> t = g.rank_full; g.rank_full = g.rank_tmp; g.rank_tmp = t; }
-                wave_sync();
-            }
-            RCN_PHASE(5);
         }
-
-        if (g.overflow) {
-            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (g.overflow == 1 || g.overflow == 3) ? kFlagOverflow : kFlagError; }
+        if (overflow) {
+            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (overflow == 1 || overflow == 3) ? kFlagOverflow : kFlagError; }
             continue;
         }
-        // ---- consensus (window.cpp:122-146): needs spoa's exact rank order once ----
-        int nx = 0;
-        if (lane == 0) nx = graph_toposort(g, g.rank_x.ptr(), false, g.stack.ptr());
-        nx = bcast0(nx);
-        wave_sync();
-        if (nx != g.n_nodes) {
-            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = kFlagError; }
-            continue;
-        }
-        for (int r = lane; r < g.n_nodes; r += 64) g.n2r_x[g.rank_x[r]] = r;
-        wave_sync();
-        int clen = 0, cb = 0, flags = kFlagPolished;
-        if (lane == 0) {
-            int32_t* cn = g.path_node.ptr();
-            const int k = graph_consensus(g, g.rank_x.ptr(), g.n2r_x, cn);
-            int bgn = 0, end = k - 1;
-            if (P.win_type[w] == 1 && P.trim) {
-                const uint32_t avg = static_cast<uint32_t>(ns - 1) / 2;
-                for (; bgn < k; ++bgn) if (consensus_coverage(g, cn[bgn]) >= avg) break;
-                for (; end >= 0; --end) if (consensus_coverage(g, cn[end]) >= avg) break;
-                if (bgn >= end) { bgn = 0; end = k - 1; flags |= kFlagChimeric; }
-            }
-            cb = bgn; clen = end - bgn + 1;
-        }
-        clen = bcast0(clen); cb = bcast0(cb); flags = bcast0(flags);
-        wave_sync();
-        if (static_cast<uint64_t>(clen) > P.out_stride) {
-            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = kFlagOverflow; }
-            continue;
-        }
-        for (int t = lane; t < clen; t += 64) out[t] = g.code[g.path_node[cb + t]];
-        if (lane == 0) { P.out_len[wi] = clen; P.out_flags[wi] = static_cast<uint8_t>(flags); }
-        wave_sync();
+        phase_consensus(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
         RCN_PHASE(6);
     }
-    if (lane == 0) { atomicAdd(&P.stats[0], st_cells); atomicAdd(&P.stats[1], st_pred); atomicAdd(&P.stats[2], st_bytes);
-                     for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[3 + k], ph[k]);
-                     atomicAdd(&P.stats[11], st_ties);
-                     for (int k = 0; k < 7; ++k) atomicAdd(&P.stats[12 + k], dbg[k]); }
+    if (lane == 0) {
+        atomicAdd(&P.stats[0], ctx->cells); atomicAdd(&P.stats[1], ctx->pred); atomicAdd(&P.stats[2], ctx->bytes);
+        for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[3 + k], ph[k]);
+        atomicAdd(&P.stats[11], ctx->ties);
+    }
 }
 
 }  // namespace rcn
