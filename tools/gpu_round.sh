@@ -1,0 +1,40 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats + HBM counters.
+# Usage (from the repo root on the GPU box):  bash tools/gpu_round.sh [tag] [what...]
+#   what: tests bench prof pmc   (default: all)
+# Everything lands under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01}; shift || true
+WHAT=${*:-tests bench prof pmc}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+
+(nproc; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; rocm-smi --showproductname 2>/dev/null | head -20) > "$OUT/box.txt" 2>&1
+
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
+  tail -5 "$OUT/pytest_gpu.log"
+fi
+if has bench; then
+  timeout 900 python bench.py --steps 5 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "bench exit $?"; cat "$OUT/bench.json"; tail -3 "$OUT/bench.err"
+fi
+BENCH_PROF="python bench.py --steps 3 --warmup 1 --no-cpu"
+if has prof; then
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- $BENCH_PROF > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+  echo "prof exit $?"; cat "$OUT/prof_bench.json"
+  find "$OUT/prof" -name "*kernel_stats.csv" -exec head -5 {} \;
+fi
+if has pmc; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- $BENCH_PROF > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
+    echo "pmc $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; cat "$OUT/pmc_summary.txt"
+fi
+# keep the merge-back small: drop bulky raw traces, keep stats + counter tables
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+du -sh "$OUT"
