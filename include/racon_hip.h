@@ -99,6 +99,9 @@ int  rcn_engine_upload(rcn_engine* e, const rcn_batch* b);
 int  rcn_engine_run(rcn_engine* e);
 int  rcn_engine_result(rcn_engine* e, rcn_result* out);
 int  rcn_engine_stats(rcn_engine* e, rcn_run_stats* out);
+/* Changes the trim flag (Window::generate_consensus takes it per call, reference
+ * src/window.hpp:47-48); takes effect at the next rcn_engine_run.                 */
+int  rcn_engine_set_trim(rcn_engine* e, int trim);
 
 /* --- incremental form (replaces CUDABatchProcessor::addWindow / hasWindows /
  *     generateConsensus / reset, cudabatch.hpp:39-64) ----------------------- */

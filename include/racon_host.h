@@ -1,0 +1,67 @@
+/*
+ * racon_host.h — C ABI of the host layer around the MI355X consensus engine
+ * (racon_amd/host, libracon_host.so): racon's Polisher surface
+ * (reference src/polisher.hpp:42-57: createPolisher / initialize / polish) for
+ * callers that cannot use the C++ classes directly (the Python bindings and the
+ * parity harness).  CPU-only code; the consensus stage itself is include/racon_hip.h.
+ *
+ * The two halves of Polisher::polish are also exposed separately —
+ *   rcnh_polisher_windows : every racon::Window flattened into an rcn_batch
+ *   rcnh_polisher_assemble: per-target stitching + tags from per-window results
+ * — so that any consensus backend (the HIP engine in production, the CPU oracle
+ * in tests/) can be run on exactly the same window bytes.
+ *
+ * Errors: functions return 0 on success, <0 on failure; rcnh_last_error() gives
+ * the message the reference would have printed before exit(1).
+ */
+#ifndef RACON_HOST_H_
+#define RACON_HOST_H_
+
+#include <stdint.h>
+#include "racon_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rcnh_polisher rcnh_polisher;
+
+typedef struct rcnh_params {
+    uint32_t type;               /* 0 = kC contig polishing, 1 = kF fragment correction (polisher.hpp:28-31) */
+    uint32_t window_length;      /* -w */
+    double   quality_threshold;  /* -q */
+    double   error_threshold;    /* -e */
+    uint8_t  trim;               /* !--no-trimming */
+    int8_t   match, mismatch, gap;
+    uint32_t num_threads;        /* -t */
+    uint32_t hip_batches;        /* -c: engines per device (0 = 1) */
+} rcnh_params;
+
+/* createPolisher (reference src/polisher.cpp:57-163) */
+int  rcnh_polisher_create(const char* sequences_path, const char* overlaps_path, const char* target_path,
+                          const rcnh_params* params, rcnh_polisher** out);
+/* Polisher::initialize (reference src/polisher.cpp:190-464) */
+int  rcnh_polisher_initialize(rcnh_polisher* p);
+/* All windows as one packed batch; pointers stay valid until assemble/destroy. */
+int  rcnh_polisher_windows(rcnh_polisher* p, rcn_batch* out);
+/* Stitch per-window results (same order as the batch) into FASTA text
+ * ">name tags\nsequence\n..." exactly as reference src/main.cpp:159-161 prints it. */
+int  rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* results, int drop_unpolished_sequences,
+                            const char** fasta, uint64_t* fasta_length);
+/* Polisher::polish on the MI355X (loads libracon_hip.so; fails without a device) + FASTA text. */
+int  rcnh_polisher_polish(rcnh_polisher* p, int drop_unpolished_sequences, const char** fasta, uint64_t* fasta_length);
+void rcnh_polisher_destroy(rcnh_polisher* p);
+
+/* Pairwise global alignment used for overlaps without CIGAR (reference src/overlap.cpp:205-224).
+ * Writes a NUL-terminated CIGAR into a malloc'ed buffer (*cigar, release with rcnh_free). */
+int  rcnh_align_cigar(const char* query, uint32_t query_length, const char* target, uint32_t target_length, char** cigar);
+/* Global edit distance (the test helper of reference test/racon_test.cpp:14-23). */
+uint64_t rcnh_edit_distance(const char* query, uint64_t query_length, const char* target, uint64_t target_length);
+void rcnh_free(void* p);
+
+const char* rcnh_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RACON_HOST_H_ */

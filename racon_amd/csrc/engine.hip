@@ -378,6 +378,12 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
     return RCN_OK;
 }
 
+int rcn_engine_set_trim(rcn_engine* e, int trim) {
+    if (!e) return RCN_E_ARG;
+    e->cfg.trim = trim ? 1 : 0;
+    return RCN_OK;
+}
+
 // ---- incremental form (CUDABatchProcessor::addWindow & co.) ----------------
 int rcn_engine_add_window(rcn_engine* e, const rcn_window_desc* w) {
     if (!e || !w || w->n_seqs == 0 || !w->seq || !w->seq_len || !w->begin || !w->end) return RCN_E_ARG;

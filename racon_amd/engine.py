@@ -38,7 +38,7 @@ class RcnWindowDesc(C.Structure):
 
 
 EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_engine_run", "rcn_engine_result",
-           "rcn_engine_stats", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
+           "rcn_engine_stats", "rcn_engine_set_trim", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version"]
 
 _lib = None
@@ -60,6 +60,7 @@ def load_library():
     lib.rcn_engine_run.argtypes = [C.c_void_p]
     lib.rcn_engine_result.argtypes = [C.c_void_p, C.POINTER(RcnResult)]
     lib.rcn_engine_stats.argtypes = [C.c_void_p, C.POINTER(RcnRunStats)]
+    lib.rcn_engine_set_trim.argtypes = [C.c_void_p, C.c_int]
     lib.rcn_engine_add_window.argtypes = [C.c_void_p, C.POINTER(RcnWindowDesc)]
     lib.rcn_engine_has_windows.argtypes = [C.c_void_p]
     lib.rcn_engine_generate_consensus.argtypes = [C.c_void_p]

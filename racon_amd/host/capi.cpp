@@ -1,0 +1,99 @@
+// capi.cpp — C ABI of the host layer (include/racon_host.h).
+#include "../../include/racon_host.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "fatal.hpp"
+#include "hip_engine.hpp"
+#include "nw_path.hpp"
+#include "polisher.hpp"
+#include "sequence.hpp"
+
+struct rcnh_polisher {
+    std::unique_ptr<racon::Polisher> polisher;
+    racon::PackedBatch batch;
+    std::string fasta;
+};
+
+namespace {
+thread_local std::string g_error;
+template <class F>
+int guarded(F fn) {
+    racon::set_fatal_throws(true);
+    try { fn(); return 0; }
+    catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+void to_fasta(const std::vector<std::unique_ptr<racon::Sequence>>& seqs, std::string* out) {
+    out->clear();
+    for (const auto& s : seqs) { *out += ">"; *out += s->name(); *out += "\n"; *out += s->data(); *out += "\n"; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* rcnh_last_error(void) { return g_error.c_str(); }
+
+int rcnh_polisher_create(const char* sequences_path, const char* overlaps_path, const char* target_path,
+                         const rcnh_params* q, rcnh_polisher** out) {
+    if (!sequences_path || !overlaps_path || !target_path || !q || !out) { g_error = "invalid argument"; return -1; }
+    return guarded([&] {
+        auto p = racon::createPolisher(sequences_path, overlaps_path, target_path,
+            static_cast<racon::PolisherType>(q->type), q->window_length, q->quality_threshold, q->error_threshold,
+            q->trim != 0, q->match, q->mismatch, q->gap, q->num_threads, q->hip_batches);
+        *out = new rcnh_polisher{std::move(p), {}, {}};
+    });
+}
+
+int rcnh_polisher_initialize(rcnh_polisher* p) {
+    if (!p) { g_error = "invalid argument"; return -1; }
+    return guarded([&] { p->polisher->initialize(); });
+}
+
+int rcnh_polisher_windows(rcnh_polisher* p, rcn_batch* out) {
+    if (!p || !out) { g_error = "invalid argument"; return -1; }
+    return guarded([&] { p->polisher->pack_windows(&p->batch); *out = p->batch.view(); });
+}
+
+int rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* r, int drop, const char** fasta, uint64_t* len) {
+    if (!p || !r || !fasta || !len) { g_error = "invalid argument"; return -1; }
+    return guarded([&] {
+        if (r->n_windows != p->polisher->num_windows()) throw std::runtime_error("result/window count mismatch");
+        std::vector<std::string> cons(r->n_windows);
+        for (uint32_t w = 0; w < r->n_windows; ++w)
+            cons[w].assign(reinterpret_cast<const char*>(r->cons + r->cons_off[w]), r->cons_off[w + 1] - r->cons_off[w]);
+        std::vector<std::unique_ptr<racon::Sequence>> dst;
+        p->polisher->assemble([&](uint64_t i) -> const std::string& { return cons[i]; },
+                              [&](uint64_t i) { return r->polished[i] != 0; }, dst, drop != 0);
+        to_fasta(dst, &p->fasta);
+        *fasta = p->fasta.c_str(); *len = p->fasta.size();
+    });
+}
+
+int rcnh_polisher_polish(rcnh_polisher* p, int drop, const char** fasta, uint64_t* len) {
+    if (!p || !fasta || !len) { g_error = "invalid argument"; return -1; }
+    return guarded([&] {
+        std::vector<std::unique_ptr<racon::Sequence>> dst;
+        p->polisher->polish(dst, drop != 0);
+        to_fasta(dst, &p->fasta);
+        *fasta = p->fasta.c_str(); *len = p->fasta.size();
+    });
+}
+
+void rcnh_polisher_destroy(rcnh_polisher* p) { delete p; }
+
+int rcnh_align_cigar(const char* q, uint32_t ql, const char* t, uint32_t tl, char** cigar) {
+    if (!cigar || (!q && ql) || (!t && tl)) { g_error = "invalid argument"; return -1; }
+    return guarded([&] {
+        const std::string c = racon::nwpath::align_cigar(q, ql, t, tl);
+        *cigar = static_cast<char*>(malloc(c.size() + 1));
+        memcpy(*cigar, c.c_str(), c.size() + 1);
+    });
+}
+
+uint64_t rcnh_edit_distance(const char* q, uint64_t ql, const char* t, uint64_t tl) { return racon::nwpath::edit_distance(q, ql, t, tl); }
+
+void rcnh_free(void* p) { free(p); }
+
+}  // extern "C"

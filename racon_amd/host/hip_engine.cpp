@@ -1,0 +1,140 @@
+#include "hip_engine.hpp"
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "fatal.hpp"
+#include "window.hpp"
+
+namespace racon {
+
+namespace {
+
+// Entry points of include/racon_hip.h, bound once per process.
+struct Abi {
+    void* lib = nullptr;
+    std::string error;
+    decltype(&rcn_engine_create) create = nullptr;
+    decltype(&rcn_engine_destroy) destroy = nullptr;
+    decltype(&rcn_engine_upload) upload = nullptr;
+    decltype(&rcn_engine_run) run = nullptr;
+    decltype(&rcn_engine_result) result = nullptr;
+    decltype(&rcn_engine_stats) stats = nullptr;
+    decltype(&rcn_engine_set_trim) set_trim = nullptr;
+    decltype(&rcn_device_count) device_count = nullptr;
+    decltype(&rcn_strerror) strerror_ = nullptr;
+};
+
+std::string self_directory() {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&self_directory), &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        const size_t s = p.rfind('/');
+        if (s != std::string::npos) return p.substr(0, s);
+    }
+    return ".";
+}
+
+const Abi& abi() {
+    static Abi a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> candidates;
+        if (const char* env = getenv("RACON_HIP_LIB")) candidates.emplace_back(env);
+        const std::string here = self_directory();
+        candidates.push_back(here + "/../csrc/libracon_hip.so");
+        candidates.push_back(here + "/libracon_hip.so");
+        candidates.emplace_back("libracon_hip.so");
+        for (const auto& c : candidates) {
+            a.lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+            a.error += std::string(a.error.empty() ? "" : "; ") + dlerror();
+        }
+        if (!a.lib) return;
+#define RCN_BIND(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); \
+        if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
+        RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
+        RCN_BIND(run, "rcn_engine_run") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
+        RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
+#undef RCN_BIND
+    });
+    return a;
+}
+
+}  // namespace
+
+void PackedBatch::clear() {
+    win_seq_off.assign(1, 0); seq_off.assign(1, 0);
+    win_type.clear(); seq_has_qual.clear(); seq_begin.clear(); seq_end.clear(); bases.clear(); quals.clear();
+}
+
+void PackedBatch::add(const Window& w) {
+    for (size_t i = 0; i < w.sequences_.size(); ++i) {
+        const char* s = w.sequences_[i].first; const uint32_t n = w.sequences_[i].second;
+        const char* q = w.qualities_[i].first;
+        bases.insert(bases.end(), s, s + n);
+        if (q) quals.insert(quals.end(), q, q + n); else quals.insert(quals.end(), n, static_cast<uint8_t>('!'));
+        seq_has_qual.push_back(q ? 1 : 0);
+        seq_begin.push_back(w.positions_[i].first); seq_end.push_back(w.positions_[i].second);
+        seq_off.push_back(bases.size());
+    }
+    win_type.push_back(w.type_ == WindowType::kTGS ? 1 : 0);
+    win_seq_off.push_back(static_cast<uint32_t>(seq_has_qual.size()));
+}
+
+rcn_batch PackedBatch::view() const {
+    static const uint8_t kNone = 0;
+    rcn_batch b{};
+    b.n_windows = n_windows(); b.n_seqs = static_cast<uint32_t>(seq_has_qual.size());
+    b.win_seq_off = win_seq_off.data(); b.win_type = win_type.empty() ? &kNone : win_type.data();
+    b.seq_off = seq_off.data(); b.seq_has_qual = seq_has_qual.empty() ? &kNone : seq_has_qual.data();
+    static const uint32_t kZero = 0;
+    b.seq_begin = seq_begin.empty() ? &kZero : seq_begin.data(); b.seq_end = seq_end.empty() ? &kZero : seq_end.data();
+    b.bases = bases.empty() ? &kNone : bases.data(); b.quals = quals.empty() ? &kNone : quals.data();
+    return b;
+}
+
+int32_t HipEngine::DeviceCount() {
+    const Abi& a = abi();
+    return a.lib ? a.device_count() : 0;
+}
+
+std::shared_ptr<HipEngine> HipEngine::Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap) {
+    const Abi& a = abi();
+    if (!a.lib)
+        fatal("[racon::HipEngine::Create] error: unable to load libracon_hip.so (" + a.error +
+              "); the consensus stage has no CPU fallback!");
+    rcn_engine_config cfg{};
+    cfg.device = device; cfg.match = match; cfg.mismatch = mismatch; cfg.gap = gap; cfg.trim = 1;
+    std::shared_ptr<HipEngine> e(new HipEngine());
+    const int rc = a.create(&cfg, &e->handle_);
+    if (rc != RCN_OK)
+        fatal(std::string("[racon::HipEngine::Create] error: ") + a.strerror_(rc) + "!");
+    return e;
+}
+
+HipEngine::~HipEngine() { if (handle_) abi().destroy(handle_); }
+
+void HipEngine::consensus(const PackedBatch& batch, bool trim, std::vector<std::string>* consensus,
+                          std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
+    const Abi& a = abi();
+    const rcn_batch b = batch.view();
+    int rc = a.set_trim(handle_, trim ? 1 : 0);
+    if (rc == RCN_OK) rc = a.upload(handle_, &b);
+    if (rc == RCN_OK) rc = a.run(handle_);
+    rcn_result r{};
+    if (rc == RCN_OK) rc = a.result(handle_, &r);
+    if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::consensus] error: ") + a.strerror_(rc) + "!");
+    rcn_run_stats st{};
+    if (a.stats(handle_, &st) == RCN_OK) last_kernel_ms_ = st.kernel_ms;
+    consensus->resize(r.n_windows); polished->resize(r.n_windows); chimeric->resize(r.n_windows);
+    for (uint32_t w = 0; w < r.n_windows; ++w) {
+        (*consensus)[w].assign(reinterpret_cast<const char*>(r.cons + r.cons_off[w]), r.cons_off[w + 1] - r.cons_off[w]);
+        (*polished)[w] = r.polished[w]; (*chimeric)[w] = r.chimeric[w];
+    }
+}
+
+}  // namespace racon

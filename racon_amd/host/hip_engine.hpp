@@ -1,0 +1,60 @@
+// hip_engine.hpp — C++ face of the C ABI in include/racon_hip.h.
+//
+// racon::HipEngine stands where the reference has spoa::AlignmentEngine (one per
+// worker, reference src/polisher.cpp:179-183) and CUDABatchProcessor (one per
+// device batch, reference src/cuda/cudabatch.hpp:27-122): it owns one engine
+// handle bound to one device + stream and is NOT thread safe.  The shared
+// library libracon_hip.so is resolved at run time (dlopen), so this host layer
+// builds and loads on machines without a GPU; any attempt to compute without the
+// library or without a device is a fatal error — there is no CPU fallback.
+//
+// racon::PackedBatch is the flat `rcn_batch` the ABI consumes, filled from
+// Window objects (what CUDABatchProcessor::addWindow extracts, reference
+// src/cuda/cudabatch.cpp:80-122, plus positions_.second / type, which it drops).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/racon_hip.h"
+
+namespace racon {
+
+class Window;
+
+struct PackedBatch {
+    std::vector<uint32_t> win_seq_off{0};
+    std::vector<uint8_t> win_type;
+    std::vector<uint64_t> seq_off{0};
+    std::vector<uint8_t> seq_has_qual;
+    std::vector<uint32_t> seq_begin, seq_end;
+    std::vector<uint8_t> bases, quals;
+
+    void add(const Window& w);
+    void clear();
+    uint32_t n_windows() const { return static_cast<uint32_t>(win_type.size()); }
+    uint64_t n_bases() const { return bases.size(); }
+    rcn_batch view() const;           // pointers into this object
+};
+
+class HipEngine {
+public:
+    // Fatal (racon::fatal) when the library or the device is missing.
+    static std::shared_ptr<HipEngine> Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap);
+    static int32_t DeviceCount();      // 0 when the library cannot be loaded or no device is visible
+    ~HipEngine();
+
+    // Consensus of every window of `batch` (inputs are copied to HBM, results copied back).
+    void consensus(const PackedBatch& batch, bool trim, std::vector<std::string>* consensus,
+                   std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    double last_kernel_ms() const { return last_kernel_ms_; }
+
+private:
+    HipEngine() = default;
+    HipEngine(const HipEngine&) = delete;
+    rcn_engine* handle_ = nullptr;
+    double last_kernel_ms_ = 0;
+};
+
+}  // namespace racon

@@ -1,0 +1,342 @@
+#include "polisher.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <iostream>
+#include <thread>
+#include <unordered_map>
+
+#include "fatal.hpp"
+#include "hip_engine.hpp"
+#include "overlap.hpp"
+#include "parsers.hpp"
+#include "sequence.hpp"
+
+namespace racon {
+
+// ---------------------------------------------------------------- fatal / logger
+namespace { bool g_fatal_throws = false; }
+void set_fatal_throws(bool on) { g_fatal_throws = on; }
+void fatal(const std::string& message) {
+    if (g_fatal_throws) throw FatalError(message);
+    fprintf(stderr, "%s\n", message.c_str());
+    exit(1);
+}
+
+namespace {
+double seconds_since(const std::chrono::time_point<std::chrono::steady_clock>& t) {
+    return std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t).count();
+}
+
+// fn(i) for i in [0, n) on `threads` host threads (dynamic distribution)
+template <class F>
+void parallel_for(uint64_t n, uint32_t threads, F fn) {
+    threads = std::max<uint32_t>(1, std::min<uint64_t>(threads, n));
+    if (threads == 1) { for (uint64_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < threads; ++t)
+        pool.emplace_back([&] { for (uint64_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& t : pool) t.join();
+}
+}  // namespace
+
+void Logger::log() {
+    const auto now = std::chrono::steady_clock::now();
+    if (time_point_ != std::chrono::time_point<std::chrono::steady_clock>())
+        time_ += std::chrono::duration_cast<std::chrono::duration<double>>(now - time_point_).count();
+    time_point_ = now;
+}
+void Logger::log(const std::string& msg) const { std::cerr << msg << " " << std::fixed << seconds_since(time_point_) << " s" << std::endl; }
+void Logger::bar(const std::string& msg) {
+    ++bar_;
+    std::cerr << msg << " [" << std::string(bar_, '=') << (bar_ == 20 ? "" : ">" + std::string(19 - bar_, ' ')) << "] "
+              << std::fixed << seconds_since(time_point_) << " s";
+    bar_ %= 20;
+    std::cerr << (bar_ == 0 ? "\n" : "\r") << std::flush;
+}
+void Logger::total(const std::string& msg) const { std::cerr << msg << " " << std::fixed << time_ + seconds_since(time_point_) << " s" << std::endl; }
+
+// ---------------------------------------------------------------- factory
+std::unique_ptr<Polisher> createPolisher(const std::string& sequences_path, const std::string& overlaps_path,
+    const std::string& target_path, PolisherType type, uint32_t window_length, double quality_threshold,
+    double error_threshold, bool trim, int8_t match, int8_t mismatch, int8_t gap, uint32_t num_threads,
+    uint32_t cudapoa_batches, bool cuda_banded_alignment, uint32_t cudaaligner_batches, uint32_t cudaaligner_band_width) {
+    (void)cuda_banded_alignment; (void)cudaaligner_batches; (void)cudaaligner_band_width;
+    if (type != PolisherType::kC && type != PolisherType::kF) fatal("[racon::createPolisher] error: invalid polisher type!");
+    if (window_length == 0) fatal("[racon::createPolisher] error: invalid window length!");
+    const std::string seq_ext = "(valid extensions: .fasta, .fasta.gz, .fna, .fna.gz, .fa, .fa.gz, .fastq, .fastq.gz, .fq, .fq.gz)!";
+    if (!io::is_fasta_path(sequences_path) && !io::is_fastq_path(sequences_path))
+        fatal("[racon::createPolisher] error: file " + sequences_path + " has unsupported format extension " + seq_ext);
+    bool ovl_ok = false;
+    for (const char* e : {".mhap", ".mhap.gz", ".paf", ".paf.gz", ".sam", ".sam.gz"}) ovl_ok |= io::has_suffix(overlaps_path, e);
+    if (!ovl_ok)
+        fatal("[racon::createPolisher] error: file " + overlaps_path + " has unsupported format extension "
+              "(valid extensions: .mhap, .mhap.gz, .paf, .paf.gz, .sam, .sam.gz)!");
+    if (!io::is_fasta_path(target_path) && !io::is_fastq_path(target_path))
+        fatal("[racon::createPolisher] error: file " + target_path + " has unsupported format extension " + seq_ext);
+    return std::unique_ptr<Polisher>(new Polisher(sequences_path, overlaps_path, target_path, type, window_length,
+        quality_threshold, error_threshold, trim, match, mismatch, gap, num_threads, cudapoa_batches));
+}
+
+Polisher::Polisher(const std::string& sequences_path, const std::string& overlaps_path, const std::string& target_path,
+                   PolisherType type, uint32_t window_length, double quality_threshold, double error_threshold, bool trim,
+                   int8_t match, int8_t mismatch, int8_t gap, uint32_t num_threads, uint32_t hip_batches)
+        : sequences_path_(sequences_path), overlaps_path_(overlaps_path), target_path_(target_path), type_(type),
+          quality_threshold_(quality_threshold), error_threshold_(error_threshold), trim_(trim), match_(match),
+          mismatch_(mismatch), gap_(gap), num_threads_(std::max<uint32_t>(1, num_threads)),
+          hip_batches_(std::max<uint32_t>(1, hip_batches)), dummy_quality_(window_length, '!'),
+          window_length_(window_length), logger_(new Logger()) {}
+
+Polisher::~Polisher() { logger_->total("[racon::Polisher::] total ="); }
+
+// ---------------------------------------------------------------- initialize
+namespace {
+void load_sequences(const std::string& path, std::vector<std::unique_ptr<Sequence>>& dst) {
+    auto take = [&](const io::SeqRecord& r) {
+        dst.emplace_back(r.qual ? new Sequence(r.name, r.name_len, r.data, r.data_len, r.qual, r.qual_len)
+                                : new Sequence(r.name, r.name_len, r.data, r.data_len));
+    };
+    try {
+        if (io::is_fastq_path(path)) io::read_fastq(path, take); else io::read_fasta(path, take);
+    } catch (const std::runtime_error& e) { fatal(e.what()); }
+}
+
+void load_overlaps(const std::string& path, std::vector<std::unique_ptr<Overlap>>& dst) {
+    try {
+        if (io::has_suffix(path, ".mhap") || io::has_suffix(path, ".mhap.gz"))
+            io::read_mhap(path, [&](const io::MhapRecord& r) { dst.emplace_back(new Overlap(r)); });
+        else if (io::has_suffix(path, ".paf") || io::has_suffix(path, ".paf.gz"))
+            io::read_paf(path, [&](const io::PafRecord& r) { dst.emplace_back(new Overlap(r)); });
+        else
+            io::read_sam(path, [&](const io::SamRecord& r) { dst.emplace_back(new Overlap(r)); });
+    } catch (const FatalError&) { throw; } catch (const std::runtime_error& e) { fatal(e.what()); }
+}
+}  // namespace
+
+void Polisher::initialize() {
+    if (!windows_.empty()) {
+        fprintf(stderr, "[racon::Polisher::initialize] warning: object already initialized!\n");
+        return;
+    }
+    logger_->log();
+
+    // ---- targets (reference src/polisher.cpp:200-221)
+    load_sequences(target_path_, sequences_);
+    const uint64_t targets_size = sequences_.size();
+    if (targets_size == 0) fatal("[racon::Polisher::initialize] error: empty target sequences set!");
+    std::unordered_map<std::string, uint64_t> name_to_id;     // "<name>t" / "<name>q" -> index in sequences_
+    std::unordered_map<uint64_t, uint64_t> id_to_id;          // (ordinal << 1 | is_target) -> index (MHAP numeric ids)
+    for (uint64_t i = 0; i < targets_size; ++i) { name_to_id[sequences_[i]->name() + "t"] = i; id_to_id[i << 1 | 1] = i; }
+    logger_->log("[racon::Polisher::initialize] loaded target sequences");
+    logger_->log();
+
+    // ---- reads; a read that is also a target is stored once (reference src/polisher.cpp:223-278)
+    uint64_t sequences_size = 0, total_sequences_length = 0;
+    {
+        std::vector<std::unique_ptr<Sequence>> reads;
+        load_sequences(sequences_path_, reads);
+        for (auto& read : reads) {
+            total_sequences_length += read->data().size();
+            const auto it = name_to_id.find(read->name() + "t");
+            uint64_t index;
+            if (it != name_to_id.end()) {
+                const auto& twin = sequences_[it->second];
+                if (read->data().size() != twin->data().size() || read->quality().size() != twin->quality().size())
+                    fatal("[racon::Polisher::initialize] error: duplicate sequence " + read->name() + " with unequal data");
+                index = it->second;
+            } else {
+                index = sequences_.size();
+                sequences_.emplace_back(std::move(read));
+            }
+            name_to_id[sequences_[index]->name() + "q"] = index;
+            id_to_id[sequences_size << 1 | 0] = index;
+            ++sequences_size;
+        }
+    }
+    if (sequences_size == 0) fatal("[racon::Polisher::initialize] error: empty sequences set!");
+    const WindowType window_type = static_cast<double>(total_sequences_length) / sequences_size <= 1000 ? WindowType::kNGS : WindowType::kTGS;
+    logger_->log("[racon::Polisher::initialize] loaded sequences");
+    logger_->log();
+
+    // ---- overlaps: resolve ids, then filter each run of consecutive overlaps of one query
+    //      (reference src/polisher.cpp:283-358)
+    std::vector<std::unique_ptr<Overlap>> overlaps;
+    load_overlaps(overlaps_path_, overlaps);
+    auto filter_group = [&](uint64_t begin, uint64_t end) {
+        for (uint64_t i = begin; i < end; ++i) {
+            if (!overlaps[i]) continue;
+            if (overlaps[i]->error() > error_threshold_ || overlaps[i]->q_id() == overlaps[i]->t_id()) { overlaps[i].reset(); continue; }
+            if (type_ != PolisherType::kC) continue;
+            // contig mode keeps one overlap per read: the longest, decided by pairwise duels in file order
+            for (uint64_t j = i + 1; j < end; ++j) {
+                if (!overlaps[j]) continue;
+                if (overlaps[i]->length() >= overlaps[j]->length()) overlaps[j].reset();
+                else { overlaps[i].reset(); break; }
+            }
+        }
+    };
+    {
+        uint64_t group = 0;
+        for (uint64_t i = 0; i < overlaps.size(); ++i) {
+            overlaps[i]->transmute(sequences_, name_to_id, id_to_id);
+            if (!overlaps[i]->is_valid()) { overlaps[i].reset(); continue; }
+            while (!overlaps[group]) ++group;
+            if (overlaps[group]->q_id() != overlaps[i]->q_id()) { filter_group(group, i); group = i; }
+        }
+        filter_group(group, overlaps.size());
+        overlaps.erase(std::remove(overlaps.begin(), overlaps.end(), nullptr), overlaps.end());
+    }
+    std::vector<bool> has_name(sequences_.size(), false), has_data(sequences_.size(), false), has_reverse_data(sequences_.size(), false);
+    for (uint64_t i = 0; i < targets_size; ++i) has_name[i] = has_data[i] = true;
+    for (const auto& o : overlaps) { if (o->strand()) has_reverse_data[o->q_id()] = true; else has_data[o->q_id()] = true; }
+    std::unordered_map<std::string, uint64_t>().swap(name_to_id);
+    std::unordered_map<uint64_t, uint64_t>().swap(id_to_id);
+    if (overlaps.empty()) fatal("[racon::Polisher::initialize] error: empty overlap set!");
+    logger_->log("[racon::Polisher::initialize] loaded overlaps");
+    logger_->log();
+
+    parallel_for(sequences_.size(), num_threads_, [&](uint64_t j) { sequences_[j]->transmute(has_name[j], has_data[j], has_reverse_data[j]); });
+
+    find_overlap_breaking_points(overlaps);
+    logger_->log();
+
+    // ---- windows over every target (reference src/polisher.cpp:388-403)
+    std::vector<uint64_t> first_window(targets_size + 1, 0);
+    for (uint64_t i = 0; i < targets_size; ++i) {
+        const std::string& data = sequences_[i]->data();
+        const std::string& quality = sequences_[i]->quality();
+        uint32_t k = 0;
+        for (uint32_t j = 0; j < data.size(); j += window_length_, ++k) {
+            const uint32_t length = std::min(j + window_length_, static_cast<uint32_t>(data.size())) - j;
+            windows_.emplace_back(createWindow(i, k, window_type, &data[j], length,
+                                               quality.empty() ? &dummy_quality_[0] : &quality[j], length));
+        }
+        first_window[i + 1] = first_window[i] + k;
+    }
+
+    // ---- layers (reference src/polisher.cpp:405-461): serial, in overlap order
+    targets_coverages_.assign(targets_size, 0);
+    for (auto& o : overlaps) {
+        ++targets_coverages_[o->t_id()];
+        const auto& sequence = sequences_[o->q_id()];
+        const auto& bp = o->breaking_points();
+        const bool rev = o->strand() != 0;
+        const std::string& bases = rev ? sequence->reverse_complement() : sequence->data();
+        const std::string& quality = rev ? sequence->reverse_quality() : sequence->quality();
+        const bool read_has_quality = !sequence->quality().empty() || !sequence->reverse_quality().empty();
+        for (uint32_t j = 0; j + 1 < bp.size(); j += 2) {
+            const uint32_t q0 = bp[j].second, q1 = bp[j + 1].second;
+            if (q1 - q0 < 0.02 * window_length_) continue;
+            if (read_has_quality) {
+                double average_quality = 0;
+                for (uint32_t k = q0; k < q1; ++k) average_quality += static_cast<uint32_t>(quality[k]) - 33;
+                average_quality /= q1 - q0;
+                if (average_quality < quality_threshold_) continue;
+            }
+            const uint32_t window_rank = bp[j].first / window_length_;
+            const uint32_t window_start = window_rank * window_length_;
+            const char* q = quality.empty() ? nullptr : &quality[q0];
+            windows_[first_window[o->t_id()] + window_rank]->add_layer(&bases[q0], q1 - q0, q, q ? q1 - q0 : 0,
+                bp[j].first - window_start, bp[j + 1].first - window_start - 1);
+        }
+        o.reset();
+    }
+    logger_->log("[racon::Polisher::initialize] transformed data into windows");
+}
+
+void Polisher::find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>>& overlaps) {
+    parallel_for(overlaps.size(), num_threads_, [&](uint64_t j) { overlaps[j]->find_breaking_points(sequences_, window_length_); });
+    logger_->log("[racon::Polisher::initialize] aligned overlaps");
+}
+
+// ---------------------------------------------------------------- polish
+void Polisher::pack_windows(PackedBatch* out) const {
+    out->clear();
+    for (const auto& w : windows_) out->add(*w);
+}
+
+void Polisher::assemble(const std::function<const std::string&(uint64_t)>& consensus, const std::function<bool(uint64_t)>& polished,
+                        std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {
+    std::string polished_data;
+    uint32_t num_polished_windows = 0;
+    for (uint64_t i = 0; i < windows_.size(); ++i) {
+        num_polished_windows += polished(i) ? 1 : 0;
+        polished_data += consensus(i);
+        if (i == windows_.size() - 1 || windows_[i + 1]->rank() == 0) {       // last window of this target
+            const double polished_ratio = num_polished_windows / static_cast<double>(windows_[i]->rank() + 1);
+            if (!drop_unpolished_sequences || polished_ratio > 0) {
+                std::string tags = type_ == PolisherType::kF ? "r" : "";
+                tags += " LN:i:" + std::to_string(polished_data.size());
+                tags += " RC:i:" + std::to_string(targets_coverages_[windows_[i]->id()]);
+                tags += " XC:f:" + std::to_string(polished_ratio);
+                dst.emplace_back(createSequence(sequences_[windows_[i]->id()]->name() + tags, polished_data));
+            }
+            num_polished_windows = 0;
+            polished_data.clear();
+        }
+        windows_[i].reset();
+    }
+    std::vector<std::shared_ptr<Window>>().swap(windows_);
+    std::vector<std::unique_ptr<Sequence>>().swap(sequences_);
+}
+
+void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {
+    logger_->log();
+    const int32_t n_devices = HipEngine::DeviceCount();
+    if (n_devices <= 0)
+        fatal("[racon::Polisher::polish] error: no MI355X device / libracon_hip.so available (the consensus stage has no CPU fallback)!");
+
+    // contiguous chunks of the window index space; engines pull them from a shared cursor
+    // (reference src/cuda/cudapolisher.cpp:254-276 hands out ranges the same way)
+    constexpr uint64_t kMaxChunkWindows = 16384, kMaxChunkBases = 512ull << 20;
+    const uint64_t nw = windows_.size();
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    const uint32_t n_engines = static_cast<uint32_t>(n_devices) * hip_batches_;
+    {
+        uint64_t total = 0;
+        for (const auto& w : windows_) total += w->num_sequences();
+        const uint64_t target = std::max<uint64_t>(2048, std::min<uint64_t>(kMaxChunkWindows, (nw + n_engines - 1) / n_engines));
+        for (uint64_t a = 0; a < nw;) {
+            uint64_t b = a, bases = 0;
+            while (b < nw && b - a < target && bases < kMaxChunkBases) { bases += 600ull * windows_[b]->num_sequences(); ++b; }
+            chunks.emplace_back(a, b); a = b;
+        }
+    }
+    std::vector<std::string> cons(nw);
+    std::vector<uint8_t> pol(nw, 0), chim(nw, 0);
+    std::atomic<size_t> cursor{0};
+    std::vector<std::string> errors(n_engines);
+    auto worker = [&](uint32_t k) {
+        try {
+            auto engine = HipEngine::Create(static_cast<int32_t>(k % n_devices), match_, mismatch_, gap_);
+            PackedBatch batch;
+            std::vector<std::string> c; std::vector<uint8_t> p, h;
+            for (size_t ci; (ci = cursor.fetch_add(1)) < chunks.size();) {
+                batch.clear();
+                for (uint64_t i = chunks[ci].first; i < chunks[ci].second; ++i) batch.add(*windows_[i]);
+                engine->consensus(batch, trim_, &c, &p, &h);
+                for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { cons[i].swap(c[j]); pol[i] = p[j]; chim[i] = h[j]; }
+            }
+        } catch (const std::exception& e) { errors[k] = e.what(); }
+    };
+    const bool throws = g_fatal_throws;
+    set_fatal_throws(true);                     // engine threads report through `errors`
+    {
+        std::vector<std::thread> pool;
+        for (uint32_t k = 0; k < std::min<uint32_t>(n_engines, std::max<size_t>(1, chunks.size())); ++k) pool.emplace_back(worker, k);
+        for (auto& t : pool) t.join();
+    }
+    set_fatal_throws(throws);
+    for (const auto& e : errors) if (!e.empty()) fatal(e);
+
+    for (uint64_t i = 0; i < nw; ++i)
+        if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
+                             static_cast<unsigned long>(windows_[i]->id()), windows_[i]->rank());
+    assemble([&](uint64_t i) -> const std::string& { return cons[i]; }, [&](uint64_t i) { return pol[i] != 0; },
+             dst, drop_unpolished_sequences);
+    logger_->log("[racon::Polisher::polish] generated consensus");
+}
+
+}  // namespace racon

@@ -1,0 +1,94 @@
+// polisher.hpp — racon::Polisher (reference src/polisher.hpp:33-99,
+// src/polisher.cpp): parse targets / reads / overlaps, filter overlaps, cut
+// reads into per-window layers, then polish every window and stitch the
+// consensi per target.  Same factory signature, same two public calls, same
+// output naming as the reference, so callers (reference src/main.cpp:147-161,
+// test/racon_test.cpp:25-51) keep working.  What differs is where
+// Window::generate_consensus runs: polish() batches the windows to the MI355X
+// engines (one or more per device) the way the reference's CUDAPolisher::polish
+// does (src/cuda/cudapolisher.cpp:216-413) — with the CPU path's exact results
+// and no CPU fallback.
+#pragma once
+#include <chrono>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "window.hpp"
+
+namespace racon {
+
+class Sequence;
+class Overlap;
+struct PackedBatch;
+
+enum class PolisherType { kC, kF };   // contig polishing / fragment error correction
+
+class Polisher;
+// `cudapoa_batches` keeps its place in the signature (reference src/polisher.hpp:42-48):
+// here it is the number of HIP engines (batches in flight) per device, 0 meaning 1.
+// `cuda_banded_alignment`, `cudaaligner_batches`, `cudaaligner_band_width` are accepted and
+// ignored: the DP is exact/unbanded and the pre-alignment stays on the host.
+std::unique_ptr<Polisher> createPolisher(const std::string& sequences_path, const std::string& overlaps_path,
+    const std::string& target_path, PolisherType type, uint32_t window_length, double quality_threshold,
+    double error_threshold, bool trim, int8_t match, int8_t mismatch, int8_t gap, uint32_t num_threads,
+    uint32_t cudapoa_batches = 0, bool cuda_banded_alignment = false, uint32_t cudaaligner_batches = 0,
+    uint32_t cudaaligner_band_width = 0);
+
+class Logger {                          // reference src/logger.cpp:20-54
+public:
+    void log();
+    void log(const std::string& msg) const;
+    void bar(const std::string& msg);
+    void total(const std::string& msg) const;
+private:
+    double time_ = 0; uint32_t bar_ = 0;
+    std::chrono::time_point<std::chrono::steady_clock> time_point_{};
+};
+
+class Polisher {
+public:
+    virtual ~Polisher();
+    virtual void initialize();
+    virtual void polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences);
+
+    // --- the two halves of polish(), exposed for the parity harness ------------------
+    // All windows, flattened (the bytes every consensus backend consumes).
+    void pack_windows(PackedBatch* out) const;
+    // Per-target concatenation + tags from per-window results (reference src/polisher.cpp:505-537).
+    // consensus(i) / polished(i) are indexed like windows(); consumes the windows.
+    void assemble(const std::function<const std::string&(uint64_t)>& consensus,
+                  const std::function<bool(uint64_t)>& polished,
+                  std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences);
+    uint64_t num_windows() const { return windows_.size(); }
+    const std::vector<std::shared_ptr<Window>>& windows() const { return windows_; }
+
+    friend std::unique_ptr<Polisher> createPolisher(const std::string&, const std::string&, const std::string&, PolisherType,
+        uint32_t, double, double, bool, int8_t, int8_t, int8_t, uint32_t, uint32_t, bool, uint32_t, uint32_t);
+
+protected:
+    Polisher(const std::string& sequences_path, const std::string& overlaps_path, const std::string& target_path,
+             PolisherType type, uint32_t window_length, double quality_threshold, double error_threshold, bool trim,
+             int8_t match, int8_t mismatch, int8_t gap, uint32_t num_threads, uint32_t hip_batches);
+    Polisher(const Polisher&) = delete;
+    Polisher& operator=(const Polisher&) = delete;
+    virtual void find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>>& overlaps);
+
+    std::string sequences_path_, overlaps_path_, target_path_;
+    PolisherType type_;
+    double quality_threshold_, error_threshold_;
+    bool trim_;
+    int8_t match_, mismatch_, gap_;
+    uint32_t num_threads_, hip_batches_;
+
+    std::vector<std::unique_ptr<Sequence>> sequences_;
+    std::vector<uint32_t> targets_coverages_;
+    std::string dummy_quality_;
+    uint32_t window_length_;
+    std::vector<std::shared_ptr<Window>> windows_;
+    std::unique_ptr<Logger> logger_;
+};
+
+}  // namespace racon
