@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "../../include/racon_hip.h"
-#include "poa_kernel.hpp"
+#include "poa_kernel2.hpp"
 
 namespace {
 
@@ -83,13 +83,16 @@ int upload_vec(DevBuf& d, const void* src, size_t bytes, hipStream_t s) {
     return RCN_OK;
 }
 
-struct Caps { int32_t ncap, ecap, ring, lmax, hstride; uint64_t slot_bytes; uint64_t out_stride; };
+struct Caps { int32_t ncap, ecap, ring, lmax, hstride; uint64_t slot_bytes; uint64_t out_stride; bool fast; };
 
-Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax) {
-    Caps c; c.ncap = ncap; c.ecap = ecap; c.ring = ring; c.lmax = lmax;
-    c.hstride = (lmax + 1 + 128 + 3) & ~3;
+// fast = poa_window_kernel2 (4 waves per window, int16 Z matrix); else poa_window_kernel (1 wave, int32 H)
+Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast) {
+    Caps c; c.ncap = ncap; c.ecap = ecap; c.ring = ring; c.lmax = lmax; c.fast = fast;
+    // fast: row stride in int16 cells, a multiple of 24 (16-byte aligned rows for the tile loads AND a whole
+    // number of 2/4/6/8-cell lane blocks, so no lane's store straddles two rows)
+    c.hstride = fast ? ((lmax + 1 + 23) / 24) * 24 + 24 : (lmax + 1 + 128 + 3) & ~3;
     rcn::Win tmp;
-    c.slot_bytes = rcn::win_bind(tmp, nullptr, ncap, ecap, ring, lmax, c.hstride);
+    c.slot_bytes = rcn::win_bind(tmp, nullptr, ncap, ecap, ring, lmax, c.hstride, fast ? 2 : 4);
     c.slot_bytes = (c.slot_bytes + 255) & ~uint64_t(255);
     c.out_stride = static_cast<uint64_t>(ncap);
     return c;
@@ -99,7 +102,7 @@ Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax) {
 int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work, uint64_t out_stride) {
     if (n_work == 0) return RCN_OK;
     uint64_t budget = e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>(e->free_mem * 0.80);
-    uint32_t slots = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;
+    uint32_t slots = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;   // 8 work-groups per CU (20 KiB LDS each)
     slots = std::min(slots, n_work);
     while (slots > 1 && static_cast<uint64_t>(slots) * c.slot_bytes > budget) slots = (slots + 1) / 2;
     if (static_cast<uint64_t>(slots) * c.slot_bytes > budget) return RCN_E_CAPACITY;
@@ -124,7 +127,8 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + 16);
 
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, e->stream, P);
+    if (c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(slots), dim3(rcn::kThreads2), rcn::kLdsBytes + rcn::kCtxBytes, e->stream, P);
+    else hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, e->stream, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
@@ -285,7 +289,8 @@ int rcn_engine_run(rcn_engine* e) {
         lmax = std::max(lmax, s.lmax); nsym = std::max(nsym, s.nsym);
     }
     const int32_t ring = std::max(1, nsym - 1);
-    Caps c1 = make_caps(ncap, 2 * ncap, ring, lmax);
+    const bool fast = !getenv("RCN_WIDE_ONLY");
+    Caps c1 = make_caps(ncap, 2 * ncap, ring, lmax, fast);
     int rc;
     if ((rc = e->d_out_cons.reserve(static_cast<uint64_t>(nw) * c1.out_stride))) return rc;
     if ((rc = e->d_out_len.reserve(4ull * nw))) return rc;
@@ -319,7 +324,7 @@ int rcn_engine_run(rcn_engine* e) {
             const auto& s = e->shapes[w];
             n2 = std::max<int32_t>(n2, s.L + s.sum_l + 8); l2 = std::max(l2, s.lmax);
         }
-        Caps c2 = make_caps(n2, n2 + 8, ring, l2);
+        Caps c2 = make_caps(n2, n2 + 8, ring, l2, false);     // int32 kernel, worst-case capacities
         const uint32_t nr = static_cast<uint32_t>(retry.size());
         const uint64_t stride2 = c2.out_stride;
         // first-pass bytes are already on the host in `raw`; the retry pass indexes its outputs by work item

@@ -390,6 +390,8 @@ struct Ctx {
     int32_t plen, nn, n_old; uint32_t pred_rows;
     // statistics
     unsigned long long cells, pred, bytes, ties;
+    // work-group shared scalars of poa_window_kernel2 (work item, traceback walk state)
+    int32_t wi, tb_i, tb_j, tb_n;
 };
 static_assert(sizeof(Ctx) % 4 == 0 && sizeof(Ctx) <= 512, "Ctx must fit its LDS slot");
 constexpr int kCtxBytes = 512;
@@ -397,10 +399,23 @@ constexpr int kCtxBytes = 512;
 __device__ __forceinline__ int* lds_words() { extern __shared__ int4 lds_dyn[]; return reinterpret_cast<int*>(lds_dyn); }
 __device__ __forceinline__ Ctx* ctx_lds() { return reinterpret_cast<Ctx*>(lds_words() + kLdsBytes / 4); }
 
+// Execution policies of the shared phases.  A phase is written for NT cooperating threads with
+// ids tid() in [0, NT); sync() orders their global/LDS traffic between sub-steps.
+//   OneWaveBlock : the 64-thread workgroup of poa_window_kernel (one wave per window)
+//   (poa_kernel2.hpp adds: one wave of a 4-wave workgroup, and the whole 4-wave workgroup)
+struct OneWaveBlock {
+    static constexpr int NT = 64;
+    static __device__ __forceinline__ int tid() { return threadIdx.x; }
+    static __device__ __forceinline__ void sync() { __threadfence_block(); __syncthreads(); }
+    static __device__ __forceinline__ Ctx* ctx() { return ctx_lds(); }
+    static __device__ __forceinline__ int* work() { return lds_words(); }
+};
+
 // Loads the context from LDS and makes every dword provably wave-uniform (SGPR).
+template <class S>
 __device__ __forceinline__ Ctx ctx_load() {
     Ctx c;
-    const int* src = reinterpret_cast<const int*>(ctx_lds());
+    const int* src = reinterpret_cast<const int*>(S::ctx());
     int* dst = reinterpret_cast<int*>(&c);
 #pragma unroll
     for (int k = 0; k < static_cast<int>(sizeof(Ctx) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
@@ -415,12 +430,14 @@ __device__ __forceinline__ Win ctx_win(const Ctx& c) {
 }
 
 // ---- phase: Subgraph mask + filtered order (window.cpp:99-103) ----
+template <class S>
 __device__ __noinline__ void phase_subgraph() {
-    const int lane = threadIdx.x;
-    const Ctx c = ctx_load();
+    static_assert(S::NT == 64, "single-wave phase");
+    const int lane = S::tid();
+    const Ctx c = ctx_load<S>();
     Win g = ctx_win(c);
     if (lane == 0) graph_subgraph_mask(g, c.begin, c.end, g.stack.ptr());
-    wave_sync();
+    S::sync();
     int nv = 0;
     for (int base = 0; base < g.n_nodes; base += 64) {
         const int r = base + lane;
@@ -433,14 +450,14 @@ __device__ __noinline__ void phase_subgraph() {
         }
         nv += __popcll(mk);
     }
-    if (lane == 0) ctx_lds()->V = nv;
-    wave_sync();
+    if (lane == 0) S::ctx()->V = nv;
+    S::sync();
 }
 
 // ---- phase: row descriptors + row 0 ----
 __device__ __noinline__ void phase_desc() {
     const int lane = threadIdx.x;
-    const Ctx c = ctx_load();
+    const Ctx c = ctx_load<OneWaveBlock>();
     Win g = ctx_win(c);
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
@@ -452,7 +469,7 @@ __device__ __noinline__ void phase_desc() {
 // ---- phase: NW sequence-to-graph DP (window.cpp:95-97, 104-106) ----
 __device__ __noinline__ void phase_dp() {
     const int lane = threadIdx.x;
-    const Ctx c = ctx_load();
+    const Ctx c = ctx_load<OneWaveBlock>();
     Win g = ctx_win(c);
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
     DpState ds; ds.best = 0; ds.best_row = 0; ds.have_best = 0; ds.tied = 0; ds.pred_rows = 0;
@@ -491,7 +508,7 @@ __device__ __noinline__ void phase_dp() {
 // ---- phase: sink tie-break (rare) + traceback ----
 __device__ __noinline__ void phase_traceback() {
     const int lane = threadIdx.x;
-    const Ctx c = ctx_load();
+    const Ctx c = ctx_load<OneWaveBlock>();
     Win g = ctx_win(c);
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
     int best_row = c.best_row;
@@ -517,9 +534,11 @@ __device__ __noinline__ void phase_traceback() {
 }
 
 // ---- phase: AddAlignment, wave-parallel over sequence positions (window.cpp:110-119) ----
+template <class S>
 __device__ __noinline__ void phase_add() {
-    const int lane = threadIdx.x;
-    const Ctx c = ctx_load();
+    static_assert(S::NT == 64, "single-wave phase");
+    const int lane = S::tid();
+    const Ctx c = ctx_load<S>();
     Win g = ctx_win(c);
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     RCN_G const uint8_t* seq = gcast(c.seq); RCN_G const uint8_t* qual = gcast(c.qual);
@@ -530,7 +549,7 @@ __device__ __noinline__ void phase_add() {
         const int pp = g.path_pos[k];
         if (pp != -1) { const int row = g.path_node[k]; g.pos_t[pp] = row == -1 ? -1 : rank[row - 1]; }
     }
-    wave_sync();
+    S::sync();
     // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)
     RCN_G int32_t* kindv = g.path_pos.ptr();     // path arrays are free from here on
     RCN_G int32_t* idxv = g.path_node.ptr();
@@ -548,7 +567,7 @@ __device__ __noinline__ void phase_add() {
         anchor = __builtin_amdgcn_readlane(a, 63);
     }
     if (n_old + nn > g.ncap) g.overflow = 1;
-    wave_sync();
+    S::sync();
     if (!g.overflow) {
         for (int pos = lane; pos < len; pos += 64) {
             const int kind = kindv[pos];
@@ -559,7 +578,7 @@ __device__ __noinline__ void phase_add() {
             }
         }
         g.n_nodes = n_old + nn;
-        wave_sync();
+        S::sync();
         int ne = 0, ovf = 0;
         for (int base = 0; base < len; base += 64) {
             const int pos = base + lane;
@@ -575,28 +594,30 @@ __device__ __noinline__ void phase_add() {
         for (int pos = lane; pos < len; pos += 64) g.cov[g.pos_curr[pos]] += count;
     }
     if (lane == 0) {
-        Ctx* o = ctx_lds();
+        Ctx* o = S::ctx();
         o->n_old = n_old; o->nn = nn; o->n_nodes = g.n_nodes; o->n_edges = g.n_edges; o->overflow = g.overflow;
     }
-    wave_sync();
+    S::sync();
 }
 
 // ---- phase: order merge: insert the nn new nodes behind their anchors ----
+template <class S>
 __device__ __noinline__ void phase_merge() {
-    const int lane = threadIdx.x;
-    const Ctx c = ctx_load();
+    static_assert(S::NT == 64, "single-wave phase");
+    const int lane = S::tid();
+    const Ctx c = ctx_load<S>();
     Win g = ctx_win(c);
     const int n_old = c.n_old, nn = c.nn;
     RCN_G int32_t* delta = g.pred.ptr();                // [n_old + 1] scratch (pred is consensus-only)
     for (int r = lane; r <= n_old; r += 64) delta[r] = 0;
-    wave_sync();
+    S::sync();
     for (int k = lane; k < nn; k += 64) {
         const int a = g.new_anchor[k] + 1;
         atomicAdd((int*)&delta[a], 1);
         const int v = g.new_id[k];
         g.rank_tmp[a + k] = v; g.n2r[v] = a + k;
     }
-    wave_sync();
+    S::sync();
     int carry = 0;
     for (int base = 0; base < n_old; base += 64) {
         const int r = base + lane;
@@ -606,25 +627,26 @@ __device__ __noinline__ void phase_merge() {
         if (r < n_old) { const int v = g.rank_full[r]; const int pos = r + carry + sc; g.rank_tmp[pos] = v; g.n2r[v] = pos; }
         carry += __shfl(sc, 63);
     }
-    if (lane == 0) ctx_lds()->swapped = c.swapped ^ 1;
-    wave_sync();
+    if (lane == 0) S::ctx()->swapped = c.swapped ^ 1;
+    S::sync();
 }
 
 // ---- phase: consensus + coverage + trim (window.cpp:122-146); returns via out arrays ----
+template <class S>
 __device__ __noinline__ void phase_consensus(uint8_t* out_in, uint64_t out_cap, uint32_t* out_len_in, uint8_t* out_flags_in, int ns, int tgs) {
     RCN_G uint8_t* out = uptr(out_in); RCN_G uint32_t* out_len = uptr(out_len_in); RCN_G uint8_t* out_flags = uptr(out_flags_in);
     out_cap = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(out_cap >> 32))) << 32) | __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(out_cap));
     ns = uint_(ns); tgs = uint_(tgs);
-    const int lane = threadIdx.x;
-    const Ctx c = ctx_load();
+    const int lane = S::tid();
+    const Ctx c = ctx_load<S>();
     Win g = ctx_win(c);
     int nx = 0;
     if (lane == 0) nx = graph_toposort(g, g.rank_x.ptr(), false, g.stack.ptr());   // spoa's exact rank order, once
     nx = bcast0(nx);
-    wave_sync();
+    S::sync();
     if (nx != g.n_nodes) { if (lane == 0) { *out_len = 0; *out_flags = kFlagError; } return; }
     for (int r = lane; r < g.n_nodes; r += 64) g.n2r_x[g.rank_x[r]] = r;
-    wave_sync();
+    S::sync();
     int clen = 0, cb = 0, flags = kFlagPolished;
     if (lane == 0) {
         RCN_G int32_t* cn = g.path_node.ptr();
@@ -639,11 +661,11 @@ __device__ __noinline__ void phase_consensus(uint8_t* out_in, uint64_t out_cap, 
         cb = bgn; clen = end - bgn + 1;
     }
     clen = bcast0(clen); cb = bcast0(cb); flags = bcast0(flags);
-    wave_sync();
+    S::sync();
     if (static_cast<uint64_t>(clen) > out_cap) { if (lane == 0) { *out_len = 0; *out_flags = kFlagOverflow; } return; }
     for (int t = lane; t < clen; t += 64) out[t] = g.code[g.path_node[cb + t]];
     if (lane == 0) { *out_len = clen; *out_flags = static_cast<uint8_t>(flags); }
-    wave_sync();
+    S::sync();
 }
 
 __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
@@ -710,7 +732,7 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
                 ctx->V = ctx->n_nodes;
             }
             wave_sync();
-            if (P.seq_full[si] == 0) phase_subgraph();
+            if (P.seq_full[si] == 0) phase_subgraph<OneWaveBlock>();
             RCN_PHASE(0);
             phase_desc();
             RCN_PHASE(1);
@@ -720,10 +742,10 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
             RCN_PHASE(3);
             overflow = bcast0(ctx->overflow);
             if (!overflow) {
-                phase_add();
+                phase_add<OneWaveBlock>();
                 RCN_PHASE(4);
                 overflow = bcast0(ctx->overflow);
-                if (!overflow) phase_merge();
+                if (!overflow) phase_merge<OneWaveBlock>();
                 RCN_PHASE(5);
             }
         }
@@ -731,7 +753,7 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
             if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (overflow == 1 || overflow == 3) ? kFlagOverflow : kFlagError; }
             continue;
         }
-        phase_consensus(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
+        phase_consensus<OneWaveBlock>(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
         RCN_PHASE(6);
     }
     if (lane == 0) {

@@ -1,0 +1,625 @@
+// poa_kernel2.hpp — the fast path of the MI355X window-consensus engine (gfx950).
+//
+// Same per-window algorithm as poa_kernel.hpp (racon's Window::generate_consensus, reference
+// src/window.cpp:65-149), re-shaped around what the first kernel's measurements showed: with
+// ~2000 windows per launch one wave per window leaves the chip idle and the launch time IS the
+// latency of the slowest window.  Here a window is owned by a WORK-GROUP OF FOUR WAVES:
+//
+//   * sequence-to-graph NW (window.cpp:95-97,104-106): the four waves form a pipeline over
+//     column blocks.  Wave w owns columns [w*128*NP, (w+1)*128*NP) and lags one row behind
+//     wave w-1; the only things that cross a block border are one score per row (horizontal
+//     carry) and one per predecessor row (diagonal carry), both read straight out of the
+//     neighbour wave's LDS ring.  One `s_barrier` per row step keeps the skew.
+//   * scores are int16, two cells per VGPR (v_pk_max_i16 / v_pk_add_i16 / v_pk_mad_i16), in the
+//     "Z domain": Z[i][j] = H[i][j] - j*g.  The horizontal gap move then adds 0 (a plain prefix
+//     max: in-register, then six v_max_i32_dpp steps across the wave), the vertical move adds
+//     g and the diagonal move adds s(i,j) - g.  Because s(i,j) does not depend on the
+//     predecessor, max over predecessors commutes with the one-column shift: the predecessor
+//     rows are max-combined FIRST (one v_pk_max per extra in-edge) and shifted ONCE per row.
+//     Z is bounded by -|g|*V <= Z <= (max(m,x,0)+|g|)*W, so int16 holds for every racon
+//     parameterisation at w=500/1000 (checked per alignment; anything else goes to the int32
+//     kernel).  Row 0 is identically zero in this domain.
+//   * the score matrix is written to HBM once (2 B/cell, coalesced 256*NP B per wave and row)
+//     for the traceback; predecessor rows are served from registers (row i-1) or the LDS ring.
+//   * traceback (spoa priority diag > vertical > horizontal, predecessors in in-edge order):
+//     all four waves stage a 64-row x 128-column int16 tile with global_load_lds, wave 0 walks it.
+//   * graph phases (Subgraph mask, AddAlignment, order merge, consensus) are the single-wave
+//     templates of poa_kernel.hpp run by wave 0; row descriptors are built by all 256 threads.
+//
+// Integer max-plus DP on an irregular DAG: no MFMA.
+#pragma once
+#include "poa_kernel.hpp"
+
+namespace rcn {
+
+constexpr int kWaves2 = 4;
+constexpr int kThreads2 = 64 * kWaves2;
+constexpr int kNeg16 = -32000;
+constexpr int kZLimit = 31000;          // |Z| bound accepted for the int16 path
+
+// ---- execution policies (see OneWaveBlock in poa_kernel.hpp) ----
+__device__ __forceinline__ int* lds_words2() { extern __shared__ int4 lds_dyn[]; return reinterpret_cast<int*>(lds_dyn); }
+__device__ __forceinline__ Ctx* ctx_lds2() { return reinterpret_cast<Ctx*>(lds_words2() + kLdsBytes / 4); }
+struct Wave0Of4 {            // wave 0 of the 4-wave work-group, the other waves wait at the next Block4::sync()
+    static constexpr int NT = 64;
+    static __device__ __forceinline__ int tid() { return threadIdx.x; }
+    static __device__ __forceinline__ void sync() { __threadfence_block(); }
+    static __device__ __forceinline__ Ctx* ctx() { return ctx_lds2(); }
+    static __device__ __forceinline__ int* work() { return lds_words2(); }
+};
+struct Block4 {
+    static constexpr int NT = kThreads2;
+    static __device__ __forceinline__ int tid() { return threadIdx.x; }
+    static __device__ __forceinline__ void sync() { __threadfence_block(); __syncthreads(); }
+    static __device__ __forceinline__ Ctx* ctx() { return ctx_lds2(); }
+    static __device__ __forceinline__ int* work() { return lds_words2(); }
+};
+
+// LDS-only barrier: waits for this wave's LDS traffic, NOT for its outstanding HBM stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- packed int16 helpers (two cells per VGPR: low half = even column) ----
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, static_cast<s16x2>(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16); }
+// VOP3P results need one wait state before a dependent VALU read on gfx940+ (dst-sel forwarding
+// hazard); the hazard recogniser does not look into inline asm, hence the explicit s_nop.
+// (sym == seq ? m - g : x - g) for both halves: t = min(seq ^ sym, 1); t * (x - m) + (m - g)
+__device__ __forceinline__ uint32_t pk_profile(uint32_t sqx, uint32_t symsym, uint32_t one, uint32_t xm, uint32_t mg) {
+    uint32_t t = sqx ^ symsym, r;
+    asm("v_pk_min_u16 %0, %1, %2\n\ts_nop 0\n\tv_pk_mad_i16 %0, %0, %3, %4\n\ts_nop 0" : "=&v"(r) : "v"(t), "v"(one), "v"(xm), "v"(mg));
+    return r;
+}
+// {lo, max(hi, lo)}
+__device__ __forceinline__ uint32_t pk_chain_pair(uint32_t a) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %1 op_sel:[0,0] op_sel_hi:[1,0]\n\ts_nop 0" : "=v"(r) : "v"(a));
+    return r;
+}
+// {max(a.lo, b.hi), max(a.hi, b.hi)}
+__device__ __forceinline__ uint32_t pk_max_bhi(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]\n\ts_nop 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// {max(a.lo, b.lo), max(a.hi, b.lo)}
+__device__ __forceinline__ uint32_t pk_max_blo(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\ts_nop 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int wave_incl_scan_max_id(int v) {      // INT_MIN is max's identity: each step fuses into one v_max_i32_dpp
+    constexpr int I = static_cast<int>(0x80000000u);
+    v = max(v, dpp_or<0x111, 0xf>(I, v));
+    v = max(v, dpp_or<0x112, 0xf>(I, v));
+    v = max(v, dpp_or<0x114, 0xf>(I, v));
+    v = max(v, dpp_or<0x118, 0xf>(I, v));
+    v = max(v, dpp_or<0x142, 0xa>(I, v));
+    v = max(v, dpp_or<0x143, 0xc>(I, v));
+    return v;
+}
+
+// smallest NP (VGPRs of packed cells per lane) whose 4 x 64 x 2NP columns hold a layer of `len`; 0 = none
+__device__ __forceinline__ int dp2_np(int len) { const int n = (len + 1 + 511) / 512; return n <= 4 ? n : 0; }
+// rows of the register window for NP packed VGPRs per lane (16 VGPRs in all; a power of two)
+__host__ __device__ constexpr int dp2_window(int np) { return np <= 1 ? 16 : np == 2 ? 8 : 4; }
+
+// ---- phase: row descriptors (all 256 threads) + row 0 of Z ----
+__device__ __noinline__ void phase_desc2() {
+    const int t = threadIdx.x;
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
+    const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
+    const int R = dp2_window(dp2_np(c.len));
+    for (int r = t; r < c.V; r += kThreads2) {
+        RowDesc d = make_row_desc(g, nr, rank[r], c.sub != 0);
+        // "fast" rows: at most 4 predecessors, every one among the R rows right above (the DP keeps those in
+        // registers; R = dp2_window(NP)).  meta bit 13 = fast, bits 16-19 / 20-23 / 24-27 / 28-31 = distance
+        // (1..R) to predecessor 0 / 1 / 2 / 3.
+        const int np = (d.meta >> 9) & 15, i = r + 1;
+        if (np <= 4 && d.erest < 0) {
+            unsigned int bits = 1u << 13; bool ok = true;
+            for (int q = 0; q < np; ++q) {
+                const int dist = i - d.p[q];
+                ok = ok && d.p[q] != 0 && dist <= R;
+                bits |= static_cast<unsigned int>(dist & 15) << (16 + 4 * q);
+            }
+            if (ok) d.meta |= static_cast<int>(bits);
+        }
+        g.desc[r] = d;
+    }
+    RCN_G uint32_t* H = reinterpret_cast<RCN_G uint32_t*>(g.H.ptr());
+    for (int j = t; j < (g.hstride >> 1); j += kThreads2) H[j] = 0u;
+    Block4::sync();
+}
+
+// ---- phase: NW sequence-to-graph DP, 4-wave column pipeline ----
+template <int NP>
+__device__ __noinline__ void dp2_rows() {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    RCN_G const int32_t* nr = (c.sub ? g.n2r_x : g.n2r).ptr();
+    RCN_G const RowDesc* desc = g.desc.ptr();
+    RCN_G const int32_t* e_nin = g.e_nin.ptr();
+    RCN_G const int32_t* e_tail = g.e_tail.ptr();
+    RCN_G const uint8_t* inc = g.inc.ptr();
+    RCN_G uint32_t* __restrict__ H = reinterpret_cast<RCN_G uint32_t*>(g.H.ptr());
+    RCN_G const int16_t* H16 = reinterpret_cast<RCN_G const int16_t*>(g.H.ptr());
+    RCN_G const uint8_t* seq = gcast(c.seq);
+    const int V = c.V, len = c.len;
+    const bool sub = c.sub != 0;
+    const int hs = c.hstride;                   // row stride in int16 cells (multiple of 8)
+    const int hs2 = hs >> 1;                    // ... in packed dwords
+    constexpr int KT = (kLdsBytes - 64) / (1024 * NP);   // LDS row slots (19, 9, 6, 4): K ring rows + 1 staging slot
+    constexpr int K = KT - 1;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());   // [KT][256][NP]
+    int* farb = Block4::work() + (kLdsBytes - 64) / 4;   // [4] staged border cell of a far predecessor row, per wave
+    const int col0 = t * 2 * NP;                // first column of this thread
+    const bool in_row = col0 < hs;
+    const int bcol = wv * 128 * NP - 1;         // column left of this wave's block (wv > 0)
+
+    const int mg = c.m - c.gp, xg = c.x - c.gp;
+    const uint32_t MG = pack2(mg, mg), XM = pack2(xg - mg, xg - mg), GG = pack2(c.gp, c.gp), ONE = 0x00010001u;
+    uint32_t sqx[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int j0 = col0 + 2 * q, j1 = j0 + 1;
+        const int s0 = (j0 >= 1 && j0 <= len) ? seq[j0 - 1] : 0x100, s1 = (j1 >= 1 && j1 <= len) ? seq[j1 - 1] : 0x100;
+        sqx[q] = pack2(s0, s1);
+    }
+    // Register window: the last R rows of Z for this lane's columns, row r at win[(r % R) * NP + q].  The
+    // index is wave-uniform, so a read or write is s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off.
+    constexpr int R = dp2_window(NP);
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 win = {};
+    // cwin: lane (r % 64) holds Z[r][bcol], the border cell this wave received as horizontal carry of row r
+    // = the diagonal carry of predecessor row r (wave 0 has no left neighbour: -inf)
+    int cwin = wv == 0 ? kNeg16 : 0;
+    const int t_own = len / (2 * NP), own_wave = t_own >> 6, own_lane = t_own & 63, own_q = (len % (2 * NP)) >> 1, own_hi = len & 1;
+    int best = 0, best_row = 0, have_best = 0, tied = 0;
+    unsigned int pred_rows = 0;
+    int slot = 1 % K;                           // ring slot of row i is i % K
+    int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9;
+
+    // Skewed pipeline: wave wv starts wv steps late and finishes wv steps late; every wave executes
+    // exactly V + kWaves2 - 1 barriers.
+    for (int k = 0; k < wv; ++k) lds_barrier();
+#pragma unroll 1
+    for (int rbase = 0; rbase < V; rbase += 64) {
+        {
+            // 64 row descriptors per coalesced load, one per lane; read back with v_readlane.  The load is
+            // retired HERE (a wait inside the row loop would also wait for every outstanding H-row store).
+            RowDesc d; d.erest = -1; d.meta = 1 << 9;
+#pragma unroll
+            for (int q = 0; q < kInlinePreds; ++q) d.p[q] = 0;
+            if (rbase + lane < V) d = desc[rbase + lane];
+            dl_p0 = d.p[0]; dl_p1 = d.p[1]; dl_p2 = d.p[2]; dl_p3 = d.p[3]; dl_p4 = d.p[4]; dl_p5 = d.p[5]; dl_er = d.erest; dl_meta = d.meta;
+            // an (empty) asm that consumes and redefines the eight registers: the compiler has to place its
+            // s_waitcnt for the load in front of it, i.e. outside the row loop
+            asm volatile("; row descriptors retired" : "+v"(dl_p0), "+v"(dl_p1), "+v"(dl_p2), "+v"(dl_p3), "+v"(dl_p4), "+v"(dl_p5), "+v"(dl_er), "+v"(dl_meta));
+        }
+        const int rend = min(V, rbase + 64);
+#pragma unroll 1
+        for (int r = rbase; r < rend; ++r) {
+            const int k = r - rbase;
+            const int i = r + 1;
+            const int meta = __builtin_amdgcn_readlane(dl_meta, k);
+            const uint32_t sym = meta & 255;
+
+            uint32_t M[NP];
+            int mleft;                          // max over predecessors of Z[p][bcol] (diagonal carry into lane 0)
+            if (meta & (1 << 13)) {
+                // ---- fast row: predecessors come from the register window, their border cells from cwin ----
+                const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
+                const int npf = (meta >> 9) & 7;
+                {
+                    const int d = dd & 15;
+                    const int wi = ((i - d) & (R - 1)) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) M[q] = win[wi + q];
+                    mleft = __builtin_amdgcn_readlane(cwin, (i - d) & 63);
+                }
+#pragma unroll 1
+                for (int e = 1; e < npf; ++e) {
+                    const int d = (dd >> (4 * e)) & 15;
+                    const int wi = ((i - d) & (R - 1)) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], win[wi + q]);
+                    mleft = max(mleft, __builtin_amdgcn_readlane(cwin, (i - d) & 63));
+                }
+                pred_rows += npf;
+            } else {
+                // ---- general row: any number of predecessors, LDS ring or (rare) HBM ----
+                const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
+                const int er = __builtin_amdgcn_readlane(dl_er, k);
+                const int np = (meta >> 9) & 15;
+                bool first = true;
+                mleft = kNeg16;
+                auto combine = [&](int p) {
+                    uint32_t hp[NP];
+                    int bl;
+                    if (p == 0) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) hp[q] = 0u;
+                        bl = 0;
+                    } else if (i - p < K - 1) {     // LDS ring
+                        int sp = slot - (i - p); if (sp < 0) sp += K;
+                        const uint32_t* src = ring + (sp * kThreads2 + t) * NP;
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) hp[q] = src[q];
+                        bl = 0;
+                        if (wv > 0) bl = static_cast<int>(ring[(sp * kThreads2 + wv * 64 - 1) * NP + NP - 1]) >> 16;
+                    } else {
+                        // rare: older than the ring -> HBM, staged through the spare LDS slot so that the common
+                        // path never has a global load pending at the join (its s_waitcnt vmcnt would also wait
+                        // for every outstanding H-row store, every row)
+                        uint32_t* sdst = ring + (K * kThreads2 + t) * NP;
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) sdst[q] = in_row ? H[p * hs2 + t * NP + q] : 0u;
+                        if (wv > 0 && lane == 0) farb[wv] = H16[p * hs + bcol];
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) hp[q] = sdst[q];
+                        bl = 0;
+                        if (wv > 0) bl = farb[wv];
+                    }
+                    if (wv == 0) bl = kNeg16;
+                    if (first) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = hp[q];
+                        mleft = bl; first = false;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[q]);
+                        mleft = max(mleft, bl);
+                    }
+                    ++pred_rows;
+                };
+                combine(p0);
+                if (np > 1) {
+                    const int q1 = __builtin_amdgcn_readlane(dl_p1, k), q2 = __builtin_amdgcn_readlane(dl_p2, k);
+                    const int q3 = __builtin_amdgcn_readlane(dl_p3, k), q4 = __builtin_amdgcn_readlane(dl_p4, k);
+                    const int q5 = __builtin_amdgcn_readlane(dl_p5, k);
+#pragma unroll 1
+                    for (int q = 1; q < np; ++q) combine(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
+                }
+                for (int e = er; e >= 0; e = e_nin[e]) {
+                    const int tl = e_tail[e];
+                    if (sub && !inc[tl]) continue;
+                    combine(nr[tl] + 1);
+                }
+            }
+            // horizontal carry into this block: Z[i][bcol], finished by wave wv-1 one step ago
+            int cin = static_cast<int>(0x80000000u);
+            if (wv > 0) cin = static_cast<int>(ring[(slot * kThreads2 + wv * 64 - 1) * NP + NP - 1]) >> 16;
+
+            // diagonal sources = the combined predecessor row shifted right by one column
+            const uint32_t symsym = sym | (sym << 16);
+            const uint32_t mprev = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(mleft) << 16, M[NP - 1], 0x138, 0xf, 0xf, false);
+            uint32_t acc[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
+                const uint32_t P = pk_profile(sqx[q], symsym, ONE, XM, MG);
+                acc[q] = pk_max(pk_add(D, P), pk_add(M[q], GG));
+            }
+            // horizontal move (+0 in the Z domain): in-lane chain, wave-wide prefix max of the lane tails
+            acc[0] = pk_chain_pair(acc[0]);
+#pragma unroll
+            for (int q = 1; q < NP; ++q) acc[q] = pk_chain_pair(pk_max_bhi(acc[q], acc[q - 1]));
+            const int tail = static_cast<int>(acc[NP - 1]) >> 16;
+            int zex = dpp_or<0x138, 0xf>(static_cast<int>(0x80000000u), wave_incl_scan_max_id(tail));
+            zex = max(max(zex, cin), kNeg16);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
+
+            if (in_row) {
+                RCN_G uint32_t* dst = H + i * hs2 + t * NP;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) dst[q] = acc[q];
+            }
+            uint32_t* rdst = ring + (slot * kThreads2 + t) * NP;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { rdst[q] = acc[q]; win[(i & (R - 1)) * NP + q] = acc[q]; }
+            if (wv > 0) cwin = (lane == (i & 63)) ? cin : cwin;
+            slot = (slot + 1 == K) ? 0 : slot + 1;
+
+            if ((meta & 256) && wv == own_wave) {
+                uint32_t fv = acc[0];
+#pragma unroll
+                for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q];
+                const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16);
+                const int val = __builtin_amdgcn_readlane(v16, own_lane);
+                if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
+                else if (best == val) ++tied;
+            }
+            lds_barrier();
+        }
+    }
+    for (int k = wv; k < kWaves2 - 1; ++k) lds_barrier();
+    Ctx* o = Block4::ctx();
+    if (wv == own_wave && lane == 0) { o->best = best; o->best_row = best_row; o->tied = tied; }
+    if (t == 0) {
+        const int W = len + 1;
+        o->pred_rows = pred_rows;
+        o->cells += static_cast<unsigned long long>(V + 1) * W;
+        o->pred += static_cast<unsigned long long>(pred_rows) * W;
+        // SURVEY 8(d) yardstick (same formula as poa_window_kernel): cells written once + predecessor rows
+        // read once per in-edge, at 2 B/cell when the worst-case score bound fits int16, else 4 B/cell
+        const int amax = max(max(abs(c.m), abs(c.x)), abs(c.gp));
+        const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
+        o->bytes += sbytes * (static_cast<unsigned long long>(V + 1) + pred_rows) * W;
+    }
+    Block4::sync();
+}
+
+// ---- phase: sink tie-break (rare) + traceback over int16 Z tiles ----
+constexpr int kTile2Cols = 128;        // int16 cells per tile row (256 B, 16 lanes x 16 B of global_load_lds)
+
+__device__ __forceinline__ void traceback2_slow_step(Win& g, RCN_G const int32_t* nr, bool sub, RCN_G const uint8_t* seq,
+                                                     int m, int x, int gp, int& i, int& j, int& n) {
+    const int64_t hs = g.hstride;
+    RCN_G const int16_t* H = reinterpret_cast<RCN_G const int16_t*>(g.H.ptr());
+    const int hij = H[i * hs + j];
+    int pi = 0, pj = 0; bool found = false;
+    if (i != 0) {
+        const RowDesc d = g.desc[i - 1];
+        const int np = (d.meta >> 9) & 15;
+        for (int pass = (j != 0 ? 0 : 1); pass < 2 && !found; ++pass) {
+            const int col = pass == 0 ? j - 1 : j;
+            const int add = pass == 0 ? ((((d.meta & 255) == seq[j - 1]) ? m : x) - gp) : gp;
+            for (int q = 0; q < np && !found; ++q) {
+                if (hij == H[d.p[q] * hs + col] + add) { pi = d.p[q]; pj = col; found = true; }
+            }
+            for (int e = d.erest; e >= 0 && !found; e = g.e_nin[e]) {
+                const int tl = g.e_tail[e];
+                if (sub && !g.inc[tl]) continue;
+                const int p = nr[tl] + 1;
+                if (hij == H[p * hs + col] + add) { pi = p; pj = col; found = true; }
+            }
+        }
+    }
+    if (!found) {
+        if (j == 0) { g.overflow = 4; i = 0; j = 0; return; }
+        pi = i; pj = j - 1;
+    }
+    g.path_node[n] = (i == pi) ? -1 : i;
+    g.path_pos[n] = (j == pj) ? -1 : j - 1;
+    ++n; i = pi; j = pj;
+}
+
+__device__ __noinline__ void phase_traceback2() {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    RCN_G const int32_t* nr = (c.sub ? g.n2r_x : g.n2r).ptr();
+    const bool sub = c.sub != 0;
+    RCN_G const uint8_t* __restrict__ seq = gcast(c.seq);
+    const int len = c.len, m = c.m, x = c.x, gp = c.gp;
+    const int64_t hs = g.hstride;
+    RCN_G const int16_t* __restrict__ H = reinterpret_cast<RCN_G const int16_t*>(g.H.ptr());
+    Ctx* o = Block4::ctx();
+    if (t == 0) {
+        int best_row = c.best_row;
+        if (c.tied > 1) {
+            // several sinks share the best score: spoa takes the first one in ITS rank order (exact DFS order)
+            const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
+            for (int r = 0; r < nx; ++r) {
+                const int row = nr[g.rank_x[r]] + 1;
+                if ((g.desc[row - 1].meta & 256) && H[static_cast<int64_t>(row) * hs + len] == c.best) { best_row = row; break; }
+            }
+            o->ties += 1;
+        }
+        o->tb_i = best_row; o->tb_j = len; o->tb_n = 0;
+    }
+    Block4::sync();
+
+    int16_t* tile = reinterpret_cast<int16_t*>(Block4::work());                       // [64][128]
+    int* tdesc = Block4::work() + 64 * kTile2Cols / 2;                                 // 64 x RowDesc (8 ints each)
+    uint8_t* tseq = reinterpret_cast<uint8_t*>(tdesc + 64 * (sizeof(RowDesc) / 4));   // seq[c0 - 1 + k], k in [0, 128]
+    RCN_G int32_t* __restrict__ pnode = g.path_node.ptr();
+    RCN_G int32_t* __restrict__ ppos = g.path_pos.ptr();
+    int i = bcast0(o->tb_i), j = bcast0(o->tb_j), n = 0;
+    int overflow = g.overflow;
+    while (!(i == 0 && j == 0)) {
+        // ---- stage the tile: rows [i-63, i] (tile row r holds matrix row i - r), cols [c0, c0+127] ----
+        const int ti0 = i;
+        int c0 = (j - 120) & ~7; if (c0 < 0) c0 = 0;
+        const int rmin = ti0 - 63 > 0 ? ti0 - 63 : 0;
+        {
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            const int sub_row = lane >> 4, chunk = lane & 15;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * wv + kk;
+                int r = ti0 - (4 * k + sub_row); if (r < 0) r = 0;
+                RCN_G const int16_t* src = H + r * hs + c0 + chunk * 8;
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(tile + k * 4 * kTile2Cols), 16, 0, 0);
+            }
+            if (wv == 1) {
+                const int r = ti0 - lane;
+                int4 d0 = make_int4(0, -1, -1, -1), d1 = make_int4(-1, -1, -1, 1 << 9);
+                if (r >= 1) { RCN_G const int4* dsrc = reinterpret_cast<RCN_G const int4*>(g.desc.ptr() + (r - 1)); d0 = dsrc[0]; d1 = dsrc[1]; }
+                int4* ddst = reinterpret_cast<int4*>(tdesc + lane * 8);
+                ddst[0] = d0; ddst[1] = d1;
+            } else if (wv >= 2) {
+                const int kx = (wv - 2) * 64 + lane;          // 0..127
+                const int sc = c0 - 1 + kx;
+                tseq[kx] = (sc >= 0 && sc < len) ? seq[sc] : 0;
+                if (kx == 0) { const int s2 = c0 - 1 + 128; tseq[128] = (s2 >= 0 && s2 < len) ? seq[s2] : 0; }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wv == 0) {
+            // ---- walk inside the tile: wave-uniform control flow; lane q looks at predecessor q ----
+            int steps = 0, bn = 0, bp = 0, n0 = n;      // up to 64 path entries buffered one per lane
+            int hij = tile[j - c0];                      // row ti0 is tile row 0
+            for (;;) {
+                if (i == 0 && j == 0) break;
+                int pi, pj, hnext;
+                if (i == 0) {                            // only horizontal moves are left on the virtual row
+                    if (j - 1 < c0) break;
+                    pi = 0; pj = j - 1; hnext = hij;
+                } else {
+                    const int* dr = tdesc + (ti0 - i) * 8;
+                    const int pq = dr[lane < kInlinePreds ? lane : 0];
+                    const int erest = dr[6], meta = dr[7];
+                    const int symc = tseq[j - c0];                               // seq[j-1]
+                    const int np = (meta >> 9) & 15;
+                    const bool valid = lane < np;
+                    if (__ballot(valid && pq < rmin) != 0ull || erest >= 0 || (j > 0 && j - 1 < c0)) break;   // leaves the tile
+                    const int mc = (((meta & 255) == symc) ? m : x) - gp;
+                    const int16_t* cp = tile + (ti0 - (valid ? pq : ti0)) * kTile2Cols + (j - c0);
+                    const int hd = cp[j > 0 ? -1 : 0], hu = cp[0];
+                    const unsigned long long dmask = __ballot(valid && j > 0 && hij == hd + mc);
+                    const unsigned long long umask = __ballot(valid && hij == hu + gp);
+                    if (dmask) { const int q = __builtin_ctzll(dmask); pi = __builtin_amdgcn_readlane(pq, q); pj = j - 1; hnext = __builtin_amdgcn_readlane(hd, q); }
+                    else if (umask) { const int q = __builtin_ctzll(umask); pi = __builtin_amdgcn_readlane(pq, q); pj = j; hnext = __builtin_amdgcn_readlane(hu, q); }
+                    else { if (j == 0) { overflow = 4; i = 0; j = 0; break; } pi = i; pj = j - 1; hnext = hij; }
+                }
+                if (lane == steps) { bn = (i == pi) ? -1 : i; bp = (j == pj) ? -1 : j - 1; }   // ROW index (node id later)
+                ++steps;
+                i = pi; j = pj; hij = hnext;
+                if (steps == 64) { pnode[n0 + lane] = bn; ppos[n0 + lane] = bp; n0 += 64; steps = 0; }
+            }
+            if (lane < steps) { pnode[n0 + lane] = bn; ppos[n0 + lane] = bp; }
+            const bool progressed = (n0 + steps) != n;
+            n = n0 + steps;
+            if (!progressed && !(i == 0 && j == 0)) {
+                g.overflow = overflow;
+                if (lane == 0) traceback2_slow_step(g, nr, sub, seq, m, x, gp, i, j, n);
+                i = bcast0(i); j = bcast0(j); n = bcast0(n); overflow = bcast0(g.overflow);
+            }
+            if (lane == 0) { o->tb_i = i; o->tb_j = j; o->tb_n = n; o->overflow = overflow; }
+        }
+        Block4::sync();
+        i = bcast0(o->tb_i); j = bcast0(o->tb_j); n = bcast0(o->tb_n);
+        Block4::sync();                                  // everyone has read the walk state before the next tile overwrites LDS
+    }
+    if (t == 0) { o->plen = n; }
+    Block4::sync();
+}
+
+struct KParams2 {
+    KParams base;
+};
+
+__global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
+    const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub, desc, dp, traceback, add, merge, consensus, other
+    long long tck = clock64();
+#define RCN_PHASE2(k) do { long long now__ = clock64(); ph[k] += now__ - tck; tck = now__; } while (0)
+    Ctx* ctx = ctx_lds2();
+    if (t == 0) {
+        ctx->scratch = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
+        ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride;
+        ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
+        ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
+    }
+    for (;;) {
+        RCN_PHASE2(7);
+        Block4::sync();                                  // previous work item fully retired (and ctx->wi read by all)
+        if (t == 0) ctx->wi = static_cast<int32_t>(atomicAdd(P.next, 1u));
+        Block4::sync();
+        const unsigned int wi = static_cast<unsigned int>(bcast0(ctx->wi));
+        if (wi >= P.n_work) break;
+        const uint32_t w = P.win_ids ? P.win_ids[wi] : wi;
+        const uint32_t s0 = P.win_seq_off[w];
+        const int ns = static_cast<int>(P.win_seq_off[w + 1] - s0);
+        const uint8_t* bb = P.bases + P.seq_off[s0];
+        const int L = static_cast<int>(P.seq_off[s0 + 1] - P.seq_off[s0]);
+        uint8_t* out = P.out_cons + static_cast<uint64_t>(wi) * P.out_stride;   // outputs are indexed by work item
+
+        if (ns < 3) {                                          // window.cpp:68-71
+            for (int i = t; i < L; i += kThreads2) out[i] = bb[i];
+            if (t == 0) { P.out_len[wi] = L; P.out_flags[wi] = 0; }
+            continue;
+        }
+        // ---- backbone -> graph (window.cpp:73-77) ----
+        {
+            Win g;
+            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
+            RCN_G const uint8_t* q0 = P.seq_has_qual[s0] ? gcast(P.quals + P.seq_off[s0]) : nullptr;
+            for (int i = t; i < L; i += kThreads2) {
+                g.code[i] = bb[i]; g.al_cnt[i] = 0;
+                g.in_head[i] = g.in_tail[i] = (i > 0) ? i - 1 : -1;
+                g.out_head[i] = g.out_tail[i] = (i < L - 1) ? i : -1;
+                g.cov[i] = L >= 2 ? 1u : 0u;
+                g.rank_full[i] = i; g.n2r[i] = i;
+                if (i < L - 1) {
+                    g.e_tail[i] = i; g.e_head[i] = i + 1; g.e_nin[i] = -1; g.e_nout[i] = -1;
+                    g.e_w[i] = pair_weight(q0, i + 1);
+                }
+            }
+            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; }
+        }
+        Block4::sync();
+
+        int overflow = bcast0(ctx->overflow);
+        for (int jl = 1; jl < ns && !overflow; ++jl) {
+            const uint32_t si = s0 + P.order[s0 + jl];
+            const int len = static_cast<int>(P.seq_off[si + 1] - P.seq_off[si]);
+            const bool partial = P.seq_full[si] == 0;
+            if (t == 0) {
+                ctx->seq = P.bases + P.seq_off[si];
+                ctx->qual = P.seq_has_qual[si] ? P.quals + P.seq_off[si] : nullptr;
+                ctx->len = len;
+                ctx->sub = partial;
+                ctx->begin = static_cast<int32_t>(P.seq_begin[si]); ctx->end = static_cast<int32_t>(P.seq_end[si]);
+                ctx->V = ctx->n_nodes;
+            }
+            Block4::sync();
+            if (partial) { if (wv == 0) phase_subgraph<Wave0Of4>(); Block4::sync(); }
+            RCN_PHASE2(0);
+            // int16 (Z domain) validity of this alignment; otherwise the window goes to the int32 kernel
+            const int V = bcast0(ctx->V);
+            const int np_regs = dp2_np(len);
+            {
+                const int ag = P.g < 0 ? -P.g : P.g, smax = max(max(P.m, P.x), 0);
+                if (P.g >= 0 || np_regs == 0 || static_cast<long long>(ag) * (V + 2) > kZLimit ||
+                    static_cast<long long>(smax + ag) * (512 * np_regs) > kZLimit) { overflow = 5; break; }
+            }
+            phase_desc2();
+            RCN_PHASE2(1);
+            switch (np_regs) {
+                case 1: dp2_rows<1>(); break;
+                case 2: dp2_rows<2>(); break;
+                case 3: dp2_rows<3>(); break;
+                default: dp2_rows<4>(); break;
+            }
+            RCN_PHASE2(2);
+            phase_traceback2();
+            RCN_PHASE2(3);
+            overflow = bcast0(ctx->overflow);
+            if (!overflow) {
+                if (wv == 0) phase_add<Wave0Of4>();
+                Block4::sync();
+                RCN_PHASE2(4);
+                overflow = bcast0(ctx->overflow);
+                if (!overflow) { if (wv == 0) phase_merge<Wave0Of4>(); Block4::sync(); }
+                RCN_PHASE2(5);
+            }
+        }
+        if (overflow) {
+            if (t == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (overflow == 1 || overflow == 3 || overflow == 5) ? kFlagOverflow : kFlagError; }
+            continue;
+        }
+        if (wv == 0) phase_consensus<Wave0Of4>(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
+        RCN_PHASE2(6);
+    }
+    if (t == 0) {
+        atomicAdd(&P.stats[0], ctx->cells); atomicAdd(&P.stats[1], ctx->pred); atomicAdd(&P.stats[2], ctx->bytes);
+        for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[3 + k], ph[k]);
+        atomicAdd(&P.stats[11], ctx->ties);
+    }
+}
+
+}  // namespace rcn
