@@ -351,6 +351,10 @@ int rcn_engine_run(rcn_engine* e) {
     e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
     for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
     e->stats.n_sink_ties = st[11];
+#ifdef RCN_PROF_DP
+    { unsigned long long pr[8]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(rcn::g_prof_out), sizeof(pr)));
+      fprintf(stderr, "[racon_hip] dp prof (cumulative): "); for (int k = 0; k < 4; ++k) fprintf(stderr, "wave%d row %llu bar %llu | ", k, pr[2*k], pr[2*k+1]); fprintf(stderr, "\n"); }
+#endif
     if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] traceback: stage clocks %llu walk clocks %llu tiles %llu steps %llu\n", st[12], st[13], st[14], st[15]);
 
     for (uint32_t w = 0; w < nw; ++w) e->cons_off[w + 1] = e->cons_off[w] + out_len[w];

@@ -104,8 +104,14 @@ __device__ __forceinline__ int wave_incl_scan_max_id(int v) {      // INT_MIN is
     return v;
 }
 
-// smallest NP (VGPRs of packed cells per lane) whose 4 x 64 x 2NP columns hold a layer of `len`; 0 = none
-__device__ __forceinline__ int dp2_np(int len) { const int n = (len + 1 + 511) / 512; return n <= 4 ? n : 0; }
+// DP shape for a layer of `len` bases: one wave over (len+1) <= 512 columns, else the 4-wave pipeline;
+// NP = packed VGPRs per lane (2 NP columns).  Returns NP | (WV << 8), 0 = not supported (int32 kernel).
+__host__ __device__ __forceinline__ int dp2_cfg(int len) {
+    const int W = len + 1;
+    if (W <= 512) return ((W + 127) / 128) | (1 << 8);
+    const int n = (W + 511) / 512;
+    return n <= 4 ? (n | (4 << 8)) : 0;
+}
 // rows of the register window for NP packed VGPRs per lane (16 VGPRs in all; a power of two)
 __host__ __device__ constexpr int dp2_window(int np) { return np <= 1 ? 16 : np == 2 ? 8 : 4; }
 
@@ -116,7 +122,7 @@ __device__ __noinline__ void phase_desc2() {
     Win g = ctx_win(c);
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
-    const int R = dp2_window(dp2_np(c.len));
+    const int R = dp2_window(dp2_cfg(c.len) & 255);
     for (int r = t; r < c.V; r += kThreads2) {
         RowDesc d = make_row_desc(g, nr, rank[r], c.sub != 0);
         // "fast" rows: at most 4 predecessors, every one among the R rows right above (the DP keeps those in
@@ -139,10 +145,18 @@ __device__ __noinline__ void phase_desc2() {
     Block4::sync();
 }
 
-// ---- phase: NW sequence-to-graph DP, 4-wave column pipeline ----
-template <int NP>
+#ifdef RCN_PROF_DP
+__device__ unsigned long long g_prof_out[8];     // per wave: cycles in row bodies, cycles in barriers
+#endif
+// ---- phase: NW sequence-to-graph DP ----
+// WV = 1: wave 0 alone owns all columns (up to 128*NP); no barrier, no border traffic.  The default for
+//         w=500 windows: with ~2000 windows per launch the chip is latency bound, and a row costs about the
+//         same number of instructions whether a lane owns 2 or 8 columns.
+// WV = 4: the four waves form a pipeline over column blocks of 128*NP (layers longer than 511 bases).
+template <int NP, int WV>
 __device__ __noinline__ void dp2_rows() {
-    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int NTH = 64 * WV;
+    const int t = threadIdx.x, lane = t & 63, wv = WV == 1 ? 0 : __builtin_amdgcn_readfirstlane(t >> 6);
     const Ctx c = ctx_load<Block4>();
     Win g = ctx_win(c);
     RCN_G const int32_t* nr = (c.sub ? g.n2r_x : g.n2r).ptr();
@@ -155,18 +169,20 @@ __device__ __noinline__ void dp2_rows() {
     RCN_G const uint8_t* seq = gcast(c.seq);
     const int V = c.V, len = c.len;
     const bool sub = c.sub != 0;
-    const int hs = c.hstride;                   // row stride in int16 cells (multiple of 8)
+    const int hs = c.hstride;                   // row stride in int16 cells (multiple of 24)
     const int hs2 = hs >> 1;                    // ... in packed dwords
-    constexpr int KT = (kLdsBytes - 64) / (1024 * NP);   // LDS row slots (19, 9, 6, 4): K ring rows + 1 staging slot
+    constexpr int KT = (kLdsBytes - 64) / (4 * NTH * NP);   // LDS row slots: K ring rows + 1 staging slot
     constexpr int K = KT - 1;
-    uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());   // [KT][256][NP]
+    uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());   // [KT][NTH][NP]
     int* farb = Block4::work() + (kLdsBytes - 64) / 4;   // [4] staged border cell of a far predecessor row, per wave
     const int col0 = t * 2 * NP;                // first column of this thread
     const bool in_row = col0 < hs;
     const int bcol = wv * 128 * NP - 1;         // column left of this wave's block (wv > 0)
 
     const int mg = c.m - c.gp, xg = c.x - c.gp;
-    const uint32_t MG = pack2(mg, mg), XM = pack2(xg - mg, xg - mg), GG = pack2(c.gp, c.gp), ONE = 0x00010001u;
+    uint32_t MG = pack2(mg, mg), XM = pack2(xg - mg, xg - mg), ONE = 0x00010001u;
+    const uint32_t GG = pack2(c.gp, c.gp);
+    asm volatile("; constants live in VGPRs" : "+v"(MG), "+v"(XM), "+v"(ONE));
     uint32_t sqx[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -179,8 +195,8 @@ __device__ __noinline__ void dp2_rows() {
     constexpr int R = dp2_window(NP);
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
     u32x16 win = {};
-    // cwin: lane (r % 64) holds Z[r][bcol], the border cell this wave received as horizontal carry of row r
-    // = the diagonal carry of predecessor row r (wave 0 has no left neighbour: -inf)
+    // cwin (WV = 4): lane (r % 64) holds Z[r][bcol], the border cell this wave received as horizontal carry
+    // of row r = the diagonal carry of predecessor row r (wave 0 has no left neighbour: -inf)
     int cwin = wv == 0 ? kNeg16 : 0;
     const int t_own = len / (2 * NP), own_wave = t_own >> 6, own_lane = t_own & 63, own_q = (len % (2 * NP)) >> 1, own_hi = len & 1;
     int best = 0, best_row = 0, have_best = 0, tied = 0;
@@ -188,21 +204,24 @@ __device__ __noinline__ void dp2_rows() {
     int slot = 1 % K;                           // ring slot of row i is i % K
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9;
 
-    // Skewed pipeline: wave wv starts wv steps late and finishes wv steps late; every wave executes
-    // exactly V + kWaves2 - 1 barriers.
-    for (int k = 0; k < wv; ++k) lds_barrier();
+    // WV = 4, skewed pipeline: wave wv starts wv steps late and finishes wv steps late; every wave executes
+    // exactly V + WV - 1 barriers.
+    if (WV > 1) for (int k = 0; k < wv; ++k) lds_barrier();
+#ifdef RCN_PROF_DP
+    long long prof_row__ = 0, prof_bar__ = 0, tr0__ = clock64();
+#endif
 #pragma unroll 1
     for (int rbase = 0; rbase < V; rbase += 64) {
         {
-            // 64 row descriptors per coalesced load, one per lane; read back with v_readlane.  The load is
-            // retired HERE (a wait inside the row loop would also wait for every outstanding H-row store).
+            // 64 row descriptors per coalesced load, one per lane; read back with v_readlane
             RowDesc d; d.erest = -1; d.meta = 1 << 9;
 #pragma unroll
             for (int q = 0; q < kInlinePreds; ++q) d.p[q] = 0;
             if (rbase + lane < V) d = desc[rbase + lane];
             dl_p0 = d.p[0]; dl_p1 = d.p[1]; dl_p2 = d.p[2]; dl_p3 = d.p[3]; dl_p4 = d.p[4]; dl_p5 = d.p[5]; dl_er = d.erest; dl_meta = d.meta;
             // an (empty) asm that consumes and redefines the eight registers: the compiler has to place its
-            // s_waitcnt for the load in front of it, i.e. outside the row loop
+            // s_waitcnt for the load in front of it, i.e. outside the row loop (a wait inside the row loop
+            // would also wait for every outstanding H-row store, every row)
             asm volatile("; row descriptors retired" : "+v"(dl_p0), "+v"(dl_p1), "+v"(dl_p2), "+v"(dl_p3), "+v"(dl_p4), "+v"(dl_p5), "+v"(dl_er), "+v"(dl_meta));
         }
         const int rend = min(V, rbase + 64);
@@ -210,11 +229,15 @@ __device__ __noinline__ void dp2_rows() {
         for (int r = rbase; r < rend; ++r) {
             const int k = r - rbase;
             const int i = r + 1;
+            // horizontal carry into this block: Z[i][bcol], finished by wave wv-1 one step ago.  Issued first,
+            // consumed last (wave 0 reads its own slot and ignores it).
+            uint32_t cin_raw = 0;
+            if (WV > 1) cin_raw = ring[(slot * NTH + (wv == 0 ? 0 : wv * 64 - 1)) * NP + NP - 1];
             const int meta = __builtin_amdgcn_readlane(dl_meta, k);
             const uint32_t sym = meta & 255;
 
             uint32_t M[NP];
-            int mleft;                          // max over predecessors of Z[p][bcol] (diagonal carry into lane 0)
+            int mleft = kNeg16;                 // max over predecessors of Z[p][bcol] (diagonal carry into lane 0)
             if (meta & (1 << 13)) {
                 // ---- fast row: predecessors come from the register window, their border cells from cwin ----
                 const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
@@ -224,7 +247,7 @@ __device__ __noinline__ void dp2_rows() {
                     const int wi = ((i - d) & (R - 1)) * NP;
 #pragma unroll
                     for (int q = 0; q < NP; ++q) M[q] = win[wi + q];
-                    mleft = __builtin_amdgcn_readlane(cwin, (i - d) & 63);
+                    if (WV > 1) mleft = __builtin_amdgcn_readlane(cwin, (i - d) & 63);
                 }
 #pragma unroll 1
                 for (int e = 1; e < npf; ++e) {
@@ -232,7 +255,7 @@ __device__ __noinline__ void dp2_rows() {
                     const int wi = ((i - d) & (R - 1)) * NP;
 #pragma unroll
                     for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], win[wi + q]);
-                    mleft = max(mleft, __builtin_amdgcn_readlane(cwin, (i - d) & 63));
+                    if (WV > 1) mleft = max(mleft, __builtin_amdgcn_readlane(cwin, (i - d) & 63));
                 }
                 pred_rows += npf;
             } else {
@@ -241,34 +264,30 @@ __device__ __noinline__ void dp2_rows() {
                 const int er = __builtin_amdgcn_readlane(dl_er, k);
                 const int np = (meta >> 9) & 15;
                 bool first = true;
-                mleft = kNeg16;
                 auto combine = [&](int p) {
                     uint32_t hp[NP];
-                    int bl;
+                    int bl = 0;
                     if (p == 0) {
 #pragma unroll
                         for (int q = 0; q < NP; ++q) hp[q] = 0u;
-                        bl = 0;
                     } else if (i - p < K - 1) {     // LDS ring
                         int sp = slot - (i - p); if (sp < 0) sp += K;
-                        const uint32_t* src = ring + (sp * kThreads2 + t) * NP;
+                        const uint32_t* src = ring + (sp * NTH + t) * NP;
 #pragma unroll
                         for (int q = 0; q < NP; ++q) hp[q] = src[q];
-                        bl = 0;
-                        if (wv > 0) bl = static_cast<int>(ring[(sp * kThreads2 + wv * 64 - 1) * NP + NP - 1]) >> 16;
+                        if (WV > 1 && wv > 0) bl = static_cast<int>(ring[(sp * NTH + wv * 64 - 1) * NP + NP - 1]) >> 16;
                     } else {
                         // rare: older than the ring -> HBM, staged through the spare LDS slot so that the common
                         // path never has a global load pending at the join (its s_waitcnt vmcnt would also wait
                         // for every outstanding H-row store, every row)
-                        uint32_t* sdst = ring + (K * kThreads2 + t) * NP;
+                        uint32_t* sdst = ring + (K * NTH + t) * NP;
 #pragma unroll
                         for (int q = 0; q < NP; ++q) sdst[q] = in_row ? H[p * hs2 + t * NP + q] : 0u;
-                        if (wv > 0 && lane == 0) farb[wv] = H16[p * hs + bcol];
+                        if (WV > 1 && wv > 0 && lane == 0) farb[wv] = H16[p * hs + bcol];
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
                         for (int q = 0; q < NP; ++q) hp[q] = sdst[q];
-                        bl = 0;
-                        if (wv > 0) bl = farb[wv];
+                        if (WV > 1 && wv > 0) bl = farb[wv];
                     }
                     if (wv == 0) bl = kNeg16;
                     if (first) {
@@ -296,9 +315,6 @@ __device__ __noinline__ void dp2_rows() {
                     combine(nr[tl] + 1);
                 }
             }
-            // horizontal carry into this block: Z[i][bcol], finished by wave wv-1 one step ago
-            int cin = static_cast<int>(0x80000000u);
-            if (wv > 0) cin = static_cast<int>(ring[(slot * kThreads2 + wv * 64 - 1) * NP + NP - 1]) >> 16;
 
             // diagonal sources = the combined predecessor row shifted right by one column
             const uint32_t symsym = sym | (sym << 16);
@@ -316,6 +332,11 @@ __device__ __noinline__ void dp2_rows() {
             for (int q = 1; q < NP; ++q) acc[q] = pk_chain_pair(pk_max_bhi(acc[q], acc[q - 1]));
             const int tail = static_cast<int>(acc[NP - 1]) >> 16;
             int zex = dpp_or<0x138, 0xf>(static_cast<int>(0x80000000u), wave_incl_scan_max_id(tail));
+            int cin = static_cast<int>(0x80000000u);
+            if (WV > 1) {
+                asm volatile("; carry consumed here" : "+v"(cin_raw));
+                if (wv > 0) cin = static_cast<int>(cin_raw) >> 16;
+            }
             zex = max(max(zex, cin), kNeg16);
 #pragma unroll
             for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
@@ -325,10 +346,10 @@ __device__ __noinline__ void dp2_rows() {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) dst[q] = acc[q];
             }
-            uint32_t* rdst = ring + (slot * kThreads2 + t) * NP;
+            uint32_t* rdst = ring + (slot * NTH + t) * NP;
 #pragma unroll
             for (int q = 0; q < NP; ++q) { rdst[q] = acc[q]; win[(i & (R - 1)) * NP + q] = acc[q]; }
-            if (wv > 0) cwin = (lane == (i & 63)) ? cin : cwin;
+            if (WV > 1 && wv > 0) cwin = (lane == (i & 63)) ? cin : cwin;
             slot = (slot + 1 == K) ? 0 : slot + 1;
 
             if ((meta & 256) && wv == own_wave) {
@@ -340,10 +361,27 @@ __device__ __noinline__ void dp2_rows() {
                 if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
                 else if (best == val) ++tied;
             }
-            lds_barrier();
+            if (WV > 1) {
+#ifdef RCN_PROF_DP
+                const long long tb0__ = clock64();
+                lds_barrier();
+                const long long tb1__ = clock64();
+                prof_row__ += tb0__ - tr0__; prof_bar__ += tb1__ - tb0__; tr0__ = tb1__;
+#else
+                lds_barrier();
+#endif
+            } else {
+                // one wave: LDS accesses of a wave execute in order, nothing to wait for
+#ifdef RCN_PROF_DP
+                const long long tb1__ = clock64(); prof_row__ += tb1__ - tr0__; tr0__ = tb1__;
+#endif
+            }
         }
     }
-    for (int k = wv; k < kWaves2 - 1; ++k) lds_barrier();
+#ifdef RCN_PROF_DP
+    if (lane == 0) { atomicAdd(&g_prof_out[wv * 2], (unsigned long long)prof_row__); atomicAdd(&g_prof_out[wv * 2 + 1], (unsigned long long)prof_bar__); }
+#endif
+    if (WV > 1) for (int k = wv; k < WV - 1; ++k) lds_barrier();
     Ctx* o = Block4::ctx();
     if (wv == own_wave && lane == 0) { o->best = best; o->best_row = best_row; o->tied = tied; }
     if (t == 0) {
@@ -357,7 +395,7 @@ __device__ __noinline__ void dp2_rows() {
         const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
         o->bytes += sbytes * (static_cast<unsigned long long>(V + 1) + pred_rows) * W;
     }
-    Block4::sync();
+    if (WV > 1) Block4::sync(); else Wave0Of4::sync();
 }
 
 // ---- phase: sink tie-break (rare) + traceback over int16 Z tiles ----
@@ -508,9 +546,154 @@ __device__ __noinline__ void phase_traceback2() {
     Block4::sync();
 }
 
-struct KParams2 {
-    KParams base;
-};
+// ---- phase: consensus (window.cpp:122-146) ----
+// Heaviest bundle without spoa's exact DFS order in the common case.  Scores and predecessor choices do
+// not depend on WHICH valid topological order is used; the exact order only matters (a) to pick the first
+// of several nodes that tie for the maximal score and (b) inside BranchCompletion (max node with
+// out-edges).  Both are rare (~0.5% of windows): they take the exact serial path of poa_kernel.hpp.
+//   pass A (256 threads): per rank r of rank_full, the winning in-edge by weight -> record {tail rank of
+//           the best edge, weight, up to two more tails that tie on weight (then the tail SCORE decides,
+//           later edge wins: the predicate of TraverseHeaviestBundle is a lexicographic max over
+//           (weight, score[tail], edge order))}, stored in the row-descriptor array.
+//   pass B (wave 0): 64 ranks at a time; scores of earlier chunks come from LDS, dependencies inside the
+//           chunk are resolved with one v_readlane per rank.
+constexpr int kCons2MaxNodes = kLdsBytes / 6;     // int32 score + uint16 predecessor rank per node in LDS
+struct ConsRec { int32_t trA, w, trB, trC; };     // trB/trC: -1 none; trC == -2: more than three edges tie
+
+__device__ __noinline__ void phase_cons2_edges() {
+    const int t = threadIdx.x;
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    RCN_G ConsRec* rec = reinterpret_cast<RCN_G ConsRec*>(g.desc.ptr());
+    const int n = g.n_nodes;
+    for (int r = t; r < n; r += kThreads2) {
+        const int v = g.rank_full[r];
+        ConsRec o; o.trA = -1; o.w = 0; o.trB = -1; o.trC = -1;
+        long long wmax = -1; int ntie = 0;
+        for (int e = g.in_head[v]; e >= 0; e = g.e_nin[e]) {
+            const long long w = g.e_w[e];
+            const int tr = g.n2r[g.e_tail[e]];
+            if (w > wmax) { wmax = w; ntie = 1; o.trA = tr; o.w = static_cast<int32_t>(w); o.trB = -1; o.trC = -1; }
+            else if (w == wmax) { ++ntie; if (ntie == 2) o.trB = tr; else if (ntie == 3) o.trC = tr; else o.trC = -2; }
+        }
+        rec[r] = o;
+    }
+    Block4::sync();
+}
+
+// returns (through ctx->tb_n) the consensus length, 0 = take the exact path; path ranks in LDS (reversed)
+__device__ __noinline__ void phase_cons2_bundle() {
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load<Wave0Of4>();
+    Win g = ctx_win(c);
+    RCN_G const ConsRec* rec = reinterpret_cast<RCN_G const ConsRec*>(g.desc.ptr());
+    const int n = g.n_nodes;
+    int* sc = Wave0Of4::work();                                              // [n]
+    uint16_t* pr = reinterpret_cast<uint16_t*>(Wave0Of4::work() + n);       // [n] rank of the chosen predecessor, 0xFFFF none
+    int gmax = static_cast<int>(0x80000000u), gmax_rank = -1, gtie = 0;
+#pragma unroll 1
+    for (int base = 0; base < n; base += 64) {
+        const int r = base + lane;
+        ConsRec e; e.trA = -1; e.w = 0; e.trB = -1; e.trC = -1;
+        if (r < n) e = rec[r];
+        int trA = e.trA;
+        const int tl = trA >= base ? trA - base : -1;
+        int fin = -1;
+        if (trA >= 0 && trA < base) fin = e.w + sc[trA];
+        const unsigned long long amb = __ballot(e.trB >= 0 || e.trC == -2);
+        const int cnt = min(64, n - base);
+#pragma unroll 1
+        for (int k = 0; k < cnt; ++k) {
+            if ((amb >> k) & 1ull) {
+                // several in-edges tie on weight: the tail with the larger score wins, later edge on equal scores
+                const int a = __builtin_amdgcn_readlane(e.trA, k), b = __builtin_amdgcn_readlane(e.trB, k), cc = __builtin_amdgcn_readlane(e.trC, k);
+                const int wk = __builtin_amdgcn_readlane(e.w, k);
+                int bt = -1, bs = 0; bool have = false;
+                auto consider = [&](int tr) {
+                    const int s = tr >= base ? __builtin_amdgcn_readlane(fin, tr - base) : bcast0(sc[tr]);
+                    if (!have || s >= bs) { bs = s; bt = tr; have = true; }
+                };
+                if (cc == -2) {
+                    // more than three candidates: walk the node's in-edge list again (edge order)
+                    const int v = g.rank_full[base + k];
+                    for (int ed = g.in_head[v]; ed >= 0; ed = g.e_nin[ed]) {
+                        if (static_cast<int32_t>(g.e_w[ed]) == wk) consider(bcast0(g.n2r[g.e_tail[ed]]));
+                    }
+                } else {
+                    consider(a); consider(b); if (cc >= 0) consider(cc);
+                }
+                if (lane == k) { fin = wk + bs; trA = bt; }
+            }
+            const int sk = __builtin_amdgcn_readlane(fin, k);
+            if (tl == k && !((amb >> lane) & 1ull)) fin = e.w + sk;
+        }
+        if (r < n) { sc[r] = fin; pr[r] = static_cast<uint16_t>(trA < 0 ? 0xFFFF : trA); }
+        // running maximum: first strictly greater in rank order; any equality makes the order matter
+        const int fm = r < n ? fin : static_cast<int>(0x80000000u);
+        int cm = fm;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cm = max(cm, __shfl_xor(cm, d));
+        const unsigned long long at = __ballot(fm == cm);
+        if (cm > gmax) { gmax = cm; gmax_rank = base + __builtin_ctzll(at); gtie = __popcll(at) > 1; }
+        else if (cm == gmax) gtie = 1;
+        Wave0Of4::sync();
+    }
+    Ctx* o = Wave0Of4::ctx();
+    int k = 0;
+    const int mxnode = g.rank_full[gmax_rank];
+    if (!gtie && g.out_head[mxnode] < 0) {
+        // backtrack through the LDS predecessor ranks; the rank list overwrites the scores
+        int cur = gmax_rank;
+        for (;;) {
+            const int nxt = bcast0(static_cast<int>(pr[cur]));
+            if (lane == 0) sc[k] = cur;
+            ++k;
+            if (nxt == 0xFFFF) break;
+            cur = nxt;
+        }
+    }
+    if (lane == 0) o->tb_n = k;
+    Wave0Of4::sync();
+}
+
+__device__ __noinline__ void phase_cons2_finish(uint8_t* out_in, uint64_t out_cap, uint32_t* out_len_in, uint8_t* out_flags_in, int ns, int tgs) {
+    RCN_G uint8_t* out = uptr(out_in); RCN_G uint32_t* out_len = uptr(out_len_in); RCN_G uint8_t* out_flags = uptr(out_flags_in);
+    out_cap = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(out_cap >> 32))) << 32) | __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(out_cap));
+    ns = uint_(ns); tgs = uint_(tgs);
+    const int lane = threadIdx.x;
+    const Ctx c = ctx_load<Wave0Of4>();
+    Win g = ctx_win(c);
+    const int k = c.tb_n;
+    const int* plist = Wave0Of4::work();          // reversed consensus path, as ranks of rank_full
+    RCN_G int32_t* cn = g.path_node.ptr();
+    for (int i = lane; i < k; i += 64) cn[i] = g.rank_full[plist[k - 1 - i]];
+    Wave0Of4::sync();
+    int bgn = 0, end = k - 1, flags = kFlagPolished;
+    if (tgs && c.trim) {
+        const uint32_t avg = static_cast<uint32_t>(ns - 1) / 2;
+        // first / last consensus position whose coverage reaches the threshold (window.cpp:128-137)
+        bgn = k;
+        for (int b0 = 0; b0 < k && bgn == k; b0 += 64) {
+            const int i = b0 + lane;
+            const bool ok = i < k && consensus_coverage(g, cn[i]) >= avg;
+            const unsigned long long mk = __ballot(ok);
+            if (mk) bgn = b0 + __builtin_ctzll(mk);
+        }
+        end = -1;
+        for (int b0 = 0; b0 < k && end == -1; b0 += 64) {
+            const int i = k - 1 - (b0 + lane);
+            const bool ok = i >= 0 && consensus_coverage(g, cn[i]) >= avg;
+            const unsigned long long mk = __ballot(ok);
+            if (mk) end = k - 1 - (b0 + __builtin_ctzll(mk));
+        }
+        if (bgn >= end) { bgn = 0; end = k - 1; flags |= kFlagChimeric; }
+    }
+    const int clen = end - bgn + 1;
+    if (static_cast<uint64_t>(clen) > out_cap) { if (lane == 0) { *out_len = 0; *out_flags = kFlagOverflow; } return; }
+    for (int i = lane; i < clen; i += 64) out[i] = g.code[cn[bgn + i]];
+    if (lane == 0) { *out_len = clen; *out_flags = static_cast<uint8_t>(flags); }
+    Wave0Of4::sync();
+}
 
 __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
     const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -581,19 +764,30 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             RCN_PHASE2(0);
             // int16 (Z domain) validity of this alignment; otherwise the window goes to the int32 kernel
             const int V = bcast0(ctx->V);
-            const int np_regs = dp2_np(len);
+            const int cfg = dp2_cfg(len), np_regs = cfg & 255, nwv = cfg >> 8;
             {
                 const int ag = P.g < 0 ? -P.g : P.g, smax = max(max(P.m, P.x), 0);
-                if (P.g >= 0 || np_regs == 0 || static_cast<long long>(ag) * (V + 2) > kZLimit ||
-                    static_cast<long long>(smax + ag) * (512 * np_regs) > kZLimit) { overflow = 5; break; }
+                if (P.g >= 0 || cfg == 0 || static_cast<long long>(ag) * (V + 2) > kZLimit ||
+                    static_cast<long long>(smax + ag) * (128 * np_regs * nwv) > kZLimit) { overflow = 5; break; }
             }
             phase_desc2();
             RCN_PHASE2(1);
-            switch (np_regs) {
-                case 1: dp2_rows<1>(); break;
-                case 2: dp2_rows<2>(); break;
-                case 3: dp2_rows<3>(); break;
-                default: dp2_rows<4>(); break;
+            if (nwv == 1) {
+                if (wv == 0) {
+                    switch (np_regs) {
+                        case 1: dp2_rows<1, 1>(); break;
+                        case 2: dp2_rows<2, 1>(); break;
+                        case 3: dp2_rows<3, 1>(); break;
+                        default: dp2_rows<4, 1>(); break;
+                    }
+                }
+                Block4::sync();
+            } else {
+                switch (np_regs) {
+                    case 2: dp2_rows<2, 4>(); break;
+                    case 3: dp2_rows<3, 4>(); break;
+                    default: dp2_rows<4, 4>(); break;
+                }
             }
             RCN_PHASE2(2);
             phase_traceback2();
@@ -612,7 +806,22 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             if (t == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (overflow == 1 || overflow == 3 || overflow == 5) ? kFlagOverflow : kFlagError; }
             continue;
         }
-        if (wv == 0) phase_consensus<Wave0Of4>(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
+        {
+            // 32-bit bundle scores: every edge weight is a sum of (quality - 33) pairs, at most 444 per base pair
+            const uint64_t wbases = P.seq_off[s0 + ns] - P.seq_off[s0];
+            const bool fast_cons = bcast0(ctx->n_nodes) <= kCons2MaxNodes && wbases * 444ull < 0x7fffffffull;
+            int k = 0;
+            if (fast_cons) {
+                phase_cons2_edges();
+                if (wv == 0) phase_cons2_bundle();
+                Block4::sync();
+                k = bcast0(ctx->tb_n);
+            }
+            if (wv == 0) {
+                if (k > 0) phase_cons2_finish(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
+                else phase_consensus<Wave0Of4>(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
+            }
+        }
         RCN_PHASE2(6);
     }
     if (t == 0) {
