@@ -353,7 +353,9 @@ int rcn_engine_run(rcn_engine* e) {
     e->stats.n_sink_ties = st[11];
 #ifdef RCN_PROF_DP
     { unsigned long long pr[8]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(rcn::g_prof_out), sizeof(pr)));
-      fprintf(stderr, "[racon_hip] dp prof (cumulative): "); for (int k = 0; k < 4; ++k) fprintf(stderr, "wave%d row %llu bar %llu | ", k, pr[2*k], pr[2*k+1]); fprintf(stderr, "\n"); }
+      fprintf(stderr, "[racon_hip] dp prof (cumulative): "); for (int k = 0; k < 2; ++k) fprintf(stderr, "wave%d row %llu bar %llu | ", k, pr[2*k], pr[2*k+1]);
+      { unsigned long long db[8]; HIP_TRY(hipMemcpyFromSymbol(db, HIP_SYMBOL(rcn::g_dbg), sizeof(db))); fprintf(stderr, "dbg: "); for (int k = 0; k < 8; ++k) fprintf(stderr, "%llu ", db[k]); fprintf(stderr, "\n"); }
+      fprintf(stderr, "traceback: stage %llu walk %llu tiles %llu boxes %llu\n", pr[4], pr[5], pr[6], pr[7]); }
 #endif
     if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] traceback: stage clocks %llu walk clocks %llu tiles %llu steps %llu\n", st[12], st[13], st[14], st[15]);
 

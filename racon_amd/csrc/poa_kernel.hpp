@@ -545,9 +545,14 @@ __device__ __noinline__ void phase_add() {
     const int len = c.len, plen = c.plen, n_old = g.n_nodes;
     const uint32_t count = len >= 2 ? 1u : 0u;
     int nn = 0;
-    for (int k = lane; k < plen; k += 64) {
-        const int pp = g.path_pos[k];
-        if (pp != -1) { const int row = g.path_node[k]; g.pos_t[pp] = row == -1 ? -1 : rank[row - 1]; }
+    if (plen >= 0) {
+        for (int k = lane; k < plen; k += 64) {
+            const int pp = g.path_pos[k];
+            if (pp != -1) { const int row = g.path_node[k]; g.pos_t[pp] = row == -1 ? -1 : rank[row - 1]; }
+        }
+    } else {
+        // poa_window_kernel2's traceback leaves, per sequence position, the DP row it is aligned to (-1 = none)
+        for (int pos = lane; pos < len; pos += 64) { const int row = g.pos_t[pos]; g.pos_t[pos] = row <= 0 ? -1 : rank[row - 1]; }
     }
     S::sync();
     // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)

@@ -146,7 +146,8 @@ __device__ __noinline__ void phase_desc2() {
 }
 
 #ifdef RCN_PROF_DP
-__device__ unsigned long long g_prof_out[8];     // per wave: cycles in row bodies, cycles in barriers
+__device__ unsigned long long g_prof_out[8];
+__device__ unsigned long long g_dbg[8];     // per wave: cycles in row bodies, cycles in barriers
 #endif
 // ---- phase: NW sequence-to-graph DP ----
 // WV = 1: wave 0 alone owns all columns (up to 128*NP); no barrier, no border traffic.  The default for
@@ -399,7 +400,9 @@ __device__ __noinline__ void dp2_rows() {
 }
 
 // ---- phase: sink tie-break (rare) + traceback over int16 Z tiles ----
-constexpr int kTile2Cols = 128;        // int16 cells per tile row (256 B, 16 lanes x 16 B of global_load_lds)
+constexpr int kTile2Cols = 128;        // int16 cells per tile row (256 B = one 64-lane x 4 B global_load_lds)
+constexpr int kTile2Stride = 136;      // LDS row stride in cells: 272 B, i.e. 4 banks of skew per row -- the lanes of a
+                                       // box read the same column of up to 10 consecutive rows in one instruction
 
 __device__ __forceinline__ void traceback2_slow_step(Win& g, RCN_G const int32_t* nr, bool sub, RCN_G const uint8_t* seq,
                                                      int m, int x, int gp, int& i, int& j, int& n) {
@@ -433,7 +436,17 @@ __device__ __forceinline__ void traceback2_slow_step(Win& g, RCN_G const int32_t
     ++n; i = pi; j = pj;
 }
 
-__device__ __noinline__ void phase_traceback2() {
+// ---- phase: traceback, box walker ----
+// Same decisions as phase_traceback2 (spoa priority diag > vertical > horizontal, predecessors in in-edge
+// order) but organised around what a single wave is good at: the 64 lanes evaluate, in parallel, the move
+// of every cell of an 8-row x 8-column box below/left of the current cell from the staged int16 Z tile
+// (two LDS round trips per box), and the walk inside the box then costs one v_readlane per step instead of
+// LDS round trips and ballots.  Output: pos_t[pos] = DP row aligned to sequence position pos, or -1.
+constexpr int kMvDiag = 0, kMvUp = 1, kMvLeft = 2, kMvInvalid = 3;
+constexpr int kBoxRows = 10, kBoxCols = 6;           // 60 cells (lanes 60-63 idle): the path drops ~1.7 rows per column
+constexpr int kNxExit = 64, kNxInvalid = 65;
+
+__device__ __noinline__ void phase_traceback3() {
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const Ctx c = ctx_load<Block4>();
     Win g = ctx_win(c);
@@ -459,27 +472,28 @@ __device__ __noinline__ void phase_traceback2() {
     }
     Block4::sync();
 
-    int16_t* tile = reinterpret_cast<int16_t*>(Block4::work());                       // [64][128]
-    int* tdesc = Block4::work() + 64 * kTile2Cols / 2;                                 // 64 x RowDesc (8 ints each)
+    int16_t* tile = reinterpret_cast<int16_t*>(Block4::work());                       // [64][kTile2Stride]
+    int* tdesc = Block4::work() + 64 * kTile2Stride / 2;                               // 64 x RowDesc (8 ints each)
     uint8_t* tseq = reinterpret_cast<uint8_t*>(tdesc + 64 * (sizeof(RowDesc) / 4));   // seq[c0 - 1 + k], k in [0, 128]
-    RCN_G int32_t* __restrict__ pnode = g.path_node.ptr();
-    RCN_G int32_t* __restrict__ ppos = g.path_pos.ptr();
-    int i = bcast0(o->tb_i), j = bcast0(o->tb_j), n = 0;
+    RCN_G int32_t* __restrict__ prow = g.pos_t.ptr();
+    int i = bcast0(o->tb_i), j = bcast0(o->tb_j);
     int overflow = g.overflow;
     while (!(i == 0 && j == 0)) {
         // ---- stage the tile: rows [i-63, i] (tile row r holds matrix row i - r), cols [c0, c0+127] ----
-        const int ti0 = i;
+#ifdef RCN_PROF_DP
+        const long long tp0__ = clock64();
+#endif
+        const int ti0 = i, j_stage = j;
         int c0 = (j - 120) & ~7; if (c0 < 0) c0 = 0;
         const int rmin = ti0 - 63 > 0 ? ti0 - 63 : 0;
         {
             typedef __attribute__((address_space(3))) void* lds_ptr;
-            const int sub_row = lane >> 4, chunk = lane & 15;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = 4 * wv + kk;
-                int r = ti0 - (4 * k + sub_row); if (r < 0) r = 0;
-                RCN_G const int16_t* src = H + r * hs + c0 + chunk * 8;
-                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(tile + k * 4 * kTile2Cols), 16, 0, 0);
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = 16 * wv + kk;                   // tile row
+                int r = ti0 - k; if (r < 0) r = 0;
+                RCN_G const int16_t* src = H + r * hs + c0 + lane * 2;
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(tile + k * kTile2Stride), 4, 0, 0);
             }
             if (wv == 1) {
                 const int r = ti0 - lane;
@@ -496,53 +510,110 @@ __device__ __noinline__ void phase_traceback2() {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef RCN_PROF_DP
+        const long long tp1__ = clock64();
+        int nbox__ = 0;
+#endif
         if (wv == 0) {
-            // ---- walk inside the tile: wave-uniform control flow; lane q looks at predecessor q ----
-            int steps = 0, bn = 0, bp = 0, n0 = n;      // up to 64 path entries buffered one per lane
-            int hij = tile[j - c0];                      // row ti0 is tile row 0
+            // box = kBoxRows x kBoxCols cells below/left of the current cell, one per lane: (i - a, j - b)
+            const int a = lane / kBoxCols, b = lane % kBoxCols;
             for (;;) {
                 if (i == 0 && j == 0) break;
-                int pi, pj, hnext;
-                if (i == 0) {                            // only horizontal moves are left on the virtual row
-                    if (j - 1 < c0) break;
-                    pi = 0; pj = j - 1; hnext = hij;
-                } else {
-                    const int* dr = tdesc + (ti0 - i) * 8;
-                    const int pq = dr[lane < kInlinePreds ? lane : 0];
-                    const int erest = dr[6], meta = dr[7];
-                    const int symc = tseq[j - c0];                               // seq[j-1]
-                    const int np = (meta >> 9) & 15;
-                    const bool valid = lane < np;
-                    if (__ballot(valid && pq < rmin) != 0ull || erest >= 0 || (j > 0 && j - 1 < c0)) break;   // leaves the tile
-                    const int mc = (((meta & 255) == symc) ? m : x) - gp;
-                    const int16_t* cp = tile + (ti0 - (valid ? pq : ti0)) * kTile2Cols + (j - c0);
-                    const int hd = cp[j > 0 ? -1 : 0], hu = cp[0];
-                    const unsigned long long dmask = __ballot(valid && j > 0 && hij == hd + mc);
-                    const unsigned long long umask = __ballot(valid && hij == hu + gp);
-                    if (dmask) { const int q = __builtin_ctzll(dmask); pi = __builtin_amdgcn_readlane(pq, q); pj = j - 1; hnext = __builtin_amdgcn_readlane(hd, q); }
-                    else if (umask) { const int q = __builtin_ctzll(umask); pi = __builtin_amdgcn_readlane(pq, q); pj = j; hnext = __builtin_amdgcn_readlane(hu, q); }
-                    else { if (j == 0) { overflow = 4; i = 0; j = 0; break; } pi = i; pj = j - 1; hnext = hij; }
+#ifdef RCN_PROF_DP
+                ++nbox__;
+#endif
+                // ---- move of every cell of the box anchored at (i, j): all LDS reads first, compares after ----
+                const int ii = i - a, jj = j - b;
+                const bool inside = a < kBoxRows && ii >= rmin && ii >= 0 && jj >= c0 && jj >= 0 && !(jj > 0 && jj - 1 < c0);
+                const int trow = inside ? ti0 - ii : 0, tcol = inside ? jj - c0 : 1;
+                const int* dr = tdesc + trow * 8;
+                const int4 pa = *reinterpret_cast<const int4*>(dr);
+                const int4 pb = *reinterpret_cast<const int4*>(dr + 4);
+                const int hij = tile[trow * kTile2Stride + tcol];
+                const int symc = tseq[tcol];                                    // seq[jj - 1]
+                const int meta = pb.w, erest = pb.z;
+                const int np = (meta >> 9) & 15;
+                const int pq[6] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y};
+                bool ok = inside && erest < 0;
+                const int mc = (((meta & 255) == symc) ? m : x) - gp;
+                // first match in spoa's order (diagonal over the in-edges, then vertical over the in-edges, then
+                // horizontal), branch-free per cell: later q first, earlier q overrides.  In-edges are looked
+                // at in pairs, the later pairs only if some cell of the box has that many.
+                int dlD = 0, dlU = 0, fD = 0, fU = 0;
+                const int colok = jj > 0;
+                const int npb = inside ? np : 0;
+                auto look = [&](int q) {
+                    const int useq = q < npb;
+                    if (useq && pq[q] < rmin) ok = false;
+                    const int16_t* zp = tile + ((useq && pq[q] >= rmin) ? ti0 - pq[q] : 0) * kTile2Stride + tcol;
+                    const int hdq = zp[tcol > 0 ? -1 : 0], huq = zp[0];
+                    const int isd = useq & colok & (hij == hdq + mc);
+                    const int isu = useq & (hij == huq + gp);
+                    dlD = isd ? ii - pq[q] : dlD; fD |= isd;
+                    dlU = isu ? ii - pq[q] : dlU; fU |= isu;
+                };
+                if (__ballot(npb > 4)) { look(5); look(4); }
+                if (__ballot(npb > 2)) { look(3); look(2); }
+                look(1); look(0);
+                int mv = fD ? kMvDiag : (fU ? kMvUp : (colok ? kMvLeft : kMvInvalid));
+                int dl = fD ? dlD : dlU;
+                if (ii == 0) { mv = colok ? kMvLeft : kMvInvalid; dl = 0; }
+                if (!ok) mv = kMvInvalid;
+                // successor of this cell: a lane of the box, or one of the exits
+                const int ni = ii - (mv == kMvLeft ? 0 : dl), nj = jj - (mv == kMvUp ? 0 : 1);
+                const int na = i - ni, nb = j - nj;
+                int nx;
+                if (mv == kMvInvalid) nx = kNxInvalid;
+                else if (ni == 0 && nj == 0) nx = kNxExit;
+                else if (na >= kBoxRows || nb >= kBoxCols) nx = kNxExit;
+                else nx = na * kBoxCols + nb;
+                // ---- walk: one v_readlane per step ----
+                int idx = 0, nxt;
+                unsigned long long vis = 0ull;
+                for (;;) {
+                    nxt = __builtin_amdgcn_readlane(nx, idx);
+                    if (nxt == kNxInvalid) break;
+                    vis |= 1ull << idx;
+                    if (nxt >= 64) break;
+                    idx = nxt;
                 }
-                if (lane == steps) { bn = (i == pi) ? -1 : i; bp = (j == pj) ? -1 : j - 1; }   // ROW index (node id later)
-                ++steps;
-                i = pi; j = pj; hij = hnext;
-                if (steps == 64) { pnode[n0 + lane] = bn; ppos[n0 + lane] = bp; n0 += 64; steps = 0; }
+                // emit the sequence positions consumed inside the box
+                if (((vis >> lane) & 1ull) && mv != kMvUp) prow[jj - 1] = (mv == kMvDiag) ? ii : -1;
+                bool stuck = false;
+                if (nxt == kNxInvalid) { stuck = idx == 0; i = __builtin_amdgcn_readlane(ii, idx); j = __builtin_amdgcn_readlane(jj, idx); }
+                else { i = __builtin_amdgcn_readlane(ni, idx); j = __builtin_amdgcn_readlane(nj, idx); }
+#ifdef RCN_PROF_DP
+                if (lane == 0) { atomicAdd(&g_dbg[6], (unsigned long long)__popcll(vis)); if (stuck) atomicAdd(&g_dbg[1], 1ull);
+                    if (nxt == kNxInvalid && !stuck) atomicAdd(&g_dbg[2], 1ull); }
+                { const int lna = __builtin_amdgcn_readlane(na, idx), lnb = __builtin_amdgcn_readlane(nb, idx), ldl = __builtin_amdgcn_readlane(dl, idx);
+                  if (lane == 0 && nxt == kNxExit) { if (lnb >= kBoxCols) atomicAdd(&g_dbg[3], 1ull); else if (lna >= kBoxRows) atomicAdd(&g_dbg[4], 1ull); else atomicAdd(&g_dbg[5], 1ull);
+                                                     if (ldl >= 8) atomicAdd(&g_dbg[7], 1ull); } }
+#endif
+                if (stuck) break;
             }
-            if (lane < steps) { pnode[n0 + lane] = bn; ppos[n0 + lane] = bp; }
-            const bool progressed = (n0 + steps) != n;
-            n = n0 + steps;
-            if (!progressed && !(i == 0 && j == 0)) {
+            if (!(i == 0 && j == 0) && i == ti0 && j == j_stage) {
+                // no progress on a freshly anchored tile (predecessor > 63 rows back or > 6 in-edges): one
+                // step against HBM
                 g.overflow = overflow;
-                if (lane == 0) traceback2_slow_step(g, nr, sub, seq, m, x, gp, i, j, n);
-                i = bcast0(i); j = bcast0(j); n = bcast0(n); overflow = bcast0(g.overflow);
+                int pi = i, pj = j, n_dummy = 0;
+                if (lane == 0) {
+                    traceback2_slow_step(g, nr, sub, seq, m, x, gp, pi, pj, n_dummy);
+                    if (pj != j) prow[j - 1] = (pi != i) ? i : -1;
+                }
+                i = bcast0(pi); j = bcast0(pj); overflow = bcast0(g.overflow);
             }
-            if (lane == 0) { o->tb_i = i; o->tb_j = j; o->tb_n = n; o->overflow = overflow; }
+            if (lane == 0) { o->tb_i = i; o->tb_j = j; o->overflow = overflow; }
+#ifdef RCN_PROF_DP
+            if (lane == 0) { const long long tp2__ = clock64(); atomicAdd(&g_prof_out[4], (unsigned long long)(tp1__ - tp0__)); atomicAdd(&g_prof_out[5], (unsigned long long)(tp2__ - tp1__));
+                             atomicAdd(&g_prof_out[6], 1ull); atomicAdd(&g_prof_out[7], (unsigned long long)nbox__); }
+#endif
         }
         Block4::sync();
-        i = bcast0(o->tb_i); j = bcast0(o->tb_j); n = bcast0(o->tb_n);
+        i = bcast0(o->tb_i); j = bcast0(o->tb_j);
+        if (bcast0(o->overflow)) break;
         Block4::sync();                                  // everyone has read the walk state before the next tile overwrites LDS
     }
-    if (t == 0) { o->plen = n; }
+    if (t == 0) { o->plen = -1; }
     Block4::sync();
 }
 
@@ -790,7 +861,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 }
             }
             RCN_PHASE2(2);
-            phase_traceback2();
+            phase_traceback3();
             RCN_PHASE2(3);
             overflow = bcast0(ctx->overflow);
             if (!overflow) {
