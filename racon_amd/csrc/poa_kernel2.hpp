@@ -115,6 +115,144 @@ __host__ __device__ __forceinline__ int dp2_cfg(int len) {
 // rows of the register window for NP packed VGPRs per lane (16 VGPRs in all; a power of two)
 __host__ __device__ constexpr int dp2_window(int np) { return np <= 1 ? 16 : np == 2 ? 8 : 4; }
 
+// ---- phase: Subgraph mask + filtered order (window.cpp:99-103), without the serial DFS ----
+// spoa's ExtractSubgraph(end, begin) = nodes with id >= begin that are backward-reachable from `end` over
+// in-edges and aligned-node links.  On a ring-contiguous topological order (rank_full) this is one
+// descending sweep over RING BLOCKS: a block is taken when any of its members (with id >= begin) is
+// pending, then all its members (id >= begin) are taken and all their in-edge tails become pending.
+//   pass A (256 threads): per rank, {tail ranks (6 inline + overflow edge), block start / size, id >= begin}
+//   pass B (wave 0): 64 ranks per step, block decisions on the scalar unit over 64-bit masks
+//   pass C: inc[] per node, compaction into rank_sub / n2r_x
+struct SubRec { int32_t tr[6]; int32_t erest; int32_t info; };   // info: bit0 id>=begin, bits 4-7 #inline tails,
+                                                                  // bits 8-15 rank - (first rank of its block), bits 16-23 block size
+static_assert(sizeof(SubRec) == sizeof(RowDesc), "SubRec lives in the row-descriptor array");
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int k) {
+    return (static_cast<unsigned long long>(static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), k))) << 32) |
+           static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), k));
+}
+
+// returns false (through ctx->tb_i = 0) when a node has more than six in-edges: the caller then takes the
+// serial DFS of poa_kernel.hpp for this layer
+__device__ __noinline__ void phase_subgraph2() {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    const int n = g.n_nodes;
+    RCN_G SubRec* rec = reinterpret_cast<RCN_G SubRec*>(g.desc.ptr());
+    uint8_t* pend = reinterpret_cast<uint8_t*>(Block4::work());          // [n] pending / finally: included, by rank
+    Ctx* o = Block4::ctx();
+    int top;
+    {
+        int r = g.n2r[c.end];
+        const int na = g.al_cnt[c.end];
+        for (int a = 0; a < na; ++a) r = max(r, g.n2r[g.al_nodes[c.end * g.ring + a]]);
+        top = bcast0(r);
+    }
+    if (t == 0) o->tb_i = 1;
+    Block4::sync();
+    // ---- pass A ----
+    for (int r = t; r < n; r += kThreads2) pend[r] = 0;
+    bool wide = false;
+    for (int r = t; r <= top; r += kThreads2) {
+        const int v = g.rank_full[r];
+        SubRec e; e.erest = -1;
+        int k = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) e.tr[q] = -1;
+        for (int ed = g.in_head[v]; ed >= 0; ed = g.e_nin[ed]) {
+            if (k == 6) { e.erest = ed; wide = true; break; }
+            e.tr[k++] = g.n2r[g.e_tail[ed]];
+        }
+        int rb = r;
+        const int na = g.al_cnt[v];
+        for (int a = 0; a < na; ++a) rb = min(rb, g.n2r[g.al_nodes[v * g.ring + a]]);
+        e.info = (v >= c.begin ? 1 : 0) | (k << 4) | ((r - rb) << 8) | ((na + 1) << 16);
+        rec[r] = e;
+    }
+    if (wide) o->tb_i = 0;
+    Block4::sync();
+    if (bcast0(o->tb_i) == 0) return;
+    if (t == 0) pend[g.n2r[c.end]] = 1;
+    Block4::sync();
+    // ---- pass B ----
+    if (wv == 0) {
+        int hi = top, minpend = g.n2r[c.end];
+        while (hi >= 0 && minpend <= hi) {
+            const int base = hi - 63;                                      // lane l <-> rank base + l
+            const int r = base + lane;
+            SubRec e; e.erest = -1; e.info = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) e.tr[q] = -1;
+            if (r >= 0) e = rec[r];
+            const int off = (e.info >> 8) & 255, bsz = (e.info >> 16) & 255;
+            // lanes whose ring block starts below the chunk are left to the next chunk
+            const bool mine = r >= 0 && r - off >= base && r - off >= 0;
+            const unsigned long long minemask = __ballot(mine);
+            const int lo_lane = __builtin_ctzll(minemask);                 // lowest lane processed here (a block start)
+            const bool idok = mine && (e.info & 1);
+            unsigned long long pendmask = __ballot(mine && pend[r >= 0 ? r : 0] != 0);
+            // in-edge tails inside the processed part of the chunk, as lane bits
+            unsigned long long own_t = 0ull;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { const int tl = e.tr[q] - base; if (e.tr[q] >= 0 && tl >= lo_lane) own_t |= 1ull << tl; }
+            if (!idok) own_t = 0ull;
+            const unsigned long long own_b = idok ? (1ull << lane) : 0ull;
+            // per block, at its first lane: members with id >= begin, union of their tail masks
+            unsigned long long bmask = own_b, btmask = own_t;
+            for (int d = 1; d < 8; ++d) {
+                const unsigned long long mb = __shfl_down(own_b, d), mt = __shfl_down(own_t, d);
+                if (d < bsz && lane + d < 64) { bmask |= mb; btmask |= mt; }
+            }
+            unsigned long long incmask = 0ull;
+            unsigned long long todo = __ballot(mine && off == 0);
+            while (todo) {
+                const int k = 63 - __builtin_clzll(todo);
+                todo &= ~(1ull << k);
+                const unsigned long long bm = readlane64(bmask, k);
+                if (bm & pendmask) { incmask |= bm; pendmask |= readlane64(btmask, k); }
+            }
+            const bool inc = (incmask >> lane) & 1ull;
+            // tails below the processed part become pending
+            int lowest = 0x7fffffff;
+            if (inc) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int tr = e.tr[q];
+                    if (tr >= 0 && tr - base < lo_lane) { pend[tr] = 1; lowest = min(lowest, tr); }
+                }
+            }
+            if (mine) pend[r] = inc ? 1 : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) lowest = min(lowest, __shfl_xor(lowest, d));
+            Wave0Of4::sync();
+            const int lo_eff = base + lo_lane;
+            if (minpend >= lo_eff) minpend = 0x7fffffff;                   // it has just been processed
+            minpend = min(minpend, lowest);
+            hi = lo_eff - 1;
+        }
+    }
+    Block4::sync();
+    // ---- pass C ----
+    for (int r = t; r < n; r += kThreads2) g.inc[g.rank_full[r]] = pend[r];
+    if (wv == 0) {
+        int nv = 0;
+        for (int b0 = 0; b0 < n; b0 += 64) {
+            const int r = b0 + lane;
+            const bool in = r < n && pend[r] != 0;
+            const unsigned long long mk = __ballot(in);
+            if (in) {
+                const int v = g.rank_full[r];
+                const int pos = nv + __popcll(mk & ((1ull << lane) - 1ull));
+                g.rank_sub[pos] = v; g.n2r_x[v] = pos;
+            }
+            nv += __popcll(mk);
+        }
+        if (lane == 0) o->V = nv;
+    }
+    Block4::sync();
+}
+
 // ---- phase: row descriptors (all 256 threads) + row 0 of Z ----
 __device__ __noinline__ void phase_desc2() {
     const int t = threadIdx.x;
@@ -831,7 +969,11 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 ctx->V = ctx->n_nodes;
             }
             Block4::sync();
-            if (partial) { if (wv == 0) phase_subgraph<Wave0Of4>(); Block4::sync(); }
+            if (partial) {
+                bool done = false;
+                if (bcast0(ctx->n_nodes) <= kLdsBytes) { phase_subgraph2(); done = bcast0(ctx->tb_i) != 0; }
+                if (!done) { if (wv == 0) phase_subgraph<Wave0Of4>(); Block4::sync(); }
+            }
             RCN_PHASE2(0);
             // int16 (Z domain) validity of this alignment; otherwise the window goes to the int32 kernel
             const int V = bcast0(ctx->V);
