@@ -574,6 +574,90 @@ __device__ __forceinline__ void traceback2_slow_step(Win& g, RCN_G const int32_t
     ++n; i = pi; j = pj;
 }
 
+// ---- phase: AddAlignment over 256 threads (window.cpp:110-119) ----
+// Same per-position phases as phase_add<> of poa_kernel.hpp (a global alignment consumes every sequence
+// position exactly once, so positions are independent up to the node / edge numbering and the order
+// anchors), but 256 positions per step: the prefix count / prefix max across the four waves goes through
+// eight LDS words.  Four times fewer dependent HBM round trips on the critical path.
+__device__ __forceinline__ void block4_scan(int* xch, int wv, int lane, int cnt, int wmax, int& off, int& total, int& pmax, int& tmax) {
+    if (lane == 0) { xch[wv] = cnt; xch[4 + wv] = wmax; }
+    Block4::sync();
+    off = 0; total = 0; pmax = -1; tmax = -1;
+#pragma unroll
+    for (int w = 0; w < kWaves2; ++w) {
+        const int cw = xch[w], mw = xch[4 + w];
+        if (w < wv) { off += cw; pmax = max(pmax, mw); }
+        total += cw; tmax = max(tmax, mw);
+    }
+    Block4::sync();
+}
+
+__device__ __noinline__ void phase_add4() {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
+    RCN_G const uint8_t* seq = gcast(c.seq); RCN_G const uint8_t* qual = gcast(c.qual);
+    const int len = c.len, n_old = g.n_nodes;
+    const uint32_t count = len >= 2 ? 1u : 0u;
+    int* xch = Block4::work();
+    // the traceback left, per sequence position, the DP row it is aligned to (-1 = none)
+    for (int pos = t; pos < len; pos += kThreads2) { const int row = g.pos_t[pos]; g.pos_t[pos] = row <= 0 ? -1 : rank[row - 1]; }
+    Block4::sync();
+    // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)
+    RCN_G int32_t* kindv = g.path_pos.ptr();
+    RCN_G int32_t* idxv = g.path_node.ptr();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nn = 0, anchor = -1;
+    for (int base = 0; base < len; base += kThreads2) {
+        const int pos = base + t;
+        int kind = 0, a = -1;
+        if (pos < len) { kind = addp_classify(g, seq, pos); a = g.pos_a[pos]; }
+        const unsigned long long mk = __ballot(kind != 0);
+        const int la = wave_incl_scan_max(a);
+        int off, total, pmax, tmax;
+        block4_scan(xch, wv, lane, __popcll(mk), __builtin_amdgcn_readlane(la, 63), off, total, pmax, tmax);
+        if (pos < len) { kindv[pos] = kind; idxv[pos] = nn + off + __popcll(mk & lt); g.pos_a[pos] = max(max(la, pmax), anchor); }
+        nn += total; anchor = max(anchor, tmax);
+    }
+    int overflow = g.overflow;
+    if (n_old + nn > g.ncap) overflow = 1;
+    Block4::sync();
+    int n_edges = g.n_edges;
+    if (!overflow) {
+        for (int pos = t; pos < len; pos += kThreads2) {
+            const int kind = kindv[pos];
+            if (kind) {
+                const int idx = idxv[pos];
+                addp_create(g, seq, pos, kind, n_old + idx, count);
+                g.new_id[idx] = n_old + idx; g.new_anchor[idx] = g.pos_a[pos];
+            }
+        }
+        g.n_nodes = n_old + nn;
+        Block4::sync();
+        int ovf = 0;
+        for (int base = 0; base < len; base += kThreads2) {
+            const int pos = base + t;
+            int f = 0;
+            if (pos >= 1 && pos < len) f = addp_edge_find(g, qual, pos);
+            const unsigned long long mk = __ballot(f != 0);
+            int off, total, pmax, tmax;
+            block4_scan(xch, wv, lane, __popcll(mk), 0, off, total, pmax, tmax);
+            const int e = n_edges + off + __popcll(mk & lt);
+            if (f) { if (e < g.ecap) addp_edge_create(g, qual, pos, e); else ovf = 1; }
+            n_edges += total;
+        }
+        if (n_edges > g.ecap) { overflow = 1; n_edges = g.ecap; }
+        (void)ovf;
+        for (int pos = t; pos < len; pos += kThreads2) g.cov[g.pos_curr[pos]] += count;
+    }
+    if (t == 0) {
+        Ctx* o = Block4::ctx();
+        o->n_old = n_old; o->nn = nn; o->n_nodes = overflow ? n_old : n_old + nn; o->n_edges = n_edges; o->overflow = overflow;
+    }
+    Block4::sync();
+}
+
 // ---- phase: traceback, box walker ----
 // Same decisions as phase_traceback2 (spoa priority diag > vertical > horizontal, predecessors in in-edge
 // order) but organised around what a single wave is good at: the 64 lanes evaluate, in parallel, the move
@@ -1007,8 +1091,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             RCN_PHASE2(3);
             overflow = bcast0(ctx->overflow);
             if (!overflow) {
-                if (wv == 0) phase_add<Wave0Of4>();
-                Block4::sync();
+                phase_add4();
                 RCN_PHASE2(4);
                 overflow = bcast0(ctx->overflow);
                 if (!overflow) { if (wv == 0) phase_merge<Wave0Of4>(); Block4::sync(); }
