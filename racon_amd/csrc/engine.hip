@@ -59,6 +59,7 @@ struct rcn_engine {
     DevBuf d_win_seq_off, d_win_type, d_seq_off, d_has_qual, d_begin, d_end, d_bases, d_quals, d_order, d_full;
     DevBuf d_win_ids, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
     std::vector<WinShape> shapes;
+    int32_t heavy_ns = 0, prio_ns = 0;
     std::vector<uint32_t> h_win_seq_off;
     bool uploaded = false, ran = false;
 
@@ -88,9 +89,9 @@ struct Caps { int32_t ncap, ecap, ring, lmax, hstride; uint64_t slot_bytes; uint
 // fast = poa_window_kernel2 (4 waves per window, int16 Z matrix); else poa_window_kernel (1 wave, int32 H)
 Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast) {
     Caps c; c.ncap = ncap; c.ecap = ecap; c.ring = ring; c.lmax = lmax; c.fast = fast;
-    // fast: row stride in int16 cells, a multiple of 24 (16-byte aligned rows for the tile loads AND a whole
-    // number of 2/4/6/8-cell lane blocks, so no lane's store straddles two rows)
-    c.hstride = fast ? ((lmax + 1 + 23) / 24) * 24 + 24 : (lmax + 1 + 128 + 3) & ~3;
+    // fast: row stride in int16 cells, a multiple of 512: every DP shape (64 or 256 lanes x 2..8 cells) then
+    // covers whole rows only, so the row store needs no lane mask
+    c.hstride = fast ? ((lmax + 1 + 511) / 512) * 512 : (lmax + 1 + 128 + 3) & ~3;
     rcn::Win tmp;
     c.slot_bytes = rcn::win_bind(tmp, nullptr, ncap, ecap, ring, lmax, c.hstride, fast ? 2 : 4);
     c.slot_bytes = (c.slot_bytes + 255) & ~uint64_t(255);
@@ -119,6 +120,7 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.order = e->d_order.as<uint32_t>(); P.seq_full = e->d_full.as<uint8_t>();
     P.win_ids = ids ? e->d_win_ids.as<uint32_t>() : nullptr; P.n_work = n_work;
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
+    P.heavy_ns = e->heavy_ns; P.prio_ns = e->prio_ns;
     P.scratch = e->d_scratch.as<uint8_t>(); P.slot_bytes = c.slot_bytes;
     P.ncap = c.ncap; P.ecap = c.ecap; P.ring = c.ring; P.lmax = c.lmax; P.hstride = c.hstride;
     P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_stride = out_stride;
@@ -290,6 +292,27 @@ int rcn_engine_run(rcn_engine* e) {
     }
     const int32_t ring = std::max(1, nsym - 1);
     const bool fast = !getenv("RCN_WIDE_ONLY");
+    {
+        // windows in the top tail of the depth distribution decide when a launch ends (one wave per window is
+        // latency bound): they get the 4-wave DP.  Threshold = a high percentile of sequences per window.
+        std::vector<uint32_t> depth(nw);
+        for (uint32_t w = 0; w < nw; ++w) depth[w] = e->h_win_seq_off[w + 1] - e->h_win_seq_off[w];
+        std::vector<uint32_t> sorted = depth;
+        const char* pe = getenv("RCN_HEAVY_PCT");
+        const double pct = pe ? atof(pe) : 1.0;
+        {
+            const char* pp = getenv("RCN_PRIO_PCT");
+            const double ppct = pp ? atof(pp) : 1.0;
+            std::vector<uint32_t> s2 = depth;
+            const size_t k2 = std::min<size_t>(nw - 1, static_cast<size_t>(ppct * nw));
+            std::nth_element(s2.begin(), s2.begin() + k2, s2.end());
+            e->prio_ns = ppct >= 1.0 ? 0 : static_cast<int32_t>(std::max<uint32_t>(s2[k2], 3));
+        }
+        const size_t kth = std::min<size_t>(nw - 1, static_cast<size_t>(pct * nw));
+        std::nth_element(sorted.begin(), sorted.begin() + kth, sorted.end());
+        e->heavy_ns = pct >= 1.0 ? 0 : static_cast<int32_t>(std::max<uint32_t>(sorted[kth], 3));
+        if (pct <= 0.0) e->heavy_ns = 1;
+    }
     Caps c1 = make_caps(ncap, 2 * ncap, ring, lmax, fast);
     int rc;
     if ((rc = e->d_out_cons.reserve(static_cast<uint64_t>(nw) * c1.out_stride))) return rc;
@@ -351,6 +374,17 @@ int rcn_engine_run(rcn_engine* e) {
     e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
     for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
     e->stats.n_sink_ties = st[11];
+#ifdef RCN_PROF_WIN
+    { static unsigned long long wc[4096][8]; HIP_TRY(hipMemcpyFromSymbol(wc, HIP_SYMBOL(rcn::g_wclk), sizeof(wc)));
+      std::vector<std::pair<unsigned long long, int>> tot;
+      for (int w = 0; w < 4096 && w < (int)nw; ++w) { unsigned long long s = 0; for (int k = 0; k < 7; ++k) s += wc[w][k]; tot.push_back({s, w}); }
+      std::sort(tot.rbegin(), tot.rend());
+      unsigned long long all = 0; for (auto& p : tot) all += p.first;
+      fprintf(stderr, "[racon_hip] per-window clocks: mean %.3g\n", (double)all / std::max<size_t>(1, tot.size()));
+      for (int k = 0; k < 3 && k < (int)tot.size(); ++k) { int w = tot[k].second; fprintf(stderr, "  window %d (%u seqs): total %.3g | sub %.3g desc %.3g dp %.3g tb %.3g add %.3g merge %.3g cons %.3g | tiles %llu boxes %llu slow %llu\n", w,
+          e->h_win_seq_off[w + 1] - e->h_win_seq_off[w], (double)tot[k].first, (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6], wc[w][7] >> 40, (wc[w][7] >> 20) & 0xfffff, wc[w][7] & 0xfffff); }
+      { int w = tot[tot.size() / 2].second; fprintf(stderr, "  median window %d: total %.3g tb %.3g tiles %llu boxes %llu slow %llu\n", w, (double)tot[tot.size() / 2].first, (double)wc[w][3], wc[w][7] >> 40, (wc[w][7] >> 20) & 0xfffff, wc[w][7] & 0xfffff); } }
+#endif
 #ifdef RCN_PROF_DP
     { unsigned long long pr[8]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(rcn::g_prof_out), sizeof(pr)));
       fprintf(stderr, "[racon_hip] dp prof (cumulative): "); for (int k = 0; k < 2; ++k) fprintf(stderr, "wave%d row %llu bar %llu | ", k, pr[2*k], pr[2*k+1]);

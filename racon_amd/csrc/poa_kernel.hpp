@@ -34,6 +34,8 @@ struct KParams {
     const uint8_t*  seq_full;     // [n_seqs] 1 = full-span layer (window.cpp:93-94), else Subgraph
     const uint32_t* win_ids;      // [n_work] indirection (retry pass) or nullptr
     uint32_t n_work;
+    int32_t prio_ns;              // poa_window_kernel2: windows with at least this many sequences run at raised wave priority (0 = none)
+    int32_t heavy_ns;             // poa_window_kernel2: windows with at least this many sequences use the 4-wave DP (0 = none)
     int32_t m, x, g, trim;
     // per-slot scratch
     uint8_t* scratch; uint64_t slot_bytes; int32_t ncap, ecap, ring, lmax, hstride;
@@ -392,6 +394,9 @@ struct Ctx {
     unsigned long long cells, pred, bytes, ties;
     // work-group shared scalars of poa_window_kernel2 (work item, traceback walk state)
     int32_t wi, tb_i, tb_j, tb_n;
+    int32_t dbg_tiles, dbg_boxes, dbg_slow, bblen;
+    int32_t tie_rows[8];          // rows of the sinks that share the best score (first 8)
+    int32_t tie_why, tie_pad[3];
 };
 static_assert(sizeof(Ctx) % 4 == 0 && sizeof(Ctx) <= 512, "Ctx must fit its LDS slot");
 constexpr int kCtxBytes = 512;

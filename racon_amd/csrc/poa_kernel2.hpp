@@ -67,32 +67,22 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, static_cast<s16x2>(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
 }
 __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16); }
-// VOP3P results need one wait state before a dependent VALU read on gfx940+ (dst-sel forwarding
-// hazard); the hazard recogniser does not look into inline asm, hence the explicit s_nop.
-// (sym == seq ? m - g : x - g) for both halves: t = min(seq ^ sym, 1); t * (x - m) + (m - g)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// (sym == seq ? m - g : x - g) for both halves: t = min(seq ^ sym, 1); t * (x - m) + (m - g).  The empty asm
+// keeps the compiler from turning min(a ^ b, 1) back into compare + select chains (five instructions).
 __device__ __forceinline__ uint32_t pk_profile(uint32_t sqx, uint32_t symsym, uint32_t one, uint32_t xm, uint32_t mg) {
-    uint32_t t = sqx ^ symsym, r;
-    asm("v_pk_min_u16 %0, %1, %2\n\ts_nop 0\n\tv_pk_mad_i16 %0, %0, %3, %4\n\ts_nop 0" : "=&v"(r) : "v"(t), "v"(one), "v"(xm), "v"(mg));
-    return r;
+    uint32_t t = sqx ^ symsym;
+    asm("" : "+v"(t));
+    const u16x2 mn = __builtin_elementwise_min(__builtin_bit_cast(u16x2, t), __builtin_bit_cast(u16x2, one));
+    uint32_t u = __builtin_bit_cast(uint32_t, mn);
+    asm("" : "+v"(u));
+    const s16x2 r = __builtin_bit_cast(s16x2, u) * __builtin_bit_cast(s16x2, xm) + __builtin_bit_cast(s16x2, mg);
+    return __builtin_bit_cast(uint32_t, r);
 }
 // {lo, max(hi, lo)}
-__device__ __forceinline__ uint32_t pk_chain_pair(uint32_t a) {
-    uint32_t r;
-    asm("v_pk_max_i16 %0, %1, %1 op_sel:[0,0] op_sel_hi:[1,0]\n\ts_nop 0" : "=v"(r) : "v"(a));
-    return r;
-}
+__device__ __forceinline__ uint32_t pk_chain_pair(uint32_t a) { return pk_max(a, __builtin_amdgcn_perm(a, a, 0x01000100u)); }
 // {max(a.lo, b.hi), max(a.hi, b.hi)}
-__device__ __forceinline__ uint32_t pk_max_bhi(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]\n\ts_nop 0" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// {max(a.lo, b.lo), max(a.hi, b.lo)}
-__device__ __forceinline__ uint32_t pk_max_blo(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_max_i16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\ts_nop 0" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+__device__ __forceinline__ uint32_t pk_max_bhi(uint32_t a, uint32_t b) { return pk_max(a, __builtin_amdgcn_perm(b, b, 0x03020302u)); }
 __device__ __forceinline__ int wave_incl_scan_max_id(int v) {      // INT_MIN is max's identity: each step fuses into one v_max_i32_dpp
     constexpr int I = static_cast<int>(0x80000000u);
     v = max(v, dpp_or<0x111, 0xf>(I, v));
@@ -106,9 +96,11 @@ __device__ __forceinline__ int wave_incl_scan_max_id(int v) {      // INT_MIN is
 
 // DP shape for a layer of `len` bases: one wave over (len+1) <= 512 columns, else the 4-wave pipeline;
 // NP = packed VGPRs per lane (2 NP columns).  Returns NP | (WV << 8), 0 = not supported (int32 kernel).
-__host__ __device__ __forceinline__ int dp2_cfg(int len) {
+// `wide` (heavy windows, see KParams::heavy_ns): the pipeline also for short layers -- twice the instructions
+// in total but about half the latency per row, which is what counts for the windows that finish last.
+__host__ __device__ __forceinline__ int dp2_cfg(int len, bool wide) {
     const int W = len + 1;
-    if (W <= 512) return ((W + 127) / 128) | (1 << 8);
+    if (W <= 512 && !wide) return ((W + 127) / 128) | (1 << 8);
     const int n = (W + 511) / 512;
     return n <= 4 ? (n | (4 << 8)) : 0;
 }
@@ -161,7 +153,7 @@ __device__ __noinline__ void phase_subgraph2() {
 #pragma unroll
         for (int q = 0; q < 6; ++q) e.tr[q] = -1;
         for (int ed = g.in_head[v]; ed >= 0; ed = g.e_nin[ed]) {
-            if (k == 6) { e.erest = ed; wide = true; break; }
+            if (k == 6) { e.erest = ed; break; }
             e.tr[k++] = g.n2r[g.e_tail[ed]];
         }
         int rb = r;
@@ -196,6 +188,10 @@ __device__ __noinline__ void phase_subgraph2() {
             unsigned long long own_t = 0ull;
 #pragma unroll
             for (int q = 0; q < 6; ++q) { const int tl = e.tr[q] - base; if (e.tr[q] >= 0 && tl >= lo_lane) own_t |= 1ull << tl; }
+            for (int ed = e.erest; ed >= 0; ed = g.e_nin[ed]) {              // more than six in-edges (rare)
+                const int tl = g.n2r[g.e_tail[ed]] - base;
+                if (tl >= lo_lane) own_t |= 1ull << tl;
+            }
             if (!idok) own_t = 0ull;
             const unsigned long long own_b = idok ? (1ull << lane) : 0ull;
             // per block, at its first lane: members with id >= begin, union of their tail masks
@@ -221,6 +217,10 @@ __device__ __noinline__ void phase_subgraph2() {
                     const int tr = e.tr[q];
                     if (tr >= 0 && tr - base < lo_lane) { pend[tr] = 1; lowest = min(lowest, tr); }
                 }
+                for (int ed = e.erest; ed >= 0; ed = g.e_nin[ed]) {
+                    const int tr = g.n2r[g.e_tail[ed]];
+                    if (tr - base < lo_lane) { pend[tr] = 1; lowest = min(lowest, tr); }
+                }
             }
             if (mine) pend[r] = inc ? 1 : 0;
 #pragma unroll
@@ -234,6 +234,12 @@ __device__ __noinline__ void phase_subgraph2() {
     }
     Block4::sync();
     // ---- pass C ----
+    if (c.tb_j == 1) {
+        // closure query (phase_sink_tie_*): only DFS marks, nothing of the current alignment is touched
+        for (int r = t; r < n; r += kThreads2) g.mark[g.rank_full[r]] = pend[r] ? 2 : 0;
+        Block4::sync();
+        return;
+    }
     for (int r = t; r < n; r += kThreads2) g.inc[g.rank_full[r]] = pend[r];
     if (wv == 0) {
         int nv = 0;
@@ -260,14 +266,14 @@ __device__ __noinline__ void phase_desc2() {
     Win g = ctx_win(c);
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
-    const int R = dp2_window(dp2_cfg(c.len) & 255);
+    const int R = dp2_window(dp2_cfg(c.len, c.pad0 != 0) & 255);
     for (int r = t; r < c.V; r += kThreads2) {
         RowDesc d = make_row_desc(g, nr, rank[r], c.sub != 0);
         // "fast" rows: at most 4 predecessors, every one among the R rows right above (the DP keeps those in
         // registers; R = dp2_window(NP)).  meta bit 13 = fast, bits 16-19 / 20-23 / 24-27 / 28-31 = distance
         // (1..R) to predecessor 0 / 1 / 2 / 3.
         const int np = (d.meta >> 9) & 15, i = r + 1;
-        if (np <= 4 && d.erest < 0) {
+        if (np <= 4 && d.erest < 0 && !(d.meta & 256)) {
             unsigned int bits = 1u << 13; bool ok = true;
             for (int q = 0; q < np; ++q) {
                 const int dist = i - d.p[q];
@@ -285,7 +291,10 @@ __device__ __noinline__ void phase_desc2() {
 
 #ifdef RCN_PROF_DP
 __device__ unsigned long long g_prof_out[8];
-__device__ unsigned long long g_dbg[8];     // per wave: cycles in row bodies, cycles in barriers
+__device__ unsigned long long g_dbg[8];
+#endif
+#ifdef RCN_PROF_WIN
+__device__ unsigned long long g_wclk[4096][8];   // per work item: phase clocks     // per wave: cycles in row bodies, cycles in barriers
 #endif
 // ---- phase: NW sequence-to-graph DP ----
 // WV = 1: wave 0 alone owns all columns (up to 128*NP); no barrier, no border traffic.  The default for
@@ -308,14 +317,13 @@ __device__ __noinline__ void dp2_rows() {
     RCN_G const uint8_t* seq = gcast(c.seq);
     const int V = c.V, len = c.len;
     const bool sub = c.sub != 0;
-    const int hs = c.hstride;                   // row stride in int16 cells (multiple of 24)
+    const int hs = c.hstride;                   // row stride in int16 cells (multiple of 512)
     const int hs2 = hs >> 1;                    // ... in packed dwords
     constexpr int KT = (kLdsBytes - 64) / (4 * NTH * NP);   // LDS row slots: K ring rows + 1 staging slot
     constexpr int K = KT - 1;
     uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());   // [KT][NTH][NP]
     int* farb = Block4::work() + (kLdsBytes - 64) / 4;   // [4] staged border cell of a far predecessor row, per wave
     const int col0 = t * 2 * NP;                // first column of this thread
-    const bool in_row = col0 < hs;
     const int bcol = wv * 128 * NP - 1;         // column left of this wave's block (wv > 0)
 
     const int mg = c.m - c.gp, xg = c.x - c.gp;
@@ -364,6 +372,15 @@ __device__ __noinline__ void dp2_rows() {
             asm volatile("; row descriptors retired" : "+v"(dl_p0), "+v"(dl_p1), "+v"(dl_p2), "+v"(dl_p3), "+v"(dl_p4), "+v"(dl_p5), "+v"(dl_er), "+v"(dl_meta));
         }
         const int rend = min(V, rbase + 64);
+        // software pipeline: the descriptor word and the substitution profile of row r + 1 are produced while
+        // row r is in its scan (v_readlane -> SALU has ~20 cycles of latency; the profile fills DPP wait states)
+        int meta_next = __builtin_amdgcn_readlane(dl_meta, 0);
+        uint32_t Pn[NP];
+        {
+            const uint32_t sy = meta_next & 255, symsym = sy | (sy << 16);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) Pn[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
+        }
 #pragma unroll 1
         for (int r = rbase; r < rend; ++r) {
             const int k = r - rbase;
@@ -372,8 +389,11 @@ __device__ __noinline__ void dp2_rows() {
             // consumed last (wave 0 reads its own slot and ignores it).
             uint32_t cin_raw = 0;
             if (WV > 1) cin_raw = ring[(slot * NTH + (wv == 0 ? 0 : wv * 64 - 1)) * NP + NP - 1];
-            const int meta = __builtin_amdgcn_readlane(dl_meta, k);
-            const uint32_t sym = meta & 255;
+            const int meta = meta_next;
+            meta_next = __builtin_amdgcn_readlane(dl_meta, (k + 1) & 63);
+            uint32_t P[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) P[q] = Pn[q];
 
             uint32_t M[NP];
             int mleft = kNeg16;                 // max over predecessors of Z[p][bcol] (diagonal carry into lane 0)
@@ -397,7 +417,13 @@ __device__ __noinline__ void dp2_rows() {
                     if (WV > 1) mleft = max(mleft, __builtin_amdgcn_readlane(cwin, (i - d) & 63));
                 }
                 pred_rows += npf;
+#ifdef RCN_PROF_DP
+                if (lane == 0) atomicAdd(&g_dbg[0], 1ull);
+#endif
             } else {
+#ifdef RCN_PROF_DP
+                if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); if (meta & 256) atomicAdd(&g_dbg[2], 1ull); if (((meta >> 9) & 15) > 4) atomicAdd(&g_dbg[3], 1ull); }
+#endif
                 // ---- general row: any number of predecessors, LDS ring or (rare) HBM ----
                 const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
                 const int er = __builtin_amdgcn_readlane(dl_er, k);
@@ -416,12 +442,15 @@ __device__ __noinline__ void dp2_rows() {
                         for (int q = 0; q < NP; ++q) hp[q] = src[q];
                         if (WV > 1 && wv > 0) bl = static_cast<int>(ring[(sp * NTH + wv * 64 - 1) * NP + NP - 1]) >> 16;
                     } else {
+#ifdef RCN_PROF_DP
+                        if (lane == 0) atomicAdd(&g_dbg[4], 1ull);
+#endif
                         // rare: older than the ring -> HBM, staged through the spare LDS slot so that the common
                         // path never has a global load pending at the join (its s_waitcnt vmcnt would also wait
                         // for every outstanding H-row store, every row)
                         uint32_t* sdst = ring + (K * NTH + t) * NP;
 #pragma unroll
-                        for (int q = 0; q < NP; ++q) sdst[q] = in_row ? H[p * hs2 + t * NP + q] : 0u;
+                        for (int q = 0; q < NP; ++q) sdst[q] = H[p * hs2 + t * NP + q];
                         if (WV > 1 && wv > 0 && lane == 0) farb[wv] = H16[p * hs + bcol];
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -456,20 +485,25 @@ __device__ __noinline__ void dp2_rows() {
             }
 
             // diagonal sources = the combined predecessor row shifted right by one column
-            const uint32_t symsym = sym | (sym << 16);
             const uint32_t mprev = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(mleft) << 16, M[NP - 1], 0x138, 0xf, 0xf, false);
             uint32_t acc[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
-                const uint32_t P = pk_profile(sqx[q], symsym, ONE, XM, MG);
-                acc[q] = pk_max(pk_add(D, P), pk_add(M[q], GG));
+                acc[q] = pk_max(pk_add(D, P[q]), pk_add(M[q], GG));
             }
             // horizontal move (+0 in the Z domain): in-lane chain, wave-wide prefix max of the lane tails
-            acc[0] = pk_chain_pair(acc[0]);
+            // (pairs first: NP independent ops; then NP - 1 dependent carries between the registers)
 #pragma unroll
-            for (int q = 1; q < NP; ++q) acc[q] = pk_chain_pair(pk_max_bhi(acc[q], acc[q - 1]));
+            for (int q = 0; q < NP; ++q) acc[q] = pk_chain_pair(acc[q]);
+#pragma unroll
+            for (int q = 1; q < NP; ++q) acc[q] = pk_max_bhi(acc[q], acc[q - 1]);
             const int tail = static_cast<int>(acc[NP - 1]) >> 16;
+            {
+                const uint32_t sy = meta_next & 255, symsym = sy | (sy << 16);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Pn[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
+            }
             int zex = dpp_or<0x138, 0xf>(static_cast<int>(0x80000000u), wave_incl_scan_max_id(tail));
             int cin = static_cast<int>(0x80000000u);
             if (WV > 1) {
@@ -477,11 +511,12 @@ __device__ __noinline__ void dp2_rows() {
                 if (wv > 0) cin = static_cast<int>(cin_raw) >> 16;
             }
             zex = max(max(zex, cin), kNeg16);
+            const uint32_t zz = __builtin_amdgcn_perm(static_cast<uint32_t>(zex), static_cast<uint32_t>(zex), 0x01000100u);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
+            for (int q = 0; q < NP; ++q) acc[q] = pk_max(acc[q], zz);
 
-            if (in_row) {
-                RCN_G uint32_t* dst = H + i * hs2 + t * NP;
+            {
+                RCN_G uint32_t* dst = H + i * hs2 + t * NP;       // every lane is inside the row: hstride is a multiple of 512
 #pragma unroll
                 for (int q = 0; q < NP; ++q) dst[q] = acc[q];
             }
@@ -491,14 +526,14 @@ __device__ __noinline__ void dp2_rows() {
             if (WV > 1 && wv > 0) cwin = (lane == (i & 63)) ? cin : cwin;
             slot = (slot + 1 == K) ? 0 : slot + 1;
 
-            if ((meta & 256) && wv == own_wave) {
+            if ((meta & ((1 << 13) | 256)) == 256 && wv == own_wave) {      // sink rows are never "fast"
                 uint32_t fv = acc[0];
 #pragma unroll
                 for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q];
                 const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16);
                 const int val = __builtin_amdgcn_readlane(v16, own_lane);
                 if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
-                else if (best == val) ++tied;
+                else if (best == val) { if (tied < 8 && lane == 0) Block4::ctx()->tie_rows[tied] = i; ++tied; }
             }
             if (WV > 1) {
 #ifdef RCN_PROF_DP
@@ -658,6 +693,184 @@ __device__ __noinline__ void phase_add4() {
     Block4::sync();
 }
 
+// ---- phase: several sinks share the best score (window.cpp:95-97 -> spoa's end cell) ----
+// spoa takes the first of them in ITS rank order, the exact DFS post-order of Graph::TopologicalSort whose
+// start nodes go in id order.  Three levels, cheapest first:
+//  (1) rule: the DFS runs the backbone ids 0..L-1 first, so everything in the "backbone closure" (ancestors of
+//      backbone nodes and their aligned rings) is appended before anything else, ring of backbone node b_p at
+//      start p as (b_p, aligned list of b_p = ascending id).  A sink without aligned nodes and id >= L is in
+//      nobody's closure: it is appended exactly when the start loop reaches its own id.  Hence the key
+//      (p, id) for sinks whose ring holds a backbone node, (inf, id) for lone non-backbone sinks.
+//  (2) the tied sinks include rings of non-backbone nodes: mark the backbone closure (= Subgraph(0, L-1), the
+//      parallel sweep) as done and run the exact DFS only over the few nodes outside it.
+//  (3) otherwise the full exact DFS.
+// Result in ctx->best_row.  ctx->tb_n: 0 = done, 1 = level 2 wanted, 2 = level 3 wanted.
+__device__ __noinline__ void phase_sink_tie_rule() {
+    const Ctx c = ctx_load<Wave0Of4>();
+    Win g = ctx_win(c);
+    Ctx* o = Wave0Of4::ctx();
+    if (threadIdx.x != 0) return;
+    const bool sub = c.sub != 0;
+    RCN_G const int32_t* rank = sub ? g.rank_sub.ptr() : g.rank_full.ptr();
+    RCN_G const int32_t* nr = (sub ? g.n2r_x : g.n2r).ptr();
+    int status = 2;
+    o->tie_why = 1;                       // more than 8 tied
+    if (c.tied <= 8) {
+        bool classified = true;
+        long long bestkey = 0x7fffffffffffffffll; int pick = -1;
+        for (int k = 0; k < c.tied; ++k) {
+            const int v = rank[(k == 0 ? c.best_row : o->tie_rows[k]) - 1];
+            const int na = g.al_cnt[v];
+            int rm = v;
+            for (int a = 0; a < na; ++a) rm = min(rm, g.al_nodes[v * g.ring + a]);
+            long long key;
+            if (rm < c.bblen) key = (static_cast<long long>(rm) << 32) | static_cast<unsigned int>(v);
+            else if (na == 0) key = (0x7ffffffell << 32) | static_cast<unsigned int>(v);
+            else { classified = false; break; }
+            if (key < bestkey) { bestkey = key; pick = v; }
+        }
+        if (classified) { o->best_row = nr[pick] + 1; status = 0; }
+        else if (g.n_nodes <= kLdsBytes) status = 1;
+        else o->tie_why = 2;
+    }
+    o->tb_n = status;
+}
+
+// level 2a (t == 0): p(v) = the backbone start whose DFS appends tied sink v = the smallest backbone id that is
+// forward-reachable from v over out-edges and aligned links (search stops at backbone nodes: a small bubble).
+// Leaves in ctx: tb_i = p* (smallest p, 0x7fffffff = none is in the backbone closure), tb_n = 0 when a single
+// sink has p* (best_row set), 3 when a local DFS has to decide, 2 for the full DFS.
+__device__ __noinline__ void phase_sink_tie_starts() {
+    const Ctx c = ctx_load<Wave0Of4>();
+    Win g = ctx_win(c);
+    Ctx* o = Wave0Of4::ctx();
+    if (threadIdx.x != 0) return;
+    const bool sub = c.sub != 0;
+    RCN_G const int32_t* rank = sub ? g.rank_sub.ptr() : g.rank_full.ptr();
+    RCN_G const int32_t* nr = (sub ? g.n2r_x : g.n2r).ptr();
+    RCN_G int32_t* stack = g.stack.ptr();          // [0, 256): visited list, [256, ...): work stack
+    constexpr int kInf = 0x7fffffff;
+    int ps[8], vs[8];
+    bool ok = true;
+    for (int k = 0; k < c.tied && ok; ++k) {
+        const int v = rank[(k == 0 ? c.best_row : o->tie_rows[k]) - 1];
+        vs[k] = v;
+        int nvis = 0, sp = 256, pmin = kInf;
+        stack[sp++] = v;
+        while (sp > 256 && ok) {
+            const int x = stack[--sp];
+            bool seen = false;
+            for (int q = 0; q < nvis; ++q) seen = seen || stack[q] == x;
+            if (seen) continue;
+            if (nvis == 256) { ok = false; break; }
+            stack[nvis++] = x;
+            if (x < c.bblen) { pmin = min(pmin, x); continue; }            // a backbone node: later ones only give larger p
+            for (int e = g.out_head[x]; e >= 0; e = g.e_nout[e]) { const int h = g.e_head[e]; if (!sub || g.inc[h]) stack[sp++] = h; }
+            const int na = g.al_cnt[x];
+            for (int a = 0; a < na; ++a) { const int u = g.al_nodes[x * g.ring + a]; if (!sub || g.inc[u]) stack[sp++] = u; }
+        }
+        ps[k] = pmin;
+    }
+    int status = 2;
+    o->tie_why = 3;                       // bubble too large
+    if (ok) {
+        int pstar = kInf, cnt = 0, who = -1;
+        for (int k = 0; k < c.tied; ++k) pstar = min(pstar, ps[k]);
+        for (int k = 0; k < c.tied; ++k) if (ps[k] == pstar) { ++cnt; who = vs[k]; }
+        o->tb_i = pstar;
+        if (cnt == 1) { o->best_row = nr[who] + 1; status = 0; }
+        else status = 3;
+        // the local DFS only has to look at the sinks that share p*
+        int m = 0;
+        for (int k = 0; k < c.tied; ++k) if (ps[k] == pstar) stack[512 + m++] = vs[k];
+        stack[511] = m;
+    }
+    o->tb_n = status;
+}
+
+// level 2b, after the closure sweep has preset the DFS marks: spoa's DFS (same code as graph_toposort) from the
+// single start b_p* -- or, when no tied sink is in the backbone closure, from the ids >= L in order -- until
+// one of the candidates is appended.
+__device__ __noinline__ void phase_sink_tie_local() {
+    const Ctx c = ctx_load<Wave0Of4>();
+    Win g = ctx_win(c);
+    Ctx* o = Wave0Of4::ctx();
+    if (threadIdx.x != 0) return;
+    const bool sub = c.sub != 0;
+    RCN_G const int32_t* nr = (sub ? g.n2r_x : g.n2r).ptr();
+    RCN_G int32_t* stack = g.stack.ptr();
+    const int ncand = stack[511];
+    int cand[8];
+    for (int k = 0; k < ncand; ++k) cand[k] = stack[512 + k];
+    const int n = g.n_nodes, pstar = c.tb_i;
+    const int s_lo = pstar == 0x7fffffff ? c.bblen : pstar, s_hi = pstar == 0x7fffffff ? n : pstar + 1;
+    int winner = -1;
+    for (int s = s_lo; s < s_hi && winner < 0; ++s) {
+        if (sub && !g.inc[s]) continue;
+        if ((g.mark[s] & 3) != 0) continue;
+        int sp = 1024;
+        stack[sp++] = s;
+        while (sp > 1024 && winner < 0) {
+            const int cur = stack[sp - 1];
+            bool valid = true;
+            const uint8_t mc = g.mark[cur];
+            if ((mc & 3) != 2) {
+                for (int e = g.in_head[cur]; e >= 0; e = g.e_nin[e]) {
+                    const int tl = g.e_tail[e];
+                    if (sub && !g.inc[tl]) continue;
+                    if ((g.mark[tl] & 3) != 2) { stack[sp++] = tl; valid = false; }
+                }
+                const bool ign = (mc & 4) != 0;
+                const int na = g.al_cnt[cur];
+                if (!ign) {
+                    for (int a = 0; a < na; ++a) {
+                        const int u = g.al_nodes[cur * g.ring + a];
+                        if (sub && !g.inc[u]) continue;
+                        if ((g.mark[u] & 3) != 2) { stack[sp++] = u; g.mark[u] |= 4; valid = false; }
+                    }
+                }
+                if (valid) {
+                    g.mark[cur] = (mc & 4) | 2;
+                    if (!ign) {
+                        // appended now: cur, then its aligned nodes in list order
+                        for (int k = 0; k < ncand && winner < 0; ++k) if (cand[k] == cur) winner = cur;
+                        for (int a = 0; a < na && winner < 0; ++a) {
+                            const int u = g.al_nodes[cur * g.ring + a];
+                            if (sub && !g.inc[u]) continue;
+                            for (int k = 0; k < ncand && winner < 0; ++k) if (cand[k] == u) winner = u;
+                        }
+                    }
+                } else {
+                    g.mark[cur] = (mc & 4) | 1;
+                }
+            }
+            if (valid) --sp;
+        }
+    }
+    if (winner >= 0) { o->best_row = nr[winner] + 1; o->tb_n = 0; } else { o->tb_n = 2; o->tie_why = 4; }
+}
+
+// level 3
+__device__ __noinline__ void phase_sink_tie_full() {
+    const Ctx c = ctx_load<Wave0Of4>();
+    Win g = ctx_win(c);
+    Ctx* o = Wave0Of4::ctx();
+    if (threadIdx.x != 0) return;
+    const bool sub = c.sub != 0;
+    RCN_G const int32_t* nr = (sub ? g.n2r_x : g.n2r).ptr();
+    RCN_G const int16_t* H = reinterpret_cast<RCN_G const int16_t*>(g.H.ptr());
+    const int64_t hs = g.hstride;
+    const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
+    for (int r = 0; r < nx; ++r) {
+        const int row = nr[g.rank_x[r]] + 1;
+        if ((g.desc[row - 1].meta & 256) && H[static_cast<int64_t>(row) * hs + c.len] == c.best) { o->best_row = row; break; }
+    }
+    o->ties += 1;
+#ifdef RCN_PROF_WIN
+    printf("[tie3] why %d tied %d sub %d n %d V %d pstar %d\n", o->tie_why, c.tied, c.sub, g.n_nodes, c.V, c.tb_i);
+#endif
+}
+
 // ---- phase: traceback, box walker ----
 // Same decisions as phase_traceback2 (spoa priority diag > vertical > horizontal, predecessors in in-edge
 // order) but organised around what a single wave is good at: the 64 lanes evaluate, in parallel, the move
@@ -681,15 +894,6 @@ __device__ __noinline__ void phase_traceback3() {
     Ctx* o = Block4::ctx();
     if (t == 0) {
         int best_row = c.best_row;
-        if (c.tied > 1) {
-            // several sinks share the best score: spoa takes the first one in ITS rank order (exact DFS order)
-            const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
-            for (int r = 0; r < nx; ++r) {
-                const int row = nr[g.rank_x[r]] + 1;
-                if ((g.desc[row - 1].meta & 256) && H[static_cast<int64_t>(row) * hs + len] == c.best) { best_row = row; break; }
-            }
-            o->ties += 1;
-        }
         o->tb_i = best_row; o->tb_j = len; o->tb_n = 0;
     }
     Block4::sync();
@@ -706,6 +910,9 @@ __device__ __noinline__ void phase_traceback3() {
         const long long tp0__ = clock64();
 #endif
         const int ti0 = i, j_stage = j;
+#ifdef RCN_PROF_WIN
+        if (t == 0) o->dbg_tiles += 1;
+#endif
         int c0 = (j - 120) & ~7; if (c0 < 0) c0 = 0;
         const int rmin = ti0 - 63 > 0 ? ti0 - 63 : 0;
         {
@@ -743,6 +950,9 @@ __device__ __noinline__ void phase_traceback3() {
                 if (i == 0 && j == 0) break;
 #ifdef RCN_PROF_DP
                 ++nbox__;
+#endif
+#ifdef RCN_PROF_WIN
+                if (lane == 0) o->dbg_boxes += 1;
 #endif
                 // ---- move of every cell of the box anchored at (i, j): all LDS reads first, compares after ----
                 const int ii = i - a, jj = j - b;
@@ -804,9 +1014,11 @@ __device__ __noinline__ void phase_traceback3() {
                 bool stuck = false;
                 if (nxt == kNxInvalid) { stuck = idx == 0; i = __builtin_amdgcn_readlane(ii, idx); j = __builtin_amdgcn_readlane(jj, idx); }
                 else { i = __builtin_amdgcn_readlane(ni, idx); j = __builtin_amdgcn_readlane(nj, idx); }
-#ifdef RCN_PROF_DP
+#ifdef RCN_PROF_TB
                 if (lane == 0) { atomicAdd(&g_dbg[6], (unsigned long long)__popcll(vis)); if (stuck) atomicAdd(&g_dbg[1], 1ull);
                     if (nxt == kNxInvalid && !stuck) atomicAdd(&g_dbg[2], 1ull); }
+#endif
+#ifdef RCN_PROF_TB
                 { const int lna = __builtin_amdgcn_readlane(na, idx), lnb = __builtin_amdgcn_readlane(nb, idx), ldl = __builtin_amdgcn_readlane(dl, idx);
                   if (lane == 0 && nxt == kNxExit) { if (lnb >= kBoxCols) atomicAdd(&g_dbg[3], 1ull); else if (lna >= kBoxRows) atomicAdd(&g_dbg[4], 1ull); else atomicAdd(&g_dbg[5], 1ull);
                                                      if (ldl >= 8) atomicAdd(&g_dbg[7], 1ull); } }
@@ -816,6 +1028,9 @@ __device__ __noinline__ void phase_traceback3() {
             if (!(i == 0 && j == 0) && i == ti0 && j == j_stage) {
                 // no progress on a freshly anchored tile (predecessor > 63 rows back or > 6 in-edges): one
                 // step against HBM
+#ifdef RCN_PROF_WIN
+                if (lane == 0) o->dbg_slow += 1;
+#endif
                 g.overflow = overflow;
                 int pi = i, pj = j, n_dummy = 0;
                 if (lane == 0) {
@@ -999,6 +1214,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride;
         ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
         ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
+        ctx->dbg_tiles = 0; ctx->dbg_boxes = 0; ctx->dbg_slow = 0;
     }
     for (;;) {
         RCN_PHASE2(7);
@@ -1007,6 +1223,10 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         Block4::sync();
         const unsigned int wi = static_cast<unsigned int>(bcast0(ctx->wi));
         if (wi >= P.n_work) break;
+#ifdef RCN_PROF_WIN
+        unsigned long long ph0__[8];
+        for (int k = 0; k < 8; ++k) ph0__[k] = ph[k];
+#endif
         const uint32_t w = P.win_ids ? P.win_ids[wi] : wi;
         const uint32_t s0 = P.win_seq_off[w];
         const int ns = static_cast<int>(P.win_seq_off[w + 1] - s0);
@@ -1014,6 +1234,11 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         const int L = static_cast<int>(P.seq_off[s0 + 1] - P.seq_off[s0]);
         uint8_t* out = P.out_cons + static_cast<uint64_t>(wi) * P.out_stride;   // outputs are indexed by work item
 
+        // deep windows finish last (their serial chain is the launch time): give their waves issue priority while
+        // the chip is still crowded
+        const bool deep = P.prio_ns > 0 && ns >= P.prio_ns;
+        if (deep) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        const bool heavy = P.heavy_ns > 0 && ns >= P.heavy_ns;
         if (ns < 3) {                                          // window.cpp:68-71
             for (int i = t; i < L; i += kThreads2) out[i] = bb[i];
             if (t == 0) { P.out_len[wi] = L; P.out_flags[wi] = 0; }
@@ -1035,7 +1260,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     g.e_w[i] = pair_weight(q0, i + 1);
                 }
             }
-            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; }
+            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; ctx->pad0 = heavy; ctx->bblen = L; }
         }
         Block4::sync();
 
@@ -1051,6 +1276,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 ctx->sub = partial;
                 ctx->begin = static_cast<int32_t>(P.seq_begin[si]); ctx->end = static_cast<int32_t>(P.seq_end[si]);
                 ctx->V = ctx->n_nodes;
+                ctx->tb_j = 0;                 // phase_subgraph2: 0 = normal, 1 = closure query (marks only)
             }
             Block4::sync();
             if (partial) {
@@ -1061,7 +1287,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             RCN_PHASE2(0);
             // int16 (Z domain) validity of this alignment; otherwise the window goes to the int32 kernel
             const int V = bcast0(ctx->V);
-            const int cfg = dp2_cfg(len), np_regs = cfg & 255, nwv = cfg >> 8;
+            const int cfg = dp2_cfg(len, heavy), np_regs = cfg & 255, nwv = cfg >> 8;
             {
                 const int ag = P.g < 0 ? -P.g : P.g, smax = max(max(P.m, P.x), 0);
                 if (P.g >= 0 || cfg == 0 || static_cast<long long>(ag) * (V + 2) > kZLimit ||
@@ -1081,12 +1307,52 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 Block4::sync();
             } else {
                 switch (np_regs) {
+                    case 1: dp2_rows<1, 4>(); break;
                     case 2: dp2_rows<2, 4>(); break;
                     case 3: dp2_rows<3, 4>(); break;
                     default: dp2_rows<4, 4>(); break;
                 }
             }
             RCN_PHASE2(2);
+            if (bcast0(ctx->tied) > 1) {
+                if (wv == 0) phase_sink_tie_rule();
+                Block4::sync();
+                int st = bcast0(ctx->tb_n);
+                if (st == 1) {
+                    if (wv == 0) phase_sink_tie_starts();
+                    Block4::sync();
+                    st = bcast0(ctx->tb_n);
+                    if (st == 3) {
+                        // marks of what spoa's DFS has finished before the deciding start: the closure of backbone
+                        // node p* - 1 (of L - 1 when no candidate is in the backbone closure) = a Subgraph sweep in
+                        // mark-only mode.  It borrows the descriptor array: rebuilt afterwards.
+                        const int pstar = bcast0(ctx->tb_i), sv_end = bcast0(ctx->end), sv_begin = bcast0(ctx->begin), sv_j = bcast0(ctx->tb_j);
+                        const int first = partial ? sv_begin : 0;
+                        const int upto = pstar == 0x7fffffff ? bcast0(ctx->bblen) - 1 : pstar - 1;
+                        bool swept = true;
+                        Block4::sync();
+                        if (upto >= first) {
+                            if (t == 0) { ctx->begin = first; ctx->end = upto; ctx->tb_j = 1; }
+                            Block4::sync();
+                            phase_subgraph2();
+                            swept = bcast0(ctx->tb_i) != 0;
+                            Block4::sync();
+                            if (t == 0) { ctx->begin = sv_begin; ctx->end = sv_end; ctx->tb_j = sv_j; ctx->tb_i = pstar; }
+                            Block4::sync();
+                            phase_desc2();
+                        } else {
+                            Win g;
+                            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
+                            const int nn_ = bcast0(ctx->n_nodes);
+                            for (int v = t; v < nn_; v += kThreads2) g.mark[v] = 0;
+                            Block4::sync();
+                        }
+                        if (swept) { if (wv == 0) phase_sink_tie_local(); Block4::sync(); st = bcast0(ctx->tb_n); }
+                        else { st = 2; if (t == 0) ctx->tie_why = 5; }
+                    }
+                }
+                if (st == 2) { if (wv == 0) phase_sink_tie_full(); Block4::sync(); }
+            }
             phase_traceback3();
             RCN_PHASE2(3);
             overflow = bcast0(ctx->overflow);
@@ -1119,6 +1385,11 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             }
         }
         RCN_PHASE2(6);
+#ifdef RCN_PROF_WIN
+        if (t == 0 && wi < 4096) { for (int k = 0; k < 7; ++k) g_wclk[wi][k] = ph[k] - ph0__[k];
+            g_wclk[wi][7] = (static_cast<unsigned long long>(ctx->dbg_tiles) << 40) | (static_cast<unsigned long long>(ctx->dbg_boxes) << 20) | static_cast<unsigned long long>(ctx->dbg_slow);
+            ctx->dbg_tiles = 0; ctx->dbg_boxes = 0; ctx->dbg_slow = 0; }
+#endif
     }
     if (t == 0) {
         atomicAdd(&P.stats[0], ctx->cells); atomicAdd(&P.stats[1], ctx->pred); atomicAdd(&P.stats[2], ctx->bytes);
