@@ -94,6 +94,15 @@ def main():
         # --- roofline of the dominant (only) kernel: algorithmic bytes per launch / launch duration
         alg_bytes = st["dp_bytes"] + 2 * int(batch.bases.size) + 5 * sum(len(c) for c in res.consensus)
         avg_launch_s = (kernel_ms / max(1, launches)) / 1e3
+        # measured HBM bytes per launch: PMC counters cannot be read from inside this process; the number comes
+        # from the rocprofv3 --pmc passes of THIS command (tools/gpu_round.sh), committed as profiles/traffic.json
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf) and a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0:
+            try:
+                traffic = json.load(open(tf))["bytes_per_launch"]
+            except Exception:
+                traffic = None
         achieved = alg_bytes / avg_launch_s / 1e9
         out = {
             "metric": "polished windows/sec (500 bp, 30x cov)",
@@ -102,13 +111,13 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
+            "dtype": "int16", "data": "synthetic",
             "config": {"workload": "cfg2: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d, "
                                    "scores %s, %d windows/GPU" % (a.contig, a.coverage, a.window, a.scores, batch.n_windows),
                        "windows_per_gpu": batch.n_windows, "parallelism": "windows sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "poa_window_kernel", "avg_launch_ms": avg_launch_s * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "poa_window_kernel2", "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "gcups": st["dp_cells"] / avg_launch_s / 1e9},
         }

@@ -9,6 +9,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+import json
+per_kernel = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -22,3 +24,16 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for (kn, cn), (ids, total) in sorted(acc.items()):
             n = max(1, len(ids))
             print("%s | %s | dispatches %d | sum %.6g | per dispatch %.6g" % (kn, cn, n, total, total / n))
+            if "poa_window_kernel" in kn:
+                per_kernel.setdefault(kn, {})[cn] = total / n
+# traffic.json: HBM bytes per launch of the consensus kernel.  Raw units are KB (rocprofv3 derived counters);
+# FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) prescribes for gfx950 wide reads, WRITE_SIZE is uncalibrated.
+for kn, c in per_kernel.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch = c["FETCH_SIZE"] * 1024.0 * 2.0
+        write = c["WRITE_SIZE"] * 1024.0
+        json.dump({"kernel": kn, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                   "bytes_per_launch": fetch + write,
+                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 (gfx950 correction)"},
+                  open(os.path.join(out, "traffic.json"), "w"))
+        print("traffic.json:", fetch + write, "bytes per launch")
