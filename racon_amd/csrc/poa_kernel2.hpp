@@ -693,6 +693,38 @@ __device__ __noinline__ void phase_add4() {
     Block4::sync();
 }
 
+// ---- phase: order merge over 256 threads: insert the nn new nodes behind their anchors ----
+__device__ __noinline__ void phase_merge4() {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    const int n_old = c.n_old, nn = c.nn;
+    int* xch = Block4::work();
+    RCN_G int32_t* delta = g.pred.ptr();                // [n_old + 1] scratch (pred is consensus-only)
+    for (int r = t; r <= n_old; r += kThreads2) delta[r] = 0;
+    Block4::sync();
+    for (int k = t; k < nn; k += kThreads2) {
+        const int a = g.new_anchor[k] + 1;
+        atomicAdd((int*)&delta[a], 1);
+        const int v = g.new_id[k];
+        g.rank_tmp[a + k] = v; g.n2r[v] = a + k;
+    }
+    Block4::sync();
+    int carry = 0;
+    for (int base = 0; base < n_old; base += kThreads2) {
+        const int r = base + t;
+        int sc = r < n_old ? delta[r] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(sc, d); if (lane >= d) sc += u; }
+        int off, total, pmax, tmax;
+        block4_scan(xch, wv, lane, __shfl(sc, 63), 0, off, total, pmax, tmax);
+        if (r < n_old) { const int v = g.rank_full[r]; const int pos = r + carry + off + sc; g.rank_tmp[pos] = v; g.n2r[v] = pos; }
+        carry += total;
+    }
+    if (t == 0) Block4::ctx()->swapped = c.swapped ^ 1;
+    Block4::sync();
+}
+
 // ---- phase: several sinks share the best score (window.cpp:95-97 -> spoa's end cell) ----
 // spoa takes the first of them in ITS rank order, the exact DFS post-order of Graph::TopologicalSort whose
 // start nodes go in id order.  Three levels, cheapest first:
@@ -1360,7 +1392,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 phase_add4();
                 RCN_PHASE2(4);
                 overflow = bcast0(ctx->overflow);
-                if (!overflow) { if (wv == 0) phase_merge<Wave0Of4>(); Block4::sync(); }
+                if (!overflow) phase_merge4();
                 RCN_PHASE2(5);
             }
         }
