@@ -55,6 +55,13 @@ struct Block4 {
     static __device__ __forceinline__ int* work() { return lds_words2(); }
 };
 
+// one LDS word, read now (polling loops); invisible to the compiler's memory model on purpose
+__device__ __forceinline__ uint32_t lds_poll(const uint32_t* p) {
+    uint32_t v;
+    const uint32_t a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));      // LDS addresses are the low 32 bits
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a));
+    return v;
+}
 // LDS-only barrier: waits for this wave's LDS traffic, NOT for its outstanding HBM stores
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -319,10 +326,19 @@ __device__ __noinline__ void dp2_rows() {
     const bool sub = c.sub != 0;
     const int hs = c.hstride;                   // row stride in int16 cells (multiple of 512)
     const int hs2 = hs >> 1;                    // ... in packed dwords
-    constexpr int KT = (kLdsBytes - 64) / (4 * NTH * NP);   // LDS row slots: K ring rows + 1 staging slot
+    // WV > 1: the waves run FREE of barriers.  Wave w hands the border cell Z[i][last column of w] to wave w + 1
+    // through a 64-entry LDS mailbox, one tagged word {row : 16 | value : 16} per row (a single 32-bit store, so the
+    // reader either sees the old word or the complete new one), and every 8 rows it publishes how far it is, so that
+    // the wave to its left never laps the mailbox.  Wave 0 depends on nobody.
+    constexpr int kMail = WV > 1 ? 64 * 4 * 4 + 64 : 0;     // bytes: mailboxes [4][64] + progress words
+    constexpr int KT = (kLdsBytes - 64 - kMail) / (4 * NTH * NP);   // LDS row slots: K ring rows + 1 staging slot
     constexpr int K = KT - 1;
     uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());   // [KT][NTH][NP]
     int* farb = Block4::work() + (kLdsBytes - 64) / 4;   // [4] staged border cell of a far predecessor row, per wave
+    // (not `volatile`: the backend brackets volatile accesses with s_waitcnt vmcnt(0), i.e. a wait for the previous
+    //  H-row store in every row; the polls below are inline-asm LDS reads instead)
+    uint32_t* mail = reinterpret_cast<uint32_t*>(Block4::work() + (kLdsBytes - 64 - kMail) / 4);   // [4][64]
+    uint32_t* prog = mail + 4 * 64;                                                                  // [4] rows finished, per wave
     const int col0 = t * 2 * NP;                // first column of this thread
     const int bcol = wv * 128 * NP - 1;         // column left of this wave's block (wv > 0)
 
@@ -353,7 +369,11 @@ __device__ __noinline__ void dp2_rows() {
 
     // WV = 4, skewed pipeline: wave wv starts wv steps late and finishes wv steps late; every wave executes
     // exactly V + WV - 1 barriers.
-    if (WV > 1) for (int k = 0; k < wv; ++k) lds_barrier();
+    int seen_next = 0;                          // progress of wave wv + 1 as last read
+    if (WV > 1) {
+        for (int k = t; k < 4 * 64 + 4; k += NTH) mail[k] = 0u;        // tag 0 never matches: rows start at 1
+        Block4::sync();
+    }
 #ifdef RCN_PROF_DP
     long long prof_row__ = 0, prof_bar__ = 0, tr0__ = clock64();
 #endif
@@ -388,7 +408,7 @@ __device__ __noinline__ void dp2_rows() {
             // horizontal carry into this block: Z[i][bcol], finished by wave wv-1 one step ago.  Issued first,
             // consumed last (wave 0 reads its own slot and ignores it).
             uint32_t cin_raw = 0;
-            if (WV > 1) cin_raw = ring[(slot * NTH + (wv == 0 ? 0 : wv * 64 - 1)) * NP + NP - 1];
+            if (WV > 1 && wv > 0) cin_raw = mail[(wv - 1) * 64 + (i & 63)];
             const int meta = meta_next;
             meta_next = __builtin_amdgcn_readlane(dl_meta, (k + 1) & 63);
             uint32_t P[NP];
@@ -417,11 +437,11 @@ __device__ __noinline__ void dp2_rows() {
                     if (WV > 1) mleft = max(mleft, __builtin_amdgcn_readlane(cwin, (i - d) & 63));
                 }
                 pred_rows += npf;
-#ifdef RCN_PROF_DP
+#ifdef RCN_PROF_CNT
                 if (lane == 0) atomicAdd(&g_dbg[0], 1ull);
 #endif
             } else {
-#ifdef RCN_PROF_DP
+#ifdef RCN_PROF_CNT
                 if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); if (meta & 256) atomicAdd(&g_dbg[2], 1ull); if (((meta >> 9) & 15) > 4) atomicAdd(&g_dbg[3], 1ull); }
 #endif
                 // ---- general row: any number of predecessors, LDS ring or (rare) HBM ----
@@ -440,9 +460,9 @@ __device__ __noinline__ void dp2_rows() {
                         const uint32_t* src = ring + (sp * NTH + t) * NP;
 #pragma unroll
                         for (int q = 0; q < NP; ++q) hp[q] = src[q];
-                        if (WV > 1 && wv > 0) bl = static_cast<int>(ring[(sp * NTH + wv * 64 - 1) * NP + NP - 1]) >> 16;
+                        if (WV > 1 && wv > 0) bl = __builtin_amdgcn_readlane(cwin, p & 63);      // i - p < K <= 63
                     } else {
-#ifdef RCN_PROF_DP
+#ifdef RCN_PROF_CNT
                         if (lane == 0) atomicAdd(&g_dbg[4], 1ull);
 #endif
                         // rare: older than the ring -> HBM, staged through the spare LDS slot so that the common
@@ -506,9 +526,16 @@ __device__ __noinline__ void dp2_rows() {
             }
             int zex = dpp_or<0x138, 0xf>(static_cast<int>(0x80000000u), wave_incl_scan_max_id(tail));
             int cin = static_cast<int>(0x80000000u);
-            if (WV > 1) {
+            if (WV > 1 && wv > 0) {
                 asm volatile("; carry consumed here" : "+v"(cin_raw));
-                if (wv > 0) cin = static_cast<int>(cin_raw) >> 16;
+                while (__builtin_amdgcn_readfirstlane(cin_raw >> 16) != static_cast<uint32_t>(i & 0xffff)) {
+                    __builtin_amdgcn_s_sleep(1);
+#ifdef RCN_PROF_DP
+                    ++prof_bar__;
+#endif
+                    cin_raw = lds_poll(mail + (wv - 1) * 64 + (i & 63));
+                }
+                cin = static_cast<int>(static_cast<int16_t>(cin_raw & 0xffffu));
             }
             zex = max(max(zex, cin), kNeg16);
             const uint32_t zz = __builtin_amdgcn_perm(static_cast<uint32_t>(zex), static_cast<uint32_t>(zex), 0x01000100u);
@@ -536,13 +563,18 @@ __device__ __noinline__ void dp2_rows() {
                 else if (best == val) { if (tied < 8 && lane == 0) Block4::ctx()->tie_rows[tied] = i; ++tied; }
             }
             if (WV > 1) {
+                if (wv < WV - 1) {
+                    // never lap the mailbox of the wave to the right: it must have consumed row i - 64 before row i
+                    // is posted (progress is published every 8 rows, so stay within 48)
+                    while (i - seen_next > 48) {
+                        seen_next = static_cast<int>(__builtin_amdgcn_readfirstlane(lds_poll(prog + wv + 1)));
+                        if (i - seen_next > 48) __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (lane == 63) mail[wv * 64 + (i & 63)] = (static_cast<uint32_t>(i) << 16) | (acc[NP - 1] >> 16);
+                }
+                if (wv > 0 && (i & 7) == 0 && lane == 0) prog[wv] = i;
 #ifdef RCN_PROF_DP
-                const long long tb0__ = clock64();
-                lds_barrier();
-                const long long tb1__ = clock64();
-                prof_row__ += tb0__ - tr0__; prof_bar__ += tb1__ - tb0__; tr0__ = tb1__;
-#else
-                lds_barrier();
+                const long long tb1__ = clock64(); prof_row__ += tb1__ - tr0__; tr0__ = tb1__;
 #endif
             } else {
                 // one wave: LDS accesses of a wave execute in order, nothing to wait for
@@ -555,7 +587,6 @@ __device__ __noinline__ void dp2_rows() {
 #ifdef RCN_PROF_DP
     if (lane == 0) { atomicAdd(&g_prof_out[wv * 2], (unsigned long long)prof_row__); atomicAdd(&g_prof_out[wv * 2 + 1], (unsigned long long)prof_bar__); }
 #endif
-    if (WV > 1) for (int k = wv; k < WV - 1; ++k) lds_barrier();
     Ctx* o = Block4::ctx();
     if (wv == own_wave && lane == 0) { o->best = best; o->best_row = best_row; o->tied = tied; }
     if (t == 0) {
