@@ -274,22 +274,68 @@ __device__ __noinline__ void phase_desc2() {
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
     const int R = dp2_window(dp2_cfg(c.len, c.pad0 != 0) & 255);
-    for (int r = t; r < c.V; r += kThreads2) {
-        RowDesc d = make_row_desc(g, nr, rank[r], c.sub != 0);
+    // Every row is a chain of dependent HBM loads (rank -> in-edge head -> edge -> tail's rank ...).  For a
+    // full-graph alignment U rows per thread are walked in lock step, with static register indices only (a
+    // runtime index into the descriptors would send them to scratch memory), so that their loads are in flight
+    // together: the phase is pure latency.  Subgraph alignments (edges filtered by the mask) go row by row.
+    constexpr int U = 4;
+    const bool sub = c.sub != 0;
+    auto finish = [&](RowDesc d, int r) {
         // "fast" rows: at most 4 predecessors, every one among the R rows right above (the DP keeps those in
         // registers; R = dp2_window(NP)).  meta bit 13 = fast, bits 16-19 / 20-23 / 24-27 / 28-31 = distance
-        // (1..R) to predecessor 0 / 1 / 2 / 3.
+        // (1..R) to predecessor 0 / 1 / 2 / 3.  Sink rows are never fast.
         const int np = (d.meta >> 9) & 15, i = r + 1;
         if (np <= 4 && d.erest < 0 && !(d.meta & 256)) {
             unsigned int bits = 1u << 13; bool ok = true;
-            for (int q = 0; q < np; ++q) {
-                const int dist = i - d.p[q];
-                ok = ok && d.p[q] != 0 && dist <= R;
-                bits |= static_cast<unsigned int>(dist & 15) << (16 + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < np) {
+                    const int dist = i - d.p[q];
+                    ok = ok && d.p[q] != 0 && dist <= R;
+                    bits |= static_cast<unsigned int>(dist & 15) << (16 + 4 * q);
+                }
             }
             if (ok) d.meta |= static_cast<int>(bits);
         }
         g.desc[r] = d;
+    };
+    if (sub) {
+        for (int r = t; r < c.V; r += kThreads2) finish(make_row_desc(g, nr, rank[r], true), r);
+    } else {
+        for (int r0 = t; r0 < c.V; r0 += kThreads2 * U) {
+            int v[U], e0[U], eo[U], code[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int r = r0 + u * kThreads2; v[u] = r < c.V ? rank[r] : 0; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { e0[u] = g.in_head[v[u]]; eo[u] = g.out_head[v[u]]; code[u] = g.code[v[u]]; }
+            int t0[U], e1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e0[u] >= 0 ? e0[u] : 0; t0[u] = g.e_tail[e]; e1[u] = e0[u] >= 0 ? g.e_nin[e] : -1; }
+            int t1[U], e2[U], p0[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e1[u] >= 0 ? e1[u] : 0; t1[u] = g.e_tail[e]; e2[u] = e1[u] >= 0 ? g.e_nin[e] : -1; p0[u] = nr[t0[u]] + 1; }
+            int p1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) p1[u] = nr[t1[u]] + 1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * kThreads2;
+                if (r >= c.V) continue;
+                RowDesc d; d.erest = -1;
+                d.p[0] = e0[u] >= 0 ? p0[u] : 0;
+                d.p[1] = e1[u] >= 0 ? p1[u] : -1;
+                d.p[2] = d.p[3] = d.p[4] = d.p[5] = -1;
+                int k = e0[u] < 0 ? 1 : (e1[u] < 0 ? 1 : 2);
+                int ed = e2[u];
+#pragma unroll
+                for (int q = 2; q < kInlinePreds; ++q) {       // third .. sixth in-edge (rare), static slots
+                    if (ed >= 0) { d.p[q] = nr[g.e_tail[ed]] + 1; ed = g.e_nin[ed]; k = q + 1; }
+                }
+                d.erest = ed;                                   // more than six: the DP / traceback walk the list
+                d.meta = code[u] | (eo[u] < 0 ? 256 : 0) | (k << 9);
+                finish(d, r);
+            }
+        }
     }
     RCN_G uint32_t* H = reinterpret_cast<RCN_G uint32_t*>(g.H.ptr());
     for (int j = t; j < (g.hstride >> 1); j += kThreads2) H[j] = 0u;
