@@ -96,3 +96,69 @@ def config_windows(name: str, scale: float = 1.0) -> WindowBatch:
     if name == "w1000":     # larger window (int32 score range)
         return simulate_windows(int(1_000_000 * scale), 1000, 30.0, 10000, seed=20260925)
     raise ValueError(name)
+
+
+def simulate_files(out_dir: str, contig_len: int = 20000, coverage: float = 25.0, read_len: int = 3000,
+                   sub: float = 0.03, ins: float = 0.03, dele: float = 0.04, backbone_errors: float = 0.03,
+                   seed: int = 20260930, n_contigs: int = 1):
+    """Writes a small polishing data set in racon's input formats (what `racon reads overlaps targets` takes,
+    reference src/main.cpp:139-157): draft contigs (FASTA, with errors), reads (FASTQ, both strands), and the
+    read-to-draft overlaps twice — SAM with the simulator's CIGAR (no pre-alignment needed, reference
+    src/overlap.cpp:192) and PAF (pre-alignment on the host).  Returns the paths and the true contigs."""
+    import gzip
+    import os
+    rng = np.random.default_rng(seed)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    os.makedirs(out_dir, exist_ok=True)
+    paths = {k: os.path.join(out_dir, n) for k, n in (("targets", "draft.fasta.gz"), ("reads", "reads.fastq.gz"),
+                                                       ("sam", "overlaps.sam.gz"), ("paf", "overlaps.paf.gz"))}
+    truth = []
+    with gzip.open(paths["targets"], "wb") as ft, gzip.open(paths["reads"], "wb") as fr, \
+            gzip.open(paths["sam"], "wb") as fs, gzip.open(paths["paf"], "wb") as fp:
+        rid = 0
+        for ci in range(n_contigs):
+            contig = _ACGT[rng.integers(0, 4, contig_len)]
+            truth.append(contig.tobytes())
+            # the draft: substitutions only, so that draft coordinates = true coordinates
+            draft = contig.copy()
+            e = rng.random(contig_len) < backbone_errors
+            draft[e] = _ACGT[(np.searchsorted(_ACGT, draft[e]) + rng.integers(1, 4, int(e.sum()))) % 4]
+            tname = b"contig%d" % ci
+            ft.write(b">" + tname + b"\n" + draft.tobytes() + b"\n")
+            fs.write(b"@SQ\tSN:" + tname + b"\tLN:%d\n" % contig_len)
+            for _ in range(int(round(coverage * contig_len / read_len))):
+                ts = int(rng.integers(0, max(1, contig_len - read_len // 2)))
+                te = min(contig_len, ts + read_len)
+                n = te - ts
+                tgt = contig[ts:te]
+                deleted = rng.random(n) < dele
+                deleted[0] = deleted[-1] = False
+                subst = rng.random(n) < sub
+                base = tgt.copy()
+                base[subst] = _ACGT[(np.searchsorted(_ACGT, tgt[subst]) + rng.integers(1, 4, int(subst.sum()))) % 4]
+                has_ins = rng.random(n) < ins
+                has_ins[-1] = False
+                out = bytearray()
+                ops = []                                   # CIGAR over the draft: M / I / D runs
+                def push(op):
+                    if ops and ops[-1][0] == op: ops[-1][1] += 1
+                    else: ops.append([op, 1])
+                for k in range(n):
+                    if deleted[k]: push("D")
+                    else: out.append(int(base[k])); push("M")
+                    if has_ins[k]: out.append(int(_ACGT[rng.integers(0, 4)])); push("I")
+                seq = bytes(out)
+                qual = bytes((np.clip(np.rint(rng.normal(15, 4, len(seq))), 5, 30).astype(np.uint8) + 33).tolist())
+                cigar = "".join("%d%s" % (c, o) for o, c in ops).encode()
+                strand = int(rng.integers(0, 2))
+                name = b"read%d" % rid
+                rid += 1
+                if strand:        # the read file holds the reverse complement; SAM lists SEQ on the forward strand
+                    fr.write(b"@" + name + b"\n" + seq.translate(comp)[::-1] + b"\n+\n" + qual[::-1] + b"\n")
+                else:
+                    fr.write(b"@" + name + b"\n" + seq + b"\n+\n" + qual + b"\n")
+                fs.write(name + b"\t%d\t" % (16 if strand else 0) + tname + b"\t%d\t60\t" % (ts + 1) + cigar +
+                         b"\t*\t0\t0\t" + seq + b"\t" + qual + b"\n")
+                fp.write(name + b"\t%d\t0\t%d\t" % (len(seq), len(seq)) + (b"-" if strand else b"+") + b"\t" + tname +
+                         b"\t%d\t%d\t%d\t%d\t%d\t60\n" % (contig_len, ts, te, n, n))
+    return paths, truth
