@@ -33,6 +33,8 @@ def lib():
                                               C.POINTER(RcnResult), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         _lib.rcn_oracle_free.argtypes = [C.c_void_p]
+        _lib.rcn_oracle_tie_stats.argtypes = [C.POINTER(C.c_uint64)]
+        _lib.rcn_oracle_tie_stats.restype = None
         _lib.rcn_oracle_edit_distance.restype = C.c_uint64
         _lib.rcn_oracle_edit_distance.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
     return _lib
@@ -64,3 +66,10 @@ def consensus(batch: WindowBatch, m: int, x: int, g: int, trim: bool = True, thr
 
 def edit_distance(a: bytes, b: bytes) -> int:
     return int(lib().rcn_oracle_edit_distance(a, len(a), b, len(b)))
+
+
+def tie_stats():
+    """(sink-tie events, events the HIP kernel's rule classifies, of those rule == exact) since the last call."""
+    a = (C.c_uint64 * 3)()
+    lib().rcn_oracle_tie_stats(a)
+    return int(a[0]), int(a[1]), int(a[2])

@@ -37,6 +37,7 @@ namespace {
 using Alignment = std::vector<std::pair<int32_t, int32_t>>;
 
 struct Graph {
+    int32_t n_backbone = 0;       // nodes 0..n_backbone-1 are backbone nodes (sink-tie rule check only)
     struct Node {
         int32_t code;
         std::vector<int32_t> in, out;      // edge ids, creation order
@@ -299,6 +300,36 @@ struct Engine {
     uint64_t cells = 0;                  // Σ (V+1)(L+1)
     double   cells_x_pred = 0;           // Σ cells * (1 + E/V)
 
+    // Statistics for tests/test_oracle_spec.py: the HIP kernel resolves "several sinks share the best score"
+    // without spoa's DFS order where a rule proves the winner (racon_amd/csrc/poa_kernel2.hpp,
+    // phase_sink_tie_rule): key (smallest id in the sink's aligned ring, sink id) when that ring holds a
+    // backbone node, (inf, id) for a non-backbone sink without aligned nodes.  Here the rule is evaluated next
+    // to the exact choice (first tied sink in rank_to_node order) and must agree whenever it applies.
+    uint64_t tie_events = 0, tie_ruled = 0, tie_rule_agrees = 0;
+    void check_sink_tie_rule(const Graph& g_, const std::vector<int32_t>& n2r, size_t W, uint32_t L, int32_t best, int32_t bi) {
+        const int32_t V = static_cast<int32_t>(g_.nodes.size());
+        std::vector<int32_t> tied;
+        for (int32_t r = 0; r < V; ++r) {
+            const int32_t v = g_.rank_to_node[r];
+            if (g_.nodes[v].out.empty() && H[static_cast<size_t>(r + 1) * W + L] == best) tied.push_back(v);
+        }
+        if (tied.size() < 2) return;
+        (void)n2r;
+        ++tie_events;
+        const int32_t exact = g_.rank_to_node[bi - 1];
+        bool classified = true; int64_t bestkey = INT64_MAX; int32_t pick = -1;
+        for (int32_t v : tied) {
+            int32_t rm = v;
+            for (int32_t a : g_.nodes[v].aligned) rm = std::min(rm, a);
+            int64_t key;
+            if (rm < g_.n_backbone) key = (static_cast<int64_t>(rm) << 32) | static_cast<uint32_t>(v);
+            else if (g_.nodes[v].aligned.empty()) key = (static_cast<int64_t>(0x7ffffffe) << 32) | static_cast<uint32_t>(v);
+            else { classified = false; break; }
+            if (key < bestkey) { bestkey = key; pick = v; }
+        }
+        if (classified) { ++tie_ruled; if (pick == exact) ++tie_rule_agrees; }
+    }
+
     Alignment Align(const uint8_t* seq, uint32_t L, const Graph& g_) {
         const int32_t V = static_cast<int32_t>(g_.nodes.size());
         if (V == 0 || L == 0) return {};
@@ -346,6 +377,7 @@ struct Engine {
             }
         }
 
+        check_sink_tie_rule(g_, n2r, W, L, best, bi);
         Alignment al;
         int32_t i = bi, j = static_cast<int32_t>(L);
         while (!(i == 0 && j == 0)) {
@@ -425,6 +457,7 @@ WindowOut window_consensus(const rcn_batch* b, uint32_t w, Engine& eng, bool tri
 
     Graph graph;
     graph.AddAlignment(Alignment(), seq_ptr(0), L, weights(0));   // window.cpp:73-77
+    graph.n_backbone = static_cast<int32_t>(L);
 
     std::vector<uint32_t> rank(nseq);
     for (uint32_t i = 0; i < nseq; ++i) rank[i] = i;
@@ -441,6 +474,7 @@ WindowOut window_consensus(const rcn_batch* b, uint32_t w, Engine& eng, bool tri
         } else {
             std::vector<int32_t> mapping;
             Graph sub = graph.Subgraph(bg, en, &mapping);
+            for (int32_t v : mapping) if (v < static_cast<int32_t>(L)) ++sub.n_backbone;   // ids keep their order
             al = eng.Align(seq_ptr(i), seq_len(i), sub);
             for (auto& p : al) if (p.first != -1) p.first = mapping[p.first];
         }
@@ -479,6 +513,10 @@ extern "C" {
 // independent, reference src/polisher.cpp:496-503).  *handle must be released
 // with rcn_oracle_free.  cells / cells_x_pred (each [n_windows], may be NULL)
 // receive Σ(V'+1)(l+1) and Σ(V'+1)(l+1)(1+E'/V') per window.
+// {sink-tie events, events the kernel's rule classifies, of those: rule == exact choice}; reset on read
+static std::atomic<uint64_t> g_tie_stats[3];
+void rcn_oracle_tie_stats(uint64_t* out3) { for (int k = 0; k < 3; ++k) out3[k] = g_tie_stats[k].exchange(0); }
+
 int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int nthreads,
                          rcn_result* out, void** handle, uint64_t* cells, double* cells_x_pred) {
     if (!b || !out || !handle) return RCN_E_ARG;
@@ -495,6 +533,7 @@ int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int 
             res[w] = window_consensus(b, w, eng, trim != 0);
             cl[w] = eng.cells; cx[w] = eng.cells_x_pred;
         }
+        g_tie_stats[0] += eng.tie_events; g_tie_stats[1] += eng.tie_ruled; g_tie_stats[2] += eng.tie_rule_agrees;
     };
     if (nthreads <= 1) worker();
     else {

@@ -62,3 +62,27 @@ def test_edit_distance_helper(oracle):
                 prev, D[j] = D[j], cur
         assert oracle.edit_distance(a, b) == D[-1]
     assert oracle.edit_distance(b"", b"ACG") == 3
+
+
+def test_sink_tie_rule_agrees_with_exact_order(oracle):
+    """The rule the HIP kernel uses instead of spoa's DFS order when several sinks share the best score
+    (racon_amd/csrc/poa_kernel2.hpp, phase_sink_tie_rule) must pick the same sink as the exact rank order
+    whenever it applies — on synthetic sets and on the reference's own data (tests/golden)."""
+    import os
+    from racon_amd.batch import WindowBatch
+    from racon_amd.synth import simulate_windows
+    sets = [(simulate_windows(60000, 500, 30, 10000, seed=20260921), (3, -5, -4)),
+            (simulate_windows(40000, 500, 30, 10000, seed=5, with_quality=False), (3, -5, -4)),
+            (simulate_windows(40000, 500, 30, 10000, seed=8), (1, -1, -1))]
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sets += [(WindowBatch.load(os.path.join(gold, "sam_fasta_w500.npz")), (5, -4, -8)),
+             (WindowBatch.load(os.path.join(gold, "frag_kF_fastq_first200.npz")), (1, -1, -1))]
+    oracle.tie_stats()
+    events = ruled = 0
+    for b, sc in sets:
+        oracle.consensus(b, *sc, True, 0)
+        e, r, a = oracle.tie_stats()
+        assert r == a, f"rule disagrees with the exact order in {r - a} of {r} classified ties"
+        events += e
+        ruled += r
+    assert events > 50 and ruled > 0.6 * events
