@@ -113,6 +113,10 @@ __host__ __device__ __forceinline__ int dp2_cfg(int len, bool wide) {
 }
 // rows of the register window for NP packed VGPRs per lane (16 VGPRs in all; a power of two)
 __host__ __device__ constexpr int dp2_window(int np) { return np <= 1 ? 16 : np == 2 ? 8 : 4; }
+// rows of the LDS ring behind it (K of dp2_rows<NP, WV>)
+__host__ __device__ constexpr int dp2_ring_rows(int np, int wv) {
+    return (kLdsBytes - 64 - (wv > 1 ? 64 * 4 * 4 + 64 : 0)) / (4 * 64 * wv * np) - 1;
+}
 
 // ---- phase: Subgraph mask + filtered order (window.cpp:99-103), without the serial DFS ----
 // spoa's ExtractSubgraph(end, begin) = nodes with id >= begin that are backward-reachable from `end` over
@@ -273,7 +277,10 @@ __device__ __noinline__ void phase_desc2() {
     Win g = ctx_win(c);
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
-    const int R = dp2_window(dp2_cfg(c.len, c.pad0 != 0) & 255);
+    const int cfg_ = dp2_cfg(c.len, c.pad0 != 0);
+    const int R = dp2_window(cfg_ & 255);
+    // "medium" rows: like fast rows, but some predecessor is beyond the register window and still in the LDS ring
+    const int RM = min(15, dp2_ring_rows(max(cfg_ & 255, 1), max(cfg_ >> 8, 1)) - 2);
     // Every row is a chain of dependent HBM loads (rank -> in-edge head -> edge -> tail's rank ...).  For a
     // full-graph alignment U rows per thread are walked in lock step, with static register indices only (a
     // runtime index into the descriptors would send them to scratch memory), so that their loads are in flight
@@ -286,16 +293,18 @@ __device__ __noinline__ void phase_desc2() {
         // (1..R) to predecessor 0 / 1 / 2 / 3.  Sink rows are never fast.
         const int np = (d.meta >> 9) & 15, i = r + 1;
         if (np <= 4 && d.erest < 0 && !(d.meta & 256)) {
-            unsigned int bits = 1u << 13; bool ok = true;
+            unsigned int bits = 0; bool ok = true, okm = true;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q < np) {
                     const int dist = i - d.p[q];
                     ok = ok && d.p[q] != 0 && dist <= R;
+                    okm = okm && d.p[q] != 0 && dist <= RM;
                     bits |= static_cast<unsigned int>(dist & 15) << (16 + 4 * q);
                 }
             }
-            if (ok) d.meta |= static_cast<int>(bits);
+            if (ok) d.meta |= static_cast<int>(bits | (1u << 13));
+            else if (okm) d.meta |= static_cast<int>(bits | (1u << 14));      // bit 14 = medium
         }
         g.desc[r] = d;
     };
@@ -486,6 +495,25 @@ __device__ __noinline__ void dp2_rows() {
 #ifdef RCN_PROF_CNT
                 if (lane == 0) atomicAdd(&g_dbg[0], 1ull);
 #endif
+            } else if (meta & (1 << 14)) {
+                // ---- medium row: every predecessor from the LDS ring, all reads in flight together ----
+                const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
+                const int npf = (meta >> 9) & 7;
+                uint32_t hp[4][NP];
+                int ml[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = (dd >> (4 * (e < npf ? e : 0))) & 15;      // unused slots repeat predecessor 0
+                    int sp = slot - d; if (sp < 0) sp += K;
+                    const uint32_t* src = ring + (sp * NTH + t) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) hp[e][q] = src[q];
+                    ml[e] = WV > 1 ? __builtin_amdgcn_readlane(cwin, (i - d) & 63) : kNeg16;
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
+                if (WV > 1) mleft = max(max(ml[0], ml[1]), max(ml[2], ml[3]));
+                pred_rows += npf;
             } else {
 #ifdef RCN_PROF_CNT
                 if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); if (meta & 256) atomicAdd(&g_dbg[2], 1ull); if (((meta >> 9) & 15) > 4) atomicAdd(&g_dbg[3], 1ull); }
