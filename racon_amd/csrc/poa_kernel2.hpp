@@ -1015,7 +1015,11 @@ __device__ __noinline__ void phase_sink_tie_full() {
 // (two LDS round trips per box), and the walk inside the box then costs one v_readlane per step instead of
 // LDS round trips and ballots.  Output: pos_t[pos] = DP row aligned to sequence position pos, or -1.
 constexpr int kMvDiag = 0, kMvUp = 1, kMvLeft = 2, kMvInvalid = 3;
-constexpr int kBoxRows = 10, kBoxCols = 6;           // 60 cells (lanes 60-63 idle): the path drops ~1.7 rows per column
+#ifndef RCN_BOX_ROWS
+#define RCN_BOX_ROWS 10
+#define RCN_BOX_COLS 6
+#endif
+constexpr int kBoxRows = RCN_BOX_ROWS, kBoxCols = RCN_BOX_COLS;   // <= 64 cells; the path drops ~1.7 rows per column on a 30x graph
 constexpr int kNxExit = 64, kNxInvalid = 65;
 
 __device__ __noinline__ void phase_traceback3() {

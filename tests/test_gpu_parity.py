@@ -131,3 +131,25 @@ def test_full_size_properties(Engine, oracle):
     lens = np.array([len(c) for c in r1.consensus])
     assert 450 < lens[:-1].mean() < 520
     print("cfg2 checksum-of-checksums", h.hexdigest())
+
+
+def test_int32_fallback_kernel(Engine, oracle):
+    """Scores whose Z-domain bound does not fit int16 (|g| * V > 31000) leave poa_window_kernel2 after the
+    validity check and are re-run by the int32 kernel with worst-case capacities (no CPU fallback anywhere)."""
+    b = simulate_windows(6000, 500, 20, 3000, seed=21)
+    sc = (4, -6, -100)
+    eng = Engine(*sc, True)
+    got = eng.consensus(b)
+    assert_same(got, oracle.consensus(b, *sc, True, 0), "int32 fallback")
+    deep = int((np.diff(b.win_seq_off) >= 3).sum())
+    assert eng.stats()["n_retried"] == deep
+
+
+def test_one_wave_and_pipeline_dp_agree(Engine, oracle, monkeypatch):
+    """RCN_HEAVY_PCT=0 sends every window through the 4-wave mailbox pipeline DP instead of the one-wave DP."""
+    b = simulate_windows(10000, 500, 25, 4000, seed=33)
+    ref = oracle.consensus(b, 3, -5, -4, True, 0)
+    monkeypatch.setenv("RCN_HEAVY_PCT", "0.0")
+    assert_same(Engine(3, -5, -4, True).consensus(b), ref, "pipeline DP")
+    monkeypatch.setenv("RCN_HEAVY_PCT", "1.0")
+    assert_same(Engine(3, -5, -4, True).consensus(b), ref, "one-wave DP")
