@@ -57,10 +57,11 @@ struct rcn_engine {
     uint32_t n_windows = 0, n_seqs = 0;
     uint64_t n_bases = 0;
     DevBuf d_win_seq_off, d_win_type, d_seq_off, d_has_qual, d_begin, d_end, d_bases, d_quals, d_order, d_full;
-    DevBuf d_win_ids, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
+    DevBuf d_lpt_ids, d_win_ids, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
     std::vector<WinShape> shapes;
     int32_t heavy_ns = 0, prio_ns = 0;
     std::vector<uint32_t> h_win_seq_off;
+    std::vector<uint32_t> lpt;          // work item -> window, deepest windows first (longest processing time first)
     bool uploaded = false, ran = false;
 
     // results
@@ -100,7 +101,7 @@ Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast
 }
 
 // one kernel pass over `ids` (or all windows when ids == nullptr)
-int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work, uint64_t out_stride) {
+int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work, uint64_t out_stride, const uint32_t* d_ids = nullptr) {
     if (n_work == 0) return RCN_OK;
     uint64_t budget = e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>(e->free_mem * 0.80);
     uint32_t slots = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;   // 8 work-groups per CU (20 KiB LDS each)
@@ -118,7 +119,7 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.seq_begin = e->d_begin.as<uint32_t>(); P.seq_end = e->d_end.as<uint32_t>();
     P.bases = e->d_bases.as<uint8_t>(); P.quals = e->d_quals.as<uint8_t>();
     P.order = e->d_order.as<uint32_t>(); P.seq_full = e->d_full.as<uint8_t>();
-    P.win_ids = ids ? e->d_win_ids.as<uint32_t>() : nullptr; P.n_work = n_work;
+    P.win_ids = ids ? e->d_win_ids.as<uint32_t>() : d_ids; P.n_work = n_work;
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
     P.heavy_ns = e->heavy_ns; P.prio_ns = e->prio_ns;
     P.scratch = e->d_scratch.as<uint8_t>(); P.slot_bytes = c.slot_bytes;
@@ -192,7 +193,7 @@ void rcn_engine_destroy(rcn_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     for (DevBuf* d : {&e->d_win_seq_off, &e->d_win_type, &e->d_seq_off, &e->d_has_qual, &e->d_begin, &e->d_end,
-                      &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_win_ids, &e->d_scratch,
+                      &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_lpt_ids, &e->d_win_ids, &e->d_scratch,
                       &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_ctr})
         d->release();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -249,7 +250,16 @@ int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
         for (bool p : present) sh.nsym += p;
         e->shapes[w] = sh;
     }
+    // Longest processing time first: a window's cost grows with (layers x bases), and a launch ends with its
+    // slowest window; when there are more windows than resident slots the deep ones must not start last.
+    e->lpt.resize(nw);
+    for (uint32_t w = 0; w < nw; ++w) e->lpt[w] = w;
+    std::stable_sort(e->lpt.begin(), e->lpt.end(), [&](uint32_t a, uint32_t c) {
+        const uint64_t ca = static_cast<uint64_t>(b->win_seq_off[a + 1] - b->win_seq_off[a]) * static_cast<uint64_t>(e->shapes[a].sum_l + e->shapes[a].L);
+        const uint64_t cc = static_cast<uint64_t>(b->win_seq_off[c + 1] - b->win_seq_off[c]) * static_cast<uint64_t>(e->shapes[c].sum_l + e->shapes[c].L);
+        return ca > cc; });
     int rc;
+    if ((rc = upload_vec(e->d_lpt_ids, e->lpt.data(), 4ull * nw, e->stream))) return rc;
     if ((rc = upload_vec(e->d_win_seq_off, b->win_seq_off, 4ull * (nw + 1), e->stream))) return rc;
     if ((rc = upload_vec(e->d_win_type, b->win_type, nw, e->stream))) return rc;
     if ((rc = upload_vec(e->d_seq_off, b->seq_off, 8ull * (ns + 1), e->stream))) return rc;
@@ -319,7 +329,7 @@ int rcn_engine_run(rcn_engine* e) {
     if ((rc = e->d_out_len.reserve(4ull * nw))) return rc;
     if ((rc = e->d_out_flags.reserve(nw))) return rc;
     HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 256, e->stream));
-    if ((rc = run_pass(e, c1, nullptr, nw, c1.out_stride))) return rc;
+    if ((rc = run_pass(e, c1, nullptr, nw, c1.out_stride, e->d_lpt_ids.as<uint32_t>()))) return rc;
 
     std::vector<uint32_t> out_len(nw);
     std::vector<uint8_t> flags(nw);
@@ -334,6 +344,14 @@ int rcn_engine_run(rcn_engine* e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t0, t1)); e->stats.d2h_ms += ms;
 
+    // outputs of the first pass are indexed by work item: back to window order
+    {
+        std::vector<uint32_t> ol(nw); std::vector<uint8_t> fl(nw);
+        for (uint32_t wi = 0; wi < nw; ++wi) { ol[e->lpt[wi]] = out_len[wi]; fl[e->lpt[wi]] = flags[wi]; }
+        out_len.swap(ol); flags.swap(fl);
+    }
+    std::vector<uint32_t> item_of(nw);
+    for (uint32_t wi = 0; wi < nw; ++wi) item_of[e->lpt[wi]] = wi;
     // retry pass with worst-case capacities for windows that overflowed
     std::vector<uint32_t> retry;
     for (uint32_t w = 0; w < nw; ++w) {
@@ -399,7 +417,7 @@ int rcn_engine_run(rcn_engine* e) {
     for (uint32_t w = 0; w < nw; ++w) {
         uint8_t* dst = e->cons.data() + e->cons_off[w];
         if (rk < retry.size() && retry[rk] == w) { std::memcpy(dst, retry_cons[rk].data(), out_len[w]); ++rk; }
-        else std::memcpy(dst, raw.data() + static_cast<uint64_t>(w) * c1.out_stride, out_len[w]);
+        else std::memcpy(dst, raw.data() + static_cast<uint64_t>(item_of[w]) * c1.out_stride, out_len[w]);
         e->polished[w] = (flags[w] & rcn::kFlagPolished) ? 1 : 0;
         e->chimeric[w] = (flags[w] & rcn::kFlagChimeric) ? 1 : 0;
     }
