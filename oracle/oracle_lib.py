@@ -32,6 +32,8 @@ def lib():
         _lib.rcn_oracle_consensus.argtypes = [C.POINTER(RcnBatch), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.POINTER(RcnResult), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        _lib.rcn_oracle_consensus_simd.restype = C.c_int
+        _lib.rcn_oracle_consensus_simd.argtypes = _lib.rcn_oracle_consensus.argtypes
         _lib.rcn_oracle_free.argtypes = [C.c_void_p]
         _lib.rcn_oracle_tie_stats.argtypes = [C.POINTER(C.c_uint64)]
         _lib.rcn_oracle_tie_stats.restype = None
@@ -41,7 +43,7 @@ def lib():
 
 
 def consensus(batch: WindowBatch, m: int, x: int, g: int, trim: bool = True, threads: int = 0,
-              with_stats: bool = False):
+              with_stats: bool = False, simd: bool = False):
     """Oracle consensus of every window.  Returns ConsensusResult (and, with
     with_stats, per-window (cells, cells*(1+E/V)) arrays of SURVEY §8(d))."""
     if threads <= 0:
@@ -52,7 +54,8 @@ def consensus(batch: WindowBatch, m: int, x: int, g: int, trim: bool = True, thr
     n = batch.n_windows
     cells = np.zeros(max(n, 1), np.uint64)
     cxp = np.zeros(max(n, 1), np.float64)
-    rc = lib().rcn_oracle_consensus(C.byref(cb), m, x, g, int(trim), threads, C.byref(res), C.byref(h),
+    fn = lib().rcn_oracle_consensus_simd if simd else lib().rcn_oracle_consensus
+    rc = fn(C.byref(cb), m, x, g, int(trim), threads, C.byref(res), C.byref(h),
                                     cells.ctypes.data_as(C.POINTER(C.c_uint64)),
                                     cxp.ctypes.data_as(C.POINTER(C.c_double)))
     if rc != 0:

@@ -30,6 +30,8 @@
 #include <utility>
 #include <vector>
 
+#include <immintrin.h>
+
 #include "../include/racon_hip.h"
 
 namespace {
@@ -330,9 +332,116 @@ struct Engine {
         if (classified) { ++tie_ruled; if (pick == exact) ++tie_rule_agrees; }
     }
 
+    // ---- CPU baseline variant (bench.py's cpu_baseline leg; NOT the oracle of the parity tests) ----
+    // Same recurrence, same tie-breaks, but evaluated the way spoa's SIMD engine does it: int16 row vectors
+    // (AVX2, 16 cells per op) and a log-step prefix max for the horizontal gap.  Scores are kept as
+    // Z[i][j] = H[i][j] - j*g (the horizontal move then adds 0); -|g|V <= Z <= (max(m,x,0)+|g|)W bounds them,
+    // rows that do not fit int16 take the scalar path below.  tests/test_oracle_spec.py checks it against the
+    // scalar oracle window by window.
+    bool simd = false;
+    std::vector<int16_t> Z16, prof16, mrow16;
+
+    static inline __m256i shl1(__m256i x, __m256i prevblk) {          // element j <- x[j-1], x[-1] = prevblk[15]
+        const __m256i pv = _mm256_permute2x128_si256(prevblk, x, 0x21);
+        return _mm256_alignr_epi8(x, pv, 14);
+    }
+    static inline __m256i prefix_max16(__m256i x) {
+        const __m256i NEGV = _mm256_set1_epi16(-32768);
+        __m256i pv = _mm256_permute2x128_si256(NEGV, x, 0x20);
+        x = _mm256_max_epi16(x, _mm256_alignr_epi8(x, pv, 14));
+        pv = _mm256_permute2x128_si256(NEGV, x, 0x20);
+        x = _mm256_max_epi16(x, _mm256_alignr_epi8(x, pv, 12));
+        pv = _mm256_permute2x128_si256(NEGV, x, 0x20);
+        x = _mm256_max_epi16(x, _mm256_alignr_epi8(x, pv, 8));
+        pv = _mm256_permute2x128_si256(NEGV, x, 0x20);
+        return _mm256_max_epi16(x, pv);
+    }
+
+    bool fits_z16(int32_t V, size_t Wp) const {
+        const int32_t ag = g < 0 ? -g : g, smax = std::max(std::max(m, x), 0);
+        return g < 0 && static_cast<int64_t>(ag) * (V + 2) <= 31000 && static_cast<int64_t>(smax + ag) * static_cast<int64_t>(Wp) <= 31000;
+    }
+
+    Alignment AlignZ16(const uint8_t* seq, uint32_t L, const Graph& g_) {
+        const int32_t V = static_cast<int32_t>(g_.nodes.size());
+        const size_t W = static_cast<size_t>(L) + 1, Wp = (W + 15) / 16 * 16, nb = Wp / 16;
+        Z16.resize(static_cast<size_t>(V + 1) * Wp);
+        prof16.resize(static_cast<size_t>(g_.num_codes) * Wp);
+        mrow16.resize(Wp);
+        for (int32_t c = 0; c < g_.num_codes; ++c) {
+            int16_t* P = &prof16[c * Wp];
+            P[0] = 0;
+            for (size_t j = 1; j < Wp; ++j) P[j] = static_cast<int16_t>(((j <= L && g_.decoder[c] == seq[j - 1]) ? m : x) - g);
+        }
+        cells += static_cast<uint64_t>(V + 1) * W;
+        cells_x_pred += static_cast<double>(V + 1) * W * (1.0 + static_cast<double>(g_.edges.size()) / V);
+        std::vector<int32_t> n2r(V);
+        for (int32_t r = 0; r < V; ++r) n2r[g_.rank_to_node[r]] = r;
+        std::memset(Z16.data(), 0, Wp * sizeof(int16_t));                       // row 0 of Z
+        const __m256i GV = _mm256_set1_epi16(static_cast<int16_t>(g)), NEG = _mm256_set1_epi16(-32000);
+        bool have_best = false; int32_t best = 0, bi = 0;
+        std::vector<int32_t> ps;
+        for (int32_t r = 0; r < V; ++r) {
+            const auto& node = g_.nodes[g_.rank_to_node[r]];
+            int16_t* row = &Z16[static_cast<size_t>(r + 1) * Wp];
+            const int16_t* P = &prof16[node.code * Wp];
+            ps.clear();
+            for (int32_t e : node.in) ps.push_back(n2r[g_.edges[e].tail] + 1);
+            if (ps.empty()) ps.push_back(0);
+            const int16_t* M = &Z16[static_cast<size_t>(ps[0]) * Wp];
+            if (ps.size() > 1) {
+                for (size_t b = 0; b < nb; ++b) {
+                    __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(M) + b);
+                    for (size_t k = 1; k < ps.size(); ++k)
+                        v = _mm256_max_epi16(v, _mm256_loadu_si256(reinterpret_cast<const __m256i*>(&Z16[static_cast<size_t>(ps[k]) * Wp]) + b));
+                    _mm256_storeu_si256(reinterpret_cast<__m256i*>(mrow16.data()) + b, v);
+                }
+                M = mrow16.data();
+            }
+            __m256i prevm = NEG, carry = _mm256_set1_epi16(-32768);
+            for (size_t b = 0; b < nb; ++b) {
+                const __m256i mv = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(M) + b);
+                const __m256i D = shl1(mv, prevm);
+                const __m256i pr = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(P) + b);
+                __m256i acc = _mm256_max_epi16(_mm256_adds_epi16(D, pr), _mm256_adds_epi16(mv, GV));
+                acc = _mm256_max_epi16(prefix_max16(acc), carry);
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(row) + b, acc);
+                carry = _mm256_set1_epi16(static_cast<int16_t>(_mm256_extract_epi16(acc, 15)));
+                prevm = mv;
+            }
+            if (node.out.empty()) {
+                if (!have_best || best < row[L]) { have_best = true; best = row[L]; bi = r + 1; }
+            }
+        }
+        Alignment al;
+        int32_t i = bi, j = static_cast<int32_t>(L);
+        while (!(i == 0 && j == 0)) {
+            const int32_t zij = Z16[static_cast<size_t>(i) * Wp + j];
+            int32_t pi = 0, pj = 0; bool found = false;
+            if (i != 0) {
+                const auto& node = g_.nodes[g_.rank_to_node[i - 1]];
+                ps.clear();
+                for (int32_t e : node.in) ps.push_back(n2r[g_.edges[e].tail] + 1);
+                if (ps.empty()) ps.push_back(0);
+                if (j != 0) {
+                    const int32_t mc = prof16[node.code * Wp + j];
+                    for (int32_t p : ps) if (zij == Z16[static_cast<size_t>(p) * Wp + j - 1] + mc) { pi = p; pj = j - 1; found = true; break; }
+                }
+                if (!found) for (int32_t p : ps) if (zij == Z16[static_cast<size_t>(p) * Wp + j] + g) { pi = p; pj = j; found = true; break; }
+            }
+            if (!found && j != 0 && zij == Z16[static_cast<size_t>(i) * Wp + j - 1]) { pi = i; pj = j - 1; found = true; }
+            if (!found) { fprintf(stderr, "[oracle/simd] traceback stuck at (%d,%d)\n", i, j); exit(1); }
+            al.emplace_back(i == pi ? -1 : g_.rank_to_node[i - 1], j == pj ? -1 : j - 1);
+            i = pi; j = pj;
+        }
+        std::reverse(al.begin(), al.end());
+        return al;
+    }
+
     Alignment Align(const uint8_t* seq, uint32_t L, const Graph& g_) {
         const int32_t V = static_cast<int32_t>(g_.nodes.size());
         if (V == 0 || L == 0) return {};
+        if (simd && fits_z16(V, (static_cast<size_t>(L) + 16) / 16 * 16)) return AlignZ16(seq, L, g_);
         const size_t W = static_cast<size_t>(L) + 1;
         H.resize(static_cast<size_t>(V + 1) * W);
         profile.resize(static_cast<size_t>(g_.num_codes) * W);
@@ -517,6 +626,18 @@ extern "C" {
 static std::atomic<uint64_t> g_tie_stats[3];
 void rcn_oracle_tie_stats(uint64_t* out3) { for (int k = 0; k < 3; ++k) out3[k] = g_tie_stats[k].exchange(0); }
 
+static bool g_simd_next = false;
+int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int nthreads,
+                         rcn_result* out, void** handle, uint64_t* cells, double* cells_x_pred);
+// the AVX2 int16 variant (CPU baseline of bench.py); same results as rcn_oracle_consensus
+int rcn_oracle_consensus_simd(const rcn_batch* b, int m, int x, int g, int trim, int nthreads,
+                              rcn_result* out, void** handle, uint64_t* cells, double* cells_x_pred) {
+    g_simd_next = true;
+    const int rc = rcn_oracle_consensus(b, m, x, g, trim, nthreads, out, handle, cells, cells_x_pred);
+    g_simd_next = false;
+    return rc;
+}
+
 int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int nthreads,
                          rcn_result* out, void** handle, uint64_t* cells, double* cells_x_pred) {
     if (!b || !out || !handle) return RCN_E_ARG;
@@ -524,8 +645,9 @@ int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int 
     std::vector<WindowOut> res(n);
     std::vector<uint64_t> cl(n); std::vector<double> cx(n);
     std::atomic<uint32_t> next{0};
+    const bool use_simd = g_simd_next;
     auto worker = [&]() {
-        Engine eng; eng.m = m; eng.x = x; eng.g = g;
+        Engine eng; eng.m = m; eng.x = x; eng.g = g; eng.simd = use_simd;
         for (;;) {
             uint32_t w = next.fetch_add(1);
             if (w >= n) break;

@@ -86,3 +86,16 @@ def test_sink_tie_rule_agrees_with_exact_order(oracle):
         events += e
         ruled += r
     assert events > 50 and ruled > 0.6 * events
+
+
+def test_simd_baseline_variant_equals_scalar_oracle(oracle):
+    """bench.py's CPU baseline is the oracle's AVX2 int16 variant; it must give the scalar oracle's bytes
+    (including the rows that fall back to the scalar path: g = -100 does not fit int16)."""
+    from helpers import edge_case_batch, synthetic_sets
+    cases = [(edge_case_batch(), sc) for sc in [(3, -5, -4), (5, -4, -8), (1, -1, -1), (4, -6, -100)]]
+    cases += [(b, sc) for _, b, sc in synthetic_sets()]
+    for b, sc in cases:
+        for trim in (True, False):
+            r0 = oracle.consensus(b, *sc, trim, 0)
+            r1 = oracle.consensus(b, *sc, trim, 0, simd=True)
+            assert r0.consensus == r1.consensus and (r0.polished == r1.polished).all() and (r0.chimeric == r1.chimeric).all()
