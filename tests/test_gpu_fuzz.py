@@ -1,0 +1,59 @@
+"""-m gpu: randomized windows built to stress the tie-break machinery rather than to look like data:
+low-complexity backbones (many co-optimal alignments, many sinks with equal scores, weight ties in the
+heaviest bundle), deep stacks of short partial layers (Subgraph path), layers longer than the backbone, zero
+qualities (weight-0 edges: branch completion), IUPAC symbols, duplicate `begin` values (unstable std::sort
+order), more than six in-edges per node.  HIP engine vs oracle, byte for byte."""
+import numpy as np
+import pytest
+
+from racon_amd.batch import WindowBatch
+from helpers import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def random_window(rng, style):
+    alpha = [b"ACGT", b"AC", b"A", b"ACGTN", b"ACGTRYKM"][style % 5]
+    L = int(rng.integers(8, 90))
+    if style % 3 == 0:      # tandem repeat backbone
+        unit = bytes(rng.choice(list(alpha), int(rng.integers(1, 4))).tolist())
+        bb = (unit * (L // len(unit) + 1))[:L]
+    else:
+        bb = bytes(rng.choice(list(alpha), L).tolist())
+    n_layers = int(rng.integers(0, 70))
+    seqs = [(bb, bytes([33 + int(rng.integers(0, 20))]) * L if rng.random() < 0.5 else b"!" * L, 0, 0)]
+    for _ in range(n_layers):
+        full = rng.random() < 0.5
+        b0 = 0 if full else int(rng.integers(0, max(1, L - 2)))
+        e0 = L - 1 if full else int(rng.integers(b0 + 1, L))
+        src = bytearray(bb[b0:e0 + 1])
+        out = bytearray()
+        for ch in src:                                     # noisy copy
+            r = rng.random()
+            if r < 0.08:
+                continue
+            out.append(int(rng.choice(list(alpha))) if r < 0.20 else ch)
+            if rng.random() < 0.08:
+                out.append(int(rng.choice(list(alpha))))
+        if rng.random() < 0.1:
+            out += bytes(rng.choice(list(alpha), int(rng.integers(1, 12))).tolist())      # overhanging tail
+        if len(out) == 0:
+            out = bytearray(b"A")
+        s = bytes(out)
+        q = None if rng.random() < 0.3 else bytes((rng.integers(0, 3, len(s)) * int(rng.integers(0, 15)) + 33).astype(np.uint8).tolist())
+        seqs.append((s, q, b0, e0))
+    return {"type": int(rng.integers(0, 2)), "seqs": seqs}
+
+
+@pytest.mark.parametrize("seed,scores", [(1, (3, -5, -4)), (2, (5, -4, -8)), (3, (1, -1, -1)), (4, (3, -5, -4)), (5, (2, -3, -2))])
+def test_fuzz_windows(oracle, seed, scores):
+    from racon_amd.engine import HipEngine
+    rng = np.random.default_rng(1000 + seed)
+    wins = [random_window(rng, k) for k in range(400)]
+    b = WindowBatch.from_windows(wins)
+    ref = oracle.consensus(b, *scores, True, 0)
+    got = HipEngine(*scores, True).consensus(b)
+    assert_same(got, ref, f"fuzz seed {seed} scores {scores}")
+    ref2 = oracle.consensus(b, *scores, False, 0)
+    got2 = HipEngine(*scores, False).consensus(b)
+    assert_same(got2, ref2, f"fuzz seed {seed} scores {scores} no trim")
