@@ -738,27 +738,73 @@ __device__ __noinline__ void phase_add4() {
     Win g = ctx_win(c);
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     RCN_G const uint8_t* seq = gcast(c.seq); RCN_G const uint8_t* qual = gcast(c.qual);
-    const int len = c.len, n_old = g.n_nodes;
+    const int len = c.len, n_old = g.n_nodes, ring = g.ring;
     const uint32_t count = len >= 2 ? 1u : 0u;
     int* xch = Block4::work();
-    // the traceback left, per sequence position, the DP row it is aligned to (-1 = none)
-    for (int pos = t; pos < len; pos += kThreads2) { const int row = g.pos_t[pos]; g.pos_t[pos] = row <= 0 ? -1 : rank[row - 1]; }
-    Block4::sync();
-    // classify positions; number the new nodes (prefix count) and propagate order anchors (prefix max)
+    constexpr int U = 2;                        // positions per thread walked in lock step (loads in flight together)
+    constexpr int RM = 4;                       // aligned-ring members looked at in lock step (more: generic loop)
     RCN_G int32_t* kindv = g.path_pos.ptr();
     RCN_G int32_t* idxv = g.path_node.ptr();
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nn = 0, anchor = -1;
-    for (int base = 0; base < len; base += kThreads2) {
-        const int pos = base + t;
-        int kind = 0, a = -1;
-        if (pos < len) { kind = addp_classify(g, seq, pos); a = g.pos_a[pos]; }
-        const unsigned long long mk = __ballot(kind != 0);
-        const int la = wave_incl_scan_max(a);
-        int off, total, pmax, tmax;
-        block4_scan(xch, wv, lane, __popcll(mk), __builtin_amdgcn_readlane(la, 63), off, total, pmax, tmax);
-        if (pos < len) { kindv[pos] = kind; idxv[pos] = nn + off + __popcll(mk & lt); g.pos_a[pos] = max(max(la, pmax), anchor); }
-        nn += total; anchor = max(anchor, tmax);
+    // classify positions (existing node / new node / new node joining a ring); number the new nodes (prefix count)
+    // and propagate order anchors (prefix max).  The anchor of a position on an existing node is the last rank of
+    // that node's ring block, the same for every member of the ring.
+    for (int base = 0; base < len; base += U * kThreads2) {
+        int pos[U], tt[U], ch[U], ct[U], na[U], ra[U], mem[U][RM], mc[U][RM], mr[U][RM], kind[U], curr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pos[u] = base + u * kThreads2 + t;
+            const int row = pos[u] < len ? g.pos_t[pos[u]] : 0;           // the traceback left DP rows (-1 / 0 = none)
+            ch[u] = pos[u] < len ? seq[pos[u]] : 0;
+            tt[u] = row <= 0 ? -1 : row;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) tt[u] = tt[u] < 0 ? -1 : rank[tt[u] - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = tt[u] < 0 ? 0 : tt[u];
+            ct[u] = g.code[v]; na[u] = tt[u] < 0 ? 0 : g.al_cnt[v]; ra[u] = tt[u] < 0 ? -1 : g.n2r[v];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a2 = 0; a2 < RM; ++a2) mem[u][a2] = a2 < na[u] ? g.al_nodes[tt[u] * ring + a2] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a2 = 0; a2 < RM; ++a2) { const int m = mem[u][a2] < 0 ? 0 : mem[u][a2]; mc[u][a2] = g.code[m]; mr[u][a2] = mem[u][a2] < 0 ? -1 : g.n2r[m]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kind[u] = 0; curr[u] = -1;
+            if (pos[u] < len) {
+                if (tt[u] < 0) { kind[u] = 1; ra[u] = -1; }
+                else {
+                    int found = ct[u] == ch[u] ? tt[u] : -1;
+#pragma unroll
+                    for (int a2 = 0; a2 < RM; ++a2) {
+                        if (a2 < na[u]) { ra[u] = max(ra[u], mr[u][a2]); if (found < 0 && mc[u][a2] == ch[u]) found = mem[u][a2]; }
+                    }
+                    for (int a2 = RM; a2 < na[u]; ++a2) {                 // rings beyond four members (IUPAC-rich input)
+                        const int m = g.al_nodes[tt[u] * ring + a2];
+                        ra[u] = max(ra[u], g.n2r[m]);
+                        if (found < 0 && g.code[m] == ch[u]) found = m;
+                    }
+                    curr[u] = found; kind[u] = found >= 0 ? 0 : 2;
+                }
+                g.pos_t[pos[u]] = tt[u]; g.pos_curr[pos[u]] = curr[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int a = pos[u] < len ? ra[u] : -1;
+            const unsigned long long mk = __ballot(kind[u] != 0);
+            const int la = wave_incl_scan_max(a);
+            int off, total, pmax, tmax;
+            block4_scan(xch, wv, lane, __popcll(mk), __builtin_amdgcn_readlane(la, 63), off, total, pmax, tmax);
+            if (pos[u] < len) { kindv[pos[u]] = kind[u]; idxv[pos[u]] = nn + off + __popcll(mk & lt); g.pos_a[pos[u]] = max(max(la, pmax), anchor); }
+            nn += total; anchor = max(anchor, tmax);
+        }
     }
     int overflow = g.overflow;
     if (n_old + nn > g.ncap) overflow = 1;
@@ -775,20 +821,43 @@ __device__ __noinline__ void phase_add4() {
         }
         g.n_nodes = n_old + nn;
         Block4::sync();
-        int ovf = 0;
-        for (int base = 0; base < len; base += kThreads2) {
-            const int pos = base + t;
-            int f = 0;
-            if (pos >= 1 && pos < len) f = addp_edge_find(g, qual, pos);
-            const unsigned long long mk = __ballot(f != 0);
-            int off, total, pmax, tmax;
-            block4_scan(xch, wv, lane, __popcll(mk), 0, off, total, pmax, tmax);
-            const int e = n_edges + off + __popcll(mk & lt);
-            if (f) { if (e < g.ecap) addp_edge_create(g, qual, pos, e); else ovf = 1; }
-            n_edges += total;
+        // edges pos-1 -> pos: reinforce an existing one or create it; the out-lists of U positions are walked in lock step
+        for (int base = 0; base < len; base += U * kThreads2) {
+            int pos[U], tail[U], head[U], e[U], f[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pos[u] = base + u * kThreads2 + t;
+                const bool act = pos[u] >= 1 && pos[u] < len;
+                tail[u] = act ? g.pos_curr[pos[u] - 1] : -1; head[u] = act ? g.pos_curr[pos[u]] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { e[u] = tail[u] >= 0 ? g.out_head[tail[u]] : -1; f[u] = tail[u] >= 0 ? 1 : 0; }
+            for (;;) {
+                bool any = false;
+                int eh[U], en[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { eh[u] = e[u] >= 0 ? g.e_head[e[u]] : -2; en[u] = e[u] >= 0 ? g.e_nout[e[u]] : -1; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (e[u] >= 0) {
+                        if (eh[u] == head[u]) { g.e_w[e[u]] += pair_weight(qual, pos[u]); f[u] = 0; e[u] = -1; }
+                        else e[u] = en[u];
+                    }
+                    any = any || e[u] >= 0;
+                }
+                if (!any) break;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned long long mk = __ballot(f[u] != 0);
+                int off, total, pmax, tmax;
+                block4_scan(xch, wv, lane, __popcll(mk), 0, off, total, pmax, tmax);
+                const int ne = n_edges + off + __popcll(mk & lt);
+                if (f[u] && ne < g.ecap) addp_edge_create(g, qual, pos[u], ne);
+                n_edges += total;
+            }
         }
         if (n_edges > g.ecap) { overflow = 1; n_edges = g.ecap; }
-        (void)ovf;
         for (int pos = t; pos < len; pos += kThreads2) g.cov[g.pos_curr[pos]] += count;
     }
     if (t == 0) {
