@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verify", action="store_true", help="also check every window against the oracle (untimed)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (code-path test with several ranks on ONE GPU)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -47,9 +48,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.dist_backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if a.dist_backend != "nccl":
+        local_rank %= torch.cuda.device_count()          # several test ranks on one GPU
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if a.dist_backend == "nccl" else "cpu"
     m, x, g = [int(v) for v in a.scores.split(",")]
 
     from racon_amd.engine import HipEngine
@@ -79,10 +86,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        nw = torch.tensor([batch.n_windows], dtype=torch.float64, device="cuda")
+        nw = torch.tensor([batch.n_windows], dtype=torch.float64, device=red_dev)
         dist.all_reduce(nw, op=dist.ReduceOp.SUM)
         total_windows = int(nw.item())
     else:
