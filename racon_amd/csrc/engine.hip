@@ -42,6 +42,18 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+struct HostBuf {                       // pinned host staging (D2H of the consensus bytes at full PCIe rate)
+    void* p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap && p) return RCN_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        if (hipHostMalloc(&p, std::max<size_t>(bytes, 256), hipHostMallocDefault) != hipSuccess) { p = nullptr; return RCN_E_NOMEM; }
+        cap = std::max<size_t>(bytes, 256); return RCN_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct WinShape { int32_t L, sum_l, lmax, nsym; };
 
 }  // namespace
@@ -58,6 +70,7 @@ struct rcn_engine {
     uint64_t n_bases = 0;
     DevBuf d_win_seq_off, d_win_type, d_seq_off, d_has_qual, d_begin, d_end, d_bases, d_quals, d_order, d_full;
     DevBuf d_lpt_ids, d_win_ids, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
+    HostBuf h_raw;
     std::vector<WinShape> shapes;
     int32_t heavy_ns = 0, prio_ns = 0;
     std::vector<uint32_t> h_win_seq_off;
@@ -196,6 +209,7 @@ void rcn_engine_destroy(rcn_engine* e) {
                       &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_lpt_ids, &e->d_win_ids, &e->d_scratch,
                       &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_ctr})
         d->release();
+    e->h_raw.release();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -338,8 +352,10 @@ int rcn_engine_run(rcn_engine* e) {
     HIP_TRY(hipEventRecord(t0, e->stream));
     HIP_TRY(hipMemcpyAsync(out_len.data(), e->d_out_len.p, 4ull * nw, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(flags.data(), e->d_out_flags.p, nw, hipMemcpyDeviceToHost, e->stream));
-    std::vector<uint8_t> raw(static_cast<uint64_t>(nw) * c1.out_stride);
-    HIP_TRY(hipMemcpyAsync(raw.data(), e->d_out_cons.p, raw.size(), hipMemcpyDeviceToHost, e->stream));
+    const size_t raw_bytes = static_cast<uint64_t>(nw) * c1.out_stride;
+    if ((rc = e->h_raw.reserve(raw_bytes))) return rc;
+    uint8_t* raw = e->h_raw.as<uint8_t>();
+    HIP_TRY(hipMemcpyAsync(raw, e->d_out_cons.p, raw_bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipEventRecord(t1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t0, t1)); e->stats.d2h_ms += ms;
@@ -417,7 +433,7 @@ int rcn_engine_run(rcn_engine* e) {
     for (uint32_t w = 0; w < nw; ++w) {
         uint8_t* dst = e->cons.data() + e->cons_off[w];
         if (rk < retry.size() && retry[rk] == w) { std::memcpy(dst, retry_cons[rk].data(), out_len[w]); ++rk; }
-        else std::memcpy(dst, raw.data() + static_cast<uint64_t>(item_of[w]) * c1.out_stride, out_len[w]);
+        else std::memcpy(dst, raw + static_cast<uint64_t>(item_of[w]) * c1.out_stride, out_len[w]);
         e->polished[w] = (flags[w] & rcn::kFlagPolished) ? 1 : 0;
         e->chimeric[w] = (flags[w] & rcn::kFlagChimeric) ? 1 : 0;
     }
