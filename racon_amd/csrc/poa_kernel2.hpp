@@ -86,10 +86,42 @@ __device__ __forceinline__ uint32_t pk_profile(uint32_t sqx, uint32_t symsym, ui
     const s16x2 r = __builtin_bit_cast(s16x2, u) * __builtin_bit_cast(s16x2, xm) + __builtin_bit_cast(s16x2, mg);
     return __builtin_bit_cast(uint32_t, r);
 }
+__device__ __forceinline__ uint32_t pk_minu(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_bit_cast(uint32_t, static_cast<s16x2>(__builtin_bit_cast(s16x2, a) * __builtin_bit_cast(s16x2, b) + __builtin_bit_cast(s16x2, c)));
+}
+// One of the 3 * NP independent instructions of the next row's substitution profile (xor, min, mad per register).
+// dp2_rows pins two of them between consecutive steps of the DPP prefix scan (scheduling barriers on both sides): a DPP
+// read needs two wait states after the VALU write of its source, and every s_nop the compiler would otherwise put
+// there costs the wave a full issue slot.
+template <int NP, int O>
+__device__ __forceinline__ void dp2_gap_op(uint32_t (&pw)[NP], const uint32_t (&sqx)[NP], uint32_t symsym, uint32_t one, uint32_t xm, uint32_t mg) {
+    if constexpr (O < 3 * NP) {
+        constexpr int q = O % NP, st = O / NP;
+        if constexpr (st == 0) pw[q] = sqx[q] ^ symsym;
+        else if constexpr (st == 1) pw[q] = pk_minu(pw[q], one);
+        else pw[q] = pk_mad(pw[q], xm, mg);
+    }
+}
+// Half broadcasts written as vector shuffles: instruction selection folds them into the VOP3P op_sel / op_sel_hi
+// source modifiers of v_pk_max_i16 (no v_perm_b32 in front; inline asm would cost a hazard s_nop per use on gfx950).
 // {lo, max(hi, lo)}
-__device__ __forceinline__ uint32_t pk_chain_pair(uint32_t a) { return pk_max(a, __builtin_amdgcn_perm(a, a, 0x01000100u)); }
+__device__ __forceinline__ uint32_t pk_chain_pair(uint32_t a) {
+    const s16x2 av = __builtin_bit_cast(s16x2, a);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(av, __builtin_shufflevector(av, av, 0, 0)));
+}
 // {max(a.lo, b.hi), max(a.hi, b.hi)}
-__device__ __forceinline__ uint32_t pk_max_bhi(uint32_t a, uint32_t b) { return pk_max(a, __builtin_amdgcn_perm(b, b, 0x03020302u)); }
+__device__ __forceinline__ uint32_t pk_max_bhi(uint32_t a, uint32_t b) {
+    const s16x2 bv = __builtin_bit_cast(s16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_shufflevector(bv, bv, 1, 1)));
+}
+// {max(a.lo, b.lo), max(a.hi, b.lo)}
+__device__ __forceinline__ uint32_t pk_max_blo(uint32_t a, uint32_t b) {
+    const s16x2 bv = __builtin_bit_cast(s16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_shufflevector(bv, bv, 0, 0)));
+}
 __device__ __forceinline__ int wave_incl_scan_max_id(int v) {      // INT_MIN is max's identity: each step fuses into one v_max_i32_dpp
     constexpr int I = static_cast<int>(0x80000000u);
     v = max(v, dpp_or<0x111, 0xf>(I, v));
@@ -290,7 +322,7 @@ __device__ __noinline__ void phase_desc2() {
     auto finish = [&](RowDesc d, int r) {
         // "fast" rows: at most 4 predecessors, every one among the R rows right above (the DP keeps those in
         // registers; R = dp2_window(NP)).  meta bit 13 = fast, bits 16-19 / 20-23 / 24-27 / 28-31 = distance
-        // (1..R) to predecessor 0 / 1 / 2 / 3.  Sink rows are never fast.
+        // (1..R) to predecessor 0 / 1 / 2 / 3, bit 15 = the single predecessor is the row right above.  Sink rows are never fast.
         const int np = (d.meta >> 9) & 15, i = r + 1;
         if (np <= 4 && d.erest < 0 && !(d.meta & 256)) {
             unsigned int bits = 0; bool ok = true, okm = true;
@@ -303,7 +335,7 @@ __device__ __noinline__ void phase_desc2() {
                     bits |= static_cast<unsigned int>(dist & 15) << (16 + 4 * q);
                 }
             }
-            if (ok) d.meta |= static_cast<int>(bits | (1u << 13));
+            if (ok) d.meta |= static_cast<int>(bits | (1u << 13) | ((np == 1 && i - d.p[0] == 1) ? (1u << 15) : 0u));   // bit 15 = chain row
             else if (okm) d.meta |= static_cast<int>(bits | (1u << 14));      // bit 14 = medium
         }
         g.desc[r] = d;
@@ -413,12 +445,15 @@ __device__ __noinline__ void dp2_rows() {
     constexpr int R = dp2_window(NP);
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
     u32x16 win = {};
+    uint32_t prev[NP] = {};                      // the row just finished (what a chain row reads)
+    int zsh = static_cast<int>(0x80000000u);    // lane l: scan value of lane l - 1; lane 0: max's identity, never overwritten
+    uint32_t mpv = static_cast<uint32_t>(kNeg16) << 16;   // same for the diagonal shift (WV = 1: -inf left of column 0)
     // cwin (WV = 4): lane (r % 64) holds Z[r][bcol], the border cell this wave received as horizontal carry
     // of row r = the diagonal carry of predecessor row r (wave 0 has no left neighbour: -inf)
     int cwin = wv == 0 ? kNeg16 : 0;
     const int t_own = len / (2 * NP), own_wave = t_own >> 6, own_lane = t_own & 63, own_q = (len % (2 * NP)) >> 1, own_hi = len & 1;
     int best = 0, best_row = 0, have_best = 0, tied = 0;
-    unsigned int pred_rows = 0;
+    unsigned int pred_rows = 0, not_chain = 0;  // chain rows (one predecessor each) are counted as V - not_chain at the end
     int slot = 1 % K;                           // ring slot of row i is i % K
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9;
 
@@ -472,7 +507,13 @@ __device__ __noinline__ void dp2_rows() {
 
             uint32_t M[NP];
             int mleft = kNeg16;                 // max over predecessors of Z[p][bcol] (diagonal carry into lane 0)
-            if (meta & (1 << 13)) {
+            if (meta & (1 << 15)) {
+                // ---- chain row (most rows): the only predecessor is the row just finished, still in registers ----
+#pragma unroll
+                for (int q = 0; q < NP; ++q) M[q] = prev[q];
+                if (WV > 1) mleft = __builtin_amdgcn_readlane(cwin, (i - 1) & 63);
+            } else if (meta & (1 << 13)) {
+                ++not_chain;
                 // ---- fast row: predecessors come from the register window, their border cells from cwin ----
                 const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
                 const int npf = (meta >> 9) & 7;
@@ -514,7 +555,9 @@ __device__ __noinline__ void dp2_rows() {
                 for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
                 if (WV > 1) mleft = max(max(ml[0], ml[1]), max(ml[2], ml[3]));
                 pred_rows += npf;
+                ++not_chain;
             } else {
+                ++not_chain;
 #ifdef RCN_PROF_CNT
                 if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); if (meta & 256) atomicAdd(&g_dbg[2], 1ull); if (((meta >> 9) & 15) > 4) atomicAdd(&g_dbg[3], 1ull); }
 #endif
@@ -576,10 +619,16 @@ __device__ __noinline__ void dp2_rows() {
                     if (sub && !inc[tl]) continue;
                     combine(nr[tl] + 1);
                 }
+                // retire the LDS reads here: if their s_waitcnt moved to the join below, every chain / fast row would
+                // wait there too -- for the acknowledgement of the previous row's ring write (an LDS round trip per row)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
             }
 
             // diagonal sources = the combined predecessor row shifted right by one column
-            const uint32_t mprev = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(mleft) << 16, M[NP - 1], 0x138, 0xf, 0xf, false);
+            uint32_t mprev;
+            if (WV > 1) mprev = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(mleft) << 16, M[NP - 1], 0x138, 0xf, 0xf, false);
+            else mprev = mpv = __builtin_amdgcn_update_dpp(mpv, M[NP - 1], 0x138, 0xf, 0xf, false);   // lane 0 keeps -inf (loop carried, as zsh below)
             uint32_t acc[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -592,13 +641,34 @@ __device__ __noinline__ void dp2_rows() {
             for (int q = 0; q < NP; ++q) acc[q] = pk_chain_pair(acc[q]);
 #pragma unroll
             for (int q = 1; q < NP; ++q) acc[q] = pk_max_bhi(acc[q], acc[q - 1]);
-            const int tail = static_cast<int>(acc[NP - 1]) >> 16;
+            // wave-wide exclusive prefix max of the lane tails, the next row's profile in the DPP wait states
+            int sc = static_cast<int>(acc[NP - 1]) >> 16;
             {
-                const uint32_t sy = meta_next & 255, symsym = sy | (sy << 16);
+                constexpr int I = static_cast<int>(0x80000000u);     // max's identity: each step is one v_max_i32_dpp
+                const uint32_t sy = meta_next & 255;
+                const uint32_t symsym = sy | (sy << 16);
+                uint32_t pw[NP];
+#define RCN_GAP(o) do { __builtin_amdgcn_sched_barrier(0); dp2_gap_op<NP, (o)>(pw, sqx, symsym, ONE, XM, MG); \
+                        dp2_gap_op<NP, (o) + 1>(pw, sqx, symsym, ONE, XM, MG); __builtin_amdgcn_sched_barrier(0); } while (0)
+                RCN_GAP(0);  sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
+                RCN_GAP(2);  sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
+                RCN_GAP(4);  sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
+                RCN_GAP(6);  sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
+                RCN_GAP(8);  sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
+                RCN_GAP(10); sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
+                __builtin_amdgcn_sched_barrier(0);
+#undef RCN_GAP
+                // a use inside this block: without it the profile instructions are sunk out of the gaps into the
+                // blocks that consume them
 #pragma unroll
-                for (int q = 0; q < NP; ++q) Pn[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
+                for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(pw[q]));
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Pn[q] = pw[q];
             }
-            int zex = dpp_or<0x138, 0xf>(static_cast<int>(0x80000000u), wave_incl_scan_max_id(tail));
+            // lane 0 has no source lane and keeps `old`: zsh is loop carried, so its lane 0 stays at the identity it
+            // was initialised with and no constant has to be rebuilt per row
+            zsh = dpp_or<0x138, 0xf>(zsh, sc);
+            int zex = zsh;
             int cin = static_cast<int>(0x80000000u);
             if (WV > 1 && wv > 0) {
                 asm volatile("; carry consumed here" : "+v"(cin_raw));
@@ -612,9 +682,8 @@ __device__ __noinline__ void dp2_rows() {
                 cin = static_cast<int>(static_cast<int16_t>(cin_raw & 0xffffu));
             }
             zex = max(max(zex, cin), kNeg16);
-            const uint32_t zz = __builtin_amdgcn_perm(static_cast<uint32_t>(zex), static_cast<uint32_t>(zex), 0x01000100u);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) acc[q] = pk_max(acc[q], zz);
+            for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
 
             {
                 RCN_G uint32_t* dst = H + i * hs2 + t * NP;       // every lane is inside the row: hstride is a multiple of 512
@@ -623,7 +692,7 @@ __device__ __noinline__ void dp2_rows() {
             }
             uint32_t* rdst = ring + (slot * NTH + t) * NP;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) { rdst[q] = acc[q]; win[(i & (R - 1)) * NP + q] = acc[q]; }
+            for (int q = 0; q < NP; ++q) { rdst[q] = acc[q]; win[(i & (R - 1)) * NP + q] = acc[q]; prev[q] = acc[q]; }
             if (WV > 1 && wv > 0) cwin = (lane == (i & 63)) ? cin : cwin;
             slot = (slot + 1 == K) ? 0 : slot + 1;
 
@@ -665,6 +734,7 @@ __device__ __noinline__ void dp2_rows() {
     if (wv == own_wave && lane == 0) { o->best = best; o->best_row = best_row; o->tied = tied; }
     if (t == 0) {
         const int W = len + 1;
+        pred_rows += static_cast<unsigned int>(V) - not_chain;
         o->pred_rows = pred_rows;
         o->cells += static_cast<unsigned long long>(V + 1) * W;
         o->pred += static_cast<unsigned long long>(pred_rows) * W;
