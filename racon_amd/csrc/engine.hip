@@ -134,7 +134,7 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.order = e->d_order.as<uint32_t>(); P.seq_full = e->d_full.as<uint8_t>();
     P.win_ids = ids ? e->d_win_ids.as<uint32_t>() : d_ids; P.n_work = n_work;
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
-    P.heavy_ns = e->heavy_ns; P.prio_ns = e->prio_ns;
+    P.heavy_ns = e->heavy_ns; P.prio_ns = e->prio_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.scratch = e->d_scratch.as<uint8_t>(); P.slot_bytes = c.slot_bytes;
     P.ncap = c.ncap; P.ecap = c.ecap; P.ring = c.ring; P.lmax = c.lmax; P.hstride = c.hstride;
     P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_stride = out_stride;

@@ -35,6 +35,7 @@ struct KParams {
     const uint32_t* win_ids;      // [n_work] indirection (retry pass) or nullptr
     uint32_t n_work;
     int32_t prio_ns;              // poa_window_kernel2: windows with at least this many sequences run at raised wave priority (0 = none)
+    int32_t force_exact;          // poa_window_kernel2: 1 = every window takes the exact-order consensus path (tests; env RCN_FORCE_EXACT)
     int32_t heavy_ns;             // poa_window_kernel2: windows with at least this many sequences use the 4-wave DP (0 = none)
     int32_t m, x, g, trim;
     // per-slot scratch

@@ -1334,6 +1334,151 @@ __device__ __noinline__ void phase_traceback3() {
     Block4::sync();
 }
 
+// ---- phase: spoa's exact DFS topological order, in parallel ----
+// spoa::Graph::TopologicalSort starts a DFS over in-edges and aligned rings from every not yet visited node in id
+// order.  When the DFS from start s ends its stack is empty and every node it touched is finished, so the DFS from
+// s only depends on WHICH nodes earlier starts finished, not on how: the finished set is the union of the backward
+// closures (in-edges + ring links) of the earlier starts.  Hence with
+//     key(X) = smallest node id in the FORWARD closure of X (out-edges + ring links; X itself included)
+// node X is appended by the DFS that starts at key(X) (a node is a start iff key(X) == X), spoa's order is "by key,
+// then by the post-order of that one DFS", and the DFS of different starts are independent of each other given the
+// keys: a node with a smaller key is finished, a node with a larger key is never reached.  Backbone ids are the
+// smallest ids and form a chain, so key(X) is the first backbone node X can reach (itself for a backbone node) and
+// a typical DFS covers a backbone node plus the few insertion / mismatch nodes in front of it.
+//   1. keys: descending sweep over the ring-contiguous order rank_full, 256 ranks at a time; dependencies inside a
+//      chunk (non-backbone paths) by fixed-point iteration on the LDS copy of the keys;
+//   2. nodes per key -> exclusive scan -> first exact rank of every start;
+//   3. one thread per start runs spoa's DFS restricted to its own key (graph_toposort's loop with "finished" =
+//      smaller key or local mark), writing its slice of rank_x.
+// Sets ctx->tb_i = 1 on success (0: a per-thread stack overflowed or a count did not add up -> serial path).
+__device__ __noinline__ void phase_toposort4() {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    const int n = g.n_nodes, L = c.bblen, ring = g.ring;
+    uint16_t* key = reinterpret_cast<uint16_t*>(Block4::work());                 // [n]
+    uint16_t* cnt = key + ((n + 2) & ~1);                                         // [n + 1] nodes per key, then first rank per key
+    int* flag = Block4::work() + kLdsBytes / 4 - 8;                               // [0] changed, [1] error, [2..5] wave sums
+    RCN_G const int32_t* rank_full = g.rank_full.ptr();
+    RCN_G const int32_t* out_head = g.out_head.ptr();
+    RCN_G const int32_t* e_nout = g.e_nout.ptr();
+    RCN_G const int32_t* e_head = g.e_head.ptr();
+    RCN_G const int32_t* in_head = g.in_head.ptr();
+    RCN_G const int32_t* e_nin = g.e_nin.ptr();
+    RCN_G const int32_t* e_tail = g.e_tail.ptr();
+    RCN_G const uint8_t* al_cnt = g.al_cnt.ptr();
+    RCN_G const int32_t* al_nodes = g.al_nodes.ptr();
+    RCN_G uint8_t* mark = g.mark.ptr();
+    RCN_G int32_t* rank_x = g.rank_x.ptr();
+    for (int X = t; X < n; X += kThreads2) { key[X] = static_cast<uint16_t>(X); mark[X] = 0; }
+    for (int X = t; X <= n; X += kThreads2) cnt[X] = 0;
+    if (t == 0) { flag[0] = 0; flag[1] = 0; }
+    Block4::sync();
+    // ---- 1. keys ----
+#pragma unroll 1
+    for (int hi = n; hi > 0; hi -= kThreads2) {
+        const int r = hi - 1 - t;
+        const int X = r >= 0 ? rank_full[r] : -1;
+        const bool act = X >= L;                          // a backbone node is its own key
+        const int na = act ? al_cnt[X] : 0;
+#pragma unroll 1
+        for (;;) {
+            if (act) {
+                const int cur = key[X];
+                int nb = cur;
+                // the whole ring at once (its members may straddle a chunk border): ids and out-neighbours of every member
+                for (int a = -1; a < na; ++a) {
+                    const int M = a < 0 ? X : al_nodes[X * ring + a];
+                    nb = min(nb, M);
+                    for (int e = out_head[M]; e >= 0; e = e_nout[e]) nb = min(nb, static_cast<int>(key[e_head[e]]));
+                }
+                if (nb < cur) { key[X] = static_cast<uint16_t>(nb); flag[0] = 1; }
+            }
+            Block4::sync();
+            const int ch = flag[0];
+            Block4::sync();
+            if (!ch) break;
+            if (t == 0) flag[0] = 0;
+            Block4::sync();
+        }
+    }
+    // ---- 2. nodes per key, first rank per key ----
+    {
+        unsigned int* cnt32 = reinterpret_cast<unsigned int*>(cnt);
+        for (int X = t; X < n; X += kThreads2) { const int k = key[X]; atomicAdd(&cnt32[k >> 1], 1u << (16 * (k & 1))); }
+        Block4::sync();
+        const int seg = (n + kThreads2 - 1) / kThreads2, lo = min(n, t * seg), hi2 = min(n, lo + seg);
+        int sum = 0;
+        for (int i = lo; i < hi2; ++i) sum += cnt[i];
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        if (lane == 63) flag[2 + wv] = incl;
+        Block4::sync();
+        int run = incl - sum;
+        for (int w = 0; w < kWaves2; ++w) if (w < wv) run += flag[2 + w];
+        for (int i = lo; i < hi2; ++i) { const int cc = cnt[i]; cnt[i] = static_cast<uint16_t>(run); run += cc; }
+        if (t == kThreads2 - 1) cnt[n] = static_cast<uint16_t>(run);
+        Block4::sync();
+    }
+    // ---- 3. one DFS per start ----
+    {
+        const int64_t per = g.hcap / (2 * kThreads2);          // ints per thread of the (finished) int16 score matrix
+        const int cap = static_cast<int>(per < (1 << 20) ? per : (1 << 20));
+        RCN_G int32_t* stk = reinterpret_cast<RCN_G int32_t*>(g.H.ptr()) + static_cast<int64_t>(t) * cap;
+        int err = 0;
+#pragma unroll 1
+        for (int s = t; s < n; s += kThreads2) {
+            if (key[s] != s) continue;
+            int out = cnt[s];
+            const int out_end = cnt[s + 1];
+            int sp = 0;
+            stk[sp++] = s;
+            while (sp > 0) {
+                const int cu = stk[sp - 1];
+                bool valid = true;
+                const int mc = mark[cu];
+                if ((mc & 3) != 2) {
+                    for (int e = in_head[cu]; e >= 0; e = e_nin[e]) {
+                        const int tl = e_tail[e];
+                        if (key[tl] != s) continue;                       // finished by an earlier start
+                        if ((mark[tl] & 3) != 2) { if (sp < cap) stk[sp++] = tl; else err = 1; valid = false; }
+                    }
+                    const bool ign = (mc & 4) != 0;
+                    const int na = al_cnt[cu];
+                    if (!ign) {
+                        for (int a = 0; a < na; ++a) {
+                            const int u = al_nodes[cu * ring + a];
+                            const int mu = mark[u];
+                            if ((mu & 3) != 2) { if (sp < cap) stk[sp++] = u; else err = 1; mark[u] = static_cast<uint8_t>(mu | 4); valid = false; }
+                        }
+                    }
+                    if (err) break;
+                    if (valid) {
+                        mark[cu] = static_cast<uint8_t>((mc & 4) | 2);
+                        if (!ign) {
+                            if (out + 1 + na > out_end) { err = 1; break; }
+                            rank_x[out++] = cu;
+                            for (int a = 0; a < na; ++a) rank_x[out++] = al_nodes[cu * ring + a];
+                        }
+                    } else {
+                        mark[cu] = static_cast<uint8_t>((mc & 4) | 1);
+                    }
+                }
+                if (valid) --sp;
+            }
+            if (out != out_end) err = 1;
+            if (err) break;
+        }
+        if (err) flag[1] = 1;
+        Block4::sync();
+        const int bad = flag[1];
+        for (int r = t; r < n; r += kThreads2) g.n2r_x[rank_x[r]] = r;
+        if (t == 0) Block4::ctx()->tb_i = bad ? 0 : 1;
+        Block4::sync();
+    }
+}
+
 // ---- phase: consensus (window.cpp:122-146) ----
 // Heaviest bundle without spoa's exact DFS order in the common case.  Scores and predecessor choices do
 // not depend on WHICH valid topological order is used; the exact order only matters (a) to pick the first
@@ -1348,19 +1493,23 @@ __device__ __noinline__ void phase_traceback3() {
 constexpr int kCons2MaxNodes = kLdsBytes / 6;     // int32 score + uint16 predecessor rank per node in LDS
 struct ConsRec { int32_t trA, w, trB, trC; };     // trB/trC: -1 none; trC == -2: more than three edges tie
 
-__device__ __noinline__ void phase_cons2_edges() {
+// exact = 0: over rank_full (any valid order); exact = 1: over rank_x, spoa's own order (phase_toposort4)
+__device__ __noinline__ void phase_cons2_edges(int exact) {
+    exact = uint_(exact);
     const int t = threadIdx.x;
     const Ctx c = ctx_load<Block4>();
     Win g = ctx_win(c);
     RCN_G ConsRec* rec = reinterpret_cast<RCN_G ConsRec*>(g.desc.ptr());
+    RCN_G const int32_t* rank = exact ? g.rank_x.ptr() : g.rank_full.ptr();
+    RCN_G const int32_t* n2r = exact ? g.n2r_x.ptr() : g.n2r.ptr();
     const int n = g.n_nodes;
     for (int r = t; r < n; r += kThreads2) {
-        const int v = g.rank_full[r];
+        const int v = rank[r];
         ConsRec o; o.trA = -1; o.w = 0; o.trB = -1; o.trC = -1;
         long long wmax = -1; int ntie = 0;
         for (int e = g.in_head[v]; e >= 0; e = g.e_nin[e]) {
             const long long w = g.e_w[e];
-            const int tr = g.n2r[g.e_tail[e]];
+            const int tr = n2r[g.e_tail[e]];
             if (w > wmax) { wmax = w; ntie = 1; o.trA = tr; o.w = static_cast<int32_t>(w); o.trB = -1; o.trC = -1; }
             else if (w == wmax) { ++ntie; if (ntie == 2) o.trB = tr; else if (ntie == 3) o.trC = tr; else o.trC = -2; }
         }
@@ -1370,11 +1519,14 @@ __device__ __noinline__ void phase_cons2_edges() {
 }
 
 // returns (through ctx->tb_n) the consensus length, 0 = take the exact path; path ranks in LDS (reversed)
-__device__ __noinline__ void phase_cons2_bundle() {
+__device__ __noinline__ void phase_cons2_bundle(int exact) {
+    exact = uint_(exact);
     const int lane = threadIdx.x;
     const Ctx c = ctx_load<Wave0Of4>();
     Win g = ctx_win(c);
     RCN_G const ConsRec* rec = reinterpret_cast<RCN_G const ConsRec*>(g.desc.ptr());
+    RCN_G const int32_t* rank = exact ? g.rank_x.ptr() : g.rank_full.ptr();
+    RCN_G const int32_t* n2r = exact ? g.n2r_x.ptr() : g.n2r.ptr();
     const int n = g.n_nodes;
     int* sc = Wave0Of4::work();                                              // [n]
     uint16_t* pr = reinterpret_cast<uint16_t*>(Wave0Of4::work() + n);       // [n] rank of the chosen predecessor, 0xFFFF none
@@ -1403,9 +1555,9 @@ __device__ __noinline__ void phase_cons2_bundle() {
                 };
                 if (cc == -2) {
                     // more than three candidates: walk the node's in-edge list again (edge order)
-                    const int v = g.rank_full[base + k];
+                    const int v = rank[base + k];
                     for (int ed = g.in_head[v]; ed >= 0; ed = g.e_nin[ed]) {
-                        if (static_cast<int32_t>(g.e_w[ed]) == wk) consider(bcast0(g.n2r[g.e_tail[ed]]));
+                        if (static_cast<int32_t>(g.e_w[ed]) == wk) consider(bcast0(n2r[g.e_tail[ed]]));
                     }
                 } else {
                     consider(a); consider(b); if (cc >= 0) consider(cc);
@@ -1428,7 +1580,42 @@ __device__ __noinline__ void phase_cons2_bundle() {
     }
     Ctx* o = Wave0Of4::ctx();
     int k = 0;
-    const int mxnode = g.rank_full[gmax_rank];
+    int mxnode = rank[gmax_rank];
+    if (exact) {
+        // over spoa's own order the first maximum IS spoa's choice; BranchCompletion (spoa graph.cpp, restated in
+        // graph_consensus of poa_core.hpp) runs on the LDS scores, serially: it only touches the ranks behind the
+        // maximum, normally the last few of the graph
+        int mx = gmax_rank;
+        if (lane == 0) {
+            while (g.out_head[rank[mx]] >= 0) {
+                const int start = rank[mx];
+                for (int e = g.out_head[start]; e >= 0; e = g.e_nout[e]) {
+                    for (int f = g.in_head[g.e_head[e]]; f >= 0; f = g.e_nin[f]) {
+                        const int tl = g.e_tail[f];
+                        if (tl != start) sc[n2r[tl]] = -1;
+                    }
+                }
+                int m2 = -1, m2s = 0;
+                for (int r = mx + 1; r < n; ++r) {
+                    const int it = rank[r];
+                    int sv = -1, p = -1, ps = 0;
+                    for (int f = g.in_head[it]; f >= 0; f = g.e_nin[f]) {
+                        const int tr = n2r[g.e_tail[f]];
+                        const int ts = sc[tr];
+                        if (ts == -1) continue;
+                        const int w = static_cast<int32_t>(g.e_w[f]);
+                        if (sv < w || (sv == w && ps <= ts)) { sv = w; p = tr; ps = ts; }
+                    }
+                    if (p >= 0) sv += ps;
+                    sc[r] = sv; pr[r] = static_cast<uint16_t>(p < 0 ? 0xFFFF : p);
+                    if (m2 < 0 || m2s < sv) { m2 = r; m2s = sv; }
+                }
+                mx = m2;
+            }
+        }
+        gmax_rank = bcast0(mx); gtie = 0;
+        mxnode = rank[gmax_rank];
+    }
     if (!gtie && g.out_head[mxnode] < 0) {
         // backtrack through the LDS predecessor ranks; the rank list overwrites the scores
         int cur = gmax_rank;
@@ -1440,7 +1627,7 @@ __device__ __noinline__ void phase_cons2_bundle() {
             cur = nxt;
         }
     }
-    if (lane == 0) o->tb_n = k;
+    if (lane == 0) { o->tb_n = k; o->tb_j = exact; }
     Wave0Of4::sync();
 }
 
@@ -1452,9 +1639,10 @@ __device__ __noinline__ void phase_cons2_finish(uint8_t* out_in, uint64_t out_ca
     const Ctx c = ctx_load<Wave0Of4>();
     Win g = ctx_win(c);
     const int k = c.tb_n;
-    const int* plist = Wave0Of4::work();          // reversed consensus path, as ranks of rank_full
+    const int* plist = Wave0Of4::work();          // reversed consensus path, as ranks of the order the bundle ran over
     RCN_G int32_t* cn = g.path_node.ptr();
-    for (int i = lane; i < k; i += 64) cn[i] = g.rank_full[plist[k - 1 - i]];
+    RCN_G const int32_t* rank = c.tb_j ? g.rank_x.ptr() : g.rank_full.ptr();
+    for (int i = lane; i < k; i += 64) cn[i] = rank[plist[k - 1 - i]];
     Wave0Of4::sync();
     int bgn = 0, end = k - 1, flags = kFlagPolished;
     if (tgs && c.trim) {
@@ -1654,10 +1842,32 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             const bool fast_cons = bcast0(ctx->n_nodes) <= kCons2MaxNodes && wbases * 444ull < 0x7fffffffull;
             int k = 0;
             if (fast_cons) {
-                phase_cons2_edges();
-                if (wv == 0) phase_cons2_bundle();
+                phase_cons2_edges(0);
+                if (wv == 0) phase_cons2_bundle(0);
                 Block4::sync();
                 k = bcast0(ctx->tb_n);
+                if (P.force_exact) k = 0;
+                if (k == 0) {
+                    // several nodes tie for the best score, or the best node is not a sink (BranchCompletion): both
+                    // depend on spoa's own rank order -> the same bundle over that order
+                    phase_toposort4();
+                    if (bcast0(ctx->tb_i)) {
+#ifdef RCN_VERIFY_TOPO
+                        if (t == 0) {
+                            Win g = ctx_win(*ctx);
+                            const int nx = graph_toposort(g, g.rank_tmp.ptr(), false, g.stack.ptr());
+                            int bad = nx != g.n_nodes;
+                            for (int r = 0; r < g.n_nodes && !bad; ++r) bad = g.rank_tmp[r] != g.rank_x[r];
+                            if (bad) printf("[toposort4] MISMATCH wi %d n %d\n", ctx->wi, g.n_nodes);
+                        }
+                        Block4::sync();
+#endif
+                        phase_cons2_edges(1);
+                        if (wv == 0) phase_cons2_bundle(1);
+                        Block4::sync();
+                        k = bcast0(ctx->tb_n);
+                    }
+                }
             }
             if (wv == 0) {
                 if (k > 0) phase_cons2_finish(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);

@@ -57,3 +57,22 @@ def test_fuzz_windows(oracle, seed, scores):
     ref2 = oracle.consensus(b, *scores, False, 0)
     got2 = HipEngine(*scores, False).consensus(b)
     assert_same(got2, ref2, f"fuzz seed {seed} scores {scores} no trim")
+
+
+@pytest.mark.parametrize("seed,scores", [(6, (3, -5, -4)), (7, (5, -4, -8)), (8, (1, -1, -1))])
+def test_fuzz_windows_exact_order_consensus(oracle, seed, scores, monkeypatch):
+    """Every window through the order-dependent consensus path: the parallel restatement of spoa's DFS
+    TopologicalSort (phase_toposort4), the heaviest bundle over that order and BranchCompletion on it --
+    normally taken only when the best node is not a sink or several nodes tie for the best score."""
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    monkeypatch.setenv("RCN_FORCE_EXACT", "1")
+    rng = np.random.default_rng(2000 + seed)
+    wins = [random_window(rng, k) for k in range(400)]
+    b = WindowBatch.from_windows(wins)
+    assert_same(HipEngine(*scores, True).consensus(b), oracle.consensus(b, *scores, True, 0), f"forced exact, fuzz seed {seed}")
+    b2 = simulate_windows(60000, 500, 30.0, 10000, seed=300 + seed)          # ONT-like windows (deep graphs)
+    assert_same(HipEngine(*scores, True).consensus(b2), oracle.consensus(b2, *scores, True, 0), f"forced exact, synthetic seed {seed}")
+    b3 = simulate_windows(30000, 200, 60.0, 150, sub=0.003, ins=0.0005, dele=0.0005, seed=400 + seed,
+                          phred_mean=30.0, phred_sd=0.0, phred_lo=30, phred_hi=30)    # short reads: Subgraph layers
+    assert_same(HipEngine(*scores, True).consensus(b3), oracle.consensus(b3, *scores, True, 0), f"forced exact, short reads seed {seed}")
