@@ -121,6 +121,58 @@ int  rcn_engine_has_windows(rcn_engine* e);
 int  rcn_engine_generate_consensus(rcn_engine* e);
 int  rcn_engine_reset(rcn_engine* e);
 
+/* --- device-side window construction -----------------
+ * Replaces the two serial host loops at the end of Polisher::initialize: targets
+ * cut into backbone windows (reference src/polisher.cpp:388-403, createWindow
+ * src/window.cpp:15-40) and every overlap cut into layers at its breaking points
+ * (reference src/polisher.cpp:405-461: length filter :415, mean-quality filter
+ * :419-433, window rank / begin / end :436-457; Window::add_layer
+ * src/window.cpp:42-63; reverse strand = Sequence::create_reverse_complement,
+ * src/sequence.cpp:49-84).  Reads, qualities and breaking points go to HBM once;
+ * filter, per-window counting, stable ordering (layers keep overlap order, as
+ * the serial loop adds them) and the gather (with reverse complement) run there,
+ * and the packed batch stays resident for rcn_engine_run -- no host packing, no
+ * second copy of the bases over PCIe.                                            */
+typedef struct rcn_read_set {
+    uint64_t n_seqs;               /* Polisher::sequences_ (src/polisher.hpp:86): targets first   */
+    uint64_t n_targets;            /* sequences [0, n_targets) are the targets                    */
+    const uint64_t* seq_off;       /* [n_seqs+1] byte offsets into bases / quals                   */
+    const uint8_t*  bases;         /* forward strand, upper case (Sequence ctor, sequence.cpp:19-31) */
+    const uint8_t*  quals;         /* phred+33 at the same offsets; ignored where !seq_has_qual     */
+    const uint8_t*  seq_has_qual;  /* [n_seqs] 0 = FASTA record or all-'!' quality (sequence.cpp:33-47) */
+} rcn_read_set;
+
+typedef struct rcn_overlap_set {
+    uint64_t n_overlaps;           /* valid overlaps, in the order Polisher::initialize keeps them */
+    const uint32_t* q_id;          /* [n_overlaps] index into the read set                         */
+    const uint32_t* t_id;          /* [n_overlaps] target index (< n_targets)                      */
+    const uint8_t*  strand;        /* [n_overlaps] 1 = query reverse-complemented                  */
+    const uint64_t* bp_off;        /* [n_overlaps+1] offsets, in points, into bp_t / bp_q (even counts) */
+    const uint32_t* bp_t;          /* Overlap::breaking_points_[k].first  (target position)        */
+    const uint32_t* bp_q;          /* Overlap::breaking_points_[k].second (query position on the overlap's strand) */
+} rcn_overlap_set;
+
+typedef struct rcn_build_stats {
+    double   h2d_ms;               /* reads + overlaps to HBM                                      */
+    double   kernel_ms;            /* filter + sort + scans + gather, HIP events                   */
+    double   gather_ms;            /* the gather kernel alone (the HBM-bound part)                 */
+    uint64_t n_pairs, n_layers;    /* breaking-point pairs seen / layers kept                      */
+    uint64_t gather_bytes;         /* bytes read + written by the gather (bases and qualities)     */
+} rcn_build_stats;
+
+/* Builds the resident batch (every window of every target, in target order).  window_type: 0 kNGS,
+ * 1 kTGS (src/polisher.cpp:277-278).  RCN_E_ARG when a layer violates the add_layer contract
+ * (src/window.cpp:49-58), as the reference's fatal error would.                                   */
+int  rcn_engine_build_windows(rcn_engine* e, const rcn_read_set* reads, const rcn_overlap_set* overlaps,
+                              uint32_t window_length, double quality_threshold, uint8_t window_type);
+int  rcn_engine_build_stats(rcn_engine* e, rcn_build_stats* out);
+
+/* Dimensions and a copy (D2H) of the resident batch, uploaded or built; any output pointer may be NULL. */
+typedef struct rcn_batch_dims { uint32_t n_windows, n_seqs; uint64_t n_bases; } rcn_batch_dims;
+int  rcn_engine_batch_dims(rcn_engine* e, rcn_batch_dims* out);
+int  rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_type, uint64_t* seq_off,
+                             uint8_t* seq_has_qual, uint32_t* seq_begin, uint32_t* seq_end, uint8_t* bases, uint8_t* quals);
+
 /* --- misc ------------------------------------------------------------------ */
 int  rcn_device_count(void);
 const char* rcn_strerror(int code);

@@ -44,6 +44,12 @@ int  rcnh_polisher_create(const char* sequences_path, const char* overlaps_path,
 int  rcnh_polisher_initialize(rcnh_polisher* p);
 /* All windows as one packed batch; pointers stay valid until assemble/destroy. */
 int  rcnh_polisher_windows(rcnh_polisher* p, rcn_batch* out);
+/* The flattened input of those windows -- sequences (forward strand) and kept overlaps with their breaking points,
+ * i.e. what reference src/polisher.cpp:388-461 loops over -- for rcn_engine_build_windows (include/racon_hip.h).
+ * rcnh_polisher_keep_layout(p, 1) must precede rcnh_polisher_initialize; pointers stay valid until destroy. */
+int  rcnh_polisher_keep_layout(rcnh_polisher* p, int on);
+int  rcnh_polisher_layout(rcnh_polisher* p, rcn_read_set* reads, rcn_overlap_set* overlaps, uint8_t* window_type,
+                          uint32_t* window_length, double* quality_threshold);
 /* Stitch per-window results (same order as the batch) into FASTA text
  * ">name tags\nsequence\n..." exactly as reference src/main.cpp:159-161 prints it. */
 int  rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* results, int drop_unpolished_sequences,

@@ -81,6 +81,8 @@ struct rcn_engine {
     std::vector<uint64_t> cons_off;
     std::vector<uint8_t> cons, polished, chimeric;
     rcn_run_stats stats{};
+    rcn_build_stats bstats{};
+    DevBuf d_build[16];                 // rcn_engine_build_windows: resident reads / overlaps / work arrays
 
     // incremental builder (addWindow form)
     std::vector<uint32_t> b_win_seq_off{0};
@@ -155,6 +157,63 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
 
 }  // namespace
 
+// Host-side preparation shared by rcn_engine_upload and rcn_engine_build_windows: layer order (window.cpp:79-86: the
+// reference's std::sort, unstable -- libstdc++'s introsort is what decides ties), full-span flags (window.cpp:88,93-94),
+// shape statistics for the scratch capacities, deepest-first work order.  `bases` may be null (batch built on the
+// device): every window then gets the batch-wide symbol count `nsym_all`.
+int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* win_seq_off, const uint64_t* seq_off,
+                            const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all) {
+    e->h_win_seq_off.assign(win_seq_off, win_seq_off + nw + 1);
+    std::vector<uint32_t> order(ns);
+    std::vector<uint8_t> full(ns, 0);
+    e->shapes.resize(nw);
+    std::vector<uint32_t> rank;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t s0 = win_seq_off[w], n = win_seq_off[w + 1] - s0;
+        if (n == 0) return RCN_E_ARG;
+        rank.resize(n);
+        for (uint32_t i = 0; i < n; ++i) rank[i] = i;
+        std::sort(rank.begin() + 1, rank.end(), [&](uint32_t lhs, uint32_t rhs) {
+            return seq_begin[s0 + lhs] < seq_begin[s0 + rhs]; });
+        const uint32_t L = static_cast<uint32_t>(seq_off[s0 + 1] - seq_off[s0]);
+        if (L == 0) return RCN_E_ARG;                         // createWindow rejects empty backbones (window.cpp:19-23)
+        const uint32_t offset = static_cast<uint32_t>(0.01 * L);
+        bool present[256] = {false};
+        WinShape sh{static_cast<int32_t>(L), 0, 0, 0};
+        for (uint32_t i = 0; i < n; ++i) {
+            order[s0 + i] = rank[i];
+            const uint32_t si = s0 + i;
+            const uint64_t a = seq_off[si], z = seq_off[si + 1];
+            if (i > 0) {
+                const uint32_t bg = seq_begin[si], en = seq_end[si];
+                if (z == a || bg >= en || bg > L || en > L) return RCN_E_ARG;   // add_layer contract (window.cpp:45-58)
+                full[si] = (bg < offset && en > L - offset) ? 1 : 0;
+                sh.sum_l += static_cast<int32_t>(z - a);
+                sh.lmax = std::max<int32_t>(sh.lmax, static_cast<int32_t>(z - a));
+            }
+            if (bases) for (uint64_t k = a; k < z; ++k) present[bases[k]] = true;
+        }
+        if (bases) { for (bool p : present) sh.nsym += p; } else sh.nsym = nsym_all;
+        e->shapes[w] = sh;
+    }
+    // Longest processing time first: a window's cost grows with (layers x bases), and a launch ends with its
+    // slowest window; when there are more windows than resident slots the deep ones must not start last.
+    e->lpt.resize(nw);
+    for (uint32_t w = 0; w < nw; ++w) e->lpt[w] = w;
+    std::stable_sort(e->lpt.begin(), e->lpt.end(), [&](uint32_t a, uint32_t c) {
+        const uint64_t ca = static_cast<uint64_t>(win_seq_off[a + 1] - win_seq_off[a]) * static_cast<uint64_t>(e->shapes[a].sum_l + e->shapes[a].L);
+        const uint64_t cc = static_cast<uint64_t>(win_seq_off[c + 1] - win_seq_off[c]) * static_cast<uint64_t>(e->shapes[c].sum_l + e->shapes[c].L);
+        return ca > cc; });
+    int rc;
+    if ((rc = upload_vec(e->d_lpt_ids, e->lpt.data(), 4ull * nw, e->stream))) return rc;
+    if ((rc = upload_vec(e->d_order, order.data(), 4ull * ns, e->stream))) return rc;
+    if ((rc = upload_vec(e->d_full, full.data(), ns, e->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));                 // order / full are stack-scoped
+    return RCN_OK;
+}
+
+#include "window_build.hpp"
+
 extern "C" {
 
 int rcn_device_count(void) {
@@ -209,6 +268,7 @@ void rcn_engine_destroy(rcn_engine* e) {
                       &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_lpt_ids, &e->d_win_ids, &e->d_scratch,
                       &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_ctr})
         d->release();
+    for (DevBuf& d : e->d_build) d.release();
     e->h_raw.release();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -228,52 +288,8 @@ int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
     const uint32_t nw = b->n_windows, ns = b->n_seqs;
     e->n_windows = nw; e->n_seqs = ns; e->n_bases = ns ? b->seq_off[ns] : 0;
     e->uploaded = false; e->ran = false;
-    e->h_win_seq_off.assign(b->win_seq_off, b->win_seq_off + nw + 1);
-
-    // host-side preparation: layer order (window.cpp:79-86), full-span flags
-    // (window.cpp:88,93-94), shape statistics for the scratch capacities.
-    std::vector<uint32_t> order(ns);
-    std::vector<uint8_t> full(ns, 0);
-    e->shapes.resize(nw);
-    std::vector<uint32_t> rank;
-    for (uint32_t w = 0; w < nw; ++w) {
-        const uint32_t s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
-        if (n == 0) return RCN_E_ARG;
-        rank.resize(n);
-        for (uint32_t i = 0; i < n; ++i) rank[i] = i;
-        std::sort(rank.begin() + 1, rank.end(), [&](uint32_t lhs, uint32_t rhs) {
-            return b->seq_begin[s0 + lhs] < b->seq_begin[s0 + rhs]; });
-        const uint32_t L = static_cast<uint32_t>(b->seq_off[s0 + 1] - b->seq_off[s0]);
-        if (L == 0) return RCN_E_ARG;                         // createWindow rejects empty backbones (window.cpp:19-23)
-        const uint32_t offset = static_cast<uint32_t>(0.01 * L);
-        bool present[256] = {false};
-        WinShape sh{static_cast<int32_t>(L), 0, 0, 0};
-        for (uint32_t i = 0; i < n; ++i) {
-            order[s0 + i] = rank[i];
-            const uint32_t si = s0 + i;
-            const uint64_t a = b->seq_off[si], z = b->seq_off[si + 1];
-            if (i > 0) {
-                const uint32_t bg = b->seq_begin[si], en = b->seq_end[si];
-                if (z == a || bg >= en || bg > L || en > L) return RCN_E_ARG;   // add_layer contract (window.cpp:45-58)
-                full[si] = (bg < offset && en > L - offset) ? 1 : 0;
-                sh.sum_l += static_cast<int32_t>(z - a);
-                sh.lmax = std::max<int32_t>(sh.lmax, static_cast<int32_t>(z - a));
-            }
-            for (uint64_t k = a; k < z; ++k) present[b->bases[k]] = true;
-        }
-        for (bool p : present) sh.nsym += p;
-        e->shapes[w] = sh;
-    }
-    // Longest processing time first: a window's cost grows with (layers x bases), and a launch ends with its
-    // slowest window; when there are more windows than resident slots the deep ones must not start last.
-    e->lpt.resize(nw);
-    for (uint32_t w = 0; w < nw; ++w) e->lpt[w] = w;
-    std::stable_sort(e->lpt.begin(), e->lpt.end(), [&](uint32_t a, uint32_t c) {
-        const uint64_t ca = static_cast<uint64_t>(b->win_seq_off[a + 1] - b->win_seq_off[a]) * static_cast<uint64_t>(e->shapes[a].sum_l + e->shapes[a].L);
-        const uint64_t cc = static_cast<uint64_t>(b->win_seq_off[c + 1] - b->win_seq_off[c]) * static_cast<uint64_t>(e->shapes[c].sum_l + e->shapes[c].L);
-        return ca > cc; });
     int rc;
-    if ((rc = upload_vec(e->d_lpt_ids, e->lpt.data(), 4ull * nw, e->stream))) return rc;
+    if ((rc = prepare_resident(e, nw, ns, b->win_seq_off, b->seq_off, b->seq_begin, b->seq_end, b->bases, 0))) return rc;
     if ((rc = upload_vec(e->d_win_seq_off, b->win_seq_off, 4ull * (nw + 1), e->stream))) return rc;
     if ((rc = upload_vec(e->d_win_type, b->win_type, nw, e->stream))) return rc;
     if ((rc = upload_vec(e->d_seq_off, b->seq_off, 8ull * (ns + 1), e->stream))) return rc;
@@ -282,8 +298,6 @@ int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
     if ((rc = upload_vec(e->d_end, b->seq_end, 4ull * ns, e->stream))) return rc;
     if ((rc = upload_vec(e->d_bases, b->bases, e->n_bases, e->stream))) return rc;
     if ((rc = upload_vec(e->d_quals, b->quals, e->n_bases, e->stream))) return rc;
-    if ((rc = upload_vec(e->d_order, order.data(), 4ull * ns, e->stream))) return rc;
-    if ((rc = upload_vec(e->d_full, full.data(), ns, e->stream))) return rc;
     HIP_TRY(hipEventRecord(t1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
@@ -292,6 +306,47 @@ int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
     e->stats.h2d_ms = ms;
     e->stats.bytes_in = 2 * e->n_bases + 17ull * ns + 5ull * nw;
     e->uploaded = true;
+    return RCN_OK;
+}
+
+int rcn_engine_build_windows(rcn_engine* e, const rcn_read_set* reads, const rcn_overlap_set* ovl,
+                             uint32_t window_length, double quality_threshold, uint8_t window_type) {
+    if (!e || !reads || !ovl || window_length == 0) return RCN_E_ARG;
+    return rcn::build_windows(e, *reads, *ovl, window_length, quality_threshold, window_type);
+}
+
+int rcn_engine_build_stats(rcn_engine* e, rcn_build_stats* out) {
+    if (!e || !out) return RCN_E_ARG;
+    *out = e->bstats;
+    return RCN_OK;
+}
+
+int rcn_engine_batch_dims(rcn_engine* e, rcn_batch_dims* out) {
+    if (!e || !out) return RCN_E_ARG;
+    if (!e->uploaded) return RCN_E_STATE;
+    out->n_windows = e->n_windows; out->n_seqs = e->n_seqs; out->n_bases = e->n_bases;
+    return RCN_OK;
+}
+
+int rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_type, uint64_t* seq_off,
+                            uint8_t* seq_has_qual, uint32_t* seq_begin, uint32_t* seq_end, uint8_t* bases, uint8_t* quals) {
+    if (!e) return RCN_E_ARG;
+    if (!e->uploaded) return RCN_E_STATE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint64_t nw = e->n_windows, ns = e->n_seqs;
+    auto get = [&](void* dst, const DevBuf& src, size_t bytes) -> int {
+        if (dst && bytes) HIP_TRY(hipMemcpy(dst, src.p, bytes, hipMemcpyDeviceToHost));
+        return RCN_OK;
+    };
+    int rc;
+    if ((rc = get(win_seq_off, e->d_win_seq_off, 4 * (nw + 1)))) return rc;
+    if ((rc = get(win_type, e->d_win_type, nw))) return rc;
+    if ((rc = get(seq_off, e->d_seq_off, 8 * (ns + 1)))) return rc;
+    if ((rc = get(seq_has_qual, e->d_has_qual, ns))) return rc;
+    if ((rc = get(seq_begin, e->d_begin, 4 * ns))) return rc;
+    if ((rc = get(seq_end, e->d_end, 4 * ns))) return rc;
+    if ((rc = get(bases, e->d_bases, e->n_bases))) return rc;
+    if ((rc = get(quals, e->d_quals, e->n_bases))) return rc;
     return RCN_OK;
 }
 

@@ -1,0 +1,327 @@
+// window_build.hpp — rcn_engine_build_windows: racon's windows built in HBM.
+//
+// What the reference does serially on the host at the end of Polisher::initialize —
+//   * cut every target into backbone windows              (reference src/polisher.cpp:388-403, src/window.cpp:15-40)
+//   * cut every overlap into layers at its breaking points (reference src/polisher.cpp:405-461), i.e. per pair of points
+//     the length filter (:415), the mean-quality filter (:419-433), window rank / begin / end (:436-457) and
+//     Window::add_layer (src/window.cpp:42-63), reading the reverse complement for strand 1 (src/sequence.cpp:49-84)
+// — as four data-parallel steps over arrays that are uploaded once:
+//   1. k_layer_filter : one wave per breaking-point pair: filters, window id, begin / end; layers per window (atomics)
+//   2. stable radix sort of the kept pairs by window id (hipCUB): inside a window the layers keep overlap order, which
+//      is the order the serial loop calls add_layer in (the engine's std::sort emulation depends on it)
+//   3. exclusive scans -> win_seq_off, seq_off; k_seq_table writes one source descriptor per sequence of the batch
+//   4. k_gather       : one wave per sequence copies (or reverse-complements) bases and qualities into the packed batch
+// Everything is integer / byte work bounded by HBM traffic; the only floating point is the reference's own
+// `q1 - q0 < 0.02 * w` and `mean quality < threshold` comparisons, evaluated in double exactly as there.
+#pragma once
+
+#include <hipcub/hipcub.hpp>
+
+namespace rcn {
+
+struct BuildParams {
+    // reads (rcn_read_set, device copies)
+    const uint64_t* seq_off; const uint8_t* bases; const uint8_t* quals; const uint8_t* has_qual;
+    uint32_t n_targets;
+    // overlaps (rcn_overlap_set, device copies)
+    const uint32_t* q_id; const uint32_t* t_id; const uint8_t* strand; const uint64_t* bp_off;
+    const uint32_t* bp_t; const uint32_t* bp_q;
+    uint64_t n_overlaps, n_pairs;
+    // windows
+    const uint32_t* first_window;              // [n_targets + 1]
+    uint32_t n_windows, W, window_type;
+    double qthr;
+    // per pair
+    uint32_t* key; uint32_t* val; uint32_t* pair_begin; uint32_t* pair_end; uint32_t* pair_q0; uint32_t* pair_len; uint32_t* pair_ovl;
+    uint32_t* win_cnt;                         // [n_windows + 1]: layers per window, then (+1 backbone) scanned into win_seq_off
+    uint32_t* err;                             // [0] add_layer contract violations, [1..8] symbols seen (256 bits)
+};
+
+// largest i in [0, n) with a[i] <= x (a ascending, a[0] <= x)
+template <class T>
+__device__ __forceinline__ uint64_t last_le(const T* a, uint64_t n, T x) {
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_layer_filter(BuildParams P) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (p >= P.n_pairs) return;
+    const uint64_t o = last_le<uint64_t>(P.bp_off, P.n_overlaps + 1, 2 * p);
+    const uint32_t t0 = P.bp_t[2 * p], t1 = P.bp_t[2 * p + 1], q0 = P.bp_q[2 * p], q1 = P.bp_q[2 * p + 1];
+    const uint32_t qi = P.q_id[o], ti = P.t_id[o];
+    const bool rev = P.strand[o] != 0;
+    const uint32_t dl = q1 - q0;                                               // uint32 arithmetic, as the reference
+    bool keep = !(static_cast<double>(dl) < 0.02 * static_cast<double>(P.W));  // polisher.cpp:415
+    if (keep && P.has_qual[qi]) {                                              // polisher.cpp:419-433
+        const uint64_t a = P.seq_off[qi], rlen = P.seq_off[qi + 1] - a;
+        unsigned long long sum = 0;
+        if (q1 > q0) for (uint32_t k = q0 + lane; k < q1; k += 64) sum += static_cast<uint32_t>(P.quals[a + (rev ? rlen - 1 - k : k)]) - 33u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        const double average_quality = static_cast<double>(sum) / static_cast<double>(dl);
+        if (average_quality < P.qthr) keep = false;
+    }
+    uint32_t wid = P.n_windows, begin = 0, end = 0;
+    if (keep) {
+        const uint32_t rank = t0 / P.W, window_start = rank * P.W;
+        const uint32_t n_win_t = P.first_window[ti + 1] - P.first_window[ti];
+        begin = t0 - window_start; end = t1 - window_start - 1;                 // polisher.cpp:454-457
+        if (dl == 0 || begin == end) keep = false;                             // window.cpp:45-47: silently ignored
+        else {
+            const uint64_t tlen = P.seq_off[ti + 1] - P.seq_off[ti];
+            const uint64_t L = rank < n_win_t ? min(static_cast<uint64_t>(P.W), tlen - static_cast<uint64_t>(window_start)) : 0;
+            if (rank >= n_win_t || begin >= end || begin > L || end > L) { keep = false; if (lane == 0) atomicAdd(&P.err[0], 1u); }   // window.cpp:49-58: fatal
+            else wid = P.first_window[ti] + rank;
+        }
+    }
+    if (lane == 0) {
+        P.key[p] = keep ? wid : P.n_windows; P.val[p] = static_cast<uint32_t>(p);
+        P.pair_begin[p] = begin; P.pair_end[p] = end; P.pair_q0[p] = q0; P.pair_len[p] = dl; P.pair_ovl[p] = static_cast<uint32_t>(o);
+        if (keep) atomicAdd(&P.win_cnt[wid], 1u);
+    }
+}
+
+__global__ void k_plus_one(uint32_t* cnt, uint32_t n) {      // layers -> sequences per window (backbone); slot n ends the scan
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n) cnt[w] += 1u; else if (w == n) cnt[w] = 0u;
+}
+
+struct SeqTable {
+    const uint32_t* win_seq_off; const uint32_t* key_sorted; const uint32_t* val_sorted;
+    uint64_t n_layers;
+    uint64_t* seq_len;          // [n_seqs + 1] -> scanned into seq_off
+    uint32_t* begin; uint32_t* end; uint8_t* has_qual; uint8_t* win_type;
+    uint32_t* src_id; uint32_t* src_pos; uint8_t* src_flags;      // flags: 1 = reverse strand, 2 = dummy '!' quality
+};
+
+__global__ __launch_bounds__(256) void k_seq_table(BuildParams P, SeqTable T) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < P.n_windows) {                                   // backbone of window i (createWindow, window.cpp:29-37)
+        const uint32_t w = static_cast<uint32_t>(i);
+        const uint32_t ti = static_cast<uint32_t>(last_le<uint32_t>(P.first_window, static_cast<uint64_t>(P.n_targets) + 1, w));
+        const uint32_t rank = w - P.first_window[ti];
+        const uint64_t tlen = P.seq_off[ti + 1] - P.seq_off[ti];
+        const uint32_t s = T.win_seq_off[w];
+        T.seq_len[s] = min(static_cast<uint64_t>(P.W), tlen - static_cast<uint64_t>(rank) * P.W);
+        T.begin[s] = 0; T.end[s] = 0; T.has_qual[s] = 1;     // a backbone always has a quality pointer: the target's or the dummy
+        T.src_id[s] = ti; T.src_pos[s] = rank * P.W; T.src_flags[s] = P.has_qual[ti] ? 0 : 2;
+        T.win_type[w] = static_cast<uint8_t>(P.window_type);
+        if (w == 0) T.seq_len[T.win_seq_off[P.n_windows]] = 0;
+    }
+    if (i < T.n_layers) {                                    // layer number i of the window-sorted list
+        const uint32_t w = T.key_sorted[i], p = T.val_sorted[i];
+        const uint64_t s = i + w + 1;                         // = win_seq_off[w] + 1 + (i - layers before window w)
+        const uint32_t o = P.pair_ovl[p], qi = P.q_id[o];
+        T.seq_len[s] = P.pair_len[p];
+        T.begin[s] = P.pair_begin[p]; T.end[s] = P.pair_end[p]; T.has_qual[s] = P.has_qual[qi] ? 1 : 0;
+        T.src_id[s] = qi; T.src_pos[s] = P.pair_q0[p]; T.src_flags[s] = P.strand[o] ? 1 : 0;
+    }
+}
+
+struct GatherParams {
+    const uint64_t* read_off; const uint8_t* read_bases; const uint8_t* read_quals;
+    const uint64_t* seq_off; const uint32_t* src_id; const uint32_t* src_pos; const uint8_t* src_flags; const uint8_t* has_qual;
+    uint8_t* bases; uint8_t* quals; uint64_t n_seqs;
+};
+
+// one wave per sequence, 256 consecutive bytes per step: four bytes per lane through (unaligned) dword accesses, the tail
+// byte by byte.  Reverse strand: base k of the layer is the complement of base (rlen - 1 - (q0 + k)) of the read, its
+// quality the quality of that base (Sequence::create_reverse_complement).
+__device__ __forceinline__ uint32_t comp_byte(uint32_t b) { return b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'C' ? 'G' : b == 'G' ? 'C' : b; }
+
+__global__ __launch_bounds__(256) void k_gather(GatherParams G) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t s = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (s >= G.n_seqs) return;
+    const uint64_t dst = G.seq_off[s], len = G.seq_off[s + 1] - dst;
+    const uint32_t id = G.src_id[s], pos = G.src_pos[s], fl = G.src_flags[s];
+    const uint64_t a = G.read_off[id], rlen = G.read_off[id + 1] - a;
+    const bool rev = (fl & 1) != 0, real_q = !(fl & 2) && G.has_qual[s] != 0;
+    const uint64_t len4 = len & ~3ull;
+    for (uint64_t k = 4ull * lane; k < len4; k += 256) {
+        // forward: bytes src .. src + 3; reverse: the four bytes ending at the mirrored position, reversed
+        const uint64_t src = a + (rev ? rlen - 4 - (pos + k) : pos + k);
+        uint32_t vb = *reinterpret_cast<const uint32_t*>(G.read_bases + src);
+        uint32_t vq = real_q ? *reinterpret_cast<const uint32_t*>(G.read_quals + src) : 0x21212121u;
+        if (rev) {
+            vb = __builtin_bswap32(vb); vq = __builtin_bswap32(vq);
+            vb = comp_byte(vb & 255) | (comp_byte((vb >> 8) & 255) << 8) | (comp_byte((vb >> 16) & 255) << 16) | (comp_byte(vb >> 24) << 24);
+        }
+        *reinterpret_cast<uint32_t*>(G.bases + dst + k) = vb;
+        *reinterpret_cast<uint32_t*>(G.quals + dst + k) = vq;
+    }
+    for (uint64_t k = len4 + lane; k < len; k += 64) {
+        const uint64_t src = a + (rev ? rlen - 1 - (pos + k) : pos + k);
+        uint32_t b8 = G.read_bases[src];
+        if (rev) b8 = comp_byte(b8);
+        G.bases[dst + k] = static_cast<uint8_t>(b8);
+        G.quals[dst + k] = real_q ? G.read_quals[src] : static_cast<uint8_t>('!');
+    }
+}
+
+// which byte values occur in the reads (256 bits): bounds the number of distinct symbols of any window, i.e. the size
+// of an aligned ring (the engine sizes its per-node ring slots with it)
+__global__ __launch_bounds__(256) void k_symbols(const uint8_t* bases, uint64_t n, uint32_t* bits) {
+    __shared__ uint32_t pres[8];
+    if (threadIdx.x < 8) pres[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t acgt = 0;                                       // symbols 64..95, where ACGT live; anything else through LDS
+    for (uint64_t k = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; k < n; k += static_cast<uint64_t>(gridDim.x) * blockDim.x * 4) {
+        for (int j = 0; j < 4 && k + j < n; ++j) {
+            const uint32_t b = bases[k + j];
+            if ((b >> 5) == 2) acgt |= 1u << (b & 31); else atomicOr(&pres[b >> 5], 1u << (b & 31));
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acgt |= __shfl_xor(acgt, d);
+    if ((threadIdx.x & 63) == 0 && acgt) atomicOr(&pres[2], acgt);
+    __syncthreads();
+    if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&bits[threadIdx.x], pres[threadIdx.x]);
+}
+
+// slots of rcn_engine::d_build
+enum { kBReadOff, kBReadBases, kBReadQuals, kBReadHasQual, kBQid, kBTid, kBStrand, kBBpOff, kBBpT, kBBpQ, kBFirstWin, kBPairs, kBTemp, kBSeqSrc, kBMisc, kBSeqLen };
+
+inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap_set& O, uint32_t W, double qthr, uint8_t window_type) {
+    if (R.n_seqs == 0 || R.n_targets == 0 || R.n_targets > R.n_seqs || !R.seq_off || !R.bases || !R.quals || !R.seq_has_qual) return RCN_E_ARG;
+    if (O.n_overlaps && (!O.q_id || !O.t_id || !O.strand || !O.bp_off || !O.bp_t || !O.bp_q)) return RCN_E_ARG;
+    if (R.n_seqs > 0xfffffffeull || O.n_overlaps > 0xfffffffeull) return RCN_E_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    e->uploaded = false; e->ran = false;
+    e->bstats = rcn_build_stats{};
+    hipStream_t st = e->stream;
+    hipEvent_t ev[4];
+    for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+    auto drop_events = [&]() { for (auto& x : ev) (void)hipEventDestroy(x); };
+
+    // windows per target (polisher.cpp:392-401): ceil(len / W), none for an empty target
+    std::vector<uint32_t> first_window(R.n_targets + 1, 0);
+    for (uint64_t i = 0; i < R.n_targets; ++i) {
+        const uint64_t len = R.seq_off[i + 1] - R.seq_off[i];
+        const uint64_t k = (len + W - 1) / W;
+        if (first_window[i] + k > 0xfffffff0ull) { drop_events(); return RCN_E_CAPACITY; }
+        first_window[i + 1] = first_window[i] + static_cast<uint32_t>(k);
+    }
+    const uint32_t nw = first_window[R.n_targets];
+    const uint64_t n_points = O.n_overlaps ? O.bp_off[O.n_overlaps] : 0;
+    if (nw == 0 || (n_points & 1) || n_points / 2 > 0x7fffffffull) { drop_events(); return RCN_E_ARG; }
+    const uint64_t n_pairs = n_points / 2;
+    const uint64_t read_bytes = R.seq_off[R.n_seqs];
+
+    HIP_TRY(hipEventRecord(ev[0], st));
+    int rc;
+    DevBuf* B = e->d_build;
+    if ((rc = upload_vec(B[kBReadOff], R.seq_off, 8 * (R.n_seqs + 1), st)) || (rc = upload_vec(B[kBReadBases], R.bases, read_bytes, st)) ||
+        (rc = upload_vec(B[kBReadQuals], R.quals, read_bytes, st)) || (rc = upload_vec(B[kBReadHasQual], R.seq_has_qual, R.n_seqs, st)) ||
+        (rc = upload_vec(B[kBQid], O.q_id, 4 * O.n_overlaps, st)) || (rc = upload_vec(B[kBTid], O.t_id, 4 * O.n_overlaps, st)) ||
+        (rc = upload_vec(B[kBStrand], O.strand, O.n_overlaps, st)) || (rc = upload_vec(B[kBBpOff], O.bp_off ? O.bp_off : &n_points, 8 * (O.n_overlaps + 1), st)) ||
+        (rc = upload_vec(B[kBBpT], O.bp_t, 4 * n_points, st)) || (rc = upload_vec(B[kBBpQ], O.bp_q, 4 * n_points, st)) ||
+        (rc = upload_vec(B[kBFirstWin], first_window.data(), 4 * (R.n_targets + 1), st))) { drop_events(); return rc; }
+    // per-pair work arrays: key, val, key_sorted, val_sorted, begin, end, q0, len, ovl
+    const uint64_t np_al = (n_pairs + 63) & ~63ull;
+    if ((rc = B[kBPairs].reserve(std::max<uint64_t>(9 * 4 * np_al, 256))) || (rc = B[kBMisc].reserve(4ull * (nw + 2) + 64)) ||
+        (rc = e->d_win_seq_off.reserve(4ull * (nw + 1))) || (rc = e->d_win_type.reserve(nw))) { drop_events(); return rc; }
+    uint32_t* pw = B[kBPairs].as<uint32_t>();
+    uint32_t* d_err = B[kBMisc].as<uint32_t>();                       // [0] errors, [1..8] symbol bits, [16..] unused
+    uint32_t* d_cnt = e->d_win_seq_off.as<uint32_t>();                 // counts, then scanned in place
+    HIP_TRY(hipMemsetAsync(d_err, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4ull * (nw + 1), st));
+    HIP_TRY(hipEventRecord(ev[1], st));
+
+    BuildParams P{};
+    P.seq_off = B[kBReadOff].as<uint64_t>(); P.bases = B[kBReadBases].as<uint8_t>(); P.quals = B[kBReadQuals].as<uint8_t>();
+    P.has_qual = B[kBReadHasQual].as<uint8_t>(); P.n_targets = static_cast<uint32_t>(R.n_targets);
+    P.q_id = B[kBQid].as<uint32_t>(); P.t_id = B[kBTid].as<uint32_t>(); P.strand = B[kBStrand].as<uint8_t>();
+    P.bp_off = B[kBBpOff].as<uint64_t>(); P.bp_t = B[kBBpT].as<uint32_t>(); P.bp_q = B[kBBpQ].as<uint32_t>();
+    P.n_overlaps = O.n_overlaps; P.n_pairs = n_pairs;
+    P.first_window = B[kBFirstWin].as<uint32_t>(); P.n_windows = nw; P.W = W; P.window_type = window_type; P.qthr = qthr;
+    P.key = pw; P.val = pw + np_al; uint32_t* key_sorted = pw + 2 * np_al; uint32_t* val_sorted = pw + 3 * np_al;
+    P.pair_begin = pw + 4 * np_al; P.pair_end = pw + 5 * np_al; P.pair_q0 = pw + 6 * np_al; P.pair_len = pw + 7 * np_al; P.pair_ovl = pw + 8 * np_al;
+    P.win_cnt = d_cnt; P.err = d_err;
+    hipLaunchKernelGGL(k_symbols, dim3(static_cast<uint32_t>(std::min<uint64_t>(1024, (read_bytes + 1023) / 1024 + 1))), dim3(256), 0, st, P.bases, read_bytes, d_err + 1);
+    if (n_pairs) hipLaunchKernelGGL(k_layer_filter, dim3(static_cast<uint32_t>((n_pairs + 3) / 4)), dim3(256), 0, st, P);
+    HIP_TRY(hipGetLastError());
+
+    // stable sort of the pairs by window id (dropped pairs carry key nw and end up behind)
+    int end_bit = 1; while ((1ull << end_bit) <= nw) ++end_bit;
+    size_t temp_sort = 0, temp_scan32 = 0, temp_scan64 = 0;
+    if (n_pairs) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_sort, P.key, key_sorted, P.val, val_sorted, static_cast<int>(n_pairs), 0, end_bit, st));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_scan32, d_cnt, d_cnt, static_cast<int>(nw + 1), st));
+    if ((rc = B[kBTemp].reserve(std::max(temp_sort, temp_scan32) + 256))) { drop_events(); return rc; }
+    if (n_pairs) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(B[kBTemp].p, temp_sort, P.key, key_sorted, P.val, val_sorted, static_cast<int>(n_pairs), 0, end_bit, st));
+    hipLaunchKernelGGL(k_plus_one, dim3((nw + 1 + 255) / 256), dim3(256), 0, st, d_cnt, nw);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(B[kBTemp].p, temp_scan32, d_cnt, d_cnt, static_cast<int>(nw + 1), st));
+    uint32_t ns = 0, h_err[16] = {0};
+    HIP_TRY(hipMemcpyAsync(&ns, d_cnt + nw, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_err[0]) { drop_events(); return RCN_E_ARG; }       // "[racon::Window::add_layer] error: layer begin and end positions are invalid!"
+    const uint64_t n_layers = ns - nw;
+
+    // sequence table + offsets
+    if ((rc = B[kBSeqLen].reserve(8ull * (ns + 1))) || (rc = B[kBSeqSrc].reserve(9ull * ns + 64)) || (rc = e->d_seq_off.reserve(8ull * (ns + 1))) ||
+        (rc = e->d_has_qual.reserve(ns)) || (rc = e->d_begin.reserve(4ull * ns)) || (rc = e->d_end.reserve(4ull * ns))) { drop_events(); return rc; }
+    SeqTable T{};
+    T.win_seq_off = d_cnt; T.key_sorted = key_sorted; T.val_sorted = val_sorted; T.n_layers = n_layers;
+    T.seq_len = B[kBSeqLen].as<uint64_t>(); T.begin = e->d_begin.as<uint32_t>(); T.end = e->d_end.as<uint32_t>();
+    T.has_qual = e->d_has_qual.as<uint8_t>(); T.win_type = e->d_win_type.as<uint8_t>();
+    T.src_id = B[kBSeqSrc].as<uint32_t>(); T.src_pos = T.src_id + ns; T.src_flags = reinterpret_cast<uint8_t*>(T.src_pos + ns);
+    const uint64_t n_tab = std::max<uint64_t>(nw, n_layers);
+    hipLaunchKernelGGL(k_seq_table, dim3(static_cast<uint32_t>((n_tab + 255) / 256)), dim3(256), 0, st, P, T);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_scan64, T.seq_len, e->d_seq_off.as<uint64_t>(), static_cast<int>(ns + 1), st));
+    if ((rc = B[kBTemp].reserve(temp_scan64 + 256))) { drop_events(); return rc; }
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(B[kBTemp].p, temp_scan64, T.seq_len, e->d_seq_off.as<uint64_t>(), static_cast<int>(ns + 1), st));
+    uint64_t n_bases = 0;
+    HIP_TRY(hipMemcpyAsync(&n_bases, e->d_seq_off.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = e->d_bases.reserve(n_bases + 16)) || (rc = e->d_quals.reserve(n_bases + 16))) { drop_events(); return rc; }
+
+    // gather
+    GatherParams G{};
+    G.read_off = P.seq_off; G.read_bases = P.bases; G.read_quals = P.quals;
+    G.seq_off = e->d_seq_off.as<uint64_t>(); G.src_id = T.src_id; G.src_pos = T.src_pos; G.src_flags = T.src_flags; G.has_qual = T.has_qual;
+    G.bases = e->d_bases.as<uint8_t>(); G.quals = e->d_quals.as<uint8_t>(); G.n_seqs = ns;
+    HIP_TRY(hipEventRecord(ev[2], st));
+    hipLaunchKernelGGL(k_gather, dim3((ns + 3) / 4), dim3(256), 0, st, G);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[3], st));
+
+    // metadata back to the host for the layer order / capacities (17 bytes per sequence), then the usual preparation
+    std::vector<uint32_t> h_wso(nw + 1), h_begin(ns), h_end(ns);
+    std::vector<uint64_t> h_seq_off(ns + 1);
+    HIP_TRY(hipMemcpyAsync(h_wso.data(), d_cnt, 4ull * (nw + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_seq_off.data(), e->d_seq_off.p, 8ull * (ns + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_begin.data(), e->d_begin.p, 4ull * ns, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_end.data(), e->d_end.p, 4ull * ns, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // the reverse strand turns A/C/G/T into T/G/C/A: close the set under the complement before counting
+    for (const auto& pr : {std::pair<int, int>('A', 'T'), std::pair<int, int>('C', 'G')}) {
+        const bool has = ((h_err[1 + (pr.first >> 5)] >> (pr.first & 31)) & 1u) || ((h_err[1 + (pr.second >> 5)] >> (pr.second & 31)) & 1u);
+        if (has && O.n_overlaps) { h_err[1 + (pr.first >> 5)] |= 1u << (pr.first & 31); h_err[1 + (pr.second >> 5)] |= 1u << (pr.second & 31); }
+    }
+    int32_t nsym = 0;
+    for (int k = 1; k <= 8; ++k) nsym += __builtin_popcount(h_err[k]);
+    e->n_windows = nw; e->n_seqs = ns; e->n_bases = n_bases;
+    if ((rc = prepare_resident(e, nw, ns, h_wso.data(), h_seq_off.data(), h_begin.data(), h_end.data(), nullptr, std::max(nsym, 1)))) { drop_events(); return rc; }
+
+    float ms_h2d = 0, ms_k = 0, ms_g = 0;
+    HIP_TRY(hipEventElapsedTime(&ms_h2d, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms_k, ev[1], ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms_g, ev[2], ev[3]));
+    drop_events();
+    e->bstats.h2d_ms = ms_h2d; e->bstats.kernel_ms = ms_k; e->bstats.gather_ms = ms_g;
+    e->bstats.n_pairs = n_pairs; e->bstats.n_layers = n_layers;
+    e->bstats.gather_bytes = 4 * n_bases;                     // bases + qualities, each read once and written once
+    e->stats = rcn_run_stats{};
+    e->stats.h2d_ms = ms_h2d;
+    e->stats.bytes_in = 2 * read_bytes + 17ull * n_points;
+    e->uploaded = true;
+    return RCN_OK;
+}
+
+}  // namespace rcn

@@ -14,6 +14,7 @@ from typing import Optional
 import numpy as np
 
 from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
+from .layout import OverlapSet, RcnBatchDims, RcnBuildStats, RcnOverlapSet, RcnReadSet, ReadSet
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libracon_hip.so")
@@ -39,7 +40,8 @@ class RcnWindowDesc(C.Structure):
 
 EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_engine_run", "rcn_engine_result",
            "rcn_engine_stats", "rcn_engine_set_trim", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
-           "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version"]
+           "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
+           "rcn_engine_build_windows", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch"]
 
 _lib = None
 
@@ -65,6 +67,10 @@ def load_library():
     lib.rcn_engine_has_windows.argtypes = [C.c_void_p]
     lib.rcn_engine_generate_consensus.argtypes = [C.c_void_p]
     lib.rcn_engine_reset.argtypes = [C.c_void_p]
+    lib.rcn_engine_build_windows.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnOverlapSet), C.c_uint32, C.c_double, C.c_uint8]
+    lib.rcn_engine_build_stats.argtypes = [C.c_void_p, C.POINTER(RcnBuildStats)]
+    lib.rcn_engine_batch_dims.argtypes = [C.c_void_p, C.POINTER(RcnBatchDims)]
+    lib.rcn_engine_export_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     lib.rcn_strerror.restype = C.c_char_p
     lib.rcn_strerror.argtypes = [C.c_int]
     lib.rcn_version.restype = C.c_char_p
@@ -130,6 +136,31 @@ class HipEngine:
     def consensus(self, batch: WindowBatch) -> ConsensusResult:
         self.upload(batch)
         return self.run()
+
+    # device-side window construction (reference src/polisher.cpp:388-461) --------
+    def build_windows(self, reads: ReadSet, overlaps: OverlapSet, window_length: int, quality_threshold: float, window_type: int):
+        """Builds every window of every target in HBM from the resident reads and breaking points; the batch stays
+        resident for run()."""
+        cr, co = reads.as_c(), overlaps.as_c()
+        self._keep = (reads, overlaps, cr, co)
+        _check(self.lib.rcn_engine_build_windows(self.h, C.byref(cr), C.byref(co), int(window_length), float(quality_threshold),
+                                                 int(window_type)), "rcn_engine_build_windows")
+
+    def build_stats(self) -> dict:
+        s = RcnBuildStats()
+        _check(self.lib.rcn_engine_build_stats(self.h, C.byref(s)), "rcn_engine_build_stats")
+        return {k: getattr(s, k) for k, _ in RcnBuildStats._fields_}
+
+    def export_batch(self) -> WindowBatch:
+        """A host copy of the resident batch (uploaded or built on the device)."""
+        d = RcnBatchDims()
+        _check(self.lib.rcn_engine_batch_dims(self.h, C.byref(d)), "rcn_engine_batch_dims")
+        nw, ns, nb = int(d.n_windows), int(d.n_seqs), int(d.n_bases)
+        b = WindowBatch(np.zeros(nw + 1, np.uint32), np.zeros(nw, np.uint8), np.zeros(ns + 1, np.uint64), np.zeros(ns, np.uint8),
+                        np.zeros(ns, np.uint32), np.zeros(ns, np.uint32), np.zeros(nb, np.uint8), np.zeros(nb, np.uint8))
+        _check(self.lib.rcn_engine_export_batch(self.h, *[a.ctypes.data_as(C.c_void_p) for a in
+               (b.win_seq_off, b.win_type, b.seq_off, b.seq_has_qual, b.seq_begin, b.seq_end, b.bases, b.quals)]), "rcn_engine_export_batch")
+        return b
 
     # incremental form (CUDABatchProcessor::addWindow ...) ------------------------
     def add_window(self, window: dict) -> bool:

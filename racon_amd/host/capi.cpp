@@ -56,6 +56,26 @@ int rcnh_polisher_windows(rcnh_polisher* p, rcn_batch* out) {
     return guarded([&] { p->polisher->pack_windows(&p->batch); *out = p->batch.view(); });
 }
 
+int rcnh_polisher_keep_layout(rcnh_polisher* p, int on) {
+    if (!p) { g_error = "invalid argument"; return -1; }
+    p->polisher->keep_layout(on != 0);
+    return 0;
+}
+
+int rcnh_polisher_layout(rcnh_polisher* p, rcn_read_set* r, rcn_overlap_set* o, uint8_t* window_type, uint32_t* window_length, double* quality_threshold) {
+    if (!p || !r || !o) { g_error = "invalid argument"; return -1; }
+    const racon::Polisher::Layout& l = p->polisher->layout();
+    if (l.seq_off.size() < 2) { g_error = "no layout recorded (rcnh_polisher_keep_layout before initialize)"; return -1; }
+    r->n_seqs = l.seq_off.size() - 1; r->n_targets = l.n_targets; r->seq_off = l.seq_off.data();
+    r->bases = l.bases.data(); r->quals = l.quals.data(); r->seq_has_qual = l.seq_has_qual.data();
+    o->n_overlaps = l.q_id.size(); o->q_id = l.q_id.data(); o->t_id = l.t_id.data(); o->strand = l.strand.data();
+    o->bp_off = l.bp_off.data(); o->bp_t = l.bp_t.data(); o->bp_q = l.bp_q.data();
+    if (window_type) *window_type = l.window_type;
+    if (window_length) *window_length = p->polisher->window_length();
+    if (quality_threshold) *quality_threshold = p->polisher->quality_threshold();
+    return 0;
+}
+
 int rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* r, int drop, const char** fasta, uint64_t* len) {
     if (!p || !r || !fasta || !len) { g_error = "invalid argument"; return -1; }
     return guarded([&] {

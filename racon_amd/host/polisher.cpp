@@ -202,6 +202,36 @@ void Polisher::initialize() {
     find_overlap_breaking_points(overlaps);
     logger_->log();
 
+    if (keep_layout_) {
+        layout_ = Layout();
+        layout_.n_targets = targets_size;
+        layout_.window_type = window_type == WindowType::kTGS ? 1 : 0;
+        for (const auto& sq : sequences_) {
+            // forward strand of every sequence (transmute() may have kept only the reverse complement: complementing
+            // again gives it back, the table of Sequence::create_reverse_complement is an involution)
+            std::string fwd = sq->data(), fq = sq->quality();
+            if (fwd.empty() && !sq->reverse_complement().empty()) {
+                auto tmp = createSequence("", sq->reverse_complement());
+                tmp->create_reverse_complement();
+                fwd = tmp->reverse_complement();
+                fq.assign(sq->reverse_quality().rbegin(), sq->reverse_quality().rend());
+            }
+            const bool hq = !fq.empty();
+            layout_.bases.insert(layout_.bases.end(), fwd.begin(), fwd.end());
+            if (hq) layout_.quals.insert(layout_.quals.end(), fq.begin(), fq.end());
+            else layout_.quals.insert(layout_.quals.end(), fwd.size(), static_cast<uint8_t>('!'));
+            layout_.seq_has_qual.push_back(hq ? 1 : 0);
+            layout_.seq_off.push_back(layout_.bases.size());
+        }
+        for (const auto& o : overlaps) {
+            layout_.q_id.push_back(static_cast<uint32_t>(o->q_id()));
+            layout_.t_id.push_back(static_cast<uint32_t>(o->t_id()));
+            layout_.strand.push_back(o->strand() ? 1 : 0);
+            for (const auto& bp : o->breaking_points()) { layout_.bp_t.push_back(bp.first); layout_.bp_q.push_back(bp.second); }
+            layout_.bp_off.push_back(layout_.bp_t.size());
+        }
+    }
+
     // ---- windows over every target (reference src/polisher.cpp:388-403)
     std::vector<uint64_t> first_window(targets_size + 1, 0);
     for (uint64_t i = 0; i < targets_size; ++i) {

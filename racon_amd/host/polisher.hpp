@@ -57,6 +57,24 @@ public:
     // --- the two halves of polish(), exposed for the parity harness ------------------
     // All windows, flattened (the bytes every consensus backend consumes).
     void pack_windows(PackedBatch* out) const;
+
+    // What the two loops at the end of initialize() consume, flattened (include/racon_hip.h: rcn_read_set /
+    // rcn_overlap_set): every sequence on its forward strand and every kept overlap with its breaking points.
+    // Recorded by initialize() when keep_layout(true) was called before it; the input of rcn_engine_build_windows.
+    struct Layout {
+        std::vector<uint64_t> seq_off{0};
+        std::vector<uint8_t> bases, quals, seq_has_qual;
+        uint64_t n_targets = 0;
+        std::vector<uint32_t> q_id, t_id;
+        std::vector<uint8_t> strand;
+        std::vector<uint64_t> bp_off{0};
+        std::vector<uint32_t> bp_t, bp_q;
+        uint8_t window_type = 0;
+    };
+    void keep_layout(bool on) { keep_layout_ = on; }
+    const Layout& layout() const { return layout_; }
+    uint32_t window_length() const { return window_length_; }
+    double quality_threshold() const { return quality_threshold_; }
     // Per-target concatenation + tags from per-window results (reference src/polisher.cpp:505-537).
     // consensus(i) / polished(i) are indexed like windows(); consumes the windows.
     void assemble(const std::function<const std::string&(uint64_t)>& consensus,
@@ -88,6 +106,8 @@ protected:
     std::string dummy_quality_;
     uint32_t window_length_;
     std::vector<std::shared_ptr<Window>> windows_;
+    bool keep_layout_ = false;
+    Layout layout_;
     std::unique_ptr<Logger> logger_;
 };
 

@@ -14,6 +14,7 @@ import subprocess
 import numpy as np
 
 from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
+from .layout import OverlapSet, RcnOverlapSet, RcnReadSet, ReadSet
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_DIR = os.path.join(_HERE, "host")
@@ -48,6 +49,8 @@ def load_library():
     lib.rcnh_polisher_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(RcnhParams), C.POINTER(C.c_void_p)]
     lib.rcnh_polisher_initialize.argtypes = [C.c_void_p]
     lib.rcnh_polisher_windows.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
+    lib.rcnh_polisher_keep_layout.argtypes = [C.c_void_p, C.c_int]
+    lib.rcnh_polisher_layout.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnOverlapSet), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     lib.rcnh_polisher_assemble.argtypes = [C.c_void_p, C.POINTER(RcnResult), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_polish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_destroy.argtypes = [C.c_void_p]
@@ -128,8 +131,19 @@ class Polisher:
         except Exception:
             pass
 
-    def initialize(self):
+    def initialize(self, keep_layout: bool = False):
+        """keep_layout: also record the flattened sequences / overlaps (see layout())."""
+        if keep_layout:
+            _check(self.lib.rcnh_polisher_keep_layout(self.h, 1))
         _check(self.lib.rcnh_polisher_initialize(self.h))
+
+    def layout(self):
+        """(ReadSet, OverlapSet, window_type, window_length, quality_threshold): the input of the window construction
+        (reference src/polisher.cpp:388-461) -- what HipEngine.build_windows / oracle.window_layout take."""
+        r, o = RcnReadSet(), RcnOverlapSet()
+        wt, wl, qt = C.c_uint8(), C.c_uint32(), C.c_double()
+        _check(self.lib.rcnh_polisher_layout(self.h, C.byref(r), C.byref(o), C.byref(wt), C.byref(wl), C.byref(qt)))
+        return ReadSet.from_c(r), OverlapSet.from_c(o), int(wt.value), int(wl.value), float(qt.value)
 
     def windows(self) -> WindowBatch:
         cb = RcnBatch()

@@ -162,3 +162,78 @@ def simulate_files(out_dir: str, contig_len: int = 20000, coverage: float = 25.0
                 fp.write(name + b"\t%d\t0\t%d\t" % (len(seq), len(seq)) + (b"-" if strand else b"+") + b"\t" + tname +
                          b"\t%d\t%d\t%d\t%d\t%d\t60\n" % (contig_len, ts, te, n, n))
     return paths, truth
+
+
+def simulate_layout(contig_lens=(30000, 12345), window_len: int = 500, coverage: float = 20.0, read_len: int = 4000,
+                    sub: float = 0.03, ins: float = 0.03, dele: float = 0.04, seed: int = 20260926,
+                    frac_no_quality: float = 0.15, frac_low_quality: float = 0.1, target_quality: bool = False):
+    """In-memory input of racon's window construction (racon_amd.layout.ReadSet / OverlapSet): draft targets, error-bearing
+    reads on both strands (some without qualities, some with low ones so that the -q filter fires), and per overlap the
+    breaking points Overlap::find_breaking_points would derive from the simulator's true alignment (first / last match of
+    every window, reference src/overlap.cpp:226-292).  Returns (reads, overlaps, window_type)."""
+    from .layout import OverlapSet, ReadSet
+    rng = np.random.default_rng(seed)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    seqs, ovl = [], []
+    targets = []
+    for n in contig_lens:
+        c = _ACGT[rng.integers(0, 4, n)]
+        targets.append(c)
+        tq = None
+        if target_quality:
+            tq = bytes((np.clip(np.rint(rng.normal(20, 5, n)), 2, 40).astype(np.uint8) + 33).tolist())
+        seqs.append((c.tobytes(), tq))
+    total_len = 0
+    for ti, contig in enumerate(targets):
+        n_t = len(contig)
+        for _ in range(int(round(coverage * n_t / read_len))):
+            ts = int(rng.integers(0, max(1, n_t - read_len // 3)))
+            te = min(n_t, ts + int(rng.integers(read_len // 4, read_len + 1)))
+            n = te - ts
+            if n < 50:
+                continue
+            tgt = contig[ts:te]
+            deleted = rng.random(n) < dele
+            deleted[0] = deleted[-1] = False
+            subst = rng.random(n) < sub
+            base = tgt.copy()
+            base[subst] = _ACGT[(np.searchsorted(_ACGT, tgt[subst]) + rng.integers(1, 4, int(subst.sum()))) % 4]
+            has_ins = rng.random(n) < ins
+            has_ins[-1] = False
+            emit = (~deleted).astype(np.int64) + has_ins.astype(np.int64)
+            qpos = np.concatenate([[0], np.cumsum(emit)])
+            qlen = int(qpos[-1])
+            read = np.empty(qlen, np.uint8)
+            mcols = np.nonzero(~deleted)[0]
+            read[qpos[mcols]] = base[mcols]
+            icols = np.nonzero(has_ins)[0]
+            read[qpos[icols] + (~deleted[icols]).astype(np.int64)] = _ACGT[rng.integers(0, 4, icols.size)]
+            r = rng.random()
+            if r < frac_no_quality:
+                q = None
+            else:
+                mean = 6.0 if r < frac_no_quality + frac_low_quality else 15.0
+                q = np.clip(np.rint(rng.normal(mean, 4, qlen)), 1, 30).astype(np.uint8) + 33
+            # breaking points on the overlap's strand (the aligned, forward-on-target orientation)
+            pts = []
+            w0, w1 = ts // window_len, (te - 1) // window_len
+            for w in range(w0, w1 + 1):
+                a = max(ts, w * window_len) - ts
+                b = min(te, (w + 1) * window_len) - ts
+                m = mcols[(mcols >= a) & (mcols < b)]
+                if m.size == 0:
+                    continue
+                pts.append((ts + int(m[0]), int(qpos[m[0]])))
+                pts.append((ts + int(m[-1]) + 1, int(qpos[m[-1]]) + 1))
+            strand = int(rng.integers(0, 2))
+            rb = read.tobytes()
+            qb = q.tobytes() if q is not None else None
+            if strand:            # the read set holds the other strand; the overlap reads its reverse complement
+                rb = rb.translate(comp)[::-1]
+                qb = qb[::-1] if qb is not None else None
+            ovl.append((len(seqs), ti, strand, pts))
+            seqs.append((rb, qb))
+            total_len += qlen
+    n_reads = len(seqs) - len(targets)
+    window_type = 1 if (total_len + sum(contig_lens)) / max(1, len(seqs)) > 1000 else 0
+    return ReadSet.from_sequences(seqs, len(targets)), OverlapSet.from_lists(ovl), window_type

@@ -1,0 +1,88 @@
+"""-m gpu: rcn_engine_build_windows (windows built in HBM from resident reads + breaking points, reference
+src/polisher.cpp:388-461) against oracle/window_layout.py, array for array, and the consensus of the built batch
+against the consensus of the same batch uploaded from the host."""
+import os
+
+import numpy as np
+import pytest
+
+from test_window_layout import DATA, GOLD, load_layout_fixture, same_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw,w,q", [
+    (dict(contig_lens=(30000, 12345), seed=11), 500, 10.0),
+    (dict(contig_lens=(9000, 2501, 499, 1), read_len=1500, coverage=12, seed=5), 500, 10.0),
+    (dict(contig_lens=(20000,), read_len=3000, coverage=25, seed=6, target_quality=True), 1000, 8.0),
+    (dict(contig_lens=(6000, 6000), read_len=150, coverage=40, seed=7, sub=0.003, ins=0.0005, dele=0.0005,
+          frac_no_quality=0.0, frac_low_quality=0.0), 200, 10.0),
+    (dict(contig_lens=(15000,), seed=8, frac_no_quality=1.0), 500, 10.0),
+])
+def test_build_windows_equals_oracle(oracle, kw, w, q):
+    from oracle.window_layout import window_layout
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_layout
+    r, o, wt = simulate_layout(window_len=w, **kw)
+    ref = window_layout(r, o, w, q, wt)
+    eng = HipEngine(3, -5, -4, True)
+    eng.build_windows(r, o, w, q, wt)
+    got = eng.export_batch()
+    same_batch(got, ref, f"build_windows {kw}")
+    st = eng.build_stats()
+    assert st["n_pairs"] == int(o.bp_off[-1]) // 2 and st["n_layers"] == ref.n_seqs - ref.n_windows
+    # the built batch polishes exactly like the uploaded one
+    built = eng.run()
+    up = HipEngine(3, -5, -4, True).consensus(ref)
+    assert built.consensus == up.consensus and (np.asarray(built.polished) == np.asarray(up.polished)).all()
+    cpu = oracle.consensus(ref, 3, -5, -4, True, 0)
+    assert built.consensus == cpu.consensus
+
+
+def test_build_windows_rejects_invalid_layer():
+    from racon_amd.engine import HipEngine
+    from racon_amd.layout import OverlapSet, ReadSet
+    r = ReadSet.from_sequences([(b"ACGT" * 50, None), (b"ACGT" * 20, None)], 1)
+    o = OverlapSet.from_lists([(1, 0, 0, [(150, 0), (100, 60)])])
+    with pytest.raises(RuntimeError):
+        HipEngine().build_windows(r, o, 500, 10.0, 0)
+
+
+def test_build_windows_without_overlaps_gives_backbones():
+    from racon_amd.engine import HipEngine
+    from racon_amd.layout import OverlapSet, ReadSet
+    r = ReadSet.from_sequences([(b"ACGT" * 300, None)], 1)
+    o = OverlapSet.from_lists([])
+    eng = HipEngine()
+    eng.build_windows(r, o, 500, 10.0, 1)
+    b = eng.export_batch()
+    assert b.n_windows == 3 and b.n_seqs == 3 and bytes(b.bases) == b"ACGT" * 300
+    res = eng.run()
+    assert b"".join(res.consensus) == b"ACGT" * 300 and not any(res.polished)
+
+
+@pytest.mark.skipif(not os.path.isdir(DATA), reason="reference test data not present")
+def test_build_windows_on_reference_data(oracle):
+    from racon_amd import polisher
+    from racon_amd.engine import HipEngine
+    polisher.build()
+    p = polisher.Polisher(DATA + "sample_reads.fastq.gz", DATA + "sample_overlaps.sam.gz", DATA + "sample_layout.fasta.gz",
+                          "kC", 500, 10.0, 0.3, True, 5, -4, -8, 2)
+    p.initialize(keep_layout=True)
+    r, o, wt, wl, qt = p.layout()
+    eng = HipEngine(5, -4, -8, True)
+    eng.build_windows(r, o, wl, qt, wt)
+    same_batch(eng.export_batch(), p.windows(), "reference sample data")
+
+
+def test_build_windows_on_committed_reference_fixture():
+    """The reference's sample reads + SAM overlaps (tests/golden/layout_sam_fastq_w500.npz) -> exactly the windows the host
+    layer builds from them (tests/golden/sam_fastq_w500.npz, golden edit distance 1317), and the same consensus."""
+    from racon_amd.batch import WindowBatch
+    from racon_amd.engine import HipEngine
+    r, o, wt, wl, qt = load_layout_fixture()
+    want = WindowBatch.load(os.path.join(GOLD, "sam_fastq_w500.npz"))
+    eng = HipEngine(5, -4, -8, True)
+    eng.build_windows(r, o, wl, qt, wt)
+    same_batch(eng.export_batch(), want, "reference fixture")
+    assert eng.run().consensus == HipEngine(5, -4, -8, True).consensus(want).consensus
