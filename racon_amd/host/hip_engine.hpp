@@ -48,11 +48,17 @@ public:
     // Consensus of every window of `batch` (inputs are copied to HBM, results copied back).
     void consensus(const PackedBatch& batch, bool trim, std::vector<std::string>* consensus,
                    std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    // The same, with the windows built on the device from the flattened sequences / overlaps
+    // (rcn_engine_build_windows: reference src/polisher.cpp:388-461 in HBM).
+    void consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,
+                   uint8_t window_type, bool trim, std::vector<std::string>* consensus,
+                   std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
     double last_kernel_ms() const { return last_kernel_ms_; }
 
 private:
     HipEngine() = default;
     HipEngine(const HipEngine&) = delete;
+    void fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
     rcn_engine* handle_ = nullptr;
     double last_kernel_ms_ = 0;
 };

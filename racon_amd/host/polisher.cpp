@@ -202,6 +202,7 @@ void Polisher::initialize() {
     find_overlap_breaking_points(overlaps);
     logger_->log();
 
+    if (const char* dv = getenv("RACON_HIP_DEVICE_WINDOWS")) { if (dv[0] == '1') device_windows(true); }
     if (keep_layout_) {
         layout_ = Layout();
         layout_.n_targets = targets_size;
@@ -248,6 +249,11 @@ void Polisher::initialize() {
 
     // ---- layers (reference src/polisher.cpp:405-461): serial, in overlap order
     targets_coverages_.assign(targets_size, 0);
+    if (device_windows_) {                      // the layers are cut on the device, from layout_ (polish())
+        for (auto& o : overlaps) { ++targets_coverages_[o->t_id()]; o.reset(); }
+        logger_->log("[racon::Polisher::initialize] transformed data into windows");
+        return;
+    }
     for (auto& o : overlaps) {
         ++targets_coverages_[o->t_id()];
         const auto& sequence = sequences_[o->q_id()];
@@ -336,6 +342,24 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
     }
     std::vector<std::string> cons(nw);
     std::vector<uint8_t> pol(nw, 0), chim(nw, 0);
+    if (device_windows_) {
+        // one engine builds every window in HBM from the resident reads and breaking points and polishes them there
+        rcn_read_set r{}; rcn_overlap_set o{};
+        r.n_seqs = layout_.seq_off.size() - 1; r.n_targets = layout_.n_targets; r.seq_off = layout_.seq_off.data();
+        r.bases = layout_.bases.data(); r.quals = layout_.quals.data(); r.seq_has_qual = layout_.seq_has_qual.data();
+        o.n_overlaps = layout_.q_id.size(); o.q_id = layout_.q_id.data(); o.t_id = layout_.t_id.data(); o.strand = layout_.strand.data();
+        o.bp_off = layout_.bp_off.data(); o.bp_t = layout_.bp_t.data(); o.bp_q = layout_.bp_q.data();
+        auto engine = HipEngine::Create(0, match_, mismatch_, gap_);
+        engine->consensus(r, o, window_length_, quality_threshold_, layout_.window_type, trim_, &cons, &pol, &chim);
+        if (cons.size() != nw) fatal("[racon::Polisher::polish] error: window count mismatch between host and device!");
+        for (uint64_t i = 0; i < nw; ++i)
+            if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
+                                 static_cast<unsigned long>(windows_[i]->id()), windows_[i]->rank());
+        assemble([&](uint64_t i) -> const std::string& { return cons[i]; }, [&](uint64_t i) { return pol[i] != 0; },
+                 dst, drop_unpolished_sequences);
+        logger_->log("[racon::Polisher::polish] generated consensus");
+        return;
+    }
     std::atomic<size_t> cursor{0};
     std::vector<std::string> errors(n_engines);
     auto worker = [&](uint32_t k) {

@@ -72,6 +72,9 @@ public:
         uint8_t window_type = 0;
     };
     void keep_layout(bool on) { keep_layout_ = on; }
+    // Windows built on the device: initialize() then skips the serial add_layer loop (windows_ keep only their backbones,
+    // which polish() needs for the stitching) and records the layout instead.  Also switched on by RACON_HIP_DEVICE_WINDOWS=1.
+    void device_windows(bool on) { device_windows_ = on; if (on) keep_layout_ = true; }
     const Layout& layout() const { return layout_; }
     uint32_t window_length() const { return window_length_; }
     double quality_threshold() const { return quality_threshold_; }
@@ -107,6 +110,7 @@ protected:
     uint32_t window_length_;
     std::vector<std::shared_ptr<Window>> windows_;
     bool keep_layout_ = false;
+    bool device_windows_ = false;   // polish(): windows built in HBM (rcn_engine_build_windows) instead of packed from windows_
     Layout layout_;
     std::unique_ptr<Logger> logger_;
 };

@@ -74,3 +74,17 @@ def test_polisher_polish_and_options(P, oracle, data):
         p2 = P.Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", w, 10.0, 0.3, trim, *scores, num_threads=4)
         p2.initialize()
         assert p2.polish(False) == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ovl", ["sam", "paf"])
+def test_cli_with_device_side_windows_matches_oracle(P, oracle, data, ovl):
+    """RACON_HIP_DEVICE_WINDOWS=1: the host only parses and finds breaking points; the windows are cut, filtered and packed
+    in HBM (rcn_engine_build_windows, reference src/polisher.cpp:388-461) and polished there — same FASTA, byte for byte."""
+    paths, _ = data
+    ref, _ = _oracle_fasta(P, oracle, paths, ovl)
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    env = dict(os.environ, RACON_HIP_DEVICE_WINDOWS="1")
+    out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
+    assert out == ref
