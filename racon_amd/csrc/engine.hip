@@ -69,7 +69,7 @@ struct rcn_engine {
     uint32_t n_windows = 0, n_seqs = 0;
     uint64_t n_bases = 0;
     DevBuf d_win_seq_off, d_win_type, d_seq_off, d_has_qual, d_begin, d_end, d_bases, d_quals, d_order, d_full;
-    DevBuf d_lpt_ids, d_win_ids, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
+    DevBuf d_lpt_ids, d_win_ids, d_win_flags, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
     HostBuf h_raw;
     std::vector<WinShape> shapes;
     int32_t heavy_ns = 0, prio_ns = 0;
@@ -135,6 +135,7 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.bases = e->d_bases.as<uint8_t>(); P.quals = e->d_quals.as<uint8_t>();
     P.order = e->d_order.as<uint32_t>(); P.seq_full = e->d_full.as<uint8_t>();
     P.win_ids = ids ? e->d_win_ids.as<uint32_t>() : d_ids; P.n_work = n_work;
+    P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : e->d_win_flags.as<uint8_t>();
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
     P.heavy_ns = e->heavy_ns; P.prio_ns = e->prio_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.scratch = e->d_scratch.as<uint8_t>(); P.slot_bytes = c.slot_bytes;
@@ -162,7 +163,8 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
 // shape statistics for the scratch capacities, deepest-first work order.  `bases` may be null (batch built on the
 // device): every window then gets the batch-wide symbol count `nsym_all`.
 int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* win_seq_off, const uint64_t* seq_off,
-                            const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all) {
+                            const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all, bool acgt_all = false) {
+    std::vector<uint8_t> wflags(nw, 0);
     e->h_win_seq_off.assign(win_seq_off, win_seq_off + nw + 1);
     std::vector<uint32_t> order(ns);
     std::vector<uint8_t> full(ns, 0);
@@ -193,7 +195,10 @@ int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* wi
             }
             if (bases) for (uint64_t k = a; k < z; ++k) present[bases[k]] = true;
         }
-        if (bases) { for (bool p : present) sh.nsym += p; } else sh.nsym = nsym_all;
+        if (bases) {
+            for (bool p : present) sh.nsym += p;
+            wflags[w] = (sh.nsym == int(present['A']) + int(present['C']) + int(present['G']) + int(present['T'])) ? 1 : 0;
+        } else { sh.nsym = nsym_all; wflags[w] = acgt_all ? 1 : 0; }
         e->shapes[w] = sh;
     }
     // Longest processing time first: a window's cost grows with (layers x bases), and a launch ends with its
@@ -208,7 +213,8 @@ int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* wi
     if ((rc = upload_vec(e->d_lpt_ids, e->lpt.data(), 4ull * nw, e->stream))) return rc;
     if ((rc = upload_vec(e->d_order, order.data(), 4ull * ns, e->stream))) return rc;
     if ((rc = upload_vec(e->d_full, full.data(), ns, e->stream))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));                 // order / full are stack-scoped
+    if ((rc = upload_vec(e->d_win_flags, wflags.data(), nw, e->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));                 // order / full / flags are stack-scoped
     return RCN_OK;
 }
 
@@ -265,7 +271,7 @@ void rcn_engine_destroy(rcn_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     for (DevBuf* d : {&e->d_win_seq_off, &e->d_win_type, &e->d_seq_off, &e->d_has_qual, &e->d_begin, &e->d_end,
-                      &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_lpt_ids, &e->d_win_ids, &e->d_scratch,
+                      &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_lpt_ids, &e->d_win_ids, &e->d_win_flags, &e->d_scratch,
                       &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_ctr})
         d->release();
     for (DevBuf& d : e->d_build) d.release();

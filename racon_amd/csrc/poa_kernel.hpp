@@ -32,6 +32,7 @@ struct KParams {
     const uint8_t* bases; const uint8_t* quals;
     const uint32_t* order;        // [n_seqs] processing order inside each window (std::sort on host)
     const uint8_t*  seq_full;     // [n_seqs] 1 = full-span layer (window.cpp:93-94), else Subgraph
+    const uint8_t* win_flags;     // [n_windows] bit 0: every base of the window is A, C, G or T (poa_window_kernel2: profile table); nullptr = unknown
     const uint32_t* win_ids;      // [n_work] indirection (retry pass) or nullptr
     uint32_t n_work;
     int32_t prio_ns;              // poa_window_kernel2: windows with at least this many sequences run at raised wave priority (0 = none)

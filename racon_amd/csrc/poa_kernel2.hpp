@@ -146,8 +146,9 @@ __host__ __device__ __forceinline__ int dp2_cfg(int len, bool wide) {
 // rows of the register window for NP packed VGPRs per lane (16 VGPRs in all; a power of two)
 __host__ __device__ constexpr int dp2_window(int np) { return np <= 1 ? 16 : np == 2 ? 8 : 4; }
 // rows of the LDS ring behind it (K of dp2_rows<NP, WV>)
-__host__ __device__ constexpr int dp2_ring_rows(int np, int wv) {
-    return (kLdsBytes - 64 - (wv > 1 ? 64 * 4 * 4 + 64 : 0)) / (4 * 64 * wv * np) - 1;
+// (tab: the one-wave DP keeps a 4-symbol substitution-profile table behind the ring, dp2_rows<NP, 1, true>)
+__host__ __device__ constexpr int dp2_ring_rows(int np, int wv, bool tab = false) {
+    return (kLdsBytes - 64 - (wv > 1 ? 64 * 4 * 4 + 64 : 0) - (tab ? 4 * 4 * 64 * wv * np : 0)) / (4 * 64 * wv * np) - 1;
 }
 
 // ---- phase: Subgraph mask + filtered order (window.cpp:99-103), without the serial DFS ----
@@ -312,7 +313,7 @@ __device__ __noinline__ void phase_desc2() {
     const int cfg_ = dp2_cfg(c.len, c.pad0 != 0);
     const int R = dp2_window(cfg_ & 255);
     // "medium" rows: like fast rows, but some predecessor is beyond the register window and still in the LDS ring
-    const int RM = min(15, dp2_ring_rows(max(cfg_ & 255, 1), max(cfg_ >> 8, 1)) - 2);
+    const int RM = min(15, dp2_ring_rows(max(cfg_ & 255, 1), max(cfg_ >> 8, 1), (cfg_ >> 8) == 1 && c.tie_pad[1] != 0) - 2);
     // Every row is a chain of dependent HBM loads (rank -> in-edge head -> edge -> tail's rank ...).  For a
     // full-graph alignment U rows per thread are walked in lock step, with static register indices only (a
     // runtime index into the descriptors would send them to scratch memory), so that their loads are in flight
@@ -395,8 +396,12 @@ __device__ unsigned long long g_wclk[4096][8];   // per work item: phase clocks 
 //         w=500 windows: with ~2000 windows per launch the chip is latency bound, and a row costs about the
 //         same number of instructions whether a lane owns 2 or 8 columns.
 // WV = 4: the four waves form a pipeline over column blocks of 128*NP (layers longer than 511 bases).
-template <int NP, int WV>
+// TAB (WV = 1, windows whose bases are all A/C/G/T): the substitution profile of a row -- 3 VALU instructions per
+// register, 12 of the ~58 of a row, and VALU instructions are what a row costs -- comes from a 4-symbol table built once
+// per layer behind the LDS ring (slot = (code >> 1) & 3: A 0, C 1, T 2, G 3): one address add and one ds_read per row.
+template <int NP, int WV, bool TAB = false>
 __device__ __noinline__ void dp2_rows() {
+    static_assert(!TAB || WV == 1, "profile table: one-wave DP only");
     constexpr int NTH = 64 * WV;
     const int t = threadIdx.x, lane = t & 63, wv = WV == 1 ? 0 : __builtin_amdgcn_readfirstlane(t >> 6);
     const Ctx c = ctx_load<Block4>();
@@ -418,7 +423,9 @@ __device__ __noinline__ void dp2_rows() {
     // reader either sees the old word or the complete new one), and every 8 rows it publishes how far it is, so that
     // the wave to its left never laps the mailbox.  Wave 0 depends on nobody.
     constexpr int kMail = WV > 1 ? 64 * 4 * 4 + 64 : 0;     // bytes: mailboxes [4][64] + progress words
-    constexpr int KT = (kLdsBytes - 64 - kMail) / (4 * NTH * NP);   // LDS row slots: K ring rows + 1 staging slot
+    constexpr int kTab = TAB ? 4 * 4 * NTH * NP : 0;       // bytes of the profile table [4 symbols][64 lanes][NP]
+    constexpr int KT = (kLdsBytes - 64 - kMail - kTab) / (4 * NTH * NP);   // LDS row slots: K ring rows + 1 staging slot
+    static_assert(KT - 1 == dp2_ring_rows(NP, WV, TAB), "phase_desc2 classifies rows with the same ring depth");
     constexpr int K = KT - 1;
     uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());   // [KT][NTH][NP]
     int* farb = Block4::work() + (kLdsBytes - 64) / 4;   // [4] staged border cell of a far predecessor row, per wave
@@ -439,6 +446,17 @@ __device__ __noinline__ void dp2_rows() {
         const int j0 = col0 + 2 * q, j1 = j0 + 1;
         const int s0 = (j0 >= 1 && j0 <= len) ? seq[j0 - 1] : 0x100, s1 = (j1 >= 1 && j1 <= len) ? seq[j1 - 1] : 0x100;
         sqx[q] = pack2(s0, s1);
+    }
+    uint32_t tie_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&Block4::ctx()->tie_rows[0]));
+    asm volatile("" : "+s"(tie_base));
+    uint32_t* ptab = ring + KT * NTH * NP;      // [4][NTH][NP] (TAB)
+    if (TAB) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const uint32_t code = sl == 0 ? 'A' : sl == 1 ? 'C' : sl == 2 ? 'T' : 'G', symsym = code | (code << 16);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) ptab[(sl * NTH + t) * NP + q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
+        }
     }
     // Register window: the last R rows of Z for this lane's columns, row r at win[(r % R) * NP + q].  The
     // index is wave-uniform, so a read or write is s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off.
@@ -486,7 +504,11 @@ __device__ __noinline__ void dp2_rows() {
         // row r is in its scan (v_readlane -> SALU has ~20 cycles of latency; the profile fills DPP wait states)
         int meta_next = __builtin_amdgcn_readlane(dl_meta, 0);
         uint32_t Pn[NP];
-        {
+        if (TAB) {
+            const uint32_t* src = ptab + ((((meta_next & 255) >> 1) & 3) * NTH + t) * NP;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) Pn[q] = src[q];
+        } else {
             const uint32_t sy = meta_next & 255, symsym = sy | (sy << 16);
 #pragma unroll
             for (int q = 0; q < NP; ++q) Pn[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
@@ -630,10 +652,21 @@ __device__ __noinline__ void dp2_rows() {
             if (WV > 1) mprev = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(mleft) << 16, M[NP - 1], 0x138, 0xf, 0xf, false);
             else mprev = mpv = __builtin_amdgcn_update_dpp(mpv, M[NP - 1], 0x138, 0xf, 0xf, false);   // lane 0 keeps -inf (loop carried, as zsh below)
             uint32_t acc[NP];
+            if (TAB) {
+                // everything that does not need the profile first: P comes from LDS and its wait (the compiler makes it an
+                // lgkmcnt(0), which also covers the previous row's ring write) should find the LDS queue drained
+                uint32_t D[NP], U[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { D[q] = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16); U[q] = pk_add(M[q], GG); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) acc[q] = pk_max(pk_add(D[q], P[q]), U[q]);
+            } else {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
                 acc[q] = pk_max(pk_add(D, P[q]), pk_add(M[q], GG));
+            }
             }
             // horizontal move (+0 in the Z domain): in-lane chain, wave-wide prefix max of the lane tails
             // (pairs first: NP independent ops; then NP - 1 dependent carries between the registers)
@@ -648,6 +681,18 @@ __device__ __noinline__ void dp2_rows() {
                 const uint32_t sy = meta_next & 255;
                 const uint32_t symsym = sy | (sy << 16);
                 uint32_t pw[NP];
+                if (TAB) {
+                    // the next row's profile: one LDS read, issued in front of the scan, retired by the next row
+                    const uint32_t* src = ptab + (((sy >> 1) & 3) * NTH + t) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) pw[q] = src[q];
+                    sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
+                    sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
+                } else {
 #define RCN_GAP(o) do { __builtin_amdgcn_sched_barrier(0); dp2_gap_op<NP, (o)>(pw, sqx, symsym, ONE, XM, MG); \
                         dp2_gap_op<NP, (o) + 1>(pw, sqx, symsym, ONE, XM, MG); __builtin_amdgcn_sched_barrier(0); } while (0)
                 RCN_GAP(0);  sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
@@ -662,6 +707,7 @@ __device__ __noinline__ void dp2_rows() {
                 // blocks that consume them
 #pragma unroll
                 for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(pw[q]));
+                }
 #pragma unroll
                 for (int q = 0; q < NP; ++q) Pn[q] = pw[q];
             }
@@ -703,7 +749,13 @@ __device__ __noinline__ void dp2_rows() {
                 const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16);
                 const int val = __builtin_amdgcn_readlane(v16, own_lane);
                 if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
-                else if (best == val) { if (tied < 8 && lane == 0) Block4::ctx()->tie_rows[tied] = i; ++tied; }
+                else if (best == val) {
+                    // (explicit LDS address from a base computed once: the backend would otherwise re-derive the dynamic-LDS
+                    //  base here with an s_load_dword, and a scalar load anywhere in the loop turns every LDS wait of the
+                    //  loop into lgkmcnt(0) -- i.e. a wait for the row's ring write at the top of the next row)
+                    if (tied < 8 && lane == 0) *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(tie_base + 4u * tied) = static_cast<uint32_t>(i);
+                    ++tied;
+                }
             }
             if (WV > 1) {
                 if (wv < WV - 1) {
@@ -1728,7 +1780,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     g.e_w[i] = pair_weight(q0, i + 1);
                 }
             }
-            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; ctx->pad0 = heavy; ctx->bblen = L; }
+            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; ctx->pad0 = heavy; ctx->bblen = L; ctx->tie_pad[1] = P.win_flags ? (P.win_flags[w] & 1) : 0; }
         }
         Block4::sync();
 
@@ -1765,11 +1817,12 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             RCN_PHASE2(1);
             if (nwv == 1) {
                 if (wv == 0) {
+                    const bool tab = bcast0(ctx->tie_pad[1]) != 0;
                     switch (np_regs) {
-                        case 1: dp2_rows<1, 1>(); break;
-                        case 2: dp2_rows<2, 1>(); break;
-                        case 3: dp2_rows<3, 1>(); break;
-                        default: dp2_rows<4, 1>(); break;
+                        case 1: if (tab) dp2_rows<1, 1, true>(); else dp2_rows<1, 1>(); break;
+                        case 2: if (tab) dp2_rows<2, 1, true>(); else dp2_rows<2, 1>(); break;
+                        case 3: if (tab) dp2_rows<3, 1, true>(); else dp2_rows<3, 1>(); break;
+                        default: if (tab) dp2_rows<4, 1, true>(); else dp2_rows<4, 1>(); break;
                     }
                 }
                 Block4::sync();

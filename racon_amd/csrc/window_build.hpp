@@ -307,7 +307,13 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     int32_t nsym = 0;
     for (int k = 1; k <= 8; ++k) nsym += __builtin_popcount(h_err[k]);
     e->n_windows = nw; e->n_seqs = ns; e->n_bases = n_bases;
-    if ((rc = prepare_resident(e, nw, ns, h_wso.data(), h_seq_off.data(), h_begin.data(), h_end.data(), nullptr, std::max(nsym, 1)))) { drop_events(); return rc; }
+    bool acgt_all = true;
+    for (int k = 1; k <= 8; ++k) {
+        uint32_t allowed = 0;
+        for (int c : {'A', 'C', 'G', 'T'}) if ((c >> 5) == k - 1) allowed |= 1u << (c & 31);
+        if (h_err[k] & ~allowed) acgt_all = false;
+    }
+    if ((rc = prepare_resident(e, nw, ns, h_wso.data(), h_seq_off.data(), h_begin.data(), h_end.data(), nullptr, std::max(nsym, 1), acgt_all))) { drop_events(); return rc; }
 
     float ms_h2d = 0, ms_k = 0, ms_g = 0;
     HIP_TRY(hipEventElapsedTime(&ms_h2d, ev[0], ev[1]));
