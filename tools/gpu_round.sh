@@ -1,11 +1,11 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats + HBM counters.
 # Usage (from the repo root on the GPU box):  bash tools/gpu_round.sh [tag] [what...]
-#   what: tests bench prof pmc   (default: all)
+#   what: tests bench prof pmc build   (default: all)
 # Everything lands under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 set -u
 TAG=${1:-r01}; shift || true
-WHAT=${*:-tests bench prof pmc}
+WHAT=${*:-tests bench prof pmc build}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -34,6 +34,14 @@ if has pmc; then
     echo "pmc $C exit $?"
   done
   python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; cat "$OUT/pmc_summary.txt"
+fi
+if has build; then
+  # window construction in HBM (rcn_engine_build_windows): timings + rocprofv3 kernel stats of the same command
+  timeout 600 python tools/build_bench.py --oracle > "$OUT/build_bench.json" 2> "$OUT/build_bench.err"
+  echo "build exit $?"; cat "$OUT/build_bench.json"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/build_prof" -o trace -- python tools/build_bench.py --contig 8000000 --reps 3 > "$OUT/build_bench_8m.json" 2> "$OUT/build_prof.err"
+  cat "$OUT/build_bench_8m.json"
+  find "$OUT/build_prof" -name "*kernel_stats.csv" -exec sh -c 'cut -c1-160 "$1" | head -8' _ {} \;
 fi
 # keep the merge-back small: drop bulky raw traces, keep stats + counter tables
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
