@@ -152,6 +152,20 @@ typedef struct rcn_overlap_set {
     const uint32_t* bp_q;          /* Overlap::breaking_points_[k].second (query position on the overlap's strand) */
 } rcn_overlap_set;
 
+/* The alignments instead of the breaking points: Overlap::find_breaking_points' CIGAR walk
+ * (reference src/overlap.cpp:226-292) then also runs on the device, one thread per overlap, and its output feeds the
+ * window construction without leaving HBM.  q_id / t_id / strand as in rcn_overlap_set.                        */
+typedef struct rcn_cigar_set {
+    uint64_t n_overlaps;
+    const uint32_t* q_id; const uint32_t* t_id; const uint8_t* strand;     /* [n_overlaps]                        */
+    const uint32_t* q_start;       /* first query position on the overlap's strand: strand ? q_length - q_end : q_begin
+                                      (reference src/overlap.cpp:241-242)                                          */
+    const uint32_t* t_begin;       /* [n_overlaps] Overlap::t_begin_                                               */
+    const uint32_t* t_end;         /* [n_overlaps] Overlap::t_end_                                                 */
+    const uint64_t* cigar_off;     /* [n_overlaps+1] byte offsets into cigar                                        */
+    const uint8_t*  cigar;         /* CIGAR text (M = X match/mismatch, I, D N, S H P ignored), as in Overlap::cigar_ */
+} rcn_cigar_set;
+
 typedef struct rcn_build_stats {
     double   h2d_ms;               /* reads + overlaps to HBM                                      */
     double   kernel_ms;            /* filter + sort + scans + gather, HIP events                   */
@@ -165,6 +179,10 @@ typedef struct rcn_build_stats {
  * (src/window.cpp:49-58), as the reference's fatal error would.                                   */
 int  rcn_engine_build_windows(rcn_engine* e, const rcn_read_set* reads, const rcn_overlap_set* overlaps,
                               uint32_t window_length, double quality_threshold, uint8_t window_type);
+/* The same from alignments: breaking points (reference src/overlap.cpp:226-292) + window construction, all in HBM.
+ * rcn_build_stats.n_pairs then counts the slots (one per window an overlap touches), kept or not.                */
+int  rcn_engine_build_windows_from_cigars(rcn_engine* e, const rcn_read_set* reads, const rcn_cigar_set* alignments,
+                                          uint32_t window_length, double quality_threshold, uint8_t window_type);
 int  rcn_engine_build_stats(rcn_engine* e, rcn_build_stats* out);
 
 /* Dimensions and a copy (D2H) of the resident batch, uploaded or built; any output pointer may be NULL. */

@@ -50,6 +50,9 @@ int  rcnh_polisher_windows(rcnh_polisher* p, rcn_batch* out);
 int  rcnh_polisher_keep_layout(rcnh_polisher* p, int on);
 int  rcnh_polisher_layout(rcnh_polisher* p, rcn_read_set* reads, rcn_overlap_set* overlaps, uint8_t* window_type,
                           uint32_t* window_length, double* quality_threshold);
+/* ... and the alignments those breaking points were derived from (the CIGAR of the overlap file or of the host's
+ * pairwise alignment), for rcn_engine_build_windows_from_cigars. */
+int  rcnh_polisher_alignments(rcnh_polisher* p, rcn_cigar_set* alignments);
 /* Stitch per-window results (same order as the batch) into FASTA text
  * ">name tags\nsequence\n..." exactly as reference src/main.cpp:159-161 prints it. */
 int  rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* results, int drop_unpolished_sequences,

@@ -80,3 +80,49 @@ def window_layout(reads, overlaps, window_length: int, quality_threshold: float,
                 raise LayoutError("[racon::Window::add_layer] error: layer begin and end positions are invalid!")
             w["seqs"].append((bases[q0:q1].tobytes(), quality[q0:q1].tobytes() if has_quality else None, begin, end))
     return WindowBatch.from_windows(windows)
+
+
+def breaking_points(alignments, window_length: int):
+    """CPU restatement of Overlap::breaking_points_from_cigar (reference src/overlap.cpp:226-292), base by base as there:
+    racon_amd.layout.CigarSet -> racon_amd.layout.OverlapSet (first / last + 1 match column of every window touched)."""
+    from racon_amd.layout import OverlapSet
+    W = int(window_length)
+    out = []
+    text = alignments.cigar.tobytes()
+    for o in range(alignments.n_overlaps):
+        t_begin, t_end = int(alignments.t_begin[o]), int(alignments.t_end[o])
+        ends = [i - 1 for i in range(0, t_end, W) if i > t_begin] + [t_end - 1]           # :228-236
+        w, opened = 0, False
+        first = last = (0, 0)
+        q, t = int(alignments.q_start[o]) - 1, t_begin - 1                                  # :241-243
+        pts = []
+        n = 0
+        for c in text[int(alignments.cigar_off[o]):int(alignments.cigar_off[o + 1])]:
+            if 48 <= c <= 57:
+                n = n * 10 + (c - 48)
+                continue
+            if c in (77, 61, 88):                                                           # M = X  (:248-267)
+                for _ in range(n):
+                    q += 1
+                    t += 1
+                    if not opened:
+                        opened, first = True, (t, q)
+                    last = (t + 1, q + 1)
+                    if w < len(ends) and t == ends[w]:
+                        if opened:
+                            pts += [first, last]
+                        opened = False
+                        w += 1
+            elif c == 73:                                                                   # I  (:268-270)
+                q += n
+            elif c in (68, 78):                                                             # D N  (:271-285)
+                for _ in range(n):
+                    t += 1
+                    if w < len(ends) and t == ends[w]:
+                        if opened:
+                            pts += [first, last]
+                        opened = False
+                        w += 1
+            n = 0
+        out.append((int(alignments.q_id[o]), int(alignments.t_id[o]), int(alignments.strand[o]), pts))
+    return OverlapSet.from_lists(out)

@@ -82,7 +82,7 @@ struct rcn_engine {
     std::vector<uint8_t> cons, polished, chimeric;
     rcn_run_stats stats{};
     rcn_build_stats bstats{};
-    DevBuf d_build[16];                 // rcn_engine_build_windows: resident reads / overlaps / work arrays
+    DevBuf d_build[24];                 // rcn_engine_build_windows: resident reads / overlaps / work arrays
 
     // incremental builder (addWindow form)
     std::vector<uint32_t> b_win_seq_off{0};
@@ -319,6 +319,12 @@ int rcn_engine_build_windows(rcn_engine* e, const rcn_read_set* reads, const rcn
                              uint32_t window_length, double quality_threshold, uint8_t window_type) {
     if (!e || !reads || !ovl || window_length == 0) return RCN_E_ARG;
     return rcn::build_windows(e, *reads, *ovl, window_length, quality_threshold, window_type);
+}
+
+int rcn_engine_build_windows_from_cigars(rcn_engine* e, const rcn_read_set* reads, const rcn_cigar_set* al,
+                                         uint32_t window_length, double quality_threshold, uint8_t window_type) {
+    if (!e || !reads || !al || window_length == 0) return RCN_E_ARG;
+    return rcn::build_windows_from_cigars(e, *reads, *al, window_length, quality_threshold, window_type);
 }
 
 int rcn_engine_build_stats(rcn_engine* e, rcn_build_stats* out) {

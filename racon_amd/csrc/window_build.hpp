@@ -182,12 +182,76 @@ __global__ __launch_bounds__(256) void k_symbols(const uint8_t* bases, uint64_t 
     if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&bits[threadIdx.x], pres[threadIdx.x]);
 }
 
-// slots of rcn_engine::d_build
-enum { kBReadOff, kBReadBases, kBReadQuals, kBReadHasQual, kBQid, kBTid, kBStrand, kBBpOff, kBBpT, kBBpQ, kBFirstWin, kBPairs, kBTemp, kBSeqSrc, kBMisc, kBSeqLen };
+// Breaking points of one overlap from its CIGAR (reference src/overlap.cpp:226-292, restated per operation instead of per
+// base): the first and the last + 1 (target, query) position of the match columns inside every window the overlap
+// touches.  Slot k of the overlap belongs to the k-th window end in {multiples of W inside (t_begin, t_end)} + {t_end};
+// a window without a match column keeps its zeroed slot, which the length filter of k_layer_filter then drops.
+struct CigarParams {
+    const uint64_t* cigar_off; const uint8_t* cigar;
+    const uint32_t* q_start; const uint32_t* t_begin; const uint32_t* t_end;
+    const uint64_t* bp_off;                       // [n_overlaps + 1] slot offsets, in points
+    uint32_t* bp_t; uint32_t* bp_q;               // zero-initialised
+    uint64_t n_overlaps; uint32_t W;
+};
 
-inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap_set& O, uint32_t W, double qthr, uint8_t window_type) {
+__global__ __launch_bounds__(256) void k_cigar_breaking_points(CigarParams C) {
+    const uint64_t o = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (o >= C.n_overlaps) return;
+    const uint64_t W = C.W;
+    const int64_t t_begin = C.t_begin[o], t_end = C.t_end[o];
+    const uint64_t out = C.bp_off[o], n_slots = (C.bp_off[o + 1] - out) / 2;
+    // window end number k: the multiples of W strictly inside (t_begin, t_end), minus one; the last one is t_end - 1
+    const int64_t k0 = t_begin / static_cast<int64_t>(W) + 1;
+    auto end_of = [&](uint64_t k) -> int64_t { return k + 1 < n_slots ? (k0 + static_cast<int64_t>(k)) * static_cast<int64_t>(W) - 1 : t_end - 1; };
+    uint64_t w = 0;
+    bool open = false;
+    uint32_t ft = 0, fq = 0, lt = 0, lq = 0;
+    int64_t q = static_cast<int64_t>(C.q_start[o]) - 1, t = t_begin - 1;
+    auto close_if_at_end = [&]() {
+        if (w < n_slots && t == end_of(w)) {
+            if (open) { C.bp_t[out + 2 * w] = ft; C.bp_q[out + 2 * w] = fq; C.bp_t[out + 2 * w + 1] = lt; C.bp_q[out + 2 * w + 1] = lq; }
+            open = false; ++w;
+        }
+    };
+    uint64_t count = 0; bool have = false;
+    for (uint64_t p = C.cigar_off[o]; p < C.cigar_off[o + 1]; ++p) {
+        const uint8_t c = C.cigar[p];
+        if (c >= '0' && c <= '9') { count = count * 10 + (c - '0'); have = true; continue; }
+        uint64_t n = static_cast<uint32_t>(have ? count : 0);
+        count = 0; have = false;
+        if (c == 'M' || c == '=' || c == 'X') {
+            while (n > 0) {
+                // up to the next window end in one step (the reference walks base by base)
+                uint64_t take = n;
+                if (w < n_slots) { const int64_t room = end_of(w) - t; if (room > 0 && static_cast<uint64_t>(room) < take) take = static_cast<uint64_t>(room); }
+                if (!open) { open = true; ft = static_cast<uint32_t>(t + 1); fq = static_cast<uint32_t>(q + 1); }
+                q += static_cast<int64_t>(take); t += static_cast<int64_t>(take); n -= take;
+                lt = static_cast<uint32_t>(t + 1); lq = static_cast<uint32_t>(q + 1);
+                close_if_at_end();
+            }
+        } else if (c == 'I') {
+            q += static_cast<int64_t>(n);
+        } else if (c == 'D' || c == 'N') {
+            while (n > 0) {
+                uint64_t take = n;
+                if (w < n_slots) { const int64_t room = end_of(w) - t; if (room > 0 && static_cast<uint64_t>(room) < take) take = static_cast<uint64_t>(room); }
+                t += static_cast<int64_t>(take); n -= take;
+                close_if_at_end();
+            }
+        }
+    }
+}
+
+// slots of rcn_engine::d_build
+enum { kBReadOff, kBReadBases, kBReadQuals, kBReadHasQual, kBQid, kBTid, kBStrand, kBBpOff, kBBpT, kBBpQ, kBFirstWin, kBPairs, kBTemp, kBSeqSrc, kBMisc, kBSeqLen,
+       kBCigarOff, kBCigar, kBQStart, kBTBegin, kBTEnd, kBuildSlots };
+
+// `C` != nullptr: the breaking points are computed on the device from the alignments (O then only carries n_overlaps,
+// q_id, t_id, strand and a host vector of slot offsets in bp_off; its bp_t / bp_q are null).
+inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap_set& O, uint32_t W, double qthr, uint8_t window_type,
+                         const rcn_cigar_set* C = nullptr) {
     if (R.n_seqs == 0 || R.n_targets == 0 || R.n_targets > R.n_seqs || !R.seq_off || !R.bases || !R.quals || !R.seq_has_qual) return RCN_E_ARG;
-    if (O.n_overlaps && (!O.q_id || !O.t_id || !O.strand || !O.bp_off || !O.bp_t || !O.bp_q)) return RCN_E_ARG;
+    if (O.n_overlaps && (!O.q_id || !O.t_id || !O.strand || !O.bp_off || (!C && (!O.bp_t || !O.bp_q)))) return RCN_E_ARG;
     if (R.n_seqs > 0xfffffffeull || O.n_overlaps > 0xfffffffeull) return RCN_E_ARG;
     HIP_TRY(hipSetDevice(e->cfg.device));
     e->uploaded = false; e->ran = false;
@@ -218,8 +282,18 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
         (rc = upload_vec(B[kBReadQuals], R.quals, read_bytes, st)) || (rc = upload_vec(B[kBReadHasQual], R.seq_has_qual, R.n_seqs, st)) ||
         (rc = upload_vec(B[kBQid], O.q_id, 4 * O.n_overlaps, st)) || (rc = upload_vec(B[kBTid], O.t_id, 4 * O.n_overlaps, st)) ||
         (rc = upload_vec(B[kBStrand], O.strand, O.n_overlaps, st)) || (rc = upload_vec(B[kBBpOff], O.bp_off ? O.bp_off : &n_points, 8 * (O.n_overlaps + 1), st)) ||
-        (rc = upload_vec(B[kBBpT], O.bp_t, 4 * n_points, st)) || (rc = upload_vec(B[kBBpQ], O.bp_q, 4 * n_points, st)) ||
         (rc = upload_vec(B[kBFirstWin], first_window.data(), 4 * (R.n_targets + 1), st))) { drop_events(); return rc; }
+    if (!C) {
+        if ((rc = upload_vec(B[kBBpT], O.bp_t, 4 * n_points, st)) || (rc = upload_vec(B[kBBpQ], O.bp_q, 4 * n_points, st))) { drop_events(); return rc; }
+    } else {
+        const uint64_t cig_bytes = C->n_overlaps ? C->cigar_off[C->n_overlaps] : 0;
+        if ((rc = B[kBBpT].reserve(4 * n_points + 16)) || (rc = B[kBBpQ].reserve(4 * n_points + 16)) ||
+            (rc = upload_vec(B[kBCigarOff], C->cigar_off, 8 * (C->n_overlaps + 1), st)) || (rc = upload_vec(B[kBCigar], C->cigar, cig_bytes, st)) ||
+            (rc = upload_vec(B[kBQStart], C->q_start, 4 * C->n_overlaps, st)) || (rc = upload_vec(B[kBTBegin], C->t_begin, 4 * C->n_overlaps, st)) ||
+            (rc = upload_vec(B[kBTEnd], C->t_end, 4 * C->n_overlaps, st))) { drop_events(); return rc; }
+        HIP_TRY(hipMemsetAsync(B[kBBpT].p, 0, 4 * n_points + 16, st));
+        HIP_TRY(hipMemsetAsync(B[kBBpQ].p, 0, 4 * n_points + 16, st));
+    }
     // per-pair work arrays: key, val, key_sorted, val_sorted, begin, end, q0, len, ovl
     const uint64_t np_al = (n_pairs + 63) & ~63ull;
     if ((rc = B[kBPairs].reserve(std::max<uint64_t>(9 * 4 * np_al, 256))) || (rc = B[kBMisc].reserve(4ull * (nw + 2) + 64)) ||
@@ -241,6 +315,13 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     P.key = pw; P.val = pw + np_al; uint32_t* key_sorted = pw + 2 * np_al; uint32_t* val_sorted = pw + 3 * np_al;
     P.pair_begin = pw + 4 * np_al; P.pair_end = pw + 5 * np_al; P.pair_q0 = pw + 6 * np_al; P.pair_len = pw + 7 * np_al; P.pair_ovl = pw + 8 * np_al;
     P.win_cnt = d_cnt; P.err = d_err;
+    if (C && C->n_overlaps) {
+        CigarParams K{};
+        K.cigar_off = B[kBCigarOff].as<uint64_t>(); K.cigar = B[kBCigar].as<uint8_t>(); K.q_start = B[kBQStart].as<uint32_t>();
+        K.t_begin = B[kBTBegin].as<uint32_t>(); K.t_end = B[kBTEnd].as<uint32_t>(); K.bp_off = P.bp_off;
+        K.bp_t = B[kBBpT].as<uint32_t>(); K.bp_q = B[kBBpQ].as<uint32_t>(); K.n_overlaps = C->n_overlaps; K.W = W;
+        hipLaunchKernelGGL(k_cigar_breaking_points, dim3(static_cast<uint32_t>((C->n_overlaps + 255) / 256)), dim3(256), 0, st, K);
+    }
     hipLaunchKernelGGL(k_symbols, dim3(static_cast<uint32_t>(std::min<uint64_t>(1024, (read_bytes + 1023) / 1024 + 1))), dim3(256), 0, st, P.bases, read_bytes, d_err + 1);
     if (n_pairs) hipLaunchKernelGGL(k_layer_filter, dim3(static_cast<uint32_t>((n_pairs + 3) / 4)), dim3(256), 0, st, P);
     HIP_TRY(hipGetLastError());
@@ -328,6 +409,22 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     e->stats.bytes_in = 2 * read_bytes + 17ull * n_points;
     e->uploaded = true;
     return RCN_OK;
+}
+
+// Breaking points from the alignments on the device, then the same construction.  One slot (two points) per window end an
+// overlap touches: the multiples of W strictly inside (t_begin, t_end) and t_end itself (reference src/overlap.cpp:228-236).
+inline int build_windows_from_cigars(rcn_engine* e, const rcn_read_set& R, const rcn_cigar_set& C, uint32_t W, double qthr, uint8_t window_type) {
+    if (C.n_overlaps && (!C.q_id || !C.t_id || !C.strand || !C.q_start || !C.t_begin || !C.t_end || !C.cigar_off || !C.cigar)) return RCN_E_ARG;
+    std::vector<uint64_t> bp_off(C.n_overlaps + 1, 0);
+    for (uint64_t o = 0; o < C.n_overlaps; ++o) {
+        const uint64_t tb = C.t_begin[o], te = C.t_end[o];
+        if (te <= tb) return RCN_E_ARG;
+        const uint64_t inside = (te - 1) / W - tb / W;            // multiples k*W with t_begin < k*W < t_end
+        bp_off[o + 1] = bp_off[o] + 2 * (inside + 1);
+    }
+    rcn_overlap_set O{};
+    O.n_overlaps = C.n_overlaps; O.q_id = C.q_id; O.t_id = C.t_id; O.strand = C.strand; O.bp_off = bp_off.data();
+    return build_windows(e, R, O, W, qthr, window_type, &C);
 }
 
 }  // namespace rcn

@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
-from .layout import OverlapSet, RcnBatchDims, RcnBuildStats, RcnOverlapSet, RcnReadSet, ReadSet
+from .layout import CigarSet, OverlapSet, RcnBatchDims, RcnBuildStats, RcnCigarSet, RcnOverlapSet, RcnReadSet, ReadSet
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libracon_hip.so")
@@ -41,7 +41,7 @@ class RcnWindowDesc(C.Structure):
 EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_engine_run", "rcn_engine_result",
            "rcn_engine_stats", "rcn_engine_set_trim", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
-           "rcn_engine_build_windows", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch"]
+           "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch"]
 
 _lib = None
 
@@ -68,6 +68,7 @@ def load_library():
     lib.rcn_engine_generate_consensus.argtypes = [C.c_void_p]
     lib.rcn_engine_reset.argtypes = [C.c_void_p]
     lib.rcn_engine_build_windows.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnOverlapSet), C.c_uint32, C.c_double, C.c_uint8]
+    lib.rcn_engine_build_windows_from_cigars.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnCigarSet), C.c_uint32, C.c_double, C.c_uint8]
     lib.rcn_engine_build_stats.argtypes = [C.c_void_p, C.POINTER(RcnBuildStats)]
     lib.rcn_engine_batch_dims.argtypes = [C.c_void_p, C.POINTER(RcnBatchDims)]
     lib.rcn_engine_export_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 8
@@ -145,6 +146,13 @@ class HipEngine:
         self._keep = (reads, overlaps, cr, co)
         _check(self.lib.rcn_engine_build_windows(self.h, C.byref(cr), C.byref(co), int(window_length), float(quality_threshold),
                                                  int(window_type)), "rcn_engine_build_windows")
+
+    def build_windows_from_cigars(self, reads: ReadSet, alignments: CigarSet, window_length: int, quality_threshold: float, window_type: int):
+        """The same from the alignments: breaking points (reference src/overlap.cpp:226-292) are also found on the device."""
+        cr, ca = reads.as_c(), alignments.as_c()
+        self._keep = (reads, alignments, cr, ca)
+        _check(self.lib.rcn_engine_build_windows_from_cigars(self.h, C.byref(cr), C.byref(ca), int(window_length), float(quality_threshold),
+                                                             int(window_type)), "rcn_engine_build_windows_from_cigars")
 
     def build_stats(self) -> dict:
         s = RcnBuildStats()

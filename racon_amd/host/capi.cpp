@@ -76,6 +76,16 @@ int rcnh_polisher_layout(rcnh_polisher* p, rcn_read_set* r, rcn_overlap_set* o, 
     return 0;
 }
 
+int rcnh_polisher_alignments(rcnh_polisher* p, rcn_cigar_set* a) {
+    if (!p || !a) { g_error = "invalid argument"; return -1; }
+    const racon::Polisher::Layout& l = p->polisher->layout();
+    if (l.seq_off.size() < 2) { g_error = "no layout recorded (rcnh_polisher_keep_layout before initialize)"; return -1; }
+    a->n_overlaps = l.q_id.size(); a->q_id = l.q_id.data(); a->t_id = l.t_id.data(); a->strand = l.strand.data();
+    a->q_start = l.q_start.data(); a->t_begin = l.t_begin.data(); a->t_end = l.t_end.data();
+    a->cigar_off = l.cigar_off.data(); a->cigar = l.cigar.data();
+    return 0;
+}
+
 int rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* r, int drop, const char** fasta, uint64_t* len) {
     if (!p || !r || !fasta || !len) { g_error = "invalid argument"; return -1; }
     return guarded([&] {

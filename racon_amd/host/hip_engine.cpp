@@ -25,6 +25,7 @@ struct Abi {
     decltype(&rcn_engine_stats) stats = nullptr;
     decltype(&rcn_engine_set_trim) set_trim = nullptr;
     decltype(&rcn_engine_build_windows) build_windows = nullptr;
+    decltype(&rcn_engine_build_windows_from_cigars) build_windows_from_cigars = nullptr;
     decltype(&rcn_device_count) device_count = nullptr;
     decltype(&rcn_strerror) strerror_ = nullptr;
 };
@@ -59,7 +60,7 @@ const Abi& abi() {
         if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
         RCN_BIND(run, "rcn_engine_run") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
-        RCN_BIND(build_windows, "rcn_engine_build_windows")
+        RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
 #undef RCN_BIND
     });
@@ -135,6 +136,16 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_overlap_set& over
     const Abi& a = abi();
     int rc = a.set_trim(handle_, trim ? 1 : 0);
     if (rc == RCN_OK) rc = a.build_windows(handle_, &reads, &overlaps, window_length, quality_threshold, window_type);
+    if (rc == RCN_E_ARG) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
+    fetch(rc, consensus, polished, chimeric);
+}
+
+void HipEngine::consensus(const rcn_read_set& reads, const rcn_cigar_set& alignments, uint32_t window_length, double quality_threshold,
+                          uint8_t window_type, bool trim, std::vector<std::string>* consensus,
+                          std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
+    const Abi& a = abi();
+    int rc = a.set_trim(handle_, trim ? 1 : 0);
+    if (rc == RCN_OK) rc = a.build_windows_from_cigars(handle_, &reads, &alignments, window_length, quality_threshold, window_type);
     if (rc == RCN_E_ARG) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
     fetch(rc, consensus, polished, chimeric);
 }

@@ -53,6 +53,10 @@ public:
     void consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,
                    uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                    std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    // ... and with the breaking points found on the device as well (rcn_engine_build_windows_from_cigars)
+    void consensus(const rcn_read_set& reads, const rcn_cigar_set& alignments, uint32_t window_length, double quality_threshold,
+                   uint8_t window_type, bool trim, std::vector<std::string>* consensus,
+                   std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
     double last_kernel_ms() const { return last_kernel_ms_; }
 
 private:

@@ -95,7 +95,7 @@ void Overlap::transmute(const std::vector<std::unique_ptr<Sequence>>& sequences,
     is_transmuted_ = true;
 }
 
-void Overlap::find_breaking_points(const std::vector<std::unique_ptr<Sequence>>& sequences, uint32_t window_length) {
+void Overlap::find_breaking_points(const std::vector<std::unique_ptr<Sequence>>& sequences, uint32_t window_length, bool keep_cigar, bool cigar_only) {
     if (!is_transmuted_) fatal("[racon::Overlap::find_breaking_points] error: overlap is not transmuted!");
     if (!breaking_points_.empty()) return;
     if (cigar_.empty()) {
@@ -104,8 +104,9 @@ void Overlap::find_breaking_points(const std::vector<std::unique_ptr<Sequence>>&
         const char* t = &(sequences[t_id_]->data()[t_begin_]);
         cigar_ = nwpath::align_cigar(q, q_end_ - q_begin_, t, t_end_ - t_begin_);
     }
+    if (cigar_only) { breaking_points_.emplace_back(0, 0); breaking_points_.emplace_back(0, 0); return; }   // (non-empty: "done")
     breaking_points_from_cigar(window_length);
-    std::string().swap(cigar_);
+    if (!keep_cigar) std::string().swap(cigar_);
 }
 
 void Overlap::breaking_points_from_cigar(uint32_t window_length) {

@@ -199,10 +199,10 @@ void Polisher::initialize() {
 
     parallel_for(sequences_.size(), num_threads_, [&](uint64_t j) { sequences_[j]->transmute(has_name[j], has_data[j], has_reverse_data[j]); });
 
+    if (const char* dv = getenv("RACON_HIP_DEVICE_WINDOWS")) { if (dv[0] == '1' || dv[0] == '2') device_windows(true, dv[0] == '2'); }
     find_overlap_breaking_points(overlaps);
     logger_->log();
 
-    if (const char* dv = getenv("RACON_HIP_DEVICE_WINDOWS")) { if (dv[0] == '1') device_windows(true); }
     if (keep_layout_) {
         layout_ = Layout();
         layout_.n_targets = targets_size;
@@ -228,8 +228,11 @@ void Polisher::initialize() {
             layout_.q_id.push_back(static_cast<uint32_t>(o->q_id()));
             layout_.t_id.push_back(static_cast<uint32_t>(o->t_id()));
             layout_.strand.push_back(o->strand() ? 1 : 0);
-            for (const auto& bp : o->breaking_points()) { layout_.bp_t.push_back(bp.first); layout_.bp_q.push_back(bp.second); }
+            if (!device_cigars_) for (const auto& bp : o->breaking_points()) { layout_.bp_t.push_back(bp.first); layout_.bp_q.push_back(bp.second); }
             layout_.bp_off.push_back(layout_.bp_t.size());
+            layout_.q_start.push_back(o->q_start_on_strand()); layout_.t_begin.push_back(o->t_begin()); layout_.t_end.push_back(o->t_end());
+            layout_.cigar.insert(layout_.cigar.end(), o->cigar().begin(), o->cigar().end());
+            layout_.cigar_off.push_back(layout_.cigar.size());
         }
     }
 
@@ -283,7 +286,7 @@ void Polisher::initialize() {
 }
 
 void Polisher::find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>>& overlaps) {
-    parallel_for(overlaps.size(), num_threads_, [&](uint64_t j) { overlaps[j]->find_breaking_points(sequences_, window_length_); });
+    parallel_for(overlaps.size(), num_threads_, [&](uint64_t j) { overlaps[j]->find_breaking_points(sequences_, window_length_, keep_layout_, device_cigars_); });
     logger_->log("[racon::Polisher::initialize] aligned overlaps");
 }
 
@@ -350,6 +353,13 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         o.n_overlaps = layout_.q_id.size(); o.q_id = layout_.q_id.data(); o.t_id = layout_.t_id.data(); o.strand = layout_.strand.data();
         o.bp_off = layout_.bp_off.data(); o.bp_t = layout_.bp_t.data(); o.bp_q = layout_.bp_q.data();
         auto engine = HipEngine::Create(0, match_, mismatch_, gap_);
+        if (device_cigars_) {
+            rcn_cigar_set a{};
+            a.n_overlaps = o.n_overlaps; a.q_id = o.q_id; a.t_id = o.t_id; a.strand = o.strand;
+            a.q_start = layout_.q_start.data(); a.t_begin = layout_.t_begin.data(); a.t_end = layout_.t_end.data();
+            a.cigar_off = layout_.cigar_off.data(); a.cigar = layout_.cigar.data();
+            engine->consensus(r, a, window_length_, quality_threshold_, layout_.window_type, trim_, &cons, &pol, &chim);
+        } else
         engine->consensus(r, o, window_length_, quality_threshold_, layout_.window_type, trim_, &cons, &pol, &chim);
         if (cons.size() != nw) fatal("[racon::Polisher::polish] error: window count mismatch between host and device!");
         for (uint64_t i = 0; i < nw; ++i)

@@ -69,12 +69,19 @@ public:
         std::vector<uint8_t> strand;
         std::vector<uint64_t> bp_off{0};
         std::vector<uint32_t> bp_t, bp_q;
+        // the alignments the breaking points came from (rcn_cigar_set): CIGAR text, first query position on the
+        // overlap's strand, target extent
+        std::vector<uint64_t> cigar_off{0};
+        std::vector<uint8_t> cigar;
+        std::vector<uint32_t> q_start, t_begin, t_end;
         uint8_t window_type = 0;
     };
     void keep_layout(bool on) { keep_layout_ = on; }
     // Windows built on the device: initialize() then skips the serial add_layer loop (windows_ keep only their backbones,
     // which polish() needs for the stitching) and records the layout instead.  Also switched on by RACON_HIP_DEVICE_WINDOWS=1.
-    void device_windows(bool on) { device_windows_ = on; if (on) keep_layout_ = true; }
+    // cigars: the CIGAR walk (Overlap::find_breaking_points, reference src/overlap.cpp:226-292) runs on the device too
+    // (rcn_engine_build_windows_from_cigars; RACON_HIP_DEVICE_WINDOWS=2).
+    void device_windows(bool on, bool cigars = false) { device_windows_ = on; device_cigars_ = on && cigars; if (on) keep_layout_ = true; }
     const Layout& layout() const { return layout_; }
     uint32_t window_length() const { return window_length_; }
     double quality_threshold() const { return quality_threshold_; }
@@ -110,6 +117,7 @@ protected:
     uint32_t window_length_;
     std::vector<std::shared_ptr<Window>> windows_;
     bool keep_layout_ = false;
+    bool device_cigars_ = false;
     bool device_windows_ = false;   // polish(): windows built in HBM (rcn_engine_build_windows) instead of packed from windows_
     Layout layout_;
     std::unique_ptr<Logger> logger_;

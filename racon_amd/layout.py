@@ -21,6 +21,12 @@ class RcnOverlapSet(C.Structure):
                 ("bp_q", C.POINTER(C.c_uint32))]
 
 
+class RcnCigarSet(C.Structure):
+    _fields_ = [("n_overlaps", C.c_uint64), ("q_id", C.POINTER(C.c_uint32)), ("t_id", C.POINTER(C.c_uint32)),
+                ("strand", C.POINTER(C.c_uint8)), ("q_start", C.POINTER(C.c_uint32)), ("t_begin", C.POINTER(C.c_uint32)),
+                ("t_end", C.POINTER(C.c_uint32)), ("cigar_off", C.POINTER(C.c_uint64)), ("cigar", C.POINTER(C.c_uint8))]
+
+
 class RcnBuildStats(C.Structure):
     _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("n_pairs", C.c_uint64),
                 ("n_layers", C.c_uint64), ("gather_bytes", C.c_uint64)]
@@ -108,3 +114,46 @@ class OverlapSet:
         return OverlapSet(np.array([o[0] for o in overlaps], np.uint32), np.array([o[1] for o in overlaps], np.uint32),
                           np.array([o[2] for o in overlaps], np.uint8), off,
                           np.array([p[0] for p in pts], np.uint32), np.array([p[1] for p in pts], np.uint32))
+
+
+@dataclass
+class CigarSet:
+    """The alignments of the kept overlaps (include/racon_hip.h: rcn_cigar_set): what Overlap::find_breaking_points walks
+    (reference src/overlap.cpp:226-292)."""
+    q_id: np.ndarray           # uint32 [n_overlaps]
+    t_id: np.ndarray
+    strand: np.ndarray         # uint8
+    q_start: np.ndarray        # uint32: first query position on the overlap's strand
+    t_begin: np.ndarray        # uint32
+    t_end: np.ndarray          # uint32
+    cigar_off: np.ndarray      # uint64 [n_overlaps + 1]
+    cigar: np.ndarray          # uint8 CIGAR text
+
+    @property
+    def n_overlaps(self) -> int:
+        return int(self.q_id.shape[0])
+
+    def as_c(self) -> RcnCigarSet:
+        for name, dt in (("q_id", np.uint32), ("t_id", np.uint32), ("strand", np.uint8), ("q_start", np.uint32), ("t_begin", np.uint32),
+                         ("t_end", np.uint32), ("cigar_off", np.uint64), ("cigar", np.uint8)):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name), dtype=dt))
+        return RcnCigarSet(self.n_overlaps, _ptr(self.q_id, C.c_uint32), _ptr(self.t_id, C.c_uint32), _ptr(self.strand, C.c_uint8),
+                           _ptr(self.q_start, C.c_uint32), _ptr(self.t_begin, C.c_uint32), _ptr(self.t_end, C.c_uint32),
+                           _ptr(self.cigar_off, C.c_uint64), _ptr(self.cigar, C.c_uint8))
+
+    @staticmethod
+    def from_c(a: RcnCigarSet) -> "CigarSet":
+        n = int(a.n_overlaps)
+        off = np.ctypeslib.as_array(a.cigar_off, shape=(n + 1,)).copy()
+        nb = int(off[-1])
+        g = lambda p, k: np.ctypeslib.as_array(p, shape=(max(k, 1),))[:k].copy()
+        return CigarSet(g(a.q_id, n), g(a.t_id, n), g(a.strand, n), g(a.q_start, n), g(a.t_begin, n), g(a.t_end, n), off, g(a.cigar, nb))
+
+    @staticmethod
+    def from_lists(al) -> "CigarSet":
+        """al: [(q_id, t_id, strand, q_start, t_begin, t_end, cigar: bytes)]"""
+        off = np.zeros(len(al) + 1, np.uint64)
+        off[1:] = np.cumsum([len(a[6]) for a in al])
+        col = lambda k, dt: np.array([a[k] for a in al], dt)
+        return CigarSet(col(0, np.uint32), col(1, np.uint32), col(2, np.uint8), col(3, np.uint32), col(4, np.uint32), col(5, np.uint32),
+                        off, np.frombuffer(b"".join(a[6] for a in al), np.uint8).copy())

@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
-from .layout import OverlapSet, RcnOverlapSet, RcnReadSet, ReadSet
+from .layout import CigarSet, OverlapSet, RcnCigarSet, RcnOverlapSet, RcnReadSet, ReadSet
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_DIR = os.path.join(_HERE, "host")
@@ -51,6 +51,7 @@ def load_library():
     lib.rcnh_polisher_windows.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
     lib.rcnh_polisher_keep_layout.argtypes = [C.c_void_p, C.c_int]
     lib.rcnh_polisher_layout.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnOverlapSet), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    lib.rcnh_polisher_alignments.argtypes = [C.c_void_p, C.POINTER(RcnCigarSet)]
     lib.rcnh_polisher_assemble.argtypes = [C.c_void_p, C.POINTER(RcnResult), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_polish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_destroy.argtypes = [C.c_void_p]
@@ -144,6 +145,12 @@ class Polisher:
         wt, wl, qt = C.c_uint8(), C.c_uint32(), C.c_double()
         _check(self.lib.rcnh_polisher_layout(self.h, C.byref(r), C.byref(o), C.byref(wt), C.byref(wl), C.byref(qt)))
         return ReadSet.from_c(r), OverlapSet.from_c(o), int(wt.value), int(wl.value), float(qt.value)
+
+    def alignments(self) -> CigarSet:
+        """The alignments (CIGAR + extents) the breaking points of layout() were derived from."""
+        a = RcnCigarSet()
+        _check(self.lib.rcnh_polisher_alignments(self.h, C.byref(a)))
+        return CigarSet.from_c(a)
 
     def windows(self) -> WindowBatch:
         cb = RcnBatch()

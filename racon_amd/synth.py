@@ -166,13 +166,15 @@ def simulate_files(out_dir: str, contig_len: int = 20000, coverage: float = 25.0
 
 def simulate_layout(contig_lens=(30000, 12345), window_len: int = 500, coverage: float = 20.0, read_len: int = 4000,
                     sub: float = 0.03, ins: float = 0.03, dele: float = 0.04, seed: int = 20260926,
-                    frac_no_quality: float = 0.15, frac_low_quality: float = 0.1, target_quality: bool = False):
+                    frac_no_quality: float = 0.15, frac_low_quality: float = 0.1, target_quality: bool = False,
+                    with_cigars: bool = False):
     """In-memory input of racon's window construction (racon_amd.layout.ReadSet / OverlapSet): draft targets, error-bearing
     reads on both strands (some without qualities, some with low ones so that the -q filter fires), and per overlap the
     breaking points Overlap::find_breaking_points would derive from the simulator's true alignment (first / last match of
     every window, reference src/overlap.cpp:226-292).  Returns (reads, overlaps, window_type)."""
-    from .layout import OverlapSet, ReadSet
+    from .layout import CigarSet, OverlapSet, ReadSet
     rng = np.random.default_rng(seed)
+    aligns = []
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     seqs, ovl = [], []
     targets = []
@@ -231,9 +233,20 @@ def simulate_layout(contig_lens=(30000, 12345), window_len: int = 500, coverage:
             if strand:            # the read set holds the other strand; the overlap reads its reverse complement
                 rb = rb.translate(comp)[::-1]
                 qb = qb[::-1] if qb is not None else None
+            if with_cigars:
+                # the true alignment as a CIGAR: per target column D or M, an I behind the columns with an insertion
+                pos = np.arange(n) + np.cumsum(has_ins) - has_ins
+                ops = np.full(n + int(has_ins.sum()), ord("I"), np.uint8)
+                ops[pos] = np.where(deleted, ord("D"), ord("M"))
+                cut = np.nonzero(np.diff(ops))[0] + 1
+                starts = np.concatenate([[0], cut]); lens = np.diff(np.concatenate([starts, [ops.size]]))
+                cigar = b"".join(b"%d%c" % (int(l), int(ops[a])) for a, l in zip(starts, lens))
+                aligns.append((len(seqs), ti, strand, 0, ts, te, cigar))
             ovl.append((len(seqs), ti, strand, pts))
             seqs.append((rb, qb))
             total_len += qlen
     n_reads = len(seqs) - len(targets)
     window_type = 1 if (total_len + sum(contig_lens)) / max(1, len(seqs)) > 1000 else 0
+    if with_cigars:
+        return ReadSet.from_sequences(seqs, len(targets)), OverlapSet.from_lists(ovl), window_type, CigarSet.from_lists(aligns)
     return ReadSet.from_sequences(seqs, len(targets)), OverlapSet.from_lists(ovl), window_type

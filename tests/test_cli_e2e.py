@@ -77,14 +77,16 @@ def test_polisher_polish_and_options(P, oracle, data):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("ovl", ["sam", "paf"])
-def test_cli_with_device_side_windows_matches_oracle(P, oracle, data, ovl):
+def test_cli_with_device_side_windows_matches_oracle(P, oracle, data, ovl, mode):
     """RACON_HIP_DEVICE_WINDOWS=1: the host only parses and finds breaking points; the windows are cut, filtered and packed
     in HBM (rcn_engine_build_windows, reference src/polisher.cpp:388-461) and polished there — same FASTA, byte for byte."""
     paths, _ = data
     ref, _ = _oracle_fasta(P, oracle, paths, ovl)
     exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
-    env = dict(os.environ, RACON_HIP_DEVICE_WINDOWS="1")
+    # mode 2: the CIGAR walk (breaking points, reference src/overlap.cpp:226-292) runs on the device as well
+    env = dict(os.environ, RACON_HIP_DEVICE_WINDOWS=mode)
     out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
     assert out == ref

@@ -86,3 +86,34 @@ def test_build_windows_on_committed_reference_fixture():
     eng.build_windows(r, o, wl, qt, wt)
     same_batch(eng.export_batch(), want, "reference fixture")
     assert eng.run().consensus == HipEngine(5, -4, -8, True).consensus(want).consensus
+
+
+@pytest.mark.parametrize("kw,w", [
+    (dict(contig_lens=(30000, 12345), seed=21), 500),
+    (dict(contig_lens=(9000, 2501, 499), read_len=1500, coverage=12, seed=22), 137),
+    (dict(contig_lens=(20000,), read_len=3000, coverage=25, seed=23, ins=0.10, dele=0.12), 1000),
+])
+def test_build_windows_from_cigars_equals_oracle(oracle, kw, w):
+    """Breaking points (reference src/overlap.cpp:226-292) on the device too: alignments in, the same batch out."""
+    from oracle.window_layout import breaking_points, window_layout
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_layout
+    r, o, wt, al = simulate_layout(window_len=w, with_cigars=True, **kw)
+    ref = window_layout(r, breaking_points(al, w), w, 10.0, wt)
+    eng = HipEngine(3, -5, -4, True)
+    eng.build_windows_from_cigars(r, al, w, 10.0, wt)
+    same_batch(eng.export_batch(), ref, f"from cigars {kw}")
+    assert eng.run().consensus == oracle.consensus(ref, 3, -5, -4, True, 0).consensus
+
+
+def test_build_windows_from_cigars_on_committed_reference_fixture():
+    """The reference sample's SAM alignments (tests/golden/layout_sam_fastq_w500.npz) -> the windows of sam_fastq_w500.npz."""
+    from racon_amd.batch import WindowBatch
+    from racon_amd.engine import HipEngine
+    from racon_amd.layout import CigarSet
+    r, o, wt, wl, qt = load_layout_fixture()
+    z = np.load(os.path.join(GOLD, "layout_sam_fastq_w500.npz"))
+    al = CigarSet(o.q_id, o.t_id, o.strand, z["q_start"], z["t_begin"], z["t_end"], z["cigar_off"], z["cigar"])
+    eng = HipEngine(5, -4, -8, True)
+    eng.build_windows_from_cigars(r, al, wl, qt, wt)
+    same_batch(eng.export_batch(), WindowBatch.load(os.path.join(GOLD, "sam_fastq_w500.npz")), "reference fixture, from CIGARs")

@@ -89,3 +89,28 @@ def test_oracle_layout_on_committed_fixture():
     from racon_amd.batch import WindowBatch
     r, o, wt, wl, qt = load_layout_fixture()
     same_batch(window_layout(r, o, wl, qt, wt), WindowBatch.load(os.path.join(GOLD, "sam_fastq_w500.npz")), "layout fixture")
+
+
+@needs_data
+@pytest.mark.parametrize("overlaps,w", [("sample_overlaps.sam.gz", 500), ("sample_overlaps.paf.gz", 500), ("sample_overlaps.sam.gz", 137)])
+def test_oracle_breaking_points_equal_host_layer_on_reference_data(overlaps, w):
+    """oracle.window_layout.breaking_points (reference src/overlap.cpp:226-292 restated) against the breaking points the host
+    layer derives from the same alignments: the SAM file's CIGARs, and for PAF the host's own pairwise alignments."""
+    from oracle.window_layout import breaking_points
+    from racon_amd import polisher
+    polisher.build()
+    p = polisher.Polisher(DATA + "sample_reads.fastq.gz", DATA + overlaps, DATA + "sample_layout.fasta.gz", "kC", w, 10.0, 0.3, True, 5, -4, -8, 2)
+    p.initialize(keep_layout=True)
+    _, o, _, _, _ = p.layout()
+    mine = breaking_points(p.alignments(), w)
+    for f in ("q_id", "t_id", "strand", "bp_off", "bp_t", "bp_q"):
+        assert (np.asarray(getattr(mine, f)) == np.asarray(getattr(o, f))).all(), f
+
+
+def test_synthetic_cigars_give_the_simulators_breaking_points():
+    from oracle.window_layout import breaking_points
+    from racon_amd.synth import simulate_layout
+    r, o, wt, al = simulate_layout(contig_lens=(7000, 1501), read_len=1200, coverage=10, seed=9, with_cigars=True, window_len=300)
+    mine = breaking_points(al, 300)
+    for f in ("q_id", "t_id", "strand", "bp_off", "bp_t", "bp_q"):
+        assert (np.asarray(getattr(mine, f)) == np.asarray(getattr(o, f))).all(), f

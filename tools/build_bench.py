@@ -22,7 +22,7 @@ from racon_amd.engine import HipEngine  # noqa: E402
 from racon_amd.synth import simulate_layout  # noqa: E402
 
 t0 = time.time()
-r, o, wt = simulate_layout(contig_lens=(args.contig,), coverage=30.0, read_len=10000, seed=20260921)
+r, o, wt, al = simulate_layout(contig_lens=(args.contig,), coverage=30.0, read_len=10000, seed=20260921, with_cigars=True)
 t_sim = time.time() - t0
 eng = HipEngine()
 best = None
@@ -46,6 +46,17 @@ if args.oracle:
     ref = window_layout(r, o, 500, 10.0, wt)
     out["python_oracle_s"] = round(time.time() - t0, 2)
     out["matches_oracle"] = bool((ref.bases == b.bases).all() and (ref.seq_off == b.seq_off).all() and (ref.seq_begin == b.seq_begin).all())
+# the same with the CIGAR walk (reference src/overlap.cpp:226-292) on the device
+bestc = None
+for _ in range(args.reps):
+    eng.build_windows_from_cigars(r, al, 500, 10.0, wt)
+    st = eng.build_stats()
+    if bestc is None or st["kernel_ms"] < bestc["kernel_ms"]:
+        bestc = st
+bc = eng.export_batch()
+out["from_cigars"] = {"cigar_bytes": int(len(al.cigar)), "h2d_ms": round(bestc["h2d_ms"], 3), "device_ms": round(bestc["kernel_ms"], 3),
+                      "same_batch": bool((bc.bases == b.bases).all() and (bc.seq_off == b.seq_off).all() and (bc.seq_begin == b.seq_begin).all()
+                                         and (bc.seq_end == b.seq_end).all() and (bc.quals == b.quals).all())}
 res = eng.run()
 out["consensus_kernel_ms"] = round(eng.stats()["kernel_ms"], 2)
 print(json.dumps(out))
