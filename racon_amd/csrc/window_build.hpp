@@ -214,8 +214,15 @@ __global__ __launch_bounds__(256) void k_cigar_breaking_points(CigarParams C) {
         }
     };
     uint64_t count = 0; bool have = false;
-    for (uint64_t p = C.cigar_off[o]; p < C.cigar_off[o + 1]; ++p) {
-        const uint8_t c = C.cigar[p];
+    const uint64_t p_end = C.cigar_off[o + 1];
+    // eight bytes of text per (unaligned) load: the walk is one dependent chain per thread, its time is the number of
+    // memory round trips (the buffer has 16 bytes of slack behind the last CIGAR)
+    for (uint64_t p8 = C.cigar_off[o]; p8 < p_end; p8 += 8) {
+      const uint64_t chunk = *reinterpret_cast<const uint64_t*>(C.cigar + p8);
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        if (p8 + kb >= p_end) break;
+        const uint8_t c = static_cast<uint8_t>(chunk >> (8 * kb));
         if (c >= '0' && c <= '9') { count = count * 10 + (c - '0'); have = true; continue; }
         uint64_t n = static_cast<uint32_t>(have ? count : 0);
         count = 0; have = false;
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(256) void k_cigar_breaking_points(CigarParams C) {
                 close_if_at_end();
             }
         }
+      }
     }
 }
 
@@ -288,7 +296,7 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     } else {
         const uint64_t cig_bytes = C->n_overlaps ? C->cigar_off[C->n_overlaps] : 0;
         if ((rc = B[kBBpT].reserve(4 * n_points + 16)) || (rc = B[kBBpQ].reserve(4 * n_points + 16)) ||
-            (rc = upload_vec(B[kBCigarOff], C->cigar_off, 8 * (C->n_overlaps + 1), st)) || (rc = upload_vec(B[kBCigar], C->cigar, cig_bytes, st)) ||
+            (rc = upload_vec(B[kBCigarOff], C->cigar_off, 8 * (C->n_overlaps + 1), st)) || (rc = B[kBCigar].reserve(cig_bytes + 16)) || (rc = upload_vec(B[kBCigar], C->cigar, cig_bytes, st)) ||
             (rc = upload_vec(B[kBQStart], C->q_start, 4 * C->n_overlaps, st)) || (rc = upload_vec(B[kBTBegin], C->t_begin, 4 * C->n_overlaps, st)) ||
             (rc = upload_vec(B[kBTEnd], C->t_end, 4 * C->n_overlaps, st))) { drop_events(); return rc; }
         HIP_TRY(hipMemsetAsync(B[kBBpT].p, 0, 4 * n_points + 16, st));
