@@ -250,9 +250,99 @@ __global__ __launch_bounds__(256) void k_cigar_breaking_points(CigarParams C) {
     }
 }
 
+// The same walk with one WAVE per overlap: 64 bytes of CIGAR text per step, no divergence.  Lanes holding an operation
+// character parse the number in front of it (the digits sit in the lanes before it, or in the carry of the previous
+// step), two wave scans turn the operation lengths into target / query start positions, and every match run writes its
+// candidates for "first match column" (min) and "last + 1" (max) of the windows it covers with 64-bit atomics on packed
+// (target << 32 | query) keys -- inside one overlap both coordinates grow together, so the packed order is the walk
+// order.  A window counts only once the walk has passed its end (the reference pushes a pair when it closes a window).
+struct CigarWaveParams {
+    CigarParams c;
+    unsigned long long* first_key;                // [slots] initialised to ~0
+    unsigned long long* last_key;                 // [slots] initialised to 0
+};
+
+__global__ __launch_bounds__(256) void k_cigar_breaking_points_wave(CigarWaveParams P) {
+    const CigarParams& C = P.c;
+    const int lane = threadIdx.x & 63;
+    const uint64_t o = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (o >= C.n_overlaps) return;
+    const uint64_t W = C.W;
+    const uint64_t t_begin = C.t_begin[o], t_end = C.t_end[o];
+    const uint64_t slot0 = C.bp_off[o] / 2, n_slots = (C.bp_off[o + 1] - C.bp_off[o]) / 2;
+    const uint64_t wb = t_begin / W;                                  // window number of slot 0
+    auto end_of = [&](uint64_t k) -> uint64_t { return k + 1 < n_slots ? (wb + 1 + k) * W - 1 : t_end - 1; };
+    const uint64_t a = C.cigar_off[o], z = C.cigar_off[o + 1];
+    uint64_t t_run = t_begin, q_run = C.q_start[o];                    // next target / query position to be consumed
+    uint64_t carry = 0;                                               // value of the digits pending from the previous step
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint64_t p0 = a; p0 < z; p0 += 64) {
+        const uint64_t p = p0 + lane;
+        const uint32_t c = p < z ? C.cigar[p] : '0';                  // padding = digits that never meet an operation
+        const bool is_digit = c >= '0' && c <= '9';
+        const unsigned long long opmask = __ballot(!is_digit);
+        // the number in front of this lane's operation: lanes (prev operation, lane) exclusive
+        const unsigned long long before = opmask & below;
+        const int first_digit = before ? 64 - __builtin_clzll(before) : 0;   // lane after the previous operation
+        const int ndig = lane - first_digit;
+        unsigned long long n = 0;
+        const int maxdig = __reduce_max_sync(~0ull, is_digit ? 0 : ndig);
+        for (int d = 0; d < maxdig; ++d) {
+            const uint32_t dc = __shfl(c, (first_digit + d) & 63);
+            if (!is_digit && d < ndig) n = n * 10 + (dc - '0');
+        }
+        if (!is_digit && first_digit == 0 && carry) {                 // the number started in the previous step
+            unsigned long long scale = 1;
+            for (int d = 0; d < ndig; ++d) scale *= 10;
+            n += carry * scale;
+        }
+        // carry out: the digits behind the last operation of this step (everything, if there is none)
+        {
+            const int tail0 = opmask ? 64 - __builtin_clzll(opmask) : 0;
+            unsigned long long v = opmask ? 0 : carry;
+            for (int d = tail0; d < 64 && p0 + d < z; ++d) v = v * 10 + (__shfl(c, d) - '0');
+            carry = v;
+        }
+        n = static_cast<uint32_t>(n);                                  // the reference parses into uint32
+        const bool isM = !is_digit && (c == 'M' || c == '=' || c == 'X');
+        const unsigned long long dt = (isM || (!is_digit && (c == 'D' || c == 'N'))) ? n : 0;
+        const unsigned long long dq = (isM || (!is_digit && c == 'I')) ? n : 0;
+        unsigned long long st = dt, sq = dq;                          // inclusive scans
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long vt = __shfl_up(st, d), vq = __shfl_up(sq, d);
+            if (lane >= d) { st += vt; sq += vq; }
+        }
+        const uint64_t ts = t_run + (st - dt), qs = q_run + (sq - dq);
+        if (isM && n > 0) {
+            const uint64_t te = ts + n;                               // match columns ts .. te - 1
+            for (uint64_t k = ts / W - wb; k < n_slots; ++k) {
+                const uint64_t wstart = k == 0 ? t_begin : (wb + k) * W, wend = end_of(k);
+                if (wstart >= te) break;
+                const uint64_t f = ts > wstart ? ts : wstart, l = te < wend + 1 ? te : wend + 1;
+                if (f < l) {
+                    atomicMin(&P.first_key[slot0 + k], (f << 32) | (qs + (f - ts)));
+                    atomicMax(&P.last_key[slot0 + k], (l << 32) | (qs + (l - ts)));
+                }
+            }
+        }
+        t_run += __shfl(st, 63); q_run += __shfl(sq, 63);
+    }
+    __threadfence();
+    // a window whose end the walk has passed is closed: its pair (if a match column was seen) is what the reference pushed
+    for (uint64_t k = lane; k < n_slots; k += 64) {
+        const unsigned long long f = P.first_key[slot0 + k], l = P.last_key[slot0 + k];
+        if (l != 0 && f != ~0ull && end_of(k) + 1 <= t_run) {
+            const uint64_t out = C.bp_off[o] + 2 * k;
+            C.bp_t[out] = static_cast<uint32_t>(f >> 32); C.bp_q[out] = static_cast<uint32_t>(f);
+            C.bp_t[out + 1] = static_cast<uint32_t>(l >> 32); C.bp_q[out + 1] = static_cast<uint32_t>(l);
+        }
+    }
+}
+
 // slots of rcn_engine::d_build
 enum { kBReadOff, kBReadBases, kBReadQuals, kBReadHasQual, kBQid, kBTid, kBStrand, kBBpOff, kBBpT, kBBpQ, kBFirstWin, kBPairs, kBTemp, kBSeqSrc, kBMisc, kBSeqLen,
-       kBCigarOff, kBCigar, kBQStart, kBTBegin, kBTEnd, kBuildSlots };
+       kBCigarOff, kBCigar, kBQStart, kBTBegin, kBTEnd, kBKeyFirst, kBKeyLast, kBuildSlots };
 
 // `C` != nullptr: the breaking points are computed on the device from the alignments (O then only carries n_overlaps,
 // q_id, t_id, strand and a host vector of slot offsets in bp_off; its bp_t / bp_q are null).
@@ -328,7 +418,16 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
         K.cigar_off = B[kBCigarOff].as<uint64_t>(); K.cigar = B[kBCigar].as<uint8_t>(); K.q_start = B[kBQStart].as<uint32_t>();
         K.t_begin = B[kBTBegin].as<uint32_t>(); K.t_end = B[kBTEnd].as<uint32_t>(); K.bp_off = P.bp_off;
         K.bp_t = B[kBBpT].as<uint32_t>(); K.bp_q = B[kBBpQ].as<uint32_t>(); K.n_overlaps = C->n_overlaps; K.W = W;
-        hipLaunchKernelGGL(k_cigar_breaking_points, dim3(static_cast<uint32_t>((C->n_overlaps + 255) / 256)), dim3(256), 0, st, K);
+        if (getenv("RCN_CIGAR_SERIAL")) {        // the per-thread restatement (kept: it is the reference's loop, operation by operation)
+            hipLaunchKernelGGL(k_cigar_breaking_points, dim3(static_cast<uint32_t>((C->n_overlaps + 255) / 256)), dim3(256), 0, st, K);
+        } else {
+            const uint64_t n_slots_all = n_points / 2;
+            if ((rc = B[kBKeyFirst].reserve(8 * n_slots_all + 16)) || (rc = B[kBKeyLast].reserve(8 * n_slots_all + 16))) { drop_events(); return rc; }
+            HIP_TRY(hipMemsetAsync(B[kBKeyFirst].p, 0xff, 8 * n_slots_all + 16, st));
+            HIP_TRY(hipMemsetAsync(B[kBKeyLast].p, 0, 8 * n_slots_all + 16, st));
+            CigarWaveParams KW{K, B[kBKeyFirst].as<unsigned long long>(), B[kBKeyLast].as<unsigned long long>()};
+            hipLaunchKernelGGL(k_cigar_breaking_points_wave, dim3(static_cast<uint32_t>((C->n_overlaps + 3) / 4)), dim3(256), 0, st, KW);
+        }
     }
     hipLaunchKernelGGL(k_symbols, dim3(static_cast<uint32_t>(std::min<uint64_t>(1024, (read_bytes + 1023) / 1024 + 1))), dim3(256), 0, st, P.bases, read_bytes, d_err + 1);
     if (n_pairs) hipLaunchKernelGGL(k_layer_filter, dim3(static_cast<uint32_t>((n_pairs + 3) / 4)), dim3(256), 0, st, P);

@@ -117,3 +117,48 @@ def test_build_windows_from_cigars_on_committed_reference_fixture():
     eng = HipEngine(5, -4, -8, True)
     eng.build_windows_from_cigars(r, al, wl, qt, wt)
     same_batch(eng.export_batch(), WindowBatch.load(os.path.join(GOLD, "sam_fastq_w500.npz")), "reference fixture, from CIGARs")
+
+
+@pytest.mark.parametrize("serial", [False, True])
+def test_cigar_walk_edge_cases(oracle, serial, monkeypatch):
+    """Hand-made alignments for both device kernels of the CIGAR walk (wave per overlap; RCN_CIGAR_SERIAL=1: thread per
+    overlap) against the base-by-base restatement of reference src/overlap.cpp:226-292: =/X/N operations, clips, zero
+    counts, runs crossing many windows, deletions swallowing whole windows, numbers that straddle the 64-byte steps of the
+    wave kernel, and a CIGAR that ends before the overlap's target extent (the last window is then never closed)."""
+    from oracle.window_layout import breaking_points, window_layout
+    from racon_amd.engine import HipEngine
+    from racon_amd.layout import CigarSet, ReadSet
+    if serial:
+        monkeypatch.setenv("RCN_CIGAR_SERIAL", "1")
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    target = acgt[rng.integers(0, 4, 5000)].tobytes()
+    reads = [(target, None)]
+    al = []
+
+    def add(cigar: bytes, t_begin: int, strand: int = 0, t_short: int = 0):
+        import re
+        ops = [(int(n or 0), op) for n, op in re.findall(rb"(\d*)([A-Z=])", cigar)]
+        qlen = sum(n for n, op in ops if op in b"M=XI")
+        tlen = sum(n for n, op in ops if op in b"M=XDN")
+        clip = sum(n for n, op in ops if op in b"S")
+        seq = acgt[rng.integers(0, 4, qlen + clip + 7)].tobytes()
+        reads.append((seq, bytes((rng.integers(10, 30, len(seq)) + 33).astype(np.uint8).tolist())))
+        al.append((len(reads) - 1, 0, strand, clip, t_begin, t_begin + tlen + t_short, cigar))
+
+    add(b"10S5M2I3D100M5H", 37)
+    add(b"2000M", 400)
+    add(b"100M600D100M", 250, strand=1)
+    add(b"50=3X0M20=1000N30X10=", 1200)
+    add(b"1M" * 40 + b"1234M" + b"7I" * 3 + b"3D2M", 100)            # "1234M" straddles byte 64 of the text
+    add(b"9M" * 31 + b"0I" + b"321M5D4M", 77)                            # the number ends exactly at the step border
+    add(b"300M", 4600, t_short=60)                                       # CIGAR stops 60 columns before t_end
+    add(b"499M", 1)
+    add(b"1M498D1M", 2500)
+    r = ReadSet.from_sequences(reads, 1)
+    a = CigarSet.from_lists(al)
+    for w in (500, 97):
+        ref = window_layout(r, breaking_points(a, w), w, 0.0, 1)
+        eng = HipEngine()
+        eng.build_windows_from_cigars(r, a, w, 0.0, 1)
+        same_batch(eng.export_batch(), ref, f"cigar edge cases w={w} serial={serial}")
