@@ -1,0 +1,44 @@
+"""-m gpu: bench.py prints ONE JSON line with the contract's keys (driver contract + the `roofline` / `cpu_baseline` objects),
+single rank and two ranks on one GPU (torch.distributed with gloo, the code path the driver launches with torchrun)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _line(out: bytes) -> dict:
+    lines = [l for l in out.decode().splitlines() if l.strip() and not l.startswith("[Gloo]")]      # gloo chats on stdout
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_single_rank_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--contig", "100000", "--cpu-sample", "64"],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT).stdout
+    j = _line(out)
+    assert KEYS <= set(j), KEYS - set(j)
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["unit"] == "windows/s" and j["dtype"] == "int16" and j["scaling"] == "weak" and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["achieved"] > 0 and abs(j["value"] - 200 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "windows/s" and c["sample"]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--contig", "100000", "--no-cpu", "--dist-backend", "gloo"],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, env=env).stdout
+    j = _line(out)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    assert abs(j["value"] - 2 * 200 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6      # whole-job aggregate over both ranks
