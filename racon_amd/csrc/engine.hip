@@ -72,7 +72,7 @@ struct rcn_engine {
     DevBuf d_lpt_ids, d_win_ids, d_win_flags, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
     HostBuf h_raw;
     std::vector<WinShape> shapes;
-    int32_t heavy_ns = 0, prio_ns = 0;
+    int32_t heavy_ns = 0;
     std::vector<uint32_t> h_win_seq_off;
     std::vector<uint32_t> lpt;          // work item -> window, deepest windows first (longest processing time first)
     bool uploaded = false, ran = false;
@@ -137,7 +137,7 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.win_ids = ids ? e->d_win_ids.as<uint32_t>() : d_ids; P.n_work = n_work;
     P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : e->d_win_flags.as<uint8_t>();
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
-    P.heavy_ns = e->heavy_ns; P.prio_ns = e->prio_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
+    P.heavy_ns = e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.scratch = e->d_scratch.as<uint8_t>(); P.slot_bytes = c.slot_bytes;
     P.ncap = c.ncap; P.ecap = c.ecap; P.ring = c.ring; P.lmax = c.lmax; P.hstride = c.hstride;
     P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_stride = out_stride;
@@ -391,14 +391,6 @@ int rcn_engine_run(rcn_engine* e) {
         std::vector<uint32_t> sorted = depth;
         const char* pe = getenv("RCN_HEAVY_PCT");
         const double pct = pe ? atof(pe) : 1.0;
-        {
-            const char* pp = getenv("RCN_PRIO_PCT");
-            const double ppct = pp ? atof(pp) : 1.0;
-            std::vector<uint32_t> s2 = depth;
-            const size_t k2 = std::min<size_t>(nw - 1, static_cast<size_t>(ppct * nw));
-            std::nth_element(s2.begin(), s2.begin() + k2, s2.end());
-            e->prio_ns = ppct >= 1.0 ? 0 : static_cast<int32_t>(std::max<uint32_t>(s2[k2], 3));
-        }
         const size_t kth = std::min<size_t>(nw - 1, static_cast<size_t>(pct * nw));
         std::nth_element(sorted.begin(), sorted.begin() + kth, sorted.end());
         e->heavy_ns = pct >= 1.0 ? 0 : static_cast<int32_t>(std::max<uint32_t>(sorted[kth], 3));

@@ -35,7 +35,6 @@ struct KParams {
     const uint8_t* win_flags;     // [n_windows] bit 0: every base of the window is A, C, G or T (poa_window_kernel2: profile table); nullptr = unknown
     const uint32_t* win_ids;      // [n_work] indirection (retry pass) or nullptr
     uint32_t n_work;
-    int32_t prio_ns;              // poa_window_kernel2: windows with at least this many sequences run at raised wave priority (0 = none)
     int32_t force_exact;          // poa_window_kernel2: 1 = every window takes the exact-order consensus path (tests; env RCN_FORCE_EXACT)
     int32_t heavy_ns;             // poa_window_kernel2: windows with at least this many sequences use the 4-wave DP (0 = none)
     int32_t m, x, g, trim;

@@ -1754,10 +1754,6 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         const int L = static_cast<int>(P.seq_off[s0 + 1] - P.seq_off[s0]);
         uint8_t* out = P.out_cons + static_cast<uint64_t>(wi) * P.out_stride;   // outputs are indexed by work item
 
-        // deep windows finish last (their serial chain is the launch time): give their waves issue priority while
-        // the chip is still crowded
-        const bool deep = P.prio_ns > 0 && ns >= P.prio_ns;
-        if (deep) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
         const bool heavy = P.heavy_ns > 0 && ns >= P.heavy_ns;
         if (ns < 3) {                                          // window.cpp:68-71
             for (int i = t; i < L; i += kThreads2) out[i] = bb[i];
