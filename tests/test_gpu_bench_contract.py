@@ -14,9 +14,11 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 
 def _line(out: bytes) -> dict:
-    lines = [l for l in out.decode().splitlines() if l.strip() and not l.startswith("[Gloo]")]      # gloo chats on stdout
-    assert len(lines) == 1, lines
-    return json.loads(lines[0])
+    # exactly one JSON object on stdout (with --dist-backend gloo the gloo library also chats there, possibly mid-line)
+    text = out.decode()
+    assert text.count('{"metric"') == 1, text
+    obj, _ = json.JSONDecoder().raw_decode(text[text.index('{"metric"'):])
+    return obj
 
 
 def test_bench_single_rank_line():
