@@ -800,9 +800,16 @@ __device__ __noinline__ void dp2_rows() {
 }
 
 // ---- phase: sink tie-break (rare) + traceback over int16 Z tiles ----
-constexpr int kTile2Cols = 128;        // int16 cells per tile row (256 B = one 64-lane x 4 B global_load_lds)
-constexpr int kTile2Stride = 136;      // LDS row stride in cells: 272 B, i.e. 4 banks of skew per row -- the lanes of a
-                                       // box read the same column of up to 10 consecutive rows in one instruction
+// Tile of the finished matrix staged in LDS for the walk: kTbRows consecutive DP rows x 64 columns.  The path climbs
+// ~3.4 rows per column on a 30x graph, so rows, not columns, are what a tile runs out of: 112 x 64 instead of 64 x 128
+// costs the same LDS and halves the number of stagings (each one is an HBM round trip plus two work-group barriers on
+// the window's serial chain).  One 64-lane x 4 B global_load_lds moves 256 B = two rows of 64 cells, which land
+// contiguously: row pair p at p * kTile2Pair cells, its odd row 64 cells further.
+constexpr int kTbRows = 112;
+constexpr int kTile2Cols = 64;         // int16 cells per tile row
+constexpr int kTile2Pair = 136;        // LDS stride of a row PAIR in cells (272 B: 4 banks of skew per pair)
+__device__ __forceinline__ int tile_at(int trow, int tcol) { return (trow >> 1) * kTile2Pair + (trow & 1) * kTile2Cols + tcol; }
+static_assert((kTbRows / 2) * kTile2Pair * 2 + kTbRows * 32 + kTile2Cols + 8 <= kLdsBytes, "tile + row descriptors + sequence slice must fit");
 
 __device__ __forceinline__ void traceback2_slow_step(Win& g, RCN_G const int32_t* nr, bool sub, RCN_G const uint8_t* seq,
                                                      int m, int x, int gp, int& i, int& j, int& n) {
@@ -1230,14 +1237,14 @@ __device__ __noinline__ void phase_traceback3() {
     }
     Block4::sync();
 
-    int16_t* tile = reinterpret_cast<int16_t*>(Block4::work());                       // [64][kTile2Stride]
-    int* tdesc = Block4::work() + 64 * kTile2Stride / 2;                               // 64 x RowDesc (8 ints each)
-    uint8_t* tseq = reinterpret_cast<uint8_t*>(tdesc + 64 * (sizeof(RowDesc) / 4));   // seq[c0 - 1 + k], k in [0, 128]
+    int16_t* tile = reinterpret_cast<int16_t*>(Block4::work());                       // [kTbRows / 2][kTile2Pair]
+    int* tdesc = Block4::work() + (kTbRows / 2) * kTile2Pair / 2;                      // kTbRows x RowDesc (8 ints each)
+    uint8_t* tseq = reinterpret_cast<uint8_t*>(tdesc + kTbRows * (sizeof(RowDesc) / 4));   // seq[c0 - 1 + k], k in [0, 64]
     RCN_G int32_t* __restrict__ prow = g.pos_t.ptr();
     int i = bcast0(o->tb_i), j = bcast0(o->tb_j);
     int overflow = g.overflow;
     while (!(i == 0 && j == 0)) {
-        // ---- stage the tile: rows [i-63, i] (tile row r holds matrix row i - r), cols [c0, c0+127] ----
+        // ---- stage the tile: rows [i - kTbRows + 1, i] (tile row r holds matrix row i - r), cols [c0, c0 + 63] ----
 #ifdef RCN_PROF_DP
         const long long tp0__ = clock64();
 #endif
@@ -1245,28 +1252,32 @@ __device__ __noinline__ void phase_traceback3() {
 #ifdef RCN_PROF_WIN
         if (t == 0) o->dbg_tiles += 1;
 #endif
-        int c0 = (j - 120) & ~7; if (c0 < 0) c0 = 0;
-        const int rmin = ti0 - 63 > 0 ? ti0 - 63 : 0;
+        int c0 = (j - 56) & ~7; if (c0 < 0) c0 = 0;
+        const int rmin = ti0 - (kTbRows - 1) > 0 ? ti0 - (kTbRows - 1) : 0;
         {
             typedef __attribute__((address_space(3))) void* lds_ptr;
+            constexpr int kPairsPerWave = kTbRows / 2 / kWaves2;       // 14
+            static_assert(kPairsPerWave * kWaves2 * 2 == kTbRows, "rows split evenly over the waves, two per load");
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const int k = 16 * wv + kk;                   // tile row
-                int r = ti0 - k; if (r < 0) r = 0;
-                RCN_G const int16_t* src = H + r * hs + c0 + lane * 2;
-                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(tile + k * kTile2Stride), 4, 0, 0);
+            for (int kk = 0; kk < kPairsPerWave; ++kk) {
+                const int pr = kPairsPerWave * wv + kk;           // row pair: tile rows 2 pr (lanes 0-31) and 2 pr + 1 (lanes 32-63)
+                int r = ti0 - (2 * pr + (lane >> 5)); if (r < 0) r = 0;
+                RCN_G const int16_t* src = H + r * hs + c0 + (lane & 31) * 2;
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(tile + pr * kTile2Pair), 4, 0, 0);
             }
-            if (wv == 1) {
-                const int r = ti0 - lane;
-                int4 d0 = make_int4(0, -1, -1, -1), d1 = make_int4(-1, -1, -1, 1 << 9);
-                if (r >= 1) { RCN_G const int4* dsrc = reinterpret_cast<RCN_G const int4*>(g.desc.ptr() + (r - 1)); d0 = dsrc[0]; d1 = dsrc[1]; }
-                int4* ddst = reinterpret_cast<int4*>(tdesc + lane * 8);
-                ddst[0] = d0; ddst[1] = d1;
-            } else if (wv >= 2) {
-                const int kx = (wv - 2) * 64 + lane;          // 0..127
-                const int sc = c0 - 1 + kx;
-                tseq[kx] = (sc >= 0 && sc < len) ? seq[sc] : 0;
-                if (kx == 0) { const int s2 = c0 - 1 + 128; tseq[128] = (s2 >= 0 && s2 < len) ? seq[s2] : 0; }
+            if (wv == 1 || wv == 2) {
+                const int k = (wv - 1) * 64 + lane;               // tile row whose descriptor this lane stages
+                if (k < kTbRows) {
+                    const int r = ti0 - k;
+                    int4 d0 = make_int4(0, -1, -1, -1), d1 = make_int4(-1, -1, -1, 1 << 9);
+                    if (r >= 1) { RCN_G const int4* dsrc = reinterpret_cast<RCN_G const int4*>(g.desc.ptr() + (r - 1)); d0 = dsrc[0]; d1 = dsrc[1]; }
+                    int4* ddst = reinterpret_cast<int4*>(tdesc + k * 8);
+                    ddst[0] = d0; ddst[1] = d1;
+                }
+            } else if (wv == 3) {
+                const int sc = c0 - 1 + lane;
+                tseq[lane] = (sc >= 0 && sc < len) ? seq[sc] : 0;
+                if (lane == 0) { const int s2 = c0 - 1 + 64; tseq[64] = (s2 >= 0 && s2 < len) ? seq[s2] : 0; }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1293,7 +1304,7 @@ __device__ __noinline__ void phase_traceback3() {
                 const int* dr = tdesc + trow * 8;
                 const int4 pa = *reinterpret_cast<const int4*>(dr);
                 const int4 pb = *reinterpret_cast<const int4*>(dr + 4);
-                const int hij = tile[trow * kTile2Stride + tcol];
+                const int hij = tile[tile_at(trow, tcol)];
                 const int symc = tseq[tcol];                                    // seq[jj - 1]
                 const int meta = pb.w, erest = pb.z;
                 const int np = (meta >> 9) & 15;
@@ -1309,7 +1320,7 @@ __device__ __noinline__ void phase_traceback3() {
                 auto look = [&](int q) {
                     const int useq = q < npb;
                     if (useq && pq[q] < rmin) ok = false;
-                    const int16_t* zp = tile + ((useq && pq[q] >= rmin) ? ti0 - pq[q] : 0) * kTile2Stride + tcol;
+                    const int16_t* zp = tile + tile_at((useq && pq[q] >= rmin) ? ti0 - pq[q] : 0, tcol);
                     const int hdq = zp[tcol > 0 ? -1 : 0], huq = zp[0];
                     const int isd = useq & colok & (hij == hdq + mc);
                     const int isu = useq & (hij == huq + gp);
@@ -1358,7 +1369,7 @@ __device__ __noinline__ void phase_traceback3() {
                 if (stuck) break;
             }
             if (!(i == 0 && j == 0) && i == ti0 && j == j_stage) {
-                // no progress on a freshly anchored tile (predecessor > 63 rows back or > 6 in-edges): one
+                // no progress on a freshly anchored tile (predecessor beyond the tile's rows or > 6 in-edges): one
                 // step against HBM
 #ifdef RCN_PROF_WIN
                 if (lane == 0) o->dbg_slow += 1;
