@@ -1214,8 +1214,8 @@ __device__ __noinline__ void phase_sink_tie_full() {
 // LDS round trips and ballots.  Output: pos_t[pos] = DP row aligned to sequence position pos, or -1.
 constexpr int kMvDiag = 0, kMvUp = 1, kMvLeft = 2, kMvInvalid = 3;
 #ifndef RCN_BOX_ROWS
-#define RCN_BOX_ROWS 10
-#define RCN_BOX_COLS 6
+#define RCN_BOX_ROWS 9
+#define RCN_BOX_COLS 7
 #endif
 constexpr int kBoxRows = RCN_BOX_ROWS, kBoxCols = RCN_BOX_COLS;   // <= 64 cells; the path drops ~1.7 rows per column on a 30x graph
 constexpr int kNxExit = 64, kNxInvalid = 65;
