@@ -138,6 +138,8 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : e->d_win_flags.as<uint8_t>();
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
     P.heavy_ns = e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
+    P.force_tie = getenv("RCN_FORCE_TIE") ? atoi(getenv("RCN_FORCE_TIE")) : 0;
+    P.force_slow_tb = getenv("RCN_FORCE_SLOW_TB") ? 1 : 0;
     P.scratch = e->d_scratch.as<uint8_t>(); P.slot_bytes = c.slot_bytes;
     P.ncap = c.ncap; P.ecap = c.ecap; P.ring = c.ring; P.lmax = c.lmax; P.hstride = c.hstride;
     P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_stride = out_stride;

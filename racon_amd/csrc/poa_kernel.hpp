@@ -37,6 +37,10 @@ struct KParams {
     uint32_t n_work;
     int32_t force_exact;          // poa_window_kernel2: 1 = every window takes the exact-order consensus path (tests; env RCN_FORCE_EXACT)
     int32_t heavy_ns;             // poa_window_kernel2: windows with at least this many sequences use the 4-wave DP (0 = none)
+    int32_t force_tie;            // poa_window_kernel2, tests (env RCN_FORCE_TIE): 2 = every sink tie skips the id / backbone-position
+                                  // rule (levels 2a/2b decide), 3 = every sink tie takes the full DFS (phase_sink_tie_full)
+    int32_t force_slow_tb;        // poa_window_kernel2, tests (env RCN_FORCE_SLOW_TB): every traceback step is the one-cell step
+                                  // against HBM (traceback2_slow_step) instead of the box walk over the staged tile
     int32_t m, x, g, trim;
     // per-slot scratch
     uint8_t* scratch; uint64_t slot_bytes; int32_t ncap, ecap, ring, lmax, hstride;

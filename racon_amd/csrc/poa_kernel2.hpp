@@ -1290,6 +1290,7 @@ __device__ __noinline__ void phase_traceback3() {
             // box = kBoxRows x kBoxCols cells below/left of the current cell, one per lane: (i - a, j - b)
             const int a = lane / kBoxCols, b = lane % kBoxCols;
             for (;;) {
+                if (c.tie_pad[2]) break;                 // test switch (KParams::force_slow_tb): no box walk at all
                 if (i == 0 && j == 0) break;
 #ifdef RCN_PROF_DP
                 ++nbox__;
@@ -1787,7 +1788,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     g.e_w[i] = pair_weight(q0, i + 1);
                 }
             }
-            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; ctx->pad0 = heavy; ctx->bblen = L; ctx->tie_pad[1] = P.win_flags ? (P.win_flags[w] & 1) : 0; }
+            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; ctx->pad0 = heavy; ctx->bblen = L; ctx->tie_pad[1] = P.win_flags ? (P.win_flags[w] & 1) : 0; ctx->tie_pad[2] = P.force_slow_tb; }
         }
         Block4::sync();
 
@@ -1846,6 +1847,13 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 if (wv == 0) phase_sink_tie_rule();
                 Block4::sync();
                 int st = bcast0(ctx->tb_n);
+                if (P.force_tie) {
+                    // test switches: the cheaper levels' answers are discarded, a later level must reproduce them
+                    // (more than eight tied sinks / graphs beyond the LDS sweep stay on the full DFS either way)
+                    if (P.force_tie >= 3) { st = 2; if (t == 0) ctx->tie_why = 6; }
+                    else if (st == 0 && bcast0(ctx->n_nodes) <= kLdsBytes) st = 1;
+                    Block4::sync();
+                }
                 if (st == 1) {
                     if (wv == 0) phase_sink_tie_starts();
                     Block4::sync();

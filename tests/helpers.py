@@ -1,8 +1,17 @@
 """Shared test helpers: hand-made edge-case windows and comparison utilities."""
+import os
+
 import numpy as np
 
 from racon_amd.batch import WindowBatch
 from racon_amd.synth import simulate_windows
+
+
+# The reference's own test inputs (reference test/data/*, 3 MB of gz files), committed as fixtures so that the
+# end-to-end goldens of reference test/racon_test.cpp:86-295 also run on the GPU box, where /root/reference does
+# not exist.  tests/test_reference_goldens.py::test_refdata_is_the_reference_data checks them byte for byte
+# against /root/reference wherever that is present.
+REFDATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdata") + os.sep
 
 
 def q(s, v=20):

@@ -76,3 +76,40 @@ def test_fuzz_windows_exact_order_consensus(oracle, seed, scores, monkeypatch):
     b3 = simulate_windows(30000, 200, 60.0, 150, sub=0.003, ins=0.0005, dele=0.0005, seed=400 + seed,
                           phred_mean=30.0, phred_sd=0.0, phred_lo=30, phred_hi=30)    # short reads: Subgraph layers
     assert_same(HipEngine(*scores, True).consensus(b3), oracle.consensus(b3, *scores, True, 0), f"forced exact, short reads seed {seed}")
+
+
+@pytest.mark.parametrize("level,seed,scores", [(3, 9, (3, -5, -4)), (3, 10, (1, -1, -1)), (2, 11, (3, -5, -4)), (2, 12, (5, -4, -8))])
+def test_fuzz_windows_forced_sink_tie_levels(oracle, level, seed, scores, monkeypatch):
+    """Sink ties (several sinks share the best NW score: spoa takes the first in ITS rank order) resolved by the later
+    levels only: RCN_FORCE_TIE=3 sends every tie to phase_sink_tie_full (spoa's whole DFS TopologicalSort -- never needed
+    on the ordinary test sets), RCN_FORCE_TIE=2 discards the id / backbone-position rule so that the bubble search plus the
+    local DFS (phase_sink_tie_starts / phase_sink_tie_local) must reproduce its answers."""
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    monkeypatch.setenv("RCN_FORCE_TIE", str(level))
+    rng = np.random.default_rng(3000 + seed)
+    wins = [random_window(rng, k) for k in range(400)]
+    b = WindowBatch.from_windows(wins)
+    eng = HipEngine(*scores, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, *scores, True, 0), f"forced tie level {level}, fuzz seed {seed}")
+    if level == 3:
+        assert eng.stats()["n_sink_ties"] > 0, "the fuzz set must contain sink ties, else this test checks nothing"
+    b3 = simulate_windows(20000, 200, 60.0, 150, sub=0.003, ins=0.0005, dele=0.0005, seed=500 + seed,
+                          phred_mean=30.0, phred_sd=0.0, phred_lo=30, phred_hi=30)    # short reads: Subgraph layers, many ties
+    eng3 = HipEngine(*scores, True)
+    assert_same(eng3.consensus(b3), oracle.consensus(b3, *scores, True, 0), f"forced tie level {level}, short reads seed {seed}")
+
+
+@pytest.mark.parametrize("seed,scores", [(13, (3, -5, -4)), (14, (5, -4, -8))])
+def test_fuzz_windows_forced_slow_traceback(oracle, seed, scores, monkeypatch):
+    """RCN_FORCE_SLOW_TB: every traceback step is the one-cell step against HBM (traceback2_slow_step: normally only taken
+    when a predecessor lies beyond the staged tile or a node has more than six in-edges)."""
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    monkeypatch.setenv("RCN_FORCE_SLOW_TB", "1")
+    rng = np.random.default_rng(4000 + seed)
+    wins = [random_window(rng, k) for k in range(200)]
+    b = WindowBatch.from_windows(wins)
+    assert_same(HipEngine(*scores, True).consensus(b), oracle.consensus(b, *scores, True, 0), f"slow traceback, fuzz seed {seed}")
+    b2 = simulate_windows(6000, 500, 12.0, 3000, seed=600 + seed)
+    assert_same(HipEngine(*scores, True).consensus(b2), oracle.consensus(b2, *scores, True, 0), f"slow traceback, synthetic seed {seed}")

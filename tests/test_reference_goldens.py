@@ -1,20 +1,34 @@
 """The reference's own test suite (reference test/racon_test.cpp:53-295), re-stated against this
 repo's host layer (racon_amd/host: createPolisher / initialize / windows / assemble) with the CPU
 ORACLE as the consensus backend.  This is what pins the oracle: every golden number of the
-reference's CPU tests must come out exactly.  Needs /root/reference/test/data (build container
-only; skipped on the GPU box, where tests/golden/ carries the derived fixtures instead).
+reference's CPU tests must come out exactly.  The inputs are the reference's own test data
+(reference test/data/*.gz), committed under tests/golden/refdata/ so that they travel to the GPU box.
 
 -m gpu twins at the bottom run the same pipelines with the HIP engine (racon::Polisher::polish
-on the MI355X) where the reference data is present.
+on the MI355X): all ten goldens of racon_test.cpp:86-295, plus the byte-level pins of SURVEY.md §4
+(md5 of the polished contig, including the CLI-default scores 3,-5,-4 that no reference test covers).
 """
+import glob
 import gzip
+import hashlib
 import os
 import re
 
 import pytest
 
-DATA = "/root/reference/test/data/"
-pytestmark = pytest.mark.skipif(not os.path.isdir(DATA), reason="reference test data not present")
+from helpers import REFDATA as DATA
+
+
+def test_refdata_is_the_reference_data():
+    """tests/golden/refdata/ is a byte-for-byte copy of reference test/data/ (checked wherever /root/reference exists)."""
+    src = "/root/reference/test/data/"
+    names = sorted(os.path.basename(f) for f in glob.glob(DATA + "*.gz"))
+    assert len(names) == 8
+    if not os.path.isdir(src):
+        pytest.skip("no /root/reference here (GPU box): nothing to compare the fixtures with")
+    assert names == sorted(os.path.basename(f) for f in glob.glob(src + "*.gz"))
+    for n in names:
+        assert open(DATA + n, "rb").read() == open(src + n, "rb").read(), n
 
 
 @pytest.fixture(scope="module")
@@ -63,6 +77,35 @@ CONTIG = [  # reads, overlaps, window, scores, golden edit distance, line of the
     ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", 1000, (5, -4, -8), 1289, 197),
     ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", 500, (1, -1, -1), 1321, 220),
 ]
+# Byte-level pins ("secondary known-answer values": md5 of the polished contig's sequence line as
+# produced by the survey's golden-matching emulation, an implementation independent of this repo's oracle and
+# kernels).  The last four are at the CLI default scores (reference src/main.cpp:51-53), which no reference test uses;
+# "line" is None for them and the edit distance is the survey's, not a golden of racon_test.cpp.
+CONTIG_MD5 = {
+    ("sample_reads.fastq.gz", "sample_overlaps.sam.gz", 500, (5, -4, -8)): (47856, "140745a3a8751649f5fd8e8249832852"),
+    ("sample_reads.fasta.gz", "sample_overlaps.sam.gz", 500, (5, -4, -8)): (47648, "396d9b2d97f7e332e3841eb133796365"),
+    ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", 500, (5, -4, -8)): (47867, "50fcf81823139653f9f42d0ce94d1532"),
+    ("sample_reads.fasta.gz", "sample_overlaps.paf.gz", 500, (5, -4, -8)): (48012, "7a15787a93caa5c38216d0d00f4f222d"),
+    ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", 1000, (5, -4, -8)): (47810, "18258270f40cc667dab261571471f77a"),
+    ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", 500, (1, -1, -1)): (47839, "bd046f6e499affa21430109256ac37ae"),
+    ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", 500, (3, -5, -4)): (47676, "fa5470d402063abecea4aa65650e7ac9"),
+    ("sample_reads.fasta.gz", "sample_overlaps.paf.gz", 500, (3, -5, -4)): (47860, "44bdcec7c523fd24b9c3e4ccf4c09d19"),
+    ("sample_reads.fastq.gz", "sample_overlaps.sam.gz", 500, (3, -5, -4)): (47714, "1a32a746668f40a882bb7e131f5894ab"),
+    ("sample_reads.fasta.gz", "sample_overlaps.sam.gz", 500, (3, -5, -4)): (47548, "a9be0f28fd30b470c0a78429069403b7"),
+}
+CLI_DEFAULT = [  # reads, overlaps, window, scores, the survey's edit distance
+    ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", 500, (3, -5, -4), 1325, None),
+    ("sample_reads.fasta.gz", "sample_overlaps.paf.gz", 500, (3, -5, -4), 1542, None),
+    ("sample_reads.fastq.gz", "sample_overlaps.sam.gz", 500, (3, -5, -4), 1319, None),
+    ("sample_reads.fasta.gz", "sample_overlaps.sam.gz", 500, (3, -5, -4), 1808, None),
+]
+KF_WINDOWS_MD5 = "cb6faddab0066d4b5b0c6227b400beda"      # the 3 461 kF fastq/ava.paf window consensi joined with '|'
+
+
+def _check_contig(P, reference_contig, seq, reads, ovl, w, sc, gold, line):
+    assert P.edit_distance(revcomp(seq), reference_contig) == gold, f"racon_test.cpp:{line}"
+    length, md5 = CONTIG_MD5[(reads, ovl, w, sc)]
+    assert (len(seq), hashlib.md5(seq).hexdigest()) == (length, md5), "SURVEY §4 byte-level pin"
 
 
 def _contig_case(P, backend, reads, ovl, w, sc):
@@ -77,10 +120,10 @@ def _contig_case(P, backend, reads, ovl, w, sc):
     return fa[0][1]
 
 
-@pytest.mark.parametrize("reads,ovl,w,sc,gold,line", CONTIG)
+@pytest.mark.parametrize("reads,ovl,w,sc,gold,line", CONTIG + CLI_DEFAULT)
 def test_contig_goldens_oracle(P, oracle, reference_contig, reads, ovl, w, sc, gold, line):
     seq = _contig_case(P, oracle, reads, ovl, w, sc)
-    assert P.edit_distance(revcomp(seq), reference_contig) == gold, f"racon_test.cpp:{line}"
+    _check_contig(P, reference_contig, seq, reads, ovl, w, sc, gold, line)
 
 
 # ---- RaconPolishingTest, fragment correction (racon_test.cpp:224-295) ------------------------------
@@ -92,31 +135,39 @@ FRAGMENT = [  # reads (= targets), overlaps, type, drop unpolished, (#sequences,
 ]
 
 
-def _fragment_case(P, backend, reads, ovl, ty, drop):
+def _fragment_case(P, backend, reads, ovl, ty, drop, windows_md5=None):
     p = P.Polisher(DATA + reads, DATA + ovl, DATA + reads, ty, 500, 10, 0.3, True, 1, -1, -1, num_threads=8)
     p.initialize()
     if backend == "hip":
+        if windows_md5:
+            from racon_amd.engine import HipEngine
+            res = HipEngine(1, -1, -1, True).consensus(p.windows())
+            assert hashlib.md5(b"|".join(res.consensus)).hexdigest() == windows_md5, "SURVEY §4 pin of the kF window consensi"
         return P.parse_fasta(p.polish(drop))
     res = backend.consensus(p.windows(), 1, -1, -1, True, 0)
+    if windows_md5:
+        assert hashlib.md5(b"|".join(res.consensus)).hexdigest() == windows_md5, "SURVEY §4 pin of the kF window consensi"
     return P.parse_fasta(p.assemble(res, drop))
 
 
 @pytest.mark.parametrize("reads,ovl,ty,drop,gold,lines", FRAGMENT)
 def test_fragment_goldens_oracle(P, oracle, reads, ovl, ty, drop, gold, lines):
-    fa = _fragment_case(P, oracle, reads, ovl, ty, drop)
+    pin = KF_WINDOWS_MD5 if (ty, reads, ovl) == ("kF", "sample_reads.fastq.gz", "sample_ava_overlaps.paf.gz") else None
+    fa = _fragment_case(P, oracle, reads, ovl, ty, drop, pin)
     assert (len(fa), sum(len(s) for _, s in fa)) == gold, f"racon_test.cpp:{lines}"
 
 
-# ---- the same pipelines end-to-end on the MI355X (only where the reference data exists) ---------------
+# ---- the same pipelines end-to-end on the MI355X: createPolisher -> initialize -> polish with the HIP engine ----
 @pytest.mark.gpu
-@pytest.mark.parametrize("reads,ovl,w,sc,gold,line", CONTIG)
+@pytest.mark.parametrize("reads,ovl,w,sc,gold,line", CONTIG + CLI_DEFAULT)
 def test_contig_goldens_hip(P, reference_contig, reads, ovl, w, sc, gold, line):
     seq = _contig_case(P, "hip", reads, ovl, w, sc)
-    assert P.edit_distance(revcomp(seq), reference_contig) == gold, f"racon_test.cpp:{line}"
+    _check_contig(P, reference_contig, seq, reads, ovl, w, sc, gold, line)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("reads,ovl,ty,drop,gold,lines", FRAGMENT[:2])
+@pytest.mark.parametrize("reads,ovl,ty,drop,gold,lines", FRAGMENT)
 def test_fragment_goldens_hip(P, reads, ovl, ty, drop, gold, lines):
-    fa = _fragment_case(P, "hip", reads, ovl, ty, drop)
+    pin = KF_WINDOWS_MD5 if (ty, reads, ovl) == ("kF", "sample_reads.fastq.gz", "sample_ava_overlaps.paf.gz") else None
+    fa = _fragment_case(P, "hip", reads, ovl, ty, drop, pin)
     assert (len(fa), sum(len(s) for _, s in fa)) == gold, f"racon_test.cpp:{lines}"

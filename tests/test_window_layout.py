@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-DATA = "/root/reference/test/data/"
+from helpers import REFDATA as DATA
 needs_data = pytest.mark.skipif(not os.path.isdir(DATA), reason="reference test data not present")
 
 FIELDS = ("win_seq_off", "win_type", "seq_off", "seq_has_qual", "seq_begin", "seq_end", "bases", "quals")
