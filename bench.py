@@ -4,10 +4,17 @@
 One "step" = one pass of the hot path (racon Window::generate_consensus for every
 window, reference src/window.cpp:65-149 as batched at src/polisher.cpp:496-503)
 over one batch of synthetic windows that is ALREADY RESIDENT IN HBM when the
-timed region starts.  Workload at N=1: BASELINE.json configs[1] — synthetic
-1 Mbp contig, 30x ONT-error reads, -w 500 (2000 windows).  For N>1 every rank
-polishes its own equally sized shard (weak scaling; windows are independent,
-there is no data-path collective: only the timing barrier/all-reduce).
+timed region starts.  Workload at N=1: BASELINE.json configs[1] (cfg2) — synthetic
+1 Mbp contig, 30x ONT-error reads, -w 500 (2000 windows).  For N>1 the default is
+configs[2] (cfg3): the 50 Mbp / 100 000-window job split evenly over the ranks
+(rank r generates its own 50/N Mbp stretch, seed 20260922 + r; total work fixed ->
+"strong"); `--contig` gives every rank that many bp instead (weak scaling).  Windows
+are independent: there is no data-path collective, only the timing barrier /
+all-reduce.
+
+Next to `value` (inputs resident) the line carries `value_incl_upload`: the same
+windows through pack-to-pinned + H2D + kernel + D2H, what Polisher::polish() pays per
+batch (reference src/polisher.cpp:493 -> :539-543 brackets exactly that interval).
 """
 from __future__ import annotations
 
@@ -32,12 +39,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--contig", type=int, default=1_000_000, help="contig bp per GPU (cfg2: 1 Mbp)")
+    ap.add_argument("--contig", type=int, default=0, help="contig bp per GPU (default: cfg2 = 1 Mbp at N=1; cfg3 = 50 Mbp / N at N>1)")
     ap.add_argument("--window", type=int, default=500)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--scores", default="3,-5,-4", help="match,mismatch,gap (racon CLI defaults, main.cpp:51-53)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
+    ap.add_argument("--cpu-threads", default="", help="comma list of thread counts for the CPU baseline sweep (default: 32,64,128,all)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verify", action="store_true", help="also check every window against the oracle (untimed)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (code-path test with several ranks on ONE GPU)")
@@ -62,7 +70,14 @@ def main():
     from racon_amd.engine import HipEngine
     from racon_amd.synth import simulate_windows
 
-    batch = simulate_windows(a.contig, a.window, a.coverage, 10000, seed=20260921 + rank)
+    if a.contig:
+        contig, seed, scaling, cfg_name = a.contig, 20260921 + rank, "weak", "cfg2-shaped"
+    elif world == 1:
+        contig, seed, scaling, cfg_name = 1_000_000, 20260921, "weak", "cfg2"
+    else:
+        contig, seed, scaling, cfg_name = 50_000_000 // world, 20260922 + rank, "strong", "cfg3 (50 Mbp / %d ranks)" % world
+    a.contig = contig
+    batch = simulate_windows(contig, a.window, a.coverage, 10000, seed=seed)
     eng = HipEngine(m, x, g, True, device=local_rank, max_slots=a.slots)
     eng.upload(batch)                                   # inputs resident in HBM from here on
 
@@ -97,17 +112,37 @@ def main():
 
     res = eng.result()
     st = eng.stats()
+    # the same windows including pack + upload (what the product's polish() pays per batch); outside the timed region above
+    eng.consensus(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.consensus(batch)
+    barrier()
+    dt_up = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_up], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_up = float(t.item())
+    st_up = eng.stats()
     if rank == 0:
         # --- roofline of the dominant (only) kernel: algorithmic bytes per launch / launch duration
         alg_bytes = st["dp_bytes"] + 2 * int(batch.bases.size) + 5 * sum(len(c) for c in res.consensus)
         avg_launch_s = (kernel_ms / max(1, launches)) / 1e3
         # measured HBM bytes per launch: PMC counters cannot be read from inside this process; the number comes
-        # from the rocprofv3 --pmc passes of THIS command (tools/gpu_round.sh), committed as profiles/traffic.json
-        traffic = None
+        # from the rocprofv3 --pmc passes of THIS command (tools/gpu_round.sh -> tools/pmc_summary.py), committed as
+        # profiles/traffic.json and stamped with the hash of the kernel sources it was measured on: a stale file
+        # (sources changed since) is reported as null, not quoted
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0:
+        if os.path.exists(tf) and world == 1 and a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0:
             try:
-                traffic = json.load(open(tf))["bytes_per_launch"]
+                tj = json.load(open(tf))
+                from tools.srchash import kernel_source_hash
+                if tj.get("kernel_source_hash") == kernel_source_hash():
+                    traffic, traffic_src = tj["bytes_per_launch"], "profiles/traffic.json (%s)" % tj.get("measured", "?")
+                else:
+                    traffic_src = "profiles/traffic.json is stale (kernel sources changed since it was measured)"
             except Exception:
                 traffic = None
         achieved = alg_bytes / avg_launch_s / 1e9
@@ -117,13 +152,16 @@ def main():
             "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "cfg2: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d, "
-                                   "scores %s, %d windows/GPU" % (a.contig, a.coverage, a.window, a.scores, batch.n_windows),
+            "value_incl_upload": total_windows * a.steps / dt_up,
+            "ms_per_step_incl_upload": dt_up / a.steps * 1e3,
+            "upload": {"h2d_ms": st_up["h2d_ms"], "d2h_ms": st_up["d2h_ms"], "bytes_in": st_up["bytes_in"]},
+            "config": {"workload": "%s: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d, "
+                                   "scores %s, %d windows/GPU" % (cfg_name, a.contig, a.coverage, a.window, a.scores, batch.n_windows),
                        "windows_per_gpu": batch.n_windows, "parallelism": "windows sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "poa_window_kernel2", "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "gcups": st["dp_cells"] / avg_launch_s / 1e9},
@@ -133,24 +171,35 @@ def main():
             # engine: row vectors + log-step prefix max), all hardware threads, whole batch, best of 3.  The scalar
             # int32 oracle is timed next to it on a sample for reference.
             from oracle import oracle_lib
-            cores = os.cpu_count() or 1
-            oracle_lib.consensus(batch.select(range(min(64, batch.n_windows))), m, x, g, True, cores, simd=True)   # warm up
-            best_dt, ref = None, None
-            for _ in range(3):
-                tc = time.perf_counter()
-                ref = oracle_lib.consensus(batch, m, x, g, True, cores, simd=True)
-                dtc = time.perf_counter() - tc
-                best_dt = dtc if best_dt is None else min(best_dt, dtc)
-            ok = ref.consensus == res.consensus
-            n_s = a.cpu_sample or min(batch.n_windows, max(64, 4 * cores))
-            sample = batch.select(range(n_s))
+            ncpu = os.cpu_count() or 1
+            # bounded sample of the same workload: at most 2000 windows (all of cfg2)
+            cb = batch if batch.n_windows <= 2000 else batch.select(range(2000))
+            want = [int(v) for v in a.cpu_threads.split(",") if v] or [32, 64, 128, ncpu]
+            sweep_threads = sorted({min(max(1, v), ncpu) for v in want})
+            oracle_lib.consensus(cb.select(range(min(64, cb.n_windows))), m, x, g, True, ncpu, simd=True)   # warm up
+            sweep, best_dt, ref, cores = {}, None, None, ncpu
+            for th in sweep_threads:                       # the box's best thread count is what the GPU is compared with
+                bt = None
+                for _ in range(3):
+                    tc = time.perf_counter()
+                    ref = oracle_lib.consensus(cb, m, x, g, True, th, simd=True)
+                    dtc = time.perf_counter() - tc
+                    bt = dtc if bt is None else min(bt, dtc)
+                sweep[str(th)] = cb.n_windows / bt
+                if best_dt is None or bt < best_dt:
+                    best_dt, cores = bt, th
+            ok = ref.consensus == res.consensus[:cb.n_windows]
+            n_s = a.cpu_sample or min(cb.n_windows, max(64, 4 * ncpu))
+            sample = cb.select(range(n_s))
             tc = time.perf_counter()
-            oracle_lib.consensus(sample, m, x, g, True, cores)
+            oracle_lib.consensus(sample, m, x, g, True, ncpu)
             dts = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": batch.n_windows / best_dt, "unit": "windows/s", "cores": cores, "kind": "port",
-                                   "sample": "all %d windows of the same workload, oracle/poa_oracle.cpp AVX2 int16 variant, "
-                                             "%d threads, best of 3 (%.2f s); scalar int32 oracle on the first %d windows: "
-                                             "%.0f windows/s" % (batch.n_windows, cores, best_dt, n_s, n_s / dts),
+            out["cpu_baseline"] = {"value": cb.n_windows / best_dt, "unit": "windows/s", "cores": cores, "kind": "port",
+                                   "sample": "%d windows of the same workload, oracle/poa_oracle.cpp AVX2 int16 variant, best thread "
+                                             "count of the sweep (%d of %d hardware threads), best of 3 (%.2f s); scalar int32 oracle "
+                                             "on the first %d windows, all threads: %.0f windows/s"
+                                             % (cb.n_windows, cores, ncpu, best_dt, n_s, n_s / dts),
+                                   "thread_sweep_windows_per_s": sweep,
                                    "matches_gpu": bool(ok)}
         if a.verify:
             from oracle import oracle_lib

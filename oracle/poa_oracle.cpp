@@ -332,6 +332,20 @@ struct Engine {
         if (classified) { ++tie_ruled; if (pick == exact) ++tie_rule_agrees; }
     }
 
+    // ---- band study (test infrastructure for the kernel's exact banded DP, racon_amd/csrc/poa_kernel2.hpp) ----
+    // Re-runs the alignment just computed with a WINDOW of band_wb columns per row (offset: a non-decreasing step
+    // function of the row's backbone coordinate, quantised to band_g columns), cells outside their row's window = -inf,
+    // and evaluates the exactness certificate next to the ground truth (the full matrix H is still in memory):
+    //   T = best banded end score; a cell is ALIVE iff H'[i][j] + m (L - j) >= T (no path through a dead cell reaches T).
+    //   exact  : every alive cell has all its DP successors inside their rows' windows  =>  every path scoring >= T is
+    //            made of alive cells with H' = H  =>  same end cell, same traceback decisions as the full matrix
+    //   cheap  : what the kernel can afford per row (Z = H - j g is non-decreasing along a row): the last window cell of
+    //            a row is dead, and for every edge p -> s whose window starts further right the cell left of s's window
+    //            start is dead even at the threshold of p's window start
+    int32_t band_wb = 0, band_g = 16;
+    struct BandStats { uint64_t n = 0, banded = 0, exact_ok = 0, cheap_ok = 0, same_path = 0, bad = 0, width_max = 0, width_sum = 0, rows = 0, shifts = 0; } bs;
+    void band_study(const uint8_t* seq, uint32_t L, const Graph& g_, const std::vector<int32_t>& n2r, int32_t bi, const Alignment& full_al);
+
     // ---- CPU baseline variant (bench.py's cpu_baseline leg; NOT the oracle of the parity tests) ----
     // Same recurrence, same tie-breaks, but evaluated the way spoa's SIMD engine does it: int16 row vectors
     // (AVX2, 16 cells per op) and a log-step prefix max for the horizontal gap.  Scores are kept as
@@ -529,9 +543,135 @@ struct Engine {
             i = pi; j = pj;
         }
         std::reverse(al.begin(), al.end());
+        if (band_wb > 0) band_study(seq, L, g_, n2r, bi, al);
         return al;
     }
 };
+
+void Engine::band_study(const uint8_t* seq, uint32_t L, const Graph& g_, const std::vector<int32_t>& n2r, int32_t bi, const Alignment& full_al) {
+    (void)seq;
+    const int32_t V = static_cast<int32_t>(g_.nodes.size());
+    const int32_t W = static_cast<int32_t>(L) + 1, Wb = band_wb, G = band_g;
+    ++bs.n;
+    if (W <= Wb) return;                                   // the whole row fits: nothing to band
+    ++bs.banded;
+    constexpr int32_t NEG = -(1 << 28);
+    // window offset per row (row 0 = virtual start row: offset 0)
+    const int32_t nbb = std::max(1, g_.n_backbone);
+    const int32_t offmax = ((W - Wb + G - 1) / G) * G;
+    std::vector<int32_t> off(V + 1, 0);
+    int32_t pi_row = -1, cur = 0;
+    for (int32_t r = 0; r < V; ++r) {
+        const int32_t v = g_.rank_to_node[r];
+        if (v < g_.n_backbone) pi_row = std::max(pi_row, v);
+        const int64_t center = static_cast<int64_t>(pi_row + 1) * L / nbb;
+        int32_t o = static_cast<int32_t>(center) - Wb / 2;
+        o = o < 0 ? 0 : (o / G) * G;
+        o = std::min(o, offmax);
+        if (o > cur) { cur = o; ++bs.shifts; }
+        off[r + 1] = cur;
+    }
+    bs.rows += V;
+    std::vector<int32_t> Hb(static_cast<size_t>(V + 1) * W, NEG);
+    auto in_win = [&](int32_t row, int32_t j) { return j >= off[row] && j < off[row] + Wb && j < W; };
+    for (int32_t j = 0; j < W && j < Wb; ++j) Hb[j] = j * g;
+    std::vector<int32_t> ps;
+    bool have_best = false; int32_t best = 0, bib = 0;
+    for (int32_t r = 0; r < V; ++r) {
+        const auto& node = g_.nodes[g_.rank_to_node[r]];
+        int32_t* row = &Hb[static_cast<size_t>(r + 1) * W];
+        const int32_t* P = &profile[node.code * W];
+        ps.clear();
+        for (int32_t e : node.in) ps.push_back(n2r[g_.edges[e].tail] + 1);
+        if (ps.empty()) ps.push_back(0);
+        const int32_t lo = off[r + 1], hi = std::min(W, lo + Wb);
+        for (int32_t j = lo; j < hi; ++j) {
+            int32_t v = NEG;
+            for (int32_t p : ps) {
+                const int32_t* Hp = &Hb[static_cast<size_t>(p) * W];
+                if (j >= 1 && Hp[j - 1] > NEG) v = std::max(v, Hp[j - 1] + P[j]);
+                if (Hp[j] > NEG) v = std::max(v, Hp[j] + g);
+            }
+            if (j == 0) { int32_t h0 = NEG; for (int32_t p : ps) h0 = std::max(h0, Hb[static_cast<size_t>(p) * W]); v = (node.in.empty() ? 0 : h0) + g; }
+            if (j > lo && row[j - 1] > NEG) v = std::max(v, row[j - 1] + g);
+            row[j] = v;
+        }
+        if (node.out.empty() && in_win(r + 1, static_cast<int32_t>(L)) && row[L] > NEG) {
+            if (!have_best || best < row[L]) { have_best = true; best = row[L]; bib = r + 1; }
+        }
+    }
+    if (!have_best) return;
+    const int32_t T = best;
+    auto alive = [&](int32_t row, int32_t j) { const int32_t h = Hb[static_cast<size_t>(row) * W + j]; return h > NEG && h + m * (static_cast<int32_t>(L) - j) >= T; };
+    // successors of row 0: nodes without in-edges
+    bool exact_ok = true, cheap_ok = true;
+    uint64_t wmax = 0;
+    auto check_edge = [&](int32_t prow, int32_t srow) {
+        const int32_t lo = off[prow], hi = std::min(W, lo + Wb);
+        for (int32_t j = lo; j < hi; ++j) {
+            if (!alive(prow, j)) continue;
+            if (!in_win(srow, j)) exact_ok = false;
+            if (j + 1 < W && !in_win(srow, j + 1)) exact_ok = false;
+        }
+        if (off[srow] > off[prow]) {
+            // cheap: Z of p at the column left of s's window start, against the threshold at p's window start
+            const int32_t jc = std::min(off[srow] - 1, hi - 1);
+            const int32_t h = Hb[static_cast<size_t>(prow) * W + jc];
+            if (h > NEG) {
+                const int64_t z = static_cast<int64_t>(h) - static_cast<int64_t>(jc) * g;
+                const int64_t thr = static_cast<int64_t>(T) - static_cast<int64_t>(m) * L + static_cast<int64_t>(m - g) * lo;
+                if (z >= thr) cheap_ok = false;
+            }
+        } else if (off[srow] < off[prow]) cheap_ok = false;
+    };
+    for (int32_t r = 0; r <= V; ++r) {
+        const int32_t lo = off[r], hi = std::min(W, lo + Wb);
+        int32_t a0 = -1, a1 = -1;
+        for (int32_t j = lo; j < hi; ++j) if (alive(r, j)) { if (a0 < 0) a0 = j; a1 = j; }
+        if (a0 >= 0) { wmax = std::max<uint64_t>(wmax, a1 - a0 + 1); bs.width_sum += a1 - a0 + 1; }
+        // horizontal successor of the last window cell
+        if (hi < W) {
+            if (alive(r, hi - 1)) exact_ok = false;
+            if (alive(r, hi - 1)) cheap_ok = false;
+        }
+        if (r >= 1) {
+            const auto& node = g_.nodes[g_.rank_to_node[r - 1]];
+            if (node.in.empty()) check_edge(0, r);
+            for (int32_t e : node.in) check_edge(n2r[g_.edges[e].tail] + 1, r);
+        }
+    }
+    bs.width_max = std::max(bs.width_max, wmax);
+    // banded traceback (cells outside their window never match: they are -inf)
+    Alignment al;
+    {
+        int32_t i = bib, j = static_cast<int32_t>(L);
+        bool stuck = false;
+        while (!(i == 0 && j == 0) && !stuck) {
+            const int32_t hij = Hb[static_cast<size_t>(i) * W + j];
+            int32_t pi = 0, pj = 0; bool found = false;
+            if (i != 0) {
+                const auto& node = g_.nodes[g_.rank_to_node[i - 1]];
+                ps.clear();
+                for (int32_t e : node.in) ps.push_back(n2r[g_.edges[e].tail] + 1);
+                if (ps.empty()) ps.push_back(0);
+                if (j != 0) {
+                    const int32_t mc = profile[node.code * W + j];
+                    for (int32_t p : ps) { const int32_t h = Hb[static_cast<size_t>(p) * W + j - 1]; if (h > NEG && hij == h + mc) { pi = p; pj = j - 1; found = true; break; } }
+                }
+                if (!found) for (int32_t p : ps) { const int32_t h = Hb[static_cast<size_t>(p) * W + j]; if (h > NEG && hij == h + g) { pi = p; pj = j; found = true; break; } }
+            }
+            if (!found && j != 0) { const int32_t h = Hb[static_cast<size_t>(i) * W + j - 1]; if (h > NEG && hij == h + g) { pi = i; pj = j - 1; found = true; } }
+            if (!found) { stuck = true; break; }
+            al.emplace_back(i == pi ? -1 : g_.rank_to_node[i - 1], j == pj ? -1 : j - 1);
+            i = pi; j = pj;
+        }
+        std::reverse(al.begin(), al.end());
+        if (stuck) al.clear();
+    }
+    const bool same = (bib == bi) && al == full_al;
+    bs.exact_ok += exact_ok; bs.cheap_ok += cheap_ok; bs.same_path += same;
+    if ((exact_ok || cheap_ok) && !same) ++bs.bad;          // a passing certificate with a different result = the theory is wrong
+}
 
 struct WindowOut {
     std::string consensus;
@@ -627,6 +767,12 @@ static std::atomic<uint64_t> g_tie_stats[3];
 void rcn_oracle_tie_stats(uint64_t* out3) { for (int k = 0; k < 3; ++k) out3[k] = g_tie_stats[k].exchange(0); }
 
 static bool g_simd_next = false;
+static int g_band_wb = 0, g_band_g = 16;
+static std::atomic<uint64_t> g_band_stats[10];
+// Band study switch + counters (n alignments, banded, exact certificate ok, cheap certificate ok, same result as the full
+// matrix, certificate ok but different result (must stay 0), max alive width, sum of alive widths, rows, window shifts).
+void rcn_oracle_band_study(int wb, int g) { g_band_wb = wb; g_band_g = g > 0 ? g : 16; }
+void rcn_oracle_band_stats(uint64_t* out10) { for (int k = 0; k < 10; ++k) out10[k] = g_band_stats[k].exchange(0); }
 int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int nthreads,
                          rcn_result* out, void** handle, uint64_t* cells, double* cells_x_pred);
 // the AVX2 int16 variant (CPU baseline of bench.py); same results as rcn_oracle_consensus
@@ -648,6 +794,7 @@ int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int 
     const bool use_simd = g_simd_next;
     auto worker = [&]() {
         Engine eng; eng.m = m; eng.x = x; eng.g = g; eng.simd = use_simd;
+        eng.band_wb = use_simd ? 0 : g_band_wb; eng.band_g = g_band_g;
         for (;;) {
             uint32_t w = next.fetch_add(1);
             if (w >= n) break;
@@ -656,6 +803,9 @@ int rcn_oracle_consensus(const rcn_batch* b, int m, int x, int g, int trim, int 
             cl[w] = eng.cells; cx[w] = eng.cells_x_pred;
         }
         g_tie_stats[0] += eng.tie_events; g_tie_stats[1] += eng.tie_ruled; g_tie_stats[2] += eng.tie_rule_agrees;
+        const uint64_t bv[10] = {eng.bs.n, eng.bs.banded, eng.bs.exact_ok, eng.bs.cheap_ok, eng.bs.same_path, eng.bs.bad, 0, eng.bs.width_sum, eng.bs.rows, eng.bs.shifts};
+        for (int k = 0; k < 10; ++k) if (k != 6) g_band_stats[k] += bv[k];
+        for (uint64_t cur = g_band_stats[6].load(); eng.bs.width_max > cur && !g_band_stats[6].compare_exchange_weak(cur, eng.bs.width_max);) {}
     };
     if (nthreads <= 1) worker();
     else {

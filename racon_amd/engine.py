@@ -17,7 +17,8 @@ from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
 from .layout import CigarSet, OverlapSet, RcnBatchDims, RcnBuildStats, RcnCigarSet, RcnOverlapSet, RcnReadSet, ReadSet
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libracon_hip.so")
+# RACON_HIP_LIB: another build of the same ABI (profiling / experiment variants under racon_amd/csrc/), as in the host layer
+LIB_PATH = os.environ.get("RACON_HIP_LIB") or os.path.join(_HERE, "csrc", "libracon_hip.so")
 
 
 class RcnEngineConfig(C.Structure):

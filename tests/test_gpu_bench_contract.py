@@ -33,6 +33,9 @@ def test_bench_single_rank_line():
     assert r["achieved"] > 0 and abs(j["value"] - 200 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "windows/s" and c["sample"]
+    assert c["matches_gpu"] is True and max(c["thread_sweep_windows_per_s"].values()) == c["value"]
+    # the upload-inclusive rate (pack + H2D + kernel + D2H per step) is reported next to `value`, never instead of it
+    assert 0 < j["value_incl_upload"] <= j["value"] * 1.05 and j["ms_per_step_incl_upload"] > 0
 
 
 def test_bench_two_ranks_on_one_gpu():

@@ -50,3 +50,50 @@ def test_cfg2_full_size_properties(oracle):
     pick = sorted(rng.choice(b.n_windows, 48, replace=False).tolist())
     ref = oracle.consensus(b.select(pick), 3, -5, -4, True, 0)
     assert ref.consensus == [r1.consensus[i] for i in pick]
+
+
+def _all_windows_vs_oracle(oracle, b, scores, tag, trim=True):
+    """Every window of `b` against the oracle (its AVX2 int16 variant on all host threads: byte-identical to the scalar
+    oracle, tests/test_oracle_spec.py), byte for byte, flags included."""
+    import os
+    from helpers import assert_same
+    from racon_amd.engine import HipEngine
+    eng = HipEngine(*scores, trim)
+    got = eng.consensus(b)
+    ref = oracle.consensus(b, *scores, trim, os.cpu_count() or 1, simd=True)
+    assert_same(got, ref, tag)
+    return eng.stats()
+
+
+def test_cfg2_every_window_against_the_oracle(oracle):
+    """BASELINE configs[1] at its stated size: all 2000 windows, not a sample."""
+    b = config_windows("cfg2")
+    assert b.n_windows == 2000
+    st = _all_windows_vs_oracle(oracle, b, (3, -5, -4), "cfg2 full size")
+    assert st["n_retried"] == 0
+
+
+def test_cfg4_full_size_against_the_oracle(oracle):
+    """BASELINE configs[3] at the size SURVEY 8(d) gives it: 1 Mbp, 150 bp reads at 60x, -w 200 -> 5000 kNGS windows of
+    ~140 short fragments each, almost every layer through the Subgraph branch (reference src/window.cpp:99-107)."""
+    b = config_windows("cfg4")
+    assert b.n_windows == 5000 and int(b.win_type.max()) == 0
+    _all_windows_vs_oracle(oracle, b, (3, -5, -4), "cfg4 full size")
+
+
+def test_w1000_full_size_against_the_oracle(oracle):
+    """-w 1000 on 1 Mbp (reference test/racon_test.cpp:179-197 uses w = 1000 on the sample): 1000 windows, layers of
+    ~1000 bases (the 4-wave DP shapes), at the reference tests' scores where |g| (V + l) leaves the int16 range."""
+    b = config_windows("w1000")
+    assert b.n_windows == 1000
+    _all_windows_vs_oracle(oracle, b, (5, -4, -8), "w1000 full size, scores 5/-4/-8")
+    _all_windows_vs_oracle(oracle, b, (3, -5, -4), "w1000 full size, scores 3/-5/-4")
+
+
+def test_batch_larger_than_the_resident_slots(oracle):
+    """9000 windows in one batch: more work items than the 2048 resident slots, so the deepest-first work queue, the
+    work-item -> window indirection of the outputs and slot re-use between windows are all on the path."""
+    from racon_amd.synth import simulate_windows
+    b = simulate_windows(4_500_000, 500, 30.0, 10000, seed=20260927)
+    assert b.n_windows == 9000
+    _all_windows_vs_oracle(oracle, b, (3, -5, -4), "9000-window batch")

@@ -32,8 +32,12 @@ for kn, c in per_kernel.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         fetch = c["FETCH_SIZE"] * 1024.0 * 2.0
         write = c["WRITE_SIZE"] * 1024.0
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from srchash import kernel_source_hash
+        import time
         json.dump({"kernel": kn, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
-                   "bytes_per_launch": fetch + write,
+                   "bytes_per_launch": fetch + write, "kernel_source_hash": kernel_source_hash(),
+                   "measured": "%s, %s" % (os.path.basename(os.path.normpath(out)), time.strftime("%Y-%m-%d")),
                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 (gfx950 correction)"},
                   open(os.path.join(out, "traffic.json"), "w"))
         print("traffic.json:", fetch + write, "bytes per launch")

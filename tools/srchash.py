@@ -1,0 +1,18 @@
+"""Hash of the consensus kernel's sources: stamps measurements that belong to one build (profiles/traffic.json)."""
+import hashlib
+import os
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_FILES = ["poa_core.hpp", "poa_kernel.hpp", "poa_kernel2.hpp", "engine.hip"]
+
+
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for f in _FILES:
+        with open(os.path.join(_ROOT, "racon_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    print(kernel_source_hash())
