@@ -85,6 +85,14 @@ typedef struct rcn_run_stats {
     uint64_t phase_clocks[8];  /* summed wave clocks: subgraph, row-desc, DP, traceback,
                                   add-alignment, toposort, consensus, queue/other           */
     uint64_t n_sink_ties;      /* alignments that needed spoa's exact rank order (sink tie)    */
+    /* exact banded DP: dp_cells / dp_pred_cells / dp_bytes count the cells actually evaluated; the figures of the
+     * full matrices (what an unbanded pass over the same alignments evaluates) are reported alongside */
+    uint64_t dp_cells_full, dp_bytes_full;
+    uint64_t n_banded;         /* alignments done by the banded pass (certificate held)               */
+    uint64_t n_band_redone;    /* alignments redone on full rows because the certificate failed       */
+    uint64_t band_redo_why[8]; /* redo reasons, counted: source row off the left edge, predecessor older than the LDS ring,
+                                  >2 window shifts inside the ring, >6 in-edges, (shift span), no end cell, alive last window
+                                  cell, alive dropped cell                                                                   */
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */
@@ -97,6 +105,12 @@ void rcn_engine_destroy(rcn_engine* e);
 int  rcn_engine_upload(rcn_engine* e, const rcn_batch* b);
 /* Runs the consensus kernel(s) over the resident batch and brings results back. */
 int  rcn_engine_run(rcn_engine* e);
+/* upload + run of one batch with the copy hidden behind the kernel: what one task of Polisher::polish does per batch
+ * (reference src/cuda/cudapolisher.cpp:254-333: fill a batch, generateConsensus, read back).  The windows are packed
+ * deepest first into pinned staging, copied in pieces on a copy stream, and each piece is polished by its own launch as
+ * soon as it has arrived.  Results and statistics as after rcn_engine_upload + rcn_engine_run; the batch stays
+ * resident (rcn_engine_run may follow).                                                                               */
+int  rcn_engine_polish(rcn_engine* e, const rcn_batch* b);
 int  rcn_engine_result(rcn_engine* e, rcn_result* out);
 int  rcn_engine_stats(rcn_engine* e, rcn_run_stats* out);
 /* Changes the trim flag (Window::generate_consensus takes it per call, reference
@@ -193,6 +207,8 @@ int  rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_
 
 /* --- misc ------------------------------------------------------------------ */
 int  rcn_device_count(void);
+/* free / total HBM of a device (several engines on one device share it: give each its part as arena_bytes) */
+int  rcn_device_free_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 const char* rcn_strerror(int code);
 const char* rcn_version(void);
 

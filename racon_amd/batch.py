@@ -134,22 +134,35 @@ class WindowBatch:
             np.concatenate([self.bases, other.bases]),
             np.concatenate([self.quals, other.quals]))
 
-    def shard(self, rank: int, world: int) -> Tuple["WindowBatch", np.ndarray]:
-        """Contiguous, cost-balanced shard of the window index space for rank
-        `rank` of `world` (cost proxy = sum of layer bases per window; windows
-        are independent, reference src/polisher.cpp:496-503).  Returns the
-        sub-batch and the global window indices it holds."""
-        n = self.n_windows
-        seq_len = np.diff(self.seq_off.astype(np.int64))
-        csum = np.concatenate([[0], np.cumsum(seq_len)])
-        wcost = csum[self.win_seq_off[1:].astype(np.int64)] - csum[self.win_seq_off[:-1].astype(np.int64)]
-        wcost = wcost.astype(np.float64) + 1.0
-        cum = np.cumsum(wcost)
-        total = cum[-1] if n else 0.0
+    @staticmethod
+    def window_costs(win_seq_off: np.ndarray, seq_off: np.ndarray) -> np.ndarray:
+        """Cost proxy of a window for load balancing: (sequences) x (bases) -- the graph a layer is aligned against grows
+        with every layer, so the DP work of a window goes with layers x bases, not with bases (the engine orders its
+        work queue by the same proxy).  Needs the offset arrays only."""
+        wso = win_seq_off.astype(np.int64)
+        so = seq_off.astype(np.int64)
+        bases = so[wso[1:]] - so[wso[:-1]]
+        return (wso[1:] - wso[:-1]).astype(np.float64) * bases.astype(np.float64) + 1.0
+
+    @staticmethod
+    def shard_bounds(win_seq_off: np.ndarray, seq_off: np.ndarray, world: int) -> list:
+        """world + 1 window indices: rank r holds windows [bounds[r], bounds[r + 1]) -- contiguous, balanced by window_costs."""
+        n = len(win_seq_off) - 1
+        if n <= 0:
+            return [0] * (world + 1)
+        cum = np.cumsum(WindowBatch.window_costs(win_seq_off, seq_off))
         bounds = [0]
         for r in range(1, world):
-            bounds.append(int(np.searchsorted(cum, total * r / world, side="left")))
+            bounds.append(max(bounds[-1], int(np.searchsorted(cum, cum[-1] * r / world, side="left"))))
         bounds.append(n)
+        return bounds
+
+    def shard(self, rank: int, world: int) -> Tuple["WindowBatch", np.ndarray]:
+        """Contiguous, cost-balanced shard of the window index space for rank
+        `rank` of `world` (windows are independent, reference
+        src/polisher.cpp:496-503).  Returns the sub-batch and the global window
+        indices it holds."""
+        bounds = self.shard_bounds(self.win_seq_off, self.seq_off, world)
         lo, hi = bounds[rank], bounds[rank + 1]
         idx = np.arange(lo, hi)
         s0, s1 = int(self.win_seq_off[lo]), int(self.win_seq_off[hi])

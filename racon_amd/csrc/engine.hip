@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/racon_hip.h"
@@ -56,25 +57,54 @@ struct HostBuf {                       // pinned host staging (D2H of the consen
 
 struct WinShape { int32_t L, sum_l, lmax, nsym; };
 
+// two HIP events for a timed interval, destroyed on every exit path
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int create() {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return RCN_E_HIP;
+        return RCN_OK;
+    }
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+// Runs fn(i) for i in [0, n) on up to `threads` host threads (contiguous blocks); exceptions are not expected from fn.
+template <class F>
+void host_parallel(size_t n, unsigned threads, F fn) {
+    threads = static_cast<unsigned>(std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, n)));
+    if (threads <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([=]() { for (size_t i = n * t / threads; i < n * (t + 1) / threads; ++i) fn(i); });
+    for (auto& th : pool) th.join();
+}
+
 }  // namespace
 
 struct rcn_engine {
     rcn_engine_config cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                   // main stream: resident-batch launches, retry pass, result copies
+    hipStream_t copy_stream = nullptr;              // H2D of a streamed batch (rcn_engine_polish)
+    static constexpr int kSubLaunches = 3;
+    hipStream_t sub_stream[kSubLaunches] = {nullptr, nullptr, nullptr};   // one per sub-launch of a streamed batch: they overlap
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
     int n_cu = 256;
     size_t free_mem = 0;
 
     // resident batch
     uint32_t n_windows = 0, n_seqs = 0;
     uint64_t n_bases = 0;
+    // lpt_layout: the device arrays hold the windows deepest first (work item k IS device window k; streamed upload);
+    // otherwise they are in caller order and d_lpt_ids maps work items to windows
+    bool lpt_layout = false;
     DevBuf d_win_seq_off, d_win_type, d_seq_off, d_has_qual, d_begin, d_end, d_bases, d_quals, d_order, d_full;
-    DevBuf d_lpt_ids, d_win_ids, d_win_flags, d_scratch, d_out_cons, d_out_len, d_out_flags, d_ctr;
-    HostBuf h_raw;
-    std::vector<WinShape> shapes;
+    DevBuf d_lpt_ids, d_win_ids, d_win_flags, d_scratch, d_out_cons, d_out_len, d_out_flags, d_out_off, d_ctr;
+    HostBuf h_out, h_stage;                         // pinned: outputs of a pass; inputs of a streamed batch
+    std::vector<WinShape> shapes;                   // by window (caller order)
     int32_t heavy_ns = 0;
     std::vector<uint32_t> h_win_seq_off;
     std::vector<uint32_t> lpt;          // work item -> window, deepest windows first (longest processing time first)
+    std::vector<uint64_t> out_off;      // [n_windows + 1] consensus byte offsets by work item (first pass)
     bool uploaded = false, ran = false;
 
     // results
@@ -93,6 +123,9 @@ struct rcn_engine {
 
 namespace {
 
+constexpr size_t kCtrBytes = 512;       // d_ctr: 16 work-queue counters (4 B each), then the statistics words at byte 64
+constexpr size_t kStatsOff = 64;
+
 int upload_vec(DevBuf& d, const void* src, size_t bytes, hipStream_t s) {
     int rc = d.reserve(bytes);
     if (rc) return rc;
@@ -100,7 +133,7 @@ int upload_vec(DevBuf& d, const void* src, size_t bytes, hipStream_t s) {
     return RCN_OK;
 }
 
-struct Caps { int32_t ncap, ecap, ring, lmax, hstride; uint64_t slot_bytes; uint64_t out_stride; bool fast; };
+struct Caps { int32_t ncap, ecap, ring, lmax, hstride; uint64_t slot_bytes; bool fast; };
 
 // fast = poa_window_kernel2 (4 waves per window, int16 Z matrix); else poa_window_kernel (1 wave, int32 H)
 Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast) {
@@ -111,46 +144,93 @@ Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast
     rcn::Win tmp;
     c.slot_bytes = rcn::win_bind(tmp, nullptr, ncap, ecap, ring, lmax, c.hstride, fast ? 2 : 4);
     c.slot_bytes = (c.slot_bytes + 255) & ~uint64_t(255);
-    c.out_stride = static_cast<uint64_t>(ncap);
     return c;
 }
 
-// one kernel pass over `ids` (or all windows when ids == nullptr)
-int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work, uint64_t out_stride, const uint32_t* d_ids = nullptr) {
-    if (n_work == 0) return RCN_OK;
-    uint64_t budget = e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>(e->free_mem * 0.80);
-    uint32_t slots = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;   // 8 work-groups per CU (20 KiB LDS each)
-    slots = std::min(slots, n_work);
-    while (slots > 1 && static_cast<uint64_t>(slots) * c.slot_bytes > budget) slots = (slots + 1) / 2;
-    if (static_cast<uint64_t>(slots) * c.slot_bytes > budget) return RCN_E_CAPACITY;
-    int rc = e->d_scratch.reserve(static_cast<uint64_t>(slots) * c.slot_bytes);
-    if (rc) return rc;
-    if (ids) { rc = upload_vec(e->d_win_ids, ids, sizeof(uint32_t) * n_work, e->stream); if (rc) return rc; }
-    HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 4, e->stream));
+// first-pass capacities of a set of windows: typical graph growth (a window that outgrows them is re-run by the retry
+// pass with worst-case capacities)
+template <class It>
+Caps first_pass_caps(It first, It last, bool fast) {
+    int32_t ncap = 0, lmax = 1, nsym = 2;
+    for (It it = first; it != last; ++it) {
+        const WinShape& s = *it;
+        const int64_t worst = static_cast<int64_t>(s.L) + s.sum_l + 8;
+        const int64_t est = static_cast<int64_t>(s.L) + s.sum_l / 4 + 256;
+        ncap = std::max<int32_t>(ncap, static_cast<int32_t>(std::min(worst, est)));
+        lmax = std::max(lmax, s.lmax); nsym = std::max(nsym, s.nsym);
+    }
+    return make_caps(ncap, 2 * ncap, std::max(1, nsym - 1), lmax, fast);
+}
 
+// Consensus bytes reserved for a window in the first pass.  The consensus is a path of the graph: it can be as long as
+// the graph in theory, about the backbone in practice; a longer one is flagged (kFlagOverflow) and comes from the retry pass.
+inline uint64_t first_pass_out_cap(const WinShape& s) {
+    const uint64_t worst = static_cast<uint64_t>(s.L) + s.sum_l + 8;
+    return (std::min<uint64_t>(worst, 2ull * s.L + 64) + 15) & ~uint64_t(15);
+}
+
+uint64_t scratch_budget(const rcn_engine* e) {
+    return e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>(e->free_mem * 0.80);
+}
+uint32_t max_slots(const rcn_engine* e) {
+    return e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;    // 8 work-groups per CU (20 KiB LDS each)
+}
+
+struct Launch {
+    Caps c;
+    const uint32_t* d_ids = nullptr;    // work item -> device window, or nullptr: work_base + work item
+    uint32_t n_work = 0, work_base = 0, out_base = 0, slots = 0;
+    uint64_t scratch_off = 0;
+    int ctr = 0;                        // which work-queue counter of d_ctr
+    hipStream_t stream = nullptr;
+};
+
+// Enqueues one kernel pass (asynchronous).  Scratch for [scratch_off, scratch_off + slots * slot_bytes) must be reserved.
+int launch_pass(rcn_engine* e, const Launch& L) {
+    if (L.n_work == 0) return RCN_OK;
+    HIP_TRY(hipMemsetAsync(e->d_ctr.as<uint8_t>() + 4 * L.ctr, 0, 4, L.stream));
     rcn::KParams P{};
     P.win_seq_off = e->d_win_seq_off.as<uint32_t>(); P.win_type = e->d_win_type.as<uint8_t>();
     P.seq_off = e->d_seq_off.as<uint64_t>(); P.seq_has_qual = e->d_has_qual.as<uint8_t>();
     P.seq_begin = e->d_begin.as<uint32_t>(); P.seq_end = e->d_end.as<uint32_t>();
     P.bases = e->d_bases.as<uint8_t>(); P.quals = e->d_quals.as<uint8_t>();
     P.order = e->d_order.as<uint32_t>(); P.seq_full = e->d_full.as<uint8_t>();
-    P.win_ids = ids ? e->d_win_ids.as<uint32_t>() : d_ids; P.n_work = n_work;
+    P.win_ids = L.d_ids; P.n_work = L.n_work; P.work_base = L.work_base;
     P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : e->d_win_flags.as<uint8_t>();
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
     P.heavy_ns = e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.force_tie = getenv("RCN_FORCE_TIE") ? atoi(getenv("RCN_FORCE_TIE")) : 0;
     P.force_slow_tb = getenv("RCN_FORCE_SLOW_TB") ? 1 : 0;
-    P.scratch = e->d_scratch.as<uint8_t>(); P.slot_bytes = c.slot_bytes;
-    P.ncap = c.ncap; P.ecap = c.ecap; P.ring = c.ring; P.lmax = c.lmax; P.hstride = c.hstride;
-    P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_stride = out_stride;
+    P.band = getenv("RCN_NO_BAND") ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : 1);
+    P.scratch = e->d_scratch.as<uint8_t>() + L.scratch_off; P.slot_bytes = L.c.slot_bytes;
+    P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride;
+    P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_off = e->d_out_off.as<uint64_t>(); P.out_base = L.out_base;
     P.out_len = e->d_out_len.as<uint32_t>(); P.out_flags = e->d_out_flags.as<uint8_t>();
-    P.next = e->d_ctr.as<unsigned int>();
-    P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + 16);
-
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    if (c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(slots), dim3(rcn::kThreads2), rcn::kLdsBytes + rcn::kCtxBytes, e->stream, P);
-    else hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, e->stream, P);
+    P.next = e->d_ctr.as<unsigned int>() + L.ctr;
+    P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + kStatsOff);
+    if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), rcn::kLdsBytes + rcn::kCtxBytes, L.stream, P);
+    else hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(L.slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, L.stream, P);
     HIP_TRY(hipGetLastError());
+    return RCN_OK;
+}
+
+// resident slots for a pass of n_work windows within the scratch budget (0: not even one slot fits)
+uint32_t slots_for(const rcn_engine* e, const Caps& c, uint32_t n_work, uint64_t budget) {
+    uint32_t slots = std::min(max_slots(e), n_work);
+    while (slots > 1 && static_cast<uint64_t>(slots) * c.slot_bytes > budget) slots = (slots + 1) / 2;
+    return static_cast<uint64_t>(slots) * c.slot_bytes > budget ? 0 : slots;
+}
+
+// one synchronous kernel pass on the main stream (resident batch / retry pass), timed with HIP events
+int run_pass(rcn_engine* e, const Caps& c, const uint32_t* d_ids, uint32_t n_work) {
+    if (n_work == 0) return RCN_OK;
+    Launch L; L.c = c; L.d_ids = d_ids; L.n_work = n_work; L.stream = e->stream;
+    L.slots = slots_for(e, c, n_work, scratch_budget(e));
+    if (L.slots == 0) return RCN_E_CAPACITY;
+    int rc = e->d_scratch.reserve(static_cast<uint64_t>(L.slots) * c.slot_bytes);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    if ((rc = launch_pass(e, L))) return rc;
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
@@ -158,51 +238,54 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* ids, uint32_t n_work,
     return RCN_OK;
 }
 
-}  // namespace
+// Host-side facts of a batch that the kernel takes as inputs (computed once per batch, caller window order):
+// layer order (window.cpp:79-86: the reference's std::sort, unstable -- libstdc++'s introsort is what decides ties),
+// full-span flags (window.cpp:88,93-94), shape statistics for the scratch capacities, the ACGT-only flag, and the
+// deepest-first work order.  `bases` may be null (batch built on the device): every window then gets the batch-wide
+// symbol count `nsym_all`.
+struct HostPrep { std::vector<uint32_t> order; std::vector<uint8_t> full, wflags; };
 
-// Host-side preparation shared by rcn_engine_upload and rcn_engine_build_windows: layer order (window.cpp:79-86: the
-// reference's std::sort, unstable -- libstdc++'s introsort is what decides ties), full-span flags (window.cpp:88,93-94),
-// shape statistics for the scratch capacities, deepest-first work order.  `bases` may be null (batch built on the
-// device): every window then gets the batch-wide symbol count `nsym_all`.
-int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* win_seq_off, const uint64_t* seq_off,
-                            const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all, bool acgt_all = false) {
-    std::vector<uint8_t> wflags(nw, 0);
+int prepare_host(rcn_engine* e, HostPrep& hp, uint32_t nw, uint32_t ns, const uint32_t* win_seq_off, const uint64_t* seq_off,
+                 const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all, bool acgt_all) {
+    hp.wflags.assign(nw, 0); hp.order.resize(ns); hp.full.assign(ns, 0);
     e->h_win_seq_off.assign(win_seq_off, win_seq_off + nw + 1);
-    std::vector<uint32_t> order(ns);
-    std::vector<uint8_t> full(ns, 0);
     e->shapes.resize(nw);
-    std::vector<uint32_t> rank;
-    for (uint32_t w = 0; w < nw; ++w) {
+    std::vector<int> bad(nw, 0);
+    const unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    host_parallel(nw, nw >= 256 ? threads : 1, [&](size_t wi) {
+        const uint32_t w = static_cast<uint32_t>(wi);
         const uint32_t s0 = win_seq_off[w], n = win_seq_off[w + 1] - s0;
-        if (n == 0) return RCN_E_ARG;
-        rank.resize(n);
+        if (n == 0) { bad[w] = 1; return; }
+        std::vector<uint32_t> rank(n);
         for (uint32_t i = 0; i < n; ++i) rank[i] = i;
         std::sort(rank.begin() + 1, rank.end(), [&](uint32_t lhs, uint32_t rhs) {
             return seq_begin[s0 + lhs] < seq_begin[s0 + rhs]; });
         const uint32_t L = static_cast<uint32_t>(seq_off[s0 + 1] - seq_off[s0]);
-        if (L == 0) return RCN_E_ARG;                         // createWindow rejects empty backbones (window.cpp:19-23)
+        if (L == 0) { bad[w] = 1; return; }                   // createWindow rejects empty backbones (window.cpp:19-23)
         const uint32_t offset = static_cast<uint32_t>(0.01 * L);
-        bool present[256] = {false};
+        uint64_t present[4] = {0, 0, 0, 0};
         WinShape sh{static_cast<int32_t>(L), 0, 0, 0};
         for (uint32_t i = 0; i < n; ++i) {
-            order[s0 + i] = rank[i];
+            hp.order[s0 + i] = rank[i];
             const uint32_t si = s0 + i;
             const uint64_t a = seq_off[si], z = seq_off[si + 1];
             if (i > 0) {
                 const uint32_t bg = seq_begin[si], en = seq_end[si];
-                if (z == a || bg >= en || bg > L || en > L) return RCN_E_ARG;   // add_layer contract (window.cpp:45-58)
-                full[si] = (bg < offset && en > L - offset) ? 1 : 0;
+                if (z == a || bg >= en || bg > L || en > L) { bad[w] = 1; return; }   // add_layer contract (window.cpp:45-58)
+                hp.full[si] = (bg < offset && en > L - offset) ? 1 : 0;
                 sh.sum_l += static_cast<int32_t>(z - a);
                 sh.lmax = std::max<int32_t>(sh.lmax, static_cast<int32_t>(z - a));
             }
-            if (bases) for (uint64_t k = a; k < z; ++k) present[bases[k]] = true;
+            if (bases) for (uint64_t k = a; k < z; ++k) present[bases[k] >> 6] |= 1ull << (bases[k] & 63);
         }
         if (bases) {
-            for (bool p : present) sh.nsym += p;
-            wflags[w] = (sh.nsym == int(present['A']) + int(present['C']) + int(present['G']) + int(present['T'])) ? 1 : 0;
-        } else { sh.nsym = nsym_all; wflags[w] = acgt_all ? 1 : 0; }
+            for (uint64_t p : present) sh.nsym += __builtin_popcountll(p);
+            const uint64_t acgt = (1ull << ('A' & 63)) | (1ull << ('C' & 63)) | (1ull << ('G' & 63)) | (1ull << ('T' & 63));
+            hp.wflags[w] = (present[0] == 0 && present[2] == 0 && present[3] == 0 && (present[1] & ~acgt) == 0) ? 1 : 0;
+        } else { sh.nsym = nsym_all; hp.wflags[w] = acgt_all ? 1 : 0; }
         e->shapes[w] = sh;
-    }
+    });
+    for (uint32_t w = 0; w < nw; ++w) if (bad[w]) return RCN_E_ARG;
     // Longest processing time first: a window's cost grows with (layers x bases), and a launch ends with its
     // slowest window; when there are more windows than resident slots the deep ones must not start last.
     e->lpt.resize(nw);
@@ -211,12 +294,28 @@ int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* wi
         const uint64_t ca = static_cast<uint64_t>(win_seq_off[a + 1] - win_seq_off[a]) * static_cast<uint64_t>(e->shapes[a].sum_l + e->shapes[a].L);
         const uint64_t cc = static_cast<uint64_t>(win_seq_off[c + 1] - win_seq_off[c]) * static_cast<uint64_t>(e->shapes[c].sum_l + e->shapes[c].L);
         return ca > cc; });
-    int rc;
+    // consensus output offsets by work item
+    e->out_off.assign(static_cast<size_t>(nw) + 1, 0);
+    for (uint32_t wi = 0; wi < nw; ++wi) e->out_off[wi + 1] = e->out_off[wi] + first_pass_out_cap(e->shapes[e->lpt[wi]]);
+    return RCN_OK;
+}
+
+}  // namespace
+
+// Preparation of a batch that is resident in caller order (rcn_engine_upload, rcn_engine_build_windows): prepare_host +
+// upload of its products.
+int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* win_seq_off, const uint64_t* seq_off,
+                            const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all, bool acgt_all = false) {
+    HostPrep hp;
+    int rc = prepare_host(e, hp, nw, ns, win_seq_off, seq_off, seq_begin, seq_end, bases, nsym_all, acgt_all);
+    if (rc) return rc;
+    e->lpt_layout = false;
     if ((rc = upload_vec(e->d_lpt_ids, e->lpt.data(), 4ull * nw, e->stream))) return rc;
-    if ((rc = upload_vec(e->d_order, order.data(), 4ull * ns, e->stream))) return rc;
-    if ((rc = upload_vec(e->d_full, full.data(), ns, e->stream))) return rc;
-    if ((rc = upload_vec(e->d_win_flags, wflags.data(), nw, e->stream))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));                 // order / full / flags are stack-scoped
+    if ((rc = upload_vec(e->d_order, hp.order.data(), 4ull * ns, e->stream))) return rc;
+    if ((rc = upload_vec(e->d_full, hp.full.data(), ns, e->stream))) return rc;
+    if ((rc = upload_vec(e->d_win_flags, hp.wflags.data(), nw, e->stream))) return rc;
+    if ((rc = upload_vec(e->d_out_off, e->out_off.data(), 8ull * (nw + 1), e->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));                 // hp is stack-scoped
     return RCN_OK;
 }
 
@@ -252,7 +351,9 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RCN_E_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= n) return RCN_E_ARG;
     HIP_TRY(hipSetDevice(cfg->device));
-    auto* e = new rcn_engine();
+    // the handle owns its streams / events from the first one on: every early return below destroys what exists
+    struct Guard { rcn_engine* e; ~Guard() { if (e) rcn_engine_destroy(e); } } guard{new rcn_engine()};
+    rcn_engine* e = guard.e;
     e->cfg = *cfg;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
@@ -261,10 +362,14 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     HIP_TRY(hipMemGetInfo(&fr, &tot));
     e->free_mem = fr;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (auto& st : e->sub_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
-    int rc = e->d_ctr.reserve(256);
-    if (rc) { delete e; return rc; }
+    for (auto& evs : e->sub_ev) for (auto& ev : evs) HIP_TRY(hipEventCreate(&ev));
+    int rc = e->d_ctr.reserve(kCtrBytes);
+    if (rc) return rc;
+    guard.e = nullptr;
     *out = e;
     return RCN_OK;
 }
@@ -274,25 +379,41 @@ void rcn_engine_destroy(rcn_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     for (DevBuf* d : {&e->d_win_seq_off, &e->d_win_type, &e->d_seq_off, &e->d_has_qual, &e->d_begin, &e->d_end,
                       &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_lpt_ids, &e->d_win_ids, &e->d_win_flags, &e->d_scratch,
-                      &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_ctr})
+                      &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_out_off, &e->d_ctr})
         d->release();
     for (DevBuf& d : e->d_build) d.release();
-    e->h_raw.release();
+    e->h_out.release(); e->h_stage.release();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (auto& evs : e->sub_ev) for (auto& ev : evs) if (ev) (void)hipEventDestroy(ev);
+    for (auto& st : e->sub_stream) if (st) (void)hipStreamDestroy(st);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
-int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
-    if (!e || !b) return RCN_E_ARG;
+int rcn_device_free_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (hipSetDevice(device) != hipSuccess) return RCN_E_ARG;
+    size_t fr = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&fr, &tot));
+    if (free_bytes) *free_bytes = fr;
+    if (total_bytes) *total_bytes = tot;
+    return RCN_OK;
+}
+
+static int check_batch(const rcn_batch* b) {
     if (b->n_windows && (!b->win_seq_off || !b->win_type || !b->seq_off || !b->seq_has_qual || !b->seq_begin ||
                          !b->seq_end || !b->bases || !b->quals))
         return RCN_E_ARG;
+    return RCN_OK;
+}
+
+int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
+    if (!e || !b || check_batch(b)) return RCN_E_ARG;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    hipEvent_t t0, t1;
-    HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
-    HIP_TRY(hipEventRecord(t0, e->stream));
+    EventPair t;
+    if (t.create()) return RCN_E_HIP;
+    HIP_TRY(hipEventRecord(t.a, e->stream));
     const uint32_t nw = b->n_windows, ns = b->n_seqs;
     e->n_windows = nw; e->n_seqs = ns; e->n_bases = ns ? b->seq_off[ns] : 0;
     e->uploaded = false; e->ran = false;
@@ -306,10 +427,9 @@ int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
     if ((rc = upload_vec(e->d_end, b->seq_end, 4ull * ns, e->stream))) return rc;
     if ((rc = upload_vec(e->d_bases, b->bases, e->n_bases, e->stream))) return rc;
     if ((rc = upload_vec(e->d_quals, b->quals, e->n_bases, e->stream))) return rc;
-    HIP_TRY(hipEventRecord(t1, e->stream));
+    HIP_TRY(hipEventRecord(t.b, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
     e->stats = rcn_run_stats{};
     e->stats.h2d_ms = ms;
     e->stats.bytes_in = 2 * e->n_bases + 17ull * ns + 5ull * nw;
@@ -364,71 +484,34 @@ int rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_t
     return RCN_OK;
 }
 
-int rcn_engine_run(rcn_engine* e) {
-    if (!e) return RCN_E_ARG;
-    if (!e->uploaded) return RCN_E_STATE;
-    HIP_TRY(hipSetDevice(e->cfg.device));
+// After the first pass over all work items: brings lengths / flags / consensus bytes back (one pinned staging buffer),
+// re-runs overflowed windows with worst-case capacities (int32 kernel), reads the device counters and assembles the
+// per-window results in caller order.
+static int collect(rcn_engine* e) {
     const uint32_t nw = e->n_windows;
-    const double h2d = e->stats.h2d_ms; const uint64_t bin = e->stats.bytes_in;
-    e->stats = rcn_run_stats{}; e->stats.h2d_ms = h2d; e->stats.bytes_in = bin;
-    e->cons_off.assign(nw + 1, 0); e->polished.assign(nw, 0); e->chimeric.assign(nw, 0); e->cons.clear();
-    if (nw == 0) { e->cons.push_back(0); e->ran = true; return RCN_OK; }
-    { size_t fr = 0, tot = 0; HIP_TRY(hipMemGetInfo(&fr, &tot)); e->free_mem = fr + e->d_scratch.cap; }
-
-    // first-pass capacities: typical growth; overflowing windows are re-run below
-    int32_t ncap = 0, lmax = 1, nsym = 2;
-    for (const auto& s : e->shapes) {
-        const int64_t worst = static_cast<int64_t>(s.L) + s.sum_l + 8;
-        const int64_t est = static_cast<int64_t>(s.L) + s.sum_l / 4 + 256;
-        ncap = std::max<int32_t>(ncap, static_cast<int32_t>(std::min(worst, est)));
-        lmax = std::max(lmax, s.lmax); nsym = std::max(nsym, s.nsym);
-    }
-    const int32_t ring = std::max(1, nsym - 1);
-    const bool fast = !getenv("RCN_WIDE_ONLY");
-    {
-        // windows in the top tail of the depth distribution decide when a launch ends (one wave per window is
-        // latency bound): they get the 4-wave DP.  Threshold = a high percentile of sequences per window.
-        std::vector<uint32_t> depth(nw);
-        for (uint32_t w = 0; w < nw; ++w) depth[w] = e->h_win_seq_off[w + 1] - e->h_win_seq_off[w];
-        std::vector<uint32_t> sorted = depth;
-        const char* pe = getenv("RCN_HEAVY_PCT");
-        const double pct = pe ? atof(pe) : 1.0;
-        const size_t kth = std::min<size_t>(nw - 1, static_cast<size_t>(pct * nw));
-        std::nth_element(sorted.begin(), sorted.begin() + kth, sorted.end());
-        e->heavy_ns = pct >= 1.0 ? 0 : static_cast<int32_t>(std::max<uint32_t>(sorted[kth], 3));
-        if (pct <= 0.0) e->heavy_ns = 1;
-    }
-    Caps c1 = make_caps(ncap, 2 * ncap, ring, lmax, fast);
+    const uint64_t cons_bytes = e->out_off[nw];
+    // pinned layout: [lengths 4 nw][flags nw, padded][consensus bytes]
+    const uint64_t off_flags = 4ull * nw, off_cons = (off_flags + nw + 15) & ~uint64_t(15);
     int rc;
-    if ((rc = e->d_out_cons.reserve(static_cast<uint64_t>(nw) * c1.out_stride))) return rc;
-    if ((rc = e->d_out_len.reserve(4ull * nw))) return rc;
-    if ((rc = e->d_out_flags.reserve(nw))) return rc;
-    HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 256, e->stream));
-    if ((rc = run_pass(e, c1, nullptr, nw, c1.out_stride, e->d_lpt_ids.as<uint32_t>()))) return rc;
-
-    std::vector<uint32_t> out_len(nw);
-    std::vector<uint8_t> flags(nw);
-    hipEvent_t t0, t1;
-    HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
-    HIP_TRY(hipEventRecord(t0, e->stream));
-    HIP_TRY(hipMemcpyAsync(out_len.data(), e->d_out_len.p, 4ull * nw, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(flags.data(), e->d_out_flags.p, nw, hipMemcpyDeviceToHost, e->stream));
-    const size_t raw_bytes = static_cast<uint64_t>(nw) * c1.out_stride;
-    if ((rc = e->h_raw.reserve(raw_bytes))) return rc;
-    uint8_t* raw = e->h_raw.as<uint8_t>();
-    HIP_TRY(hipMemcpyAsync(raw, e->d_out_cons.p, raw_bytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipEventRecord(t1, e->stream));
+    if ((rc = e->h_out.reserve(off_cons + cons_bytes + 16))) return rc;
+    uint8_t* hb = e->h_out.as<uint8_t>();
+    EventPair t;
+    if (t.create()) return RCN_E_HIP;
+    HIP_TRY(hipEventRecord(t.a, e->stream));
+    HIP_TRY(hipMemcpyAsync(hb, e->d_out_len.p, 4ull * nw, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(hb + off_flags, e->d_out_flags.p, nw, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(hb + off_cons, e->d_out_cons.p, cons_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipEventRecord(t.b, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t0, t1)); e->stats.d2h_ms += ms;
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); e->stats.d2h_ms += ms;
+    const uint32_t* len_item = reinterpret_cast<const uint32_t*>(hb);
+    const uint8_t* flag_item = hb + off_flags;
+    const uint8_t* raw = hb + off_cons;
 
     // outputs of the first pass are indexed by work item: back to window order
-    {
-        std::vector<uint32_t> ol(nw); std::vector<uint8_t> fl(nw);
-        for (uint32_t wi = 0; wi < nw; ++wi) { ol[e->lpt[wi]] = out_len[wi]; fl[e->lpt[wi]] = flags[wi]; }
-        out_len.swap(ol); flags.swap(fl);
-    }
-    std::vector<uint32_t> item_of(nw);
-    for (uint32_t wi = 0; wi < nw; ++wi) item_of[e->lpt[wi]] = wi;
+    std::vector<uint32_t> out_len(nw), item_of(nw);
+    std::vector<uint8_t> flags(nw);
+    for (uint32_t wi = 0; wi < nw; ++wi) { const uint32_t w = e->lpt[wi]; out_len[w] = len_item[wi]; flags[w] = flag_item[wi]; item_of[w] = wi; }
     // retry pass with worst-case capacities for windows that overflowed
     std::vector<uint32_t> retry;
     for (uint32_t w = 0; w < nw; ++w) {
@@ -437,38 +520,49 @@ int rcn_engine_run(rcn_engine* e) {
     }
     std::vector<std::string> retry_cons(retry.size());
     if (!retry.empty()) {
-        int32_t n2 = 0, l2 = 1;
-        for (uint32_t w : retry) {
+        int32_t n2 = 0, l2 = 1, nsym = 2;
+        std::vector<uint32_t> ids(retry.size());
+        std::vector<uint64_t> off2(retry.size() + 1, 0);
+        for (size_t k = 0; k < retry.size(); ++k) {
+            const uint32_t w = retry[k];
             const auto& s = e->shapes[w];
-            n2 = std::max<int32_t>(n2, s.L + s.sum_l + 8); l2 = std::max(l2, s.lmax);
+            n2 = std::max<int32_t>(n2, s.L + s.sum_l + 8); l2 = std::max(l2, s.lmax); nsym = std::max(nsym, s.nsym);
+            ids[k] = e->lpt_layout ? item_of[w] : w;                          // device window id
+            off2[k + 1] = off2[k] + ((static_cast<uint64_t>(s.L) + s.sum_l + 8 + 15) & ~uint64_t(15));
         }
-        Caps c2 = make_caps(n2, n2 + 8, ring, l2, false);     // int32 kernel, worst-case capacities
+        Caps c2 = make_caps(n2, n2 + 8, std::max(1, nsym - 1), l2, false);     // int32 kernel, worst-case capacities
         const uint32_t nr = static_cast<uint32_t>(retry.size());
-        const uint64_t stride2 = c2.out_stride;
-        // first-pass bytes are already on the host in `raw`; the retry pass indexes its outputs by work item
-        if ((rc = e->d_out_cons.reserve(static_cast<uint64_t>(nr) * stride2))) return rc;
-        if ((rc = run_pass(e, c2, retry.data(), nr, stride2))) return rc;
+        // first-pass bytes are already on the host; the retry pass indexes its outputs by its own work items
+        if ((rc = e->d_out_cons.reserve(off2[nr] + 16))) return rc;
+        if ((rc = upload_vec(e->d_out_off, off2.data(), 8ull * (nr + 1), e->stream))) return rc;
+        if ((rc = upload_vec(e->d_win_ids, ids.data(), 4ull * nr, e->stream))) return rc;
+        rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr);
+        // the resident batch keeps its first-pass offsets for the next rcn_engine_run
+        int rc2 = upload_vec(e->d_out_off, e->out_off.data(), 8ull * (nw + 1), e->stream);
+        if (rc) return rc;
+        if (rc2) return rc2;
         std::vector<uint32_t> len2(nr);
         std::vector<uint8_t> fl2(nr);
-        HIP_TRY(hipMemcpy(len2.data(), e->d_out_len.p, 4ull * nr, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(fl2.data(), e->d_out_flags.p, nr, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(len2.data(), e->d_out_len.p, 4ull * nr, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(fl2.data(), e->d_out_flags.p, nr, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
         for (size_t k = 0; k < retry.size(); ++k) {
             const uint32_t w = retry[k];
             if (fl2[k] & (rcn::kFlagOverflow | rcn::kFlagError)) return RCN_E_CAPACITY;
             retry_cons[k].resize(len2[k]);
-            if (len2[k]) HIP_TRY(hipMemcpy(&retry_cons[k][0], e->d_out_cons.as<uint8_t>() + static_cast<uint64_t>(k) * stride2,
-                                           len2[k], hipMemcpyDeviceToHost));
+            if (len2[k]) HIP_TRY(hipMemcpy(&retry_cons[k][0], e->d_out_cons.as<uint8_t>() + off2[k], len2[k], hipMemcpyDeviceToHost));
             out_len[w] = len2[k]; flags[w] = fl2[k];
         }
         e->stats.n_retried = static_cast<uint32_t>(retry.size());
     }
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
 
-    unsigned long long st[19] = {0};
-    HIP_TRY(hipMemcpy(st, e->d_ctr.as<uint8_t>() + 16, sizeof(st), hipMemcpyDeviceToHost));
+    unsigned long long st[24] = {0};
+    HIP_TRY(hipMemcpy(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost));
     e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
     for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
     e->stats.n_sink_ties = st[11];
+    e->stats.dp_cells_full = st[12]; e->stats.dp_bytes_full = st[13]; e->stats.n_banded = st[14]; e->stats.n_band_redone = st[15];
+    for (int k = 0; k < 8; ++k) e->stats.band_redo_why[k] = st[16 + k];
 #ifdef RCN_PROF_WIN
     { static unsigned long long wc[4096][8]; HIP_TRY(hipMemcpyFromSymbol(wc, HIP_SYMBOL(rcn::g_wclk), sizeof(wc)));
       std::vector<std::pair<unsigned long long, int>> tot;
@@ -476,31 +570,223 @@ int rcn_engine_run(rcn_engine* e) {
       std::sort(tot.rbegin(), tot.rend());
       unsigned long long all = 0; for (auto& p : tot) all += p.first;
       fprintf(stderr, "[racon_hip] per-window clocks: mean %.3g\n", (double)all / std::max<size_t>(1, tot.size()));
-      for (int k = 0; k < 3 && k < (int)tot.size(); ++k) { int w = tot[k].second; fprintf(stderr, "  window %d (%u seqs): total %.3g | sub %.3g desc %.3g dp %.3g tb %.3g add %.3g merge %.3g cons %.3g | tiles %llu boxes %llu slow %llu\n", w,
-          e->h_win_seq_off[w + 1] - e->h_win_seq_off[w], (double)tot[k].first, (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6], wc[w][7] >> 40, (wc[w][7] >> 20) & 0xfffff, wc[w][7] & 0xfffff); }
-      { int w = tot[tot.size() / 2].second; fprintf(stderr, "  median window %d: total %.3g tb %.3g tiles %llu boxes %llu slow %llu\n", w, (double)tot[tot.size() / 2].first, (double)wc[w][3], wc[w][7] >> 40, (wc[w][7] >> 20) & 0xfffff, wc[w][7] & 0xfffff); } }
+      for (int k = 0; k < 3 && k < (int)tot.size(); ++k) { int w = tot[k].second; fprintf(stderr, "  work item %d (%u seqs): total %.3g | sub %.3g desc %.3g dp %.3g tb %.3g add %.3g merge %.3g cons %.3g | tiles %llu boxes %llu slow %llu\n", w,
+          e->h_win_seq_off[e->lpt[w] + 1] - e->h_win_seq_off[e->lpt[w]], (double)tot[k].first, (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6], wc[w][7] >> 40, (wc[w][7] >> 20) & 0xfffff, wc[w][7] & 0xfffff); }
+      { int w = tot[tot.size() / 2].second; fprintf(stderr, "  median work item %d: total %.3g | sub %.3g desc %.3g dp %.3g tb %.3g add %.3g merge %.3g cons %.3g\n", w, (double)tot[tot.size() / 2].first,
+          (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6]); } }
 #endif
-#ifdef RCN_PROF_DP
-    { unsigned long long pr[8]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(rcn::g_prof_out), sizeof(pr)));
-      fprintf(stderr, "[racon_hip] dp prof (cumulative): "); for (int k = 0; k < 2; ++k) fprintf(stderr, "wave%d row %llu bar %llu | ", k, pr[2*k], pr[2*k+1]);
-      { unsigned long long db[8]; HIP_TRY(hipMemcpyFromSymbol(db, HIP_SYMBOL(rcn::g_dbg), sizeof(db))); fprintf(stderr, "dbg: "); for (int k = 0; k < 8; ++k) fprintf(stderr, "%llu ", db[k]); fprintf(stderr, "\n"); }
-      fprintf(stderr, "traceback: stage %llu walk %llu tiles %llu boxes %llu\n", pr[4], pr[5], pr[6], pr[7]); }
-#endif
-    if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] traceback: stage clocks %llu walk clocks %llu tiles %llu steps %llu\n", st[12], st[13], st[14], st[15]);
 
+    e->cons_off.assign(static_cast<size_t>(nw) + 1, 0);
     for (uint32_t w = 0; w < nw; ++w) e->cons_off[w + 1] = e->cons_off[w] + out_len[w];
     e->cons.resize(e->cons_off[nw] + 1);
+    e->polished.assign(nw, 0); e->chimeric.assign(nw, 0);
     size_t rk = 0;
     for (uint32_t w = 0; w < nw; ++w) {
         uint8_t* dst = e->cons.data() + e->cons_off[w];
         if (rk < retry.size() && retry[rk] == w) { std::memcpy(dst, retry_cons[rk].data(), out_len[w]); ++rk; }
-        else std::memcpy(dst, raw + static_cast<uint64_t>(item_of[w]) * c1.out_stride, out_len[w]);
+        else std::memcpy(dst, raw + e->out_off[item_of[w]], out_len[w]);
         e->polished[w] = (flags[w] & rcn::kFlagPolished) ? 1 : 0;
         e->chimeric[w] = (flags[w] & rcn::kFlagChimeric) ? 1 : 0;
     }
     e->stats.bytes_out = e->cons_off[nw] + 5ull * nw;
     e->ran = true;
     return RCN_OK;
+}
+
+static int begin_run(rcn_engine* e) {
+    const uint32_t nw = e->n_windows;
+    const double h2d = e->stats.h2d_ms; const uint64_t bin = e->stats.bytes_in;
+    e->stats = rcn_run_stats{}; e->stats.h2d_ms = h2d; e->stats.bytes_in = bin;
+    { size_t fr = 0, tot = 0; HIP_TRY(hipMemGetInfo(&fr, &tot)); e->free_mem = fr + e->d_scratch.cap; }
+    int rc;
+    if ((rc = e->d_out_cons.reserve(e->out_off[nw] + 16))) return rc;
+    if ((rc = e->d_out_len.reserve(4ull * nw))) return rc;
+    if ((rc = e->d_out_flags.reserve(nw))) return rc;
+    HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, kCtrBytes, e->stream));
+    {
+        // windows in the top tail of the depth distribution can be given the 4-wave DP (RCN_HEAVY_PCT; off by default:
+        // measured slower).  Threshold = a percentile of sequences per window.
+        const char* pe = getenv("RCN_HEAVY_PCT");
+        const double pct = pe ? atof(pe) : 1.0;
+        e->heavy_ns = 0;
+        if (pct < 1.0 && nw) {
+            std::vector<uint32_t> depth(nw);
+            for (uint32_t w = 0; w < nw; ++w) depth[w] = e->h_win_seq_off[w + 1] - e->h_win_seq_off[w];
+            const size_t kth = std::min<size_t>(nw - 1, static_cast<size_t>(std::max(0.0, pct) * nw));
+            std::nth_element(depth.begin(), depth.begin() + kth, depth.end());
+            e->heavy_ns = pct <= 0.0 ? 1 : static_cast<int32_t>(std::max<uint32_t>(depth[kth], 3));
+        }
+    }
+    return RCN_OK;
+}
+
+int rcn_engine_run(rcn_engine* e) {
+    if (!e) return RCN_E_ARG;
+    if (!e->uploaded) return RCN_E_STATE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint32_t nw = e->n_windows;
+    if (nw == 0) {
+        e->stats = rcn_run_stats{};
+        e->cons_off.assign(1, 0); e->polished.clear(); e->chimeric.clear(); e->cons.assign(1, 0); e->ran = true;
+        return RCN_OK;
+    }
+    int rc;
+    if ((rc = begin_run(e))) return rc;
+    const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), !getenv("RCN_WIDE_ONLY"));
+    if ((rc = run_pass(e, c1, e->lpt_layout ? nullptr : e->d_lpt_ids.as<uint32_t>(), nw))) return rc;
+    return collect(e);
+}
+
+// Upload + run of one batch with the copy hidden behind the kernel (what Polisher::polish pays per batch; reference
+// src/cuda/cudapolisher.cpp:254-333 fills and runs a batch strictly one after the other).  The windows are packed
+// DEEPEST FIRST into pinned staging by host threads, go to HBM in kSubLaunches pieces on a copy stream, and every piece is
+// polished by its own launch on its own stream as soon as it has arrived: the launches overlap on the device, the deepest
+// windows (which decide when the batch ends) start after the first, small piece.  Same results as upload + run.
+// Batches with more windows than resident slots take the plain path (their caller overlaps batches with two engines).
+int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
+    if (!e || !b || check_batch(b)) return RCN_E_ARG;
+    const uint32_t nw = b->n_windows, ns = b->n_seqs;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (nw < 64 || nw > max_slots(e) || getenv("RCN_NO_STREAM")) {
+        const int rc = rcn_engine_upload(e, b);
+        return rc ? rc : rcn_engine_run(e);
+    }
+    e->uploaded = false; e->ran = false;
+    e->n_windows = nw; e->n_seqs = ns; e->n_bases = b->seq_off[ns];
+    EventPair t;
+    if (t.create()) return RCN_E_HIP;
+    HIP_TRY(hipEventRecord(t.a, e->copy_stream));
+    HostPrep hp;
+    int rc = prepare_host(e, hp, nw, ns, b->win_seq_off, b->seq_off, b->seq_begin, b->seq_end, b->bases, 0, false);
+    if (rc) return rc;
+    e->lpt_layout = true;
+    e->stats = rcn_run_stats{};
+    if ((rc = begin_run(e))) return rc;
+
+    // ---- device layout: window k of the device arrays = work item k = caller window lpt[k] ----
+    const uint64_t nb = e->n_bases;
+    // staging: metadata block first, then bases, then qualities (each in deepest-first order)
+    const uint64_t o_wso = 0, o_type = o_wso + 4ull * (nw + 1), o_flags = o_type + nw, o_so = (o_flags + nw + 15) & ~uint64_t(15),
+                   o_hq = o_so + 8ull * (ns + 1), o_bg = (o_hq + ns + 15) & ~uint64_t(15), o_en = o_bg + 4ull * ns, o_ord = o_en + 4ull * ns,
+                   o_full = o_ord + 4ull * ns, o_bases = (o_full + ns + 255) & ~uint64_t(255), o_quals = (o_bases + nb + 255) & ~uint64_t(255),
+                   total = o_quals + nb + 256;
+    if ((rc = e->h_stage.reserve(total))) return rc;
+    uint8_t* hs = e->h_stage.as<uint8_t>();
+    uint32_t* s_wso = reinterpret_cast<uint32_t*>(hs + o_wso); uint8_t* s_type = hs + o_type; uint8_t* s_flags = hs + o_flags;
+    uint64_t* s_so = reinterpret_cast<uint64_t*>(hs + o_so); uint8_t* s_hq = hs + o_hq;
+    uint32_t* s_bg = reinterpret_cast<uint32_t*>(hs + o_bg); uint32_t* s_en = reinterpret_cast<uint32_t*>(hs + o_en);
+    uint32_t* s_ord = reinterpret_cast<uint32_t*>(hs + o_ord); uint8_t* s_full = hs + o_full;
+    std::vector<uint64_t> win_base(nw + 1, 0);         // first byte of device window k in the packed bases
+    s_wso[0] = 0; s_so[0] = 0;
+    for (uint32_t k = 0; k < nw; ++k) {
+        const uint32_t w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
+        s_wso[k + 1] = s_wso[k] + n;
+        win_base[k + 1] = win_base[k] + (b->seq_off[s0 + n] - b->seq_off[s0]);
+        s_type[k] = b->win_type[w]; s_flags[k] = hp.wflags[w];
+    }
+    const unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    host_parallel(nw, threads, [&](size_t k) {
+        const uint32_t w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0, d0 = s_wso[k];
+        const uint64_t src0 = b->seq_off[s0];
+        for (uint32_t i = 0; i < n; ++i) {
+            s_so[d0 + i + 1] = win_base[k] + (b->seq_off[s0 + i + 1] - src0);
+            s_hq[d0 + i] = b->seq_has_qual[s0 + i]; s_bg[d0 + i] = b->seq_begin[s0 + i]; s_en[d0 + i] = b->seq_end[s0 + i];
+            s_ord[d0 + i] = hp.order[s0 + i]; s_full[d0 + i] = hp.full[s0 + i];
+        }
+    });
+    if ((rc = e->d_win_seq_off.reserve(4ull * (nw + 1))) || (rc = e->d_win_type.reserve(nw)) || (rc = e->d_win_flags.reserve(nw)) ||
+        (rc = e->d_seq_off.reserve(8ull * (ns + 1))) || (rc = e->d_has_qual.reserve(ns)) || (rc = e->d_begin.reserve(4ull * ns)) ||
+        (rc = e->d_end.reserve(4ull * ns)) || (rc = e->d_order.reserve(4ull * ns)) || (rc = e->d_full.reserve(ns)) ||
+        (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16)) || (rc = e->d_out_off.reserve(8ull * (nw + 1))))
+        return rc;
+    hipStream_t cs = e->copy_stream;
+    HIP_TRY(hipMemcpyAsync(e->d_win_seq_off.p, s_wso, 4ull * (nw + 1), hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_win_type.p, s_type, nw, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_win_flags.p, s_flags, nw, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_seq_off.p, s_so, 8ull * (ns + 1), hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_has_qual.p, s_hq, ns, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_begin.p, s_bg, 4ull * ns, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_end.p, s_en, 4ull * ns, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_order.p, s_ord, 4ull * ns, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_full.p, s_full, ns, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_out_off.p, e->out_off.data(), 8ull * (nw + 1), hipMemcpyHostToDevice, cs));   // (pageable: small)
+
+    // ---- pieces: 1/8, 3/8, 1/2 of the bases, deepest windows first ----
+    uint32_t cut[rcn_engine::kSubLaunches + 1] = {0, 0, 0, nw};
+    {
+        const uint64_t q1 = nb / 8, q2 = nb / 2;
+        uint32_t k = 0;
+        while (k < nw && win_base[k] < q1) ++k;
+        cut[1] = std::min(std::max(k, 1u), nw);
+        while (k < nw && win_base[k] < q2) ++k;
+        cut[2] = std::min(std::max(k, cut[1]), nw);
+    }
+    const bool fast = !getenv("RCN_WIDE_ONLY");
+    Launch L[rcn_engine::kSubLaunches];
+    uint64_t scratch_total = 0;
+    std::vector<WinShape> sub_shapes;
+    for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
+        const uint32_t k0 = cut[c], k1 = cut[c + 1];
+        L[c].n_work = k1 - k0; L[c].work_base = k0; L[c].out_base = k0; L[c].ctr = c; L[c].stream = e->sub_stream[c];
+        if (k1 == k0) continue;
+        sub_shapes.clear();
+        for (uint32_t k = k0; k < k1; ++k) sub_shapes.push_back(e->shapes[e->lpt[k]]);
+        L[c].c = first_pass_caps(sub_shapes.begin(), sub_shapes.end(), fast);
+        L[c].slots = L[c].n_work;                                  // one resident slot per window (nw <= max_slots)
+        L[c].scratch_off = scratch_total;
+        scratch_total += static_cast<uint64_t>(L[c].slots) * L[c].c.slot_bytes;
+    }
+    if (scratch_total > scratch_budget(e)) {
+        // does not fit next to each other: the plain path shares the slots
+        HIP_TRY(hipStreamSynchronize(cs));
+        const int rc2 = rcn_engine_upload(e, b);
+        return rc2 ? rc2 : rcn_engine_run(e);
+    }
+    if ((rc = e->d_scratch.reserve(scratch_total))) return rc;
+    // the main stream zeroed the counters (begin_run): the sub-launches must not start before that
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
+        const uint32_t k0 = cut[c], k1 = cut[c + 1];
+        if (k1 == k0) continue;
+        const uint64_t b0 = win_base[k0], b1 = win_base[k1];
+        host_parallel(k1 - k0, threads, [&](size_t kk) {
+            const uint32_t k = k0 + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
+            const uint64_t src0 = b->seq_off[s0], len = b->seq_off[s0 + n] - src0;
+            std::memcpy(hs + o_bases + win_base[k], b->bases + src0, len);
+            std::memcpy(hs + o_quals + win_base[k], b->quals + src0, len);
+        });
+        HIP_TRY(hipMemcpyAsync(e->d_bases.as<uint8_t>() + b0, hs + o_bases + b0, b1 - b0, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync(e->d_quals.as<uint8_t>() + b0, hs + o_quals + b0, b1 - b0, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipEventRecord(e->sub_ev[c][0], cs));
+        HIP_TRY(hipStreamWaitEvent(L[c].stream, e->sub_ev[c][0], 0));
+        HIP_TRY(hipStreamWaitEvent(L[c].stream, e->ev0, 0));
+        HIP_TRY(hipEventRecord(e->sub_ev[c][1], L[c].stream));
+        if ((rc = launch_pass(e, L[c]))) return rc;
+        HIP_TRY(hipEventRecord(e->sub_ev[c][2], L[c].stream));
+    }
+    HIP_TRY(hipEventRecord(t.b, cs));
+    float span0 = 0, span1 = 0;
+    bool have = false;
+    for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
+        if (cut[c + 1] == cut[c]) continue;
+        HIP_TRY(hipEventSynchronize(e->sub_ev[c][2]));
+        float a0 = 0, a1 = 0;       // begin / end of this launch relative to the first copy
+        HIP_TRY(hipEventElapsedTime(&a0, t.a, e->sub_ev[c][1]));
+        HIP_TRY(hipEventElapsedTime(&a1, t.a, e->sub_ev[c][2]));
+        if (!have) { span0 = a0; span1 = a1; have = true; } else { span0 = std::min(span0, a0); span1 = std::max(span1, a1); }
+        if (getenv("RCN_DEBUG")) {
+            float cp = 0; (void)hipEventElapsedTime(&cp, t.a, e->sub_ev[c][0]);
+            fprintf(stderr, "[racon_hip] streamed piece %d: windows [%u, %u) slots %u ncap %d lmax %d | copy done %.2f ms, kernel %.2f .. %.2f ms\n",
+                    c, cut[c], cut[c + 1], L[c].slots, L[c].c.ncap, L[c].c.lmax, cp, a0, a1);
+        }
+        e->stats.n_launches += 1;
+    }
+    e->stats.kernel_ms = span1 - span0;                              // the overlapping launches as one interval
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+    e->stats.h2d_ms = ms;
+    e->stats.bytes_in = 2 * nb + 17ull * ns + 5ull * nw;
+    e->uploaded = true;
+    return collect(e);
 }
 
 int rcn_engine_result(rcn_engine* e, rcn_result* out) {

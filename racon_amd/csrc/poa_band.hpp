@@ -1,0 +1,517 @@
+// poa_band.hpp — the EXACT banded variant of the one-wave NW DP of poa_kernel2.hpp (included from there).
+//
+// What it computes: the same alignment as dp2_rows<NP, 1> (spoa::AlignmentEngine::Align, kNW, linear gap; reference
+// src/window.cpp:95-97,104-106), but every row only over a WINDOW of WB = 128 * NP columns that follows the
+// row's backbone coordinate, two cells per VGPR, NP VGPRs per lane instead of ceil((len + 1) / 128): at w = 500 half
+// the per-row instruction slots of the full row, half the matrix bytes.  Cells outside their row's window count as -inf.
+//
+// Why the result is still the full matrix's (the certificate; restated and measured on the CPU in
+// the CPU checker's band study, tools/band_study.py):
+//   Let T be the best end score the banded pass finds (some sink row, column len).  Call a computed cell ALIVE when
+//   H'[i][j] + m (len - j) >= T: no path through a dead cell can reach T, because every remaining sequence base
+//   adds at most m.  If every DP successor of every alive cell is a computed cell, then by induction along any full
+//   path P with score >= T all of P's cells are alive and carry H' = H (a successor of an alive cell is computed, its
+//   banded value is at least P's prefix score, hence alive again; and H' <= H always).  So T is the optimum, the tied
+//   sinks are the true ones, and every equality the traceback tests comes out as on the full matrix: a matching
+//   candidate lies on a co-optimal path (exact value), a non-matching one can only have become smaller.
+//   The kernel verifies "successors of alive cells are computed" with what a row costs nothing to record:
+//     (a) the LAST window cell of every row whose window ends left of column len must be dead (its horizontal and
+//         diagonal successors lie outside);
+//     (b) when the window moves right by delta columns, the delta leftmost cells of the rows that later rows can
+//         still read (register window at the shift; LDS ring rows when they are read) must be dead;
+//     (c) a source row (predecessor = the virtual row 0, alive at least in column 0) must have window offset 0;
+//     (d) a predecessor older than the LDS ring is not supported.
+//   Alive is tested as  Z - (m - g) j >= T - m len  with Z = H - j g the stored value: the left side is recorded as
+//   a running maximum while T is still unknown.  Any violation -> ctx->band_fail = 1 and the caller redoes this one
+//   alignment with the unbanded DP (measured on cfg2: < 0.2 % of the alignments).
+//
+// Matrix layout is unchanged (absolute columns, row stride hstride), so traceback / sink-tie code does not know about
+// the band; cells it may look at outside a window are kept at -inf by guard stores: the cell left of a row's window,
+// the columns a shift adds for the rows of the LDS ring, column len of sink rows whose window ends before it.
+#pragma once
+
+namespace rcn {
+
+constexpr int kBandG = 32;            // window offsets are multiples of this many columns
+constexpr int kBandSeq = 1536;        // LDS copy of the layer's bases (window shifts re-read their columns from it)
+
+// NP of the banded DP for a layer of `len` bases (0 = not banded).  The alive zone is about len / 3 wide
+// (profiles/r02/band_study.txt), so a window serves layers up to ~2.5 x its width.
+__host__ __device__ __forceinline__ int band_np(int len) {
+    const int W = len + 1;
+    if (W > 256 && W <= 640) return 2;
+    return 0;
+}
+__host__ __device__ constexpr int dp2_ring_rows_band(int np, bool tab) {
+    return (kLdsBytes - 64 - kBandSeq - (tab ? 4 * 4 * 64 * np : 0)) / (4 * 64 * np) - 1;
+}
+
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {        // saturating a - b per half (v_pk_sub_i16 clamp)
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, static_cast<s16x2>(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
+}
+
+// phase_desc2, banded alignments: window offset of every row (g.pred[r] = offset of DP row r + 1).  A row's coordinate
+// is the last backbone node at or before it in the order being aligned (new nodes sit right behind their anchors, so
+// this is the backbone position the row belongs to within a few columns); the window is centred on the column that
+// position maps to, quantised to kBandG columns, never moving left.
+__device__ __forceinline__ int band_offset_of(int pi, int bb0, float scale, int WB, int offmax) {
+    const int rel = max(0, pi - bb0 + 1);
+    int o = static_cast<int>(static_cast<float>(rel) * scale) - WB / 2;
+    o = o < 0 ? 0 : (o & ~(kBandG - 1));
+    return min(o, offmax);
+}
+
+__device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G const int32_t* rank) {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    RCN_G int32_t* roff = g.pred.ptr();
+    const int V = c.V, WB = 128 * c.band, W = c.len + 1;
+    const int offmax = min(((W - WB + kBandG - 1) / kBandG) * kBandG, c.hstride - WB);
+    const int bb0 = c.sub ? c.begin : 0, nbb = c.sub ? (c.end - c.begin + 1) : c.bblen;
+    const float scale = static_cast<float>(c.len) / static_cast<float>(nbb > 0 ? nbb : 1);
+    int* xch = Block4::work();
+    int carry = -1;
+    for (int base = 0; base < V; base += 4 * kThreads2) {
+        int pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = base + 4 * t + k;
+            const int v = r < V ? rank[r] : 0x7fffffff;
+            pv[k] = v < c.bblen ? v : -1;
+        }
+        pv[1] = max(pv[1], pv[0]); pv[2] = max(pv[2], pv[1]); pv[3] = max(pv[3], pv[2]);
+        const int incl = wave_incl_scan_max(pv[3]);
+        const int excl = wave_shr1(incl, -1);
+        int off, total, pmax, tmax;
+        block4_scan(xch, wv, lane, 0, __builtin_amdgcn_readlane(incl, 63), off, total, pmax, tmax);
+        const int before = max(max(excl, pmax), carry);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = base + 4 * t + k;
+            if (r < V) roff[r] = band_offset_of(max(before, pv[k]), bb0, scale, WB, offmax);
+        }
+        carry = max(carry, tmax);
+    }
+    Block4::sync();
+}
+
+// ---- the banded one-wave DP (wave 0 of the work-group) ----
+template <int NP, bool TAB>
+__device__ __noinline__ void dp2_rows_band() {
+    constexpr int NTH = 64, WB = 128 * NP, LPC = 2 * NP;       // window columns, columns per lane
+    const int t = threadIdx.x & 63, lane = t;
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    RCN_G const RowDesc* desc = g.desc.ptr();
+    RCN_G const int32_t* roff = g.pred.ptr();
+    RCN_G const int32_t* nr = (c.sub ? g.n2r_x : g.n2r).ptr();
+    RCN_G const int32_t* e_nin = g.e_nin.ptr();
+    RCN_G const int32_t* e_tail = g.e_tail.ptr();
+    RCN_G const uint8_t* inc = g.inc.ptr();
+    const bool sub = c.sub != 0;
+    RCN_G uint32_t* __restrict__ H = reinterpret_cast<RCN_G uint32_t*>(g.H.ptr());
+    RCN_G int16_t* H16w = reinterpret_cast<RCN_G int16_t*>(g.H.ptr());
+    RCN_G const uint8_t* seq = gcast(c.seq);
+    const int V = c.V, len = c.len;
+    const int hs = c.hstride, hs2 = hs >> 1;
+    constexpr int kTab = TAB ? 4 * 4 * NTH * NP : 0;
+    constexpr int KT = (kLdsBytes - 64 - kBandSeq - kTab) / (4 * NTH * NP);
+    constexpr int K = KT - 1;
+    static_assert(K == dp2_ring_rows_band(NP, TAB), "phase_desc2 classifies rows with the same ring depth");
+    static_assert(K >= 8 && K <= 63, "ring depth");
+    uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());          // [KT][NTH][NP]
+    uint32_t* ptab = ring + KT * NTH * NP;                                    // [4][NTH][NP] (TAB)
+    uint8_t* lseq = reinterpret_cast<uint8_t*>(ptab + kTab / 4);             // [kBandSeq]
+    for (int k = t; k < len; k += NTH) lseq[k] = seq[k];
+
+    const int mg = c.m - c.gp, xg = c.x - c.gp;
+    uint32_t MG = pack2(mg, mg), XM = pack2(xg - mg, xg - mg), ONE = 0x00010001u;
+    const uint32_t GG = pack2(c.gp, c.gp);
+    const uint32_t NEGP = pack2(kNeg16, kNeg16);
+    asm volatile("; constants live in VGPRs" : "+v"(MG), "+v"(XM), "+v"(ONE));
+    uint32_t tie_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&Block4::ctx()->tie_rows[0]));
+    asm volatile("" : "+s"(tie_base));
+
+    // ---- window state ----
+    int woff = 0;                               // first column of the window
+    int s_row1 = 0, s_row2 = 0, s_row3 = 0;     // rows >= s_row1 have offset woff, rows in [s_row2, s_row1) off1, [s_row3, s_row2) off2
+    int off1 = 0, off2 = 0;
+    int bfail = 0;
+    uint32_t sqx[NP], thrv[NP];                 // bases / alive thresholds (m - g) * column of this lane's columns
+    int own_lane = 0, own_q = 0, own_in = 0;    // where column len lives (own_in: inside the window)
+    const int own_hi = len & 1;
+    auto set_columns = [&]() {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int j0 = woff + t * LPC + 2 * q, j1 = j0 + 1;
+            const int s0 = (j0 >= 1 && j0 <= len) ? lseq[j0 - 1] : 0x100, s1 = (j1 >= 1 && j1 <= len) ? lseq[j1 - 1] : 0x100;
+            sqx[q] = pack2(s0, s1);
+            thrv[q] = pack2(mg * j0, mg * j1);
+        }
+        if (TAB) {
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const uint32_t code = sl == 0 ? 'A' : sl == 1 ? 'C' : sl == 2 ? 'T' : 'G', symsym = code | (code << 16);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) ptab[(sl * NTH + t) * NP + q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
+            }
+        }
+        const int rel = len - woff;
+        own_in = rel < WB;
+        own_lane = (rel / LPC) & 63; own_q = (rel % LPC) >> 1;
+    };
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);              // lseq written by this wave, read right below
+    set_columns();
+
+    constexpr int R = dp2_window(NP);
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 win;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) win[k] = NEGP;
+    uint32_t prev[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) prev[q] = NEGP;
+    int zsh = static_cast<int>(0x80000000u);
+    uint32_t mpv = static_cast<uint32_t>(kNeg16) << 16;
+    // certificate accumulators: dropped cells (vector, Z - (m - g) j per half, saturating), last window cells (vector
+    // of raw Z, reduced when the window moves), both as scalars in the H - m j form
+    uint32_t emaxV = pack2(-32768, -32768), edgeR = NEGP;
+    int edgeS = -(1 << 30);
+    auto flush_edge = [&]() {
+        const int lastcol = woff + WB - 1;
+        if (lastcol < len) {
+            const int zr = static_cast<int>(__builtin_amdgcn_readlane(static_cast<int>(edgeR), 63)) >> 16;
+            edgeS = max(edgeS, zr - mg * lastcol);
+        }
+        edgeR = NEGP;
+    };
+
+    int best = 0, best_row = 0, have_best = 0, tied = 0;
+    unsigned int pred_rows = 0, not_chain = 0;
+    int slot = 1 % K;
+    RCN_G uint32_t* hrow = H + hs2;             // wave-uniform: row i of the matrix at the window's first column
+    int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
+
+    // the window moves to new_off before row i is computed
+    auto shift_to = [&](int i_in, int new_off) {
+        int i = i_in, Vs = V;
+        asm volatile("; window shift (rare): nothing of it is carried in the row loop" : "+s"(i), "+s"(Vs));
+        flush_edge();
+        const int delta = new_off - woff, dl = delta / LPC;
+        {   // (b) dropped cells of the rows in the register window
+            uint32_t ev = pack2(-32768, -32768);
+#pragma unroll
+            for (int k = 0; k < R * NP; ++k) ev = pk_max(ev, pk_subs(win[k], thrv[k % NP]));
+            if (lane < dl) emaxV = pk_max(emaxV, ev);
+        }
+        {   // re-base the register window: lane l <- lane l + dl
+            const int srcl = ((lane + dl) & 63) * 4;
+            const bool keep = lane + dl < 64;
+#pragma unroll
+            for (int k = 0; k < R * NP; ++k) {
+                const uint32_t v = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(srcl, static_cast<int>(win[k])));
+                win[k] = keep ? v : NEGP;
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const uint32_t v = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(srcl, static_cast<int>(prev[q])));
+                prev[q] = keep ? v : NEGP;
+            }
+        }
+        // guards in HBM: the cell left of the window for every row still to come ...
+        for (int r = i + lane; r <= Vs; r += NTH) H16w[static_cast<int64_t>(r) * hs + new_off - 1] = static_cast<int16_t>(kNeg16);
+        {   // ... and the columns this shift adds, for the rows later rows can still name as predecessors
+            const int r0 = max(1, i - (K + 1)), dw = delta >> 1, n = (i - r0) * dw;
+            for (int idx = lane; idx < n; idx += NTH) {
+                const int r = r0 + idx / dw, cw = idx % dw;
+                H[static_cast<int64_t>(r) * hs2 + ((woff + WB) >> 1) + cw] = NEGP;
+            }
+        }
+        off2 = off1; s_row3 = s_row2; off1 = woff; s_row2 = s_row1; s_row1 = i; woff = new_off;
+        hrow = H + static_cast<int64_t>(i) * hs2 + (woff >> 1);
+        set_columns();
+    };
+
+#pragma unroll 1
+    for (int rbase = 0; rbase < V && !bfail; rbase += 64) {
+        {
+            RowDesc d; d.erest = -1; d.meta = 1 << 9;
+#pragma unroll
+            for (int q = 0; q < kInlinePreds; ++q) d.p[q] = 0;
+            int ro = 0;
+            if (rbase + lane < V) { d = desc[rbase + lane]; ro = roff[rbase + lane]; }
+            dl_p0 = d.p[0]; dl_p1 = d.p[1]; dl_p2 = d.p[2]; dl_p3 = d.p[3]; dl_p4 = d.p[4]; dl_p5 = d.p[5]; dl_er = d.erest; dl_meta = d.meta; dl_off = ro;
+            asm volatile("; row descriptors retired" : "+v"(dl_p0), "+v"(dl_p1), "+v"(dl_p2), "+v"(dl_p3), "+v"(dl_p4), "+v"(dl_p5), "+v"(dl_er), "+v"(dl_meta), "+v"(dl_off));
+        }
+        const int rend = min(V, rbase + 64);
+        int meta_next = __builtin_amdgcn_readlane(dl_meta, 0);
+        uint32_t Pn[NP];
+        auto profile_now = [&](int meta_) {
+            if (TAB) {
+                const uint32_t* src = ptab + ((((meta_ & 255) >> 1) & 3) * NTH + t) * NP;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Pn[q] = src[q];
+            } else {
+                const uint32_t sy = meta_ & 255, symsym = sy | (sy << 16);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Pn[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
+            }
+        };
+        profile_now(meta_next);
+#pragma unroll 1
+        for (int i = rbase + 1; i <= rend; ++i) {
+            const int k = (i - 1) & 63;
+            const int meta = meta_next;
+            meta_next = __builtin_amdgcn_readlane(dl_meta, i & 63);
+            if (__builtin_expect((meta & (1 << 12)) != 0, 0)) {
+                // special row: the window may move here (all on-chip state is re-based, the profile of this row redone)
+                const int new_off = __builtin_amdgcn_readlane(dl_off, k);
+                if (new_off != woff) { shift_to(i, new_off); profile_now(meta); }
+            }
+            uint32_t P[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) P[q] = Pn[q];
+
+            uint32_t M[NP];
+            if (meta & (1 << 15)) {
+                // ---- chain row: the only predecessor is the row just finished ----
+#pragma unroll
+                for (int q = 0; q < NP; ++q) M[q] = prev[q];
+            } else if (meta & (1 << 13)) {
+                ++not_chain;
+                // ---- fast row: predecessors in the register window (always in current coordinates) ----
+                const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
+                const int npf = (meta >> 9) & 7;
+                {
+                    const int d = dd & 15;
+                    const int wi = ((i - d) & (R - 1)) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) M[q] = win[wi + q];
+                }
+#pragma unroll 1
+                for (int e = 1; e < npf; ++e) {
+                    const int d = (dd >> (4 * e)) & 15;
+                    const int wi = ((i - d) & (R - 1)) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], win[wi + q]);
+                }
+                pred_rows += npf;
+            } else if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
+                // ---- medium row whose predecessors all share this row's window: LDS ring, reads in flight together ----
+                const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
+                const int npf = (meta >> 9) & 7;
+                uint32_t hp[4][NP];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = (dd >> (4 * (e < npf ? e : 0))) & 15;
+                    int sp = slot - d; if (sp < 0) sp += K;
+                    const uint32_t* src = ring + (sp * NTH + t) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) hp[e][q] = src[q];
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
+                pred_rows += npf;
+                ++not_chain;
+            } else {
+                ++not_chain;
+                // ---- general row: any number of predecessors from the LDS ring, each in the coordinates it was
+                //      written in (window offsets of the last two shifts are kept) ----
+                const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
+                const int er = __builtin_amdgcn_readlane(dl_er, k);
+                const int np = (meta >> 9) & 7;
+                bool first = true;
+                auto combine = [&](int p) {
+                    uint32_t hp[NP];
+                    if (p == 0) {
+                        if (woff > 0) bfail |= 1;                     // (c)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) hp[q] = 0u;
+                    } else if (i - p < K - 1) {
+                        int sp = slot - (i - p); if (sp < 0) sp += K;
+                        int delta = 0;
+                        if (p < s_row1) {
+                            if (p >= s_row2) delta = woff - off1;
+                            else if (p >= s_row3) delta = woff - off2;
+                            else { bfail |= 4; }
+                        }
+                        if (delta > 8 * kBandG) { bfail |= 16; delta = 0; }
+                        const int dlp = delta / LPC;
+                        if (dlp == 0) {
+                            const uint32_t* src = ring + (sp * NTH + t) * NP;
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) hp[q] = src[q];
+                        } else {
+                            // (b) for a ring row: its dlp leftmost lanes fall off
+                            const uint32_t* old = ring + (sp * NTH + t) * NP;
+                            const uint32_t dthr = pack2(mg * delta, mg * delta);
+                            uint32_t ev = pack2(-32768, -32768);
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) ev = pk_max(ev, pk_subs(old[q], pk_sub(thrv[q], dthr)));
+                            if (lane < dlp) emaxV = pk_max(emaxV, ev);
+                            const uint32_t* src = ring + (sp * NTH + min(t + dlp, 63)) * NP;
+                            const bool keep = t + dlp < 64;
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) { const uint32_t v = src[q]; hp[q] = keep ? v : NEGP; }
+                        }
+                    } else {
+                        bfail |= 2;                                    // (d)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) hp[q] = NEGP;
+                    }
+                    if (first) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = hp[q];
+                        first = false;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[q]);
+                    }
+                    ++pred_rows;
+                };
+                combine(p0);
+                if (np > 1) {
+                    const int q1 = __builtin_amdgcn_readlane(dl_p1, k), q2 = __builtin_amdgcn_readlane(dl_p2, k);
+                    const int q3 = __builtin_amdgcn_readlane(dl_p3, k), q4 = __builtin_amdgcn_readlane(dl_p4, k);
+                    const int q5 = __builtin_amdgcn_readlane(dl_p5, k);
+#pragma unroll 1
+                    for (int q = 1; q < np; ++q) combine(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
+                }
+                for (int e = er; e >= 0; e = e_nin[e]) {          // more than six in-edges: the rest of the list
+                    const int tl = e_tail[e];
+                    if (sub && !inc[tl]) continue;
+                    combine(nr[tl] + 1);
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
+            }
+
+            // diagonal sources = the combined predecessor row shifted right by one column (lane 0: -inf, the cell left of the window)
+            uint32_t mprev = mpv = __builtin_amdgcn_update_dpp(mpv, M[NP - 1], 0x138, 0xf, 0xf, false);
+            uint32_t acc[NP];
+            if (TAB) {
+                uint32_t D[NP], U[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { D[q] = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16); U[q] = pk_add(M[q], GG); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) acc[q] = pk_max(pk_add(D[q], P[q]), U[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
+                    acc[q] = pk_max(pk_add(D, P[q]), pk_add(M[q], GG));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) acc[q] = pk_chain_pair(acc[q]);
+#pragma unroll
+            for (int q = 1; q < NP; ++q) acc[q] = pk_max_bhi(acc[q], acc[q - 1]);
+            int sc = static_cast<int>(acc[NP - 1]) >> 16;
+            {
+                constexpr int I = static_cast<int>(0x80000000u);
+                const uint32_t sy = meta_next & 255;
+                const uint32_t symsym = sy | (sy << 16);
+                uint32_t pw[NP];
+                if (TAB) {
+                    const uint32_t* src = ptab + (((sy >> 1) & 3) * NTH + t) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) pw[q] = src[q];
+                    sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
+                    sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
+                    sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
+                } else {
+#define RCN_GAPB(o) do { __builtin_amdgcn_sched_barrier(0); dp2_gap_op<NP, (o)>(pw, sqx, symsym, ONE, XM, MG); \
+                        dp2_gap_op<NP, (o) + 1>(pw, sqx, symsym, ONE, XM, MG); __builtin_amdgcn_sched_barrier(0); } while (0)
+                    RCN_GAPB(0);  sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
+                    RCN_GAPB(2);  sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
+                    RCN_GAPB(4);  sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
+                    RCN_GAPB(6);  sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
+                    RCN_GAPB(8);  sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
+                    RCN_GAPB(10); sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
+                    __builtin_amdgcn_sched_barrier(0);
+#undef RCN_GAPB
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(pw[q]));
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Pn[q] = pw[q];
+            }
+            zsh = dpp_or<0x138, 0xf>(zsh, sc);
+            const int zex = max(zsh, kNeg16);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
+
+            {
+                RCN_G uint32_t* dst = hrow + t * NP;                           // absolute columns; woff + WB <= hstride
+#pragma unroll
+                for (int q = 0; q < NP; ++q) dst[q] = acc[q];
+                hrow += hs2;
+            }
+            uint32_t* rdst = ring + (slot * NTH + t) * NP;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { rdst[q] = acc[q]; win[(i & (R - 1)) * NP + q] = acc[q]; prev[q] = acc[q]; }
+            edgeR = pk_max(edgeR, acc[NP - 1]);                                // (a): lane 63's high half is the last window cell
+            slot = (slot + 1 == K) ? 0 : slot + 1;
+
+            if ((meta & ((1 << 13) | 256)) == 256) {                           // sink rows are never "fast"
+                if (own_in) {
+                    uint32_t fv = acc[0];
+#pragma unroll
+                    for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q];
+                    const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16);
+                    const int val = __builtin_amdgcn_readlane(v16, own_lane);
+                    if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
+                    else if (best == val) {
+                        if (tied < 8 && lane == 0) *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(tie_base + 4u * tied) = static_cast<uint32_t>(i);
+                        ++tied;
+                    }
+                } else if (lane == 0) {
+                    H16w[static_cast<int64_t>(i) * hs + len] = static_cast<int16_t>(kNeg16);   // never computed: the sink-tie code compares this cell
+                }
+            }
+        }
+    }
+    flush_edge();
+    // ---- certificate: no recorded cell may be alive at T = the best end score found ----
+    int ev = max(static_cast<int>(emaxV) >> 16, static_cast<int>(emaxV << 16) >> 16);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ev = max(ev, __shfl_xor(ev, d));
+    ev = __builtin_amdgcn_readfirstlane(ev);
+    const int lim = best + len * c.gp - c.m * len;          // T - m len, with T = Z + len g at column len
+    // why (statistics): 1 source row off the left edge, 2 predecessor older than the ring, 4 / 16 more than two window shifts
+    // inside the ring, 8 more than six in-edges, 32 no end cell, 64 an alive last window cell, 128 an alive dropped cell
+    const int why = bfail | (!have_best ? 32 : 0) | ((have_best && edgeS >= lim) ? 64 : 0) | ((have_best && ev >= lim) ? 128 : 0);
+    const int fail = (why || c.tie_pad[0] == 2) ? 1 : 0;
+    Ctx* o = Block4::ctx();
+    if (lane == 0) {
+        o->best = best; o->best_row = best_row; o->tied = tied; o->band_fail = fail;
+        if (!fail) {
+            const int W = len + 1;
+            pred_rows += static_cast<unsigned int>(V) - not_chain;
+            o->pred_rows = pred_rows;
+            const unsigned long long wcols = static_cast<unsigned long long>(W < WB ? W : WB);
+            o->cells += static_cast<unsigned long long>(V + 1) * wcols;
+            o->pred += static_cast<unsigned long long>(pred_rows) * wcols;
+            o->cells_full += static_cast<unsigned long long>(V + 1) * W;
+            const int amax = max(max(abs(c.m), abs(c.x)), abs(c.gp));
+            const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
+            o->bytes += sbytes * (static_cast<unsigned long long>(V + 1) + pred_rows) * wcols;
+            o->bytes_full += sbytes * (static_cast<unsigned long long>(V + 1) + pred_rows) * W;
+            o->n_banded += 1;
+        } else {
+            o->n_band_fail += 1;
+            o->band_why |= why;
+            for (int k = 0; k < 8; ++k) if (why & (1 << k)) o->band_whyn[k] += 1;
+        }
+    }
+    Wave0Of4::sync();
+}
+
+}  // namespace rcn

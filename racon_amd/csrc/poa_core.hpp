@@ -41,7 +41,7 @@ constexpr int kInlinePreds = 6;
 struct RowDesc {
     int32_t p[kInlinePreds];   // predecessor ROWS in in-edge order (p[0] = 0, the virtual start row, if none)
     int32_t erest;             // edge id from which in-edges beyond the inline ones must be walked, or -1
-    int32_t meta;              // bits 0-7 symbol, bit 8 sink, bits 9-12 number of inline predecessors (>= 1)
+    int32_t meta;              // bits 0-7 symbol, bit 8 sink, bits 9-11 number of inline predecessors (1..6), bit 12 banded DP: special row (poa_band.hpp)
 };
 
 // Array inside the slot's scratch block: one shared base pointer + a 32-bit
@@ -394,7 +394,7 @@ RCN_HD int32_t nw_traceback(Win& g, RCN_G const int32_t* rank, const Arr<int32_t
         int32_t pi = 0, pj = 0; bool found = false;
         if (i != 0) {
             const RowDesc d = g.desc[i - 1];
-            const int32_t np = (d.meta >> 9) & 15;
+            const int32_t np = (d.meta >> 9) & 7;
             for (int32_t pass = (j != 0 ? 0 : 1); pass < 2 && !found; ++pass) {     // 0: diagonal, 1: vertical
                 const int32_t col = pass == 0 ? j - 1 : j;
                 const int32_t add = pass == 0 ? (((d.meta & 255) == seq[j - 1]) ? m : x) : gp;

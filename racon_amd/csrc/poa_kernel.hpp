@@ -33,21 +33,27 @@ struct KParams {
     const uint32_t* order;        // [n_seqs] processing order inside each window (std::sort on host)
     const uint8_t*  seq_full;     // [n_seqs] 1 = full-span layer (window.cpp:93-94), else Subgraph
     const uint8_t* win_flags;     // [n_windows] bit 0: every base of the window is A, C, G or T (poa_window_kernel2: profile table); nullptr = unknown
-    const uint32_t* win_ids;      // [n_work] indirection (retry pass) or nullptr
+    const uint32_t* win_ids;      // [n_work] indirection (work item -> window: deepest-first order, retry pass) or nullptr
     uint32_t n_work;
+    uint32_t work_base;           // without win_ids: work item wi is window work_base + wi (streamed sub-launches)
     int32_t force_exact;          // poa_window_kernel2: 1 = every window takes the exact-order consensus path (tests; env RCN_FORCE_EXACT)
     int32_t heavy_ns;             // poa_window_kernel2: windows with at least this many sequences use the 4-wave DP (0 = none)
     int32_t force_tie;            // poa_window_kernel2, tests (env RCN_FORCE_TIE): 2 = every sink tie skips the id / backbone-position
                                   // rule (levels 2a/2b decide), 3 = every sink tie takes the full DFS (phase_sink_tie_full)
+    int32_t band;                 // poa_window_kernel2: 1 = exact banded DP where it applies (default), 0 = never (env RCN_NO_BAND),
+                                  // 2 = banded pass runs but every certificate is treated as failed (tests the redo path; RCN_FORCE_BAND_FAIL)
     int32_t force_slow_tb;        // poa_window_kernel2, tests (env RCN_FORCE_SLOW_TB): every traceback step is the one-cell step
                                   // against HBM (traceback2_slow_step) instead of the box walk over the staged tile
     int32_t m, x, g, trim;
     // per-slot scratch
     uint8_t* scratch; uint64_t slot_bytes; int32_t ncap, ecap, ring, lmax, hstride;
     // outputs
-    uint8_t* out_cons; uint64_t out_stride; uint32_t* out_len; uint8_t* out_flags;
+    // outputs, indexed by out_base + work item: consensus bytes at out_cons + out_off[k], capacity out_off[k + 1] - out_off[k]
+    // (a consensus that does not fit is flagged kFlagOverflow and redone by the retry pass)
+    uint8_t* out_cons; const uint64_t* out_off; uint32_t out_base; uint32_t* out_len; uint8_t* out_flags;
     // queue + counters
-    unsigned int* next; unsigned long long* stats;   // stats[0]=cells, [1]=pred cells, [2]=algorithmic DP bytes, [3..10]=phase clocks, [11]=sink ties
+    unsigned int* next; unsigned long long* stats;   // stats[0]=cells, [1]=pred cells, [2]=algorithmic DP bytes, [3..10]=phase clocks, [11]=sink ties,
+                                                      // [12]=cells of the full matrices, [13]=bytes of the full matrices, [14]=banded alignments, [15]=band redos
 };
 
 enum : uint8_t { kFlagPolished = 1, kFlagChimeric = 2, kFlagOverflow = 4, kFlagError = 8 };
@@ -161,7 +167,7 @@ __device__ __noinline__ DpState dp_tile(DpMem mem_in, int V, bool sub, const uin
         const int p0 = __builtin_amdgcn_readlane(dl.p[0], k);
         const int er = __builtin_amdgcn_readlane(dl.erest, k);
         const int meta = __builtin_amdgcn_readlane(dl.meta, k);
-        const int np = (meta >> 9) & 15;
+        const int np = (meta >> 9) & 7;
         const uint8_t sym = meta & 255;
         const int i = r + 1;
 
@@ -273,7 +279,7 @@ __device__ __forceinline__ void traceback_slow_step(Win& g, const Arr<int32_t>& 
     int pi = 0, pj = 0; bool found = false;
     if (i != 0) {
         const RowDesc d = g.desc[i - 1];
-        const int np = (d.meta >> 9) & 15;
+        const int np = (d.meta >> 9) & 7;
         for (int pass = (j != 0 ? 0 : 1); pass < 2 && !found; ++pass) {
             const int col = pass == 0 ? j - 1 : j;
             const int add = pass == 0 ? (((d.meta & 255) == seq[j - 1]) ? m : x) : gp;
@@ -348,7 +354,7 @@ __device__ __forceinline__ int traceback_tiled(Win& g, const Arr<int32_t>& nr, b
                 const int pq = dr[lane < kInlinePreds ? lane : 0];
                 const int erest = dr[6], meta = dr[7];
                 const int symc = tseq[j - c0];                               // seq[j-1]
-                const int np = (meta >> 9) & 15;
+                const int np = (meta >> 9) & 7;
                 const bool valid = lane < np;
                 if (__ballot(valid && pq < rmin) != 0ull || erest >= 0 || (j > 0 && j - 1 < c0)) break;   // leaves the tile
                 const int mc = ((meta & 255) == symc) ? m : x;
@@ -401,7 +407,12 @@ struct Ctx {
     int32_t wi, tb_i, tb_j, tb_n;
     int32_t dbg_tiles, dbg_boxes, dbg_slow, bblen;
     int32_t tie_rows[8];          // rows of the sinks that share the best score (first 8)
-    int32_t tie_why, tie_pad[3];
+    int32_t tie_why, tie_pad[3];   // tie_pad[0]: KParams::band, [1]: window is ACGT-only, [2]: KParams::force_slow_tb
+    // exact banded DP (poa_band.hpp): NP of the window for the current alignment (0 = full rows), certificate verdict, counters
+    int32_t band, band_fail;
+    unsigned long long cells_full, bytes_full;     // the full-matrix figures next to the evaluated ones (cells / bytes)
+    unsigned int n_banded, n_band_fail;
+    unsigned int band_why, band_whyn[8];            // reasons of the redos (bit k of dp2_rows_band's `why`), counted
 };
 static_assert(sizeof(Ctx) % 4 == 0 && sizeof(Ctx) <= 512, "Ctx must fit its LDS slot");
 constexpr int kCtxBytes = 512;
@@ -511,6 +522,8 @@ __device__ __noinline__ void phase_dp() {
         const int amax = max(max(abs(c.m), abs(c.x)), abs(c.gp));
         const unsigned long long sbytes = (static_cast<long long>(amax) * (c.V + W) < 32767) ? 2ull : 4ull;
         o->bytes += sbytes * (static_cast<unsigned long long>(c.V + 1) + ds.pred_rows) * W;
+        o->cells_full += static_cast<unsigned long long>(c.V + 1) * W;
+        o->bytes_full += sbytes * (static_cast<unsigned long long>(c.V + 1) + ds.pred_rows) * W;
     }
     wave_sync();
 }
@@ -693,7 +706,7 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
         ctx->scratch = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
         ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride;
         ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
-        ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
+        ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0; ctx->cells_full = 0; ctx->bytes_full = 0;
     }
     wave_sync();
 
@@ -703,16 +716,18 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
         if (lane == 0) wi = atomicAdd(P.next, 1u);
         wi = bcast0(wi);
         if (wi >= P.n_work) break;
-        const uint32_t w = P.win_ids ? P.win_ids[wi] : wi;
+        const uint32_t w = P.win_ids ? P.win_ids[wi] : P.work_base + wi;
         const uint32_t s0 = P.win_seq_off[w];
         const int ns = static_cast<int>(P.win_seq_off[w + 1] - s0);
         const uint8_t* bb = P.bases + P.seq_off[s0];
         const int L = static_cast<int>(P.seq_off[s0 + 1] - P.seq_off[s0]);
-        uint8_t* out = P.out_cons + static_cast<uint64_t>(wi) * P.out_stride;   // outputs are indexed by work item
+        const uint32_t oi = P.out_base + wi;                                       // outputs are indexed by work item
+        uint8_t* out = P.out_cons + P.out_off[oi];
+        const uint64_t out_cap = P.out_off[oi + 1] - P.out_off[oi];
 
         if (ns < 3) {                                          // window.cpp:68-71
             for (int i = lane; i < L; i += 64) out[i] = bb[i];
-            if (lane == 0) { P.out_len[wi] = L; P.out_flags[wi] = 0; }
+            if (lane == 0) { P.out_len[oi] = L; P.out_flags[oi] = 0; }
             continue;
         }
         // ---- backbone -> graph (window.cpp:73-77) ----
@@ -765,16 +780,17 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
             }
         }
         if (overflow) {
-            if (lane == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (overflow == 1 || overflow == 3) ? kFlagOverflow : kFlagError; }
+            if (lane == 0) { P.out_len[oi] = 0; P.out_flags[oi] = (overflow == 1 || overflow == 3) ? kFlagOverflow : kFlagError; }
             continue;
         }
-        phase_consensus<OneWaveBlock>(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
+        phase_consensus<OneWaveBlock>(out, out_cap, &P.out_len[oi], &P.out_flags[oi], ns, P.win_type[w] == 1);
         RCN_PHASE(6);
     }
     if (lane == 0) {
         atomicAdd(&P.stats[0], ctx->cells); atomicAdd(&P.stats[1], ctx->pred); atomicAdd(&P.stats[2], ctx->bytes);
         for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[3 + k], ph[k]);
         atomicAdd(&P.stats[11], ctx->ties);
+        atomicAdd(&P.stats[12], ctx->cells_full); atomicAdd(&P.stats[13], ctx->bytes_full);
     }
 }
 

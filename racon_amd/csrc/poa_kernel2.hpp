@@ -303,6 +303,10 @@ __device__ __noinline__ void phase_subgraph2() {
     Block4::sync();
 }
 
+__device__ __forceinline__ void block4_scan(int* xch, int wv, int lane, int cnt, int wmax, int& off, int& total, int& pmax, int& tmax);
+__device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G const int32_t* rank);
+__host__ __device__ constexpr int dp2_ring_rows_band(int np, bool tab);
+
 // ---- phase: row descriptors (all 256 threads) + row 0 of Z ----
 __device__ __noinline__ void phase_desc2() {
     const int t = threadIdx.x;
@@ -311,9 +315,14 @@ __device__ __noinline__ void phase_desc2() {
     RCN_G const int32_t* rank = c.sub ? g.rank_sub.ptr() : g.rank_full.ptr();
     const Arr<int32_t> nr = c.sub ? g.n2r_x : g.n2r;
     const int cfg_ = dp2_cfg(c.len, c.pad0 != 0);
-    const int R = dp2_window(cfg_ & 255);
+    const bool tab_ = c.tie_pad[1] != 0;
+    const int R = c.band ? dp2_window(c.band) : dp2_window(cfg_ & 255);
     // "medium" rows: like fast rows, but some predecessor is beyond the register window and still in the LDS ring
-    const int RM = min(15, dp2_ring_rows(max(cfg_ & 255, 1), max(cfg_ >> 8, 1), (cfg_ >> 8) == 1 && c.tie_pad[1] != 0) - 2);
+    const int RM = min(15, (c.band ? dp2_ring_rows_band(c.band, tab_) : dp2_ring_rows(max(cfg_ & 255, 1), max(cfg_ >> 8, 1), (cfg_ >> 8) == 1 && tab_)) - 2);
+    // banded alignment (poa_band.hpp): the window offset of every row first; the descriptors below mark the rows where
+    // the window moves or a predecessor outside the register window was written under another offset (meta bit 12)
+    RCN_G const int32_t* roff = g.pred.ptr();
+    if (c.band) band_row_offsets(c, g, rank);
     // Every row is a chain of dependent HBM loads (rank -> in-edge head -> edge -> tail's rank ...).  For a
     // full-graph alignment U rows per thread are walked in lock step, with static register indices only (a
     // runtime index into the descriptors would send them to scratch memory), so that their loads are in flight
@@ -324,7 +333,7 @@ __device__ __noinline__ void phase_desc2() {
         // "fast" rows: at most 4 predecessors, every one among the R rows right above (the DP keeps those in
         // registers; R = dp2_window(NP)).  meta bit 13 = fast, bits 16-19 / 20-23 / 24-27 / 28-31 = distance
         // (1..R) to predecessor 0 / 1 / 2 / 3, bit 15 = the single predecessor is the row right above.  Sink rows are never fast.
-        const int np = (d.meta >> 9) & 15, i = r + 1;
+        const int np = (d.meta >> 9) & 7, i = r + 1;
         if (np <= 4 && d.erest < 0 && !(d.meta & 256)) {
             unsigned int bits = 0; bool ok = true, okm = true;
 #pragma unroll
@@ -338,6 +347,16 @@ __device__ __noinline__ void phase_desc2() {
             }
             if (ok) d.meta |= static_cast<int>(bits | (1u << 13) | ((np == 1 && i - d.p[0] == 1) ? (1u << 15) : 0u));   // bit 15 = chain row
             else if (okm) d.meta |= static_cast<int>(bits | (1u << 14));      // bit 14 = medium
+        }
+        if (c.band) {
+            const int my = roff[r], before = r > 0 ? roff[r - 1] : 0;
+            bool special = my != before;
+            if (!(d.meta & (1 << 13))) {
+#pragma unroll
+                for (int q = 0; q < kInlinePreds; ++q)
+                    if (q < np && d.p[q] > 0 && roff[d.p[q] - 1] != my) special = true;
+            }
+            if (special) d.meta |= 1 << 12;
         }
         g.desc[r] = d;
     };
@@ -581,12 +600,12 @@ __device__ __noinline__ void dp2_rows() {
             } else {
                 ++not_chain;
 #ifdef RCN_PROF_CNT
-                if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); if (meta & 256) atomicAdd(&g_dbg[2], 1ull); if (((meta >> 9) & 15) > 4) atomicAdd(&g_dbg[3], 1ull); }
+                if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); if (meta & 256) atomicAdd(&g_dbg[2], 1ull); if (((meta >> 9) & 7) > 4) atomicAdd(&g_dbg[3], 1ull); }
 #endif
                 // ---- general row: any number of predecessors, LDS ring or (rare) HBM ----
                 const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
                 const int er = __builtin_amdgcn_readlane(dl_er, k);
-                const int np = (meta >> 9) & 15;
+                const int np = (meta >> 9) & 7;
                 bool first = true;
                 auto combine = [&](int p) {
                     uint32_t hp[NP];
@@ -795,9 +814,15 @@ __device__ __noinline__ void dp2_rows() {
         const int amax = max(max(abs(c.m), abs(c.x)), abs(c.gp));
         const unsigned long long sbytes = (static_cast<long long>(amax) * (V + W) < 32767) ? 2ull : 4ull;
         o->bytes += sbytes * (static_cast<unsigned long long>(V + 1) + pred_rows) * W;
+        o->cells_full += static_cast<unsigned long long>(V + 1) * W;
+        o->bytes_full += sbytes * (static_cast<unsigned long long>(V + 1) + pred_rows) * W;
     }
     if (WV > 1) Block4::sync(); else Wave0Of4::sync();
 }
+
+}  // namespace rcn
+#include "poa_band.hpp"
+namespace rcn {
 
 // ---- phase: sink tie-break (rare) + traceback over int16 Z tiles ----
 // Tile of the finished matrix staged in LDS for the walk: kTbRows consecutive DP rows x 64 columns.  The path climbs
@@ -819,7 +844,7 @@ __device__ __forceinline__ void traceback2_slow_step(Win& g, RCN_G const int32_t
     int pi = 0, pj = 0; bool found = false;
     if (i != 0) {
         const RowDesc d = g.desc[i - 1];
-        const int np = (d.meta >> 9) & 15;
+        const int np = (d.meta >> 9) & 7;
         for (int pass = (j != 0 ? 0 : 1); pass < 2 && !found; ++pass) {
             const int col = pass == 0 ? j - 1 : j;
             const int add = pass == 0 ? ((((d.meta & 255) == seq[j - 1]) ? m : x) - gp) : gp;
@@ -1308,7 +1333,7 @@ __device__ __noinline__ void phase_traceback3() {
                 const int hij = tile[tile_at(trow, tcol)];
                 const int symc = tseq[tcol];                                    // seq[jj - 1]
                 const int meta = pb.w, erest = pb.z;
-                const int np = (meta >> 9) & 15;
+                const int np = (meta >> 9) & 7;
                 const int pq[6] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y};
                 bool ok = inside && erest < 0;
                 const int mc = (((meta & 255) == symc) ? m : x) - gp;
@@ -1746,6 +1771,8 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride;
         ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
         ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
+        ctx->cells_full = 0; ctx->bytes_full = 0; ctx->n_banded = 0; ctx->n_band_fail = 0; ctx->band = 0; ctx->band_fail = 0;
+        ctx->band_why = 0; for (int k = 0; k < 8; ++k) ctx->band_whyn[k] = 0;
         ctx->dbg_tiles = 0; ctx->dbg_boxes = 0; ctx->dbg_slow = 0;
     }
     for (;;) {
@@ -1759,17 +1786,19 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         unsigned long long ph0__[8];
         for (int k = 0; k < 8; ++k) ph0__[k] = ph[k];
 #endif
-        const uint32_t w = P.win_ids ? P.win_ids[wi] : wi;
+        const uint32_t w = P.win_ids ? P.win_ids[wi] : P.work_base + wi;
         const uint32_t s0 = P.win_seq_off[w];
         const int ns = static_cast<int>(P.win_seq_off[w + 1] - s0);
         const uint8_t* bb = P.bases + P.seq_off[s0];
         const int L = static_cast<int>(P.seq_off[s0 + 1] - P.seq_off[s0]);
-        uint8_t* out = P.out_cons + static_cast<uint64_t>(wi) * P.out_stride;   // outputs are indexed by work item
+        const uint32_t oi = P.out_base + wi;                                       // outputs are indexed by work item
+        uint8_t* out = P.out_cons + P.out_off[oi];
+        const uint64_t out_cap = P.out_off[oi + 1] - P.out_off[oi];
 
         const bool heavy = P.heavy_ns > 0 && ns >= P.heavy_ns;
         if (ns < 3) {                                          // window.cpp:68-71
             for (int i = t; i < L; i += kThreads2) out[i] = bb[i];
-            if (t == 0) { P.out_len[wi] = L; P.out_flags[wi] = 0; }
+            if (t == 0) { P.out_len[oi] = L; P.out_flags[oi] = 0; }
             continue;
         }
         // ---- backbone -> graph (window.cpp:73-77) ----
@@ -1788,7 +1817,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     g.e_w[i] = pair_weight(q0, i + 1);
                 }
             }
-            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; ctx->pad0 = heavy; ctx->bblen = L; ctx->tie_pad[1] = P.win_flags ? (P.win_flags[w] & 1) : 0; ctx->tie_pad[2] = P.force_slow_tb; }
+            if (t == 0) { ctx->n_nodes = L; ctx->n_edges = L - 1; ctx->overflow = (L > P.ncap) ? 1 : 0; ctx->swapped = 0; ctx->pad0 = heavy; ctx->bblen = L; ctx->tie_pad[1] = P.win_flags ? (P.win_flags[w] & 1) : 0; ctx->tie_pad[2] = P.force_slow_tb; ctx->tie_pad[0] = P.band; }
         }
         Block4::sync();
 
@@ -1805,6 +1834,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 ctx->begin = static_cast<int32_t>(P.seq_begin[si]); ctx->end = static_cast<int32_t>(P.seq_end[si]);
                 ctx->V = ctx->n_nodes;
                 ctx->tb_j = 0;                 // phase_subgraph2: 0 = normal, 1 = closure query (marks only)
+                ctx->band = (P.band && !heavy) ? band_np(len) : 0; ctx->band_fail = 0;
             }
             Block4::sync();
             if (partial) {
@@ -1823,7 +1853,24 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             }
             phase_desc2();
             RCN_PHASE2(1);
-            if (nwv == 1) {
+            bool dp_done = false;
+            const int bnp = bcast0(ctx->band);
+            if (bnp) {
+                // exact banded DP (poa_band.hpp); an alignment whose certificate fails is redone on full rows right below
+                if (wv == 0) {
+                    if (bcast0(ctx->tie_pad[1]) != 0) dp2_rows_band<2, true>(); else dp2_rows_band<2, false>();
+                }
+                Block4::sync();
+                dp_done = bcast0(ctx->band_fail) == 0;
+                if (!dp_done) {
+                    Block4::sync();
+                    if (t == 0) ctx->band = 0;
+                    Block4::sync();
+                    phase_desc2();
+                }
+            }
+            if (dp_done) {
+            } else if (nwv == 1) {
                 if (wv == 0) {
                     const bool tab = bcast0(ctx->tie_pad[1]) != 0;
                     switch (np_regs) {
@@ -1901,7 +1948,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             }
         }
         if (overflow) {
-            if (t == 0) { P.out_len[wi] = 0; P.out_flags[wi] = (overflow == 1 || overflow == 3 || overflow == 5) ? kFlagOverflow : kFlagError; }
+            if (t == 0) { P.out_len[oi] = 0; P.out_flags[oi] = (overflow == 1 || overflow == 3 || overflow == 5) ? kFlagOverflow : kFlagError; }
             continue;
         }
         {
@@ -1938,8 +1985,8 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 }
             }
             if (wv == 0) {
-                if (k > 0) phase_cons2_finish(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
-                else phase_consensus<Wave0Of4>(out, P.out_stride, &P.out_len[wi], &P.out_flags[wi], ns, P.win_type[w] == 1);
+                if (k > 0) phase_cons2_finish(out, out_cap, &P.out_len[oi], &P.out_flags[oi], ns, P.win_type[w] == 1);
+                else phase_consensus<Wave0Of4>(out, out_cap, &P.out_len[oi], &P.out_flags[oi], ns, P.win_type[w] == 1);
             }
         }
         RCN_PHASE2(6);
@@ -1953,6 +2000,9 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         atomicAdd(&P.stats[0], ctx->cells); atomicAdd(&P.stats[1], ctx->pred); atomicAdd(&P.stats[2], ctx->bytes);
         for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[3 + k], ph[k]);
         atomicAdd(&P.stats[11], ctx->ties);
+        atomicAdd(&P.stats[12], ctx->cells_full); atomicAdd(&P.stats[13], ctx->bytes_full);
+        atomicAdd(&P.stats[14], static_cast<unsigned long long>(ctx->n_banded)); atomicAdd(&P.stats[15], static_cast<unsigned long long>(ctx->n_band_fail));
+        for (int k = 0; k < 8; ++k) if (ctx->band_whyn[k]) atomicAdd(&P.stats[16 + k], static_cast<unsigned long long>(ctx->band_whyn[k]));
     }
 }
 

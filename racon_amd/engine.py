@@ -30,7 +30,9 @@ class RcnRunStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("n_launches", C.c_uint32), ("n_retried", C.c_uint32), ("dp_cells", C.c_uint64),
                 ("dp_pred_cells", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
-                ("dp_bytes", C.c_uint64), ("phase_clocks", C.c_uint64 * 8), ("n_sink_ties", C.c_uint64)]
+                ("dp_bytes", C.c_uint64), ("phase_clocks", C.c_uint64 * 8), ("n_sink_ties", C.c_uint64),
+                ("dp_cells_full", C.c_uint64), ("dp_bytes_full", C.c_uint64), ("n_banded", C.c_uint64), ("n_band_redone", C.c_uint64),
+                ("band_redo_why", C.c_uint64 * 8)]
 
 
 class RcnWindowDesc(C.Structure):
@@ -42,7 +44,7 @@ class RcnWindowDesc(C.Structure):
 EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_engine_run", "rcn_engine_result",
            "rcn_engine_stats", "rcn_engine_set_trim", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
-           "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch"]
+           "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory"]
 
 _lib = None
 
@@ -61,6 +63,8 @@ def load_library():
     lib.rcn_engine_destroy.restype = None
     lib.rcn_engine_upload.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
     lib.rcn_engine_run.argtypes = [C.c_void_p]
+    lib.rcn_engine_polish.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
+    lib.rcn_device_free_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.rcn_engine_result.argtypes = [C.c_void_p, C.POINTER(RcnResult)]
     lib.rcn_engine_stats.argtypes = [C.c_void_p, C.POINTER(RcnRunStats)]
     lib.rcn_engine_set_trim.argtypes = [C.c_void_p, C.c_int]
@@ -133,11 +137,15 @@ class HipEngine:
         _check(self.lib.rcn_engine_stats(self.h, C.byref(s)), "rcn_engine_stats")
         d = {k: getattr(s, k) for k, _ in RcnRunStats._fields_}
         d["phase_clocks"] = list(s.phase_clocks)
+        d["band_redo_why"] = list(s.band_redo_why)
         return d
 
     def consensus(self, batch: WindowBatch) -> ConsensusResult:
-        self.upload(batch)
-        return self.run()
+        """upload + run of one batch, the copy hidden behind the kernel (rcn_engine_polish)."""
+        cb = batch.as_c()
+        self._keep = (batch, cb)
+        _check(self.lib.rcn_engine_polish(self.h, C.byref(cb)), "rcn_engine_polish")
+        return self.result()
 
     # device-side window construction (reference src/polisher.cpp:388-461) --------
     def build_windows(self, reads: ReadSet, overlaps: OverlapSet, window_length: int, quality_threshold: float, window_type: int):

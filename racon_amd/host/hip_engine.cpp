@@ -21,6 +21,8 @@ struct Abi {
     decltype(&rcn_engine_destroy) destroy = nullptr;
     decltype(&rcn_engine_upload) upload = nullptr;
     decltype(&rcn_engine_run) run = nullptr;
+    decltype(&rcn_engine_polish) polish = nullptr;
+    decltype(&rcn_device_free_memory) free_memory = nullptr;
     decltype(&rcn_engine_result) result = nullptr;
     decltype(&rcn_engine_stats) stats = nullptr;
     decltype(&rcn_engine_set_trim) set_trim = nullptr;
@@ -59,7 +61,7 @@ const Abi& abi() {
 #define RCN_BIND(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); \
         if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
-        RCN_BIND(run, "rcn_engine_run") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
+        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
         RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
 #undef RCN_BIND
@@ -105,13 +107,20 @@ int32_t HipEngine::DeviceCount() {
     return a.lib ? a.device_count() : 0;
 }
 
-std::shared_ptr<HipEngine> HipEngine::Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap) {
+uint64_t HipEngine::FreeMemory(int32_t device) {
+    const Abi& a = abi();
+    uint64_t fr = 0, tot = 0;
+    if (!a.lib || a.free_memory(device, &fr, &tot) != RCN_OK) return 0;
+    return fr;
+}
+
+std::shared_ptr<HipEngine> HipEngine::Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap, uint64_t arena_bytes) {
     const Abi& a = abi();
     if (!a.lib)
         fatal("[racon::HipEngine::Create] error: unable to load libracon_hip.so (" + a.error +
               "); the consensus stage has no CPU fallback!");
     rcn_engine_config cfg{};
-    cfg.device = device; cfg.match = match; cfg.mismatch = mismatch; cfg.gap = gap; cfg.trim = 1;
+    cfg.device = device; cfg.match = match; cfg.mismatch = mismatch; cfg.gap = gap; cfg.trim = 1; cfg.arena_bytes = arena_bytes;
     std::shared_ptr<HipEngine> e(new HipEngine());
     const int rc = a.create(&cfg, &e->handle_);
     if (rc != RCN_OK)
@@ -126,8 +135,8 @@ void HipEngine::consensus(const PackedBatch& batch, bool trim, std::vector<std::
     const Abi& a = abi();
     const rcn_batch b = batch.view();
     int rc = a.set_trim(handle_, trim ? 1 : 0);
-    if (rc == RCN_OK) rc = a.upload(handle_, &b);
-    fetch(rc, consensus, polished, chimeric);
+    if (rc == RCN_OK) rc = a.polish(handle_, &b);              // upload hidden behind the kernel
+    fetch(rc, consensus, polished, chimeric, /*run=*/false);
 }
 
 void HipEngine::consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,
@@ -150,9 +159,9 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_cigar_set& alignm
     fetch(rc, consensus, polished, chimeric);
 }
 
-void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
+void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run) {
     const Abi& a = abi();
-    if (rc == RCN_OK) rc = a.run(handle_);
+    if (rc == RCN_OK && run) rc = a.run(handle_);
     rcn_result r{};
     if (rc == RCN_OK) rc = a.result(handle_, &r);
     if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::consensus] error: ") + a.strerror_(rc) + "!");

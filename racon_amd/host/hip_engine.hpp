@@ -41,7 +41,10 @@ struct PackedBatch {
 class HipEngine {
 public:
     // Fatal (racon::fatal) when the library or the device is missing.
-    static std::shared_ptr<HipEngine> Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap);
+    // `arena_bytes`: this engine's share of the device's HBM for its scratch (0 = 80 % of what is free when it runs;
+    // several engines on one device must split it, see FreeMemory).
+    static std::shared_ptr<HipEngine> Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap, uint64_t arena_bytes = 0);
+    static uint64_t FreeMemory(int32_t device);   // free HBM in bytes (0 on error)
     static int32_t DeviceCount();      // 0 when the library cannot be loaded or no device is visible
     ~HipEngine();
 
@@ -62,7 +65,7 @@ public:
 private:
     HipEngine() = default;
     HipEngine(const HipEngine&) = delete;
-    void fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    void fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run = true);
     rcn_engine* handle_ = nullptr;
     double last_kernel_ms_ = 0;
 };

@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <exception>
+#include <mutex>
 #include <iostream>
 #include <thread>
 #include <unordered_map>
@@ -34,11 +36,24 @@ template <class F>
 void parallel_for(uint64_t n, uint32_t threads, F fn) {
     threads = std::max<uint32_t>(1, std::min<uint64_t>(threads, n));
     if (threads == 1) { for (uint64_t i = 0; i < n; ++i) fn(i); return; }
+    // an exception inside a worker (fatal() in library mode, nw_path's runtime_error, bad_alloc) must not escape its thread
+    // (std::terminate): the first one is kept and rethrown on the caller's thread after the join
     std::atomic<uint64_t> next{0};
+    std::exception_ptr first_error;
+    std::mutex error_mutex;
     std::vector<std::thread> pool;
     for (uint32_t t = 0; t < threads; ++t)
-        pool.emplace_back([&] { for (uint64_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+        pool.emplace_back([&] {
+            try {
+                for (uint64_t i; (i = next.fetch_add(1)) < n;) fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(error_mutex);
+                if (!first_error) first_error = std::current_exception();
+                next.store(n);                                     // the other workers stop at their next item
+            }
+        });
     for (auto& t : pool) t.join();
+    if (first_error) std::rethrow_exception(first_error);
 }
 }  // namespace
 
@@ -328,15 +343,17 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         fatal("[racon::Polisher::polish] error: no MI355X device / libracon_hip.so available (the consensus stage has no CPU fallback)!");
 
     // contiguous chunks of the window index space; engines pull them from a shared cursor
-    // (reference src/cuda/cudapolisher.cpp:254-276 hands out ranges the same way)
-    constexpr uint64_t kMaxChunkWindows = 16384, kMaxChunkBases = 512ull << 20;
+    // (reference src/cuda/cudapolisher.cpp:254-276 hands out ranges the same way).  A chunk is at most what one engine
+    // keeps resident at once (2048 windows): the engine then hides the chunk's upload behind its kernel
+    // (rcn_engine_polish), and with TWO engines per batch object and device the kernel of one chunk fills the compute
+    // units that the tail of the other engine's chunk leaves idle, while a host thread packs the next one.
+    constexpr uint64_t kMaxChunkWindows = 2048, kMaxChunkBases = 512ull << 20;
     const uint64_t nw = windows_.size();
     std::vector<std::pair<uint64_t, uint64_t>> chunks;
-    const uint32_t n_engines = static_cast<uint32_t>(n_devices) * hip_batches_;
+    const uint32_t engines_per_device = 2 * hip_batches_;
+    const uint32_t n_engines = static_cast<uint32_t>(n_devices) * engines_per_device;
     {
-        uint64_t total = 0;
-        for (const auto& w : windows_) total += w->num_sequences();
-        const uint64_t target = std::max<uint64_t>(2048, std::min<uint64_t>(kMaxChunkWindows, (nw + n_engines - 1) / n_engines));
+        const uint64_t target = kMaxChunkWindows;
         for (uint64_t a = 0; a < nw;) {
             uint64_t b = a, bases = 0;
             while (b < nw && b - a < target && bases < kMaxChunkBases) { bases += 600ull * windows_[b]->num_sequences(); ++b; }
@@ -372,9 +389,14 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
     }
     std::atomic<size_t> cursor{0};
     std::vector<std::string> errors(n_engines);
+    std::vector<uint64_t> arena(n_devices, 0);
+    for (int32_t d = 0; d < n_devices; ++d) arena[d] = static_cast<uint64_t>(HipEngine::FreeMemory(d) * 0.8);
     auto worker = [&](uint32_t k) {
         try {
-            auto engine = HipEngine::Create(static_cast<int32_t>(k % n_devices), match_, mismatch_, gap_);
+            const int32_t device = static_cast<int32_t>(k % n_devices);
+            // engines of one device split its free HBM (each would otherwise budget 80 % of it for its own scratch)
+            const uint32_t sharing = std::min<uint32_t>(engines_per_device, std::max<uint32_t>(1, (static_cast<uint32_t>(chunks.size()) + n_devices - 1) / n_devices));
+            auto engine = HipEngine::Create(device, match_, mismatch_, gap_, arena[device] / sharing);
             PackedBatch batch;
             std::vector<std::string> c; std::vector<uint8_t> p, h;
             for (size_t ci; (ci = cursor.fetch_add(1)) < chunks.size();) {

@@ -83,6 +83,88 @@ def simulate_windows(contig_len: int, window_len: int = 500, coverage: float = 3
     return WindowBatch.from_windows(windows)
 
 
+def simulate_fragment_windows(genome_len: int, n_reads: int, read_len: int = 10000, window_len: int = 500,
+                              sub: float = 0.03, ins: float = 0.03, dele: float = 0.04, seed: int = 20260924,
+                              min_overlap: int = 2000, quality_threshold: float = 10.0,
+                              phred_mean: float = 15.0, phred_sd: float = 4.0, phred_lo: int = 5, phred_hi: int = 30) -> WindowBatch:
+    """Fragment correction (`racon -f`, BASELINE.json configs[4]; reference src/main.cpp:18-38, src/polisher.cpp:295 keeps
+    every overlap per query in kF mode): the TARGETS are the reads themselves.  Error-bearing reads sampled from a random
+    genome; every pair that shares at least `min_overlap` genome columns overlaps in BOTH directions (dual overlaps: A is a
+    layer source for B's windows and B for A's); each target read is cut into windows of `window_len` of ITS coordinates
+    and every overlapping read contributes the stretch between the first and the last genome column that carries a base
+    in both reads inside the window -- what Overlap::find_breaking_points (reference src/overlap.cpp:226-292) derives from
+    the pair's alignment when that alignment is the true one.  Backbones carry the read's own qualities (FASTQ targets:
+    real backbone weights, reference src/polisher.cpp:396-399).  All reads are generated on the forward strand (the packed
+    batch holds oriented bases either way)."""
+    rng = np.random.default_rng(seed)
+    genome = _ACGT[rng.integers(0, 4, genome_len)]
+    starts = np.sort(rng.integers(0, max(1, genome_len - read_len // 2), n_reads))
+    reads = []          # (ts, te, bases, quals, qpos[col] = read index of the column's base or -1)
+    for ts in starts.tolist():
+        te = min(genome_len, ts + read_len)
+        n = te - ts
+        tgt = genome[ts:te]
+        deleted = rng.random(n) < dele
+        deleted[0] = deleted[-1] = False
+        subst = rng.random(n) < sub
+        base = tgt.copy()
+        base[subst] = _ACGT[(np.searchsorted(_ACGT, tgt[subst]) + rng.integers(1, 4, int(subst.sum()))) % 4]
+        has_ins = rng.random(n) < ins
+        has_ins[-1] = False
+        emit = (~deleted).astype(np.int64) + has_ins.astype(np.int64)
+        qstart = np.concatenate([[0], np.cumsum(emit)])
+        qlen = int(qstart[-1])
+        read = np.empty(qlen, np.uint8)
+        mcols = np.nonzero(~deleted)[0]
+        read[qstart[mcols]] = base[mcols]
+        icols = np.nonzero(has_ins)[0]
+        read[qstart[icols] + (~deleted[icols]).astype(np.int64)] = _ACGT[rng.integers(0, 4, icols.size)]
+        q = np.clip(np.rint(rng.normal(phred_mean, phred_sd, qlen)), phred_lo, phred_hi).astype(np.uint8) + 33
+        qpos = np.where(deleted, -1, qstart[:-1])
+        reads.append((ts, te, read, q, qpos))
+    windows = []
+    lo = 0
+    for a, (ats, ate, abases, aq, aqpos) in enumerate(reads):
+        n_win = (len(abases) + window_len - 1) // window_len
+        layers = [[] for _ in range(n_win)]
+        while lo < n_reads and reads[lo][1] <= ats:
+            lo += 1
+        for b in range(lo, n_reads):
+            bts, bte, bbases, bq, bqpos = reads[b]
+            if bts >= ate:
+                break
+            if b == a:
+                continue
+            g0, g1 = max(ats, bts), min(ate, bte)
+            if g1 - g0 < min_overlap:
+                continue
+            ca = aqpos[g0 - ats:g1 - ats]
+            cb = bqpos[g0 - bts:g1 - bts]
+            both = np.nonzero((ca >= 0) & (cb >= 0))[0]
+            if both.size == 0:
+                continue
+            pa, pb = ca[both], cb[both]
+            wid = pa // window_len
+            cuts = np.nonzero(np.diff(wid))[0] + 1
+            firsts = np.concatenate([[0], cuts]); lasts = np.concatenate([cuts - 1, [both.size - 1]])
+            for f, l in zip(firsts.tolist(), lasts.tolist()):
+                w = int(wid[f])
+                q0, q1 = int(pb[f]), int(pb[l]) + 1
+                if (q1 - q0) < 0.02 * window_len:
+                    continue
+                if float(np.mean(bq[q0:q1].astype(np.float64) - 33.0)) < quality_threshold:
+                    continue
+                begin, end = int(pa[f]) - w * window_len, int(pa[l]) - w * window_len
+                if begin == end:
+                    continue
+                layers[w].append((bbases[q0:q1].tobytes(), bq[q0:q1].tobytes(), begin, end))
+        for w in range(n_win):
+            bb = abases[w * window_len:(w + 1) * window_len].tobytes()
+            qq = aq[w * window_len:(w + 1) * window_len].tobytes()
+            windows.append({"type": 1, "seqs": [(bb, qq, 0, 0)] + layers[w]})
+    return WindowBatch.from_windows(windows)
+
+
 def config_windows(name: str, scale: float = 1.0) -> WindowBatch:
     """The named synthetic configurations of SURVEY.md §8(d).  `scale` shrinks the
     contig (tests use small scales; bench.py uses 1.0)."""
@@ -93,6 +175,8 @@ def config_windows(name: str, scale: float = 1.0) -> WindowBatch:
     if name == "cfg4":      # short reads: 150 bp at 60x, -w 200, kNGS
         return simulate_windows(int(1_000_000 * scale), 200, 60.0, 150, sub=0.003, ins=0.0005, dele=0.0005,
                                 seed=20260923, phred_mean=30.0, phred_sd=0.0, phred_lo=30, phred_hi=30)
+    if name == "cfg5":      # fragment correction (-f): 100 000 reads x 10 kbp from a 33.3 Mbp genome, dual overlaps (2 M windows at scale 1)
+        return simulate_fragment_windows(int(33_333_333 * scale), int(100_000 * scale), 10000, 500, seed=20260924)
     if name == "w1000":     # larger window (int32 score range)
         return simulate_windows(int(1_000_000 * scale), 1000, 30.0, 10000, seed=20260925)
     raise ValueError(name)

@@ -1,0 +1,105 @@
+"""-m gpu: the exact banded DP (racon_amd/csrc/poa_band.hpp).  Layers of 256..639 bases are aligned over a 256-column
+window per row; a certificate decides per alignment whether the result is provably the full matrix's, else the alignment
+is redone on full rows.  Either way the consensus must equal the oracle's (which always evaluates the full matrix), on
+ordinary data (certificate holds almost always), with the certificate forced to fail (redo path), on long pathological
+windows (repeats, junk layers, overhangs: the certificate must fail where the band is wrong), and with banding off."""
+import numpy as np
+import pytest
+
+from racon_amd.batch import WindowBatch
+from racon_amd.synth import simulate_windows
+from helpers import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def long_window(rng, style):
+    """A window whose layers are long enough for the banded pass, with structure that pulls optimal paths off the diagonal."""
+    alpha = [b"ACGT", b"AC", b"ACGT", b"ACGTN"][style % 4]
+    L = int(rng.integers(280, 620))
+    if style % 3 == 0:      # tandem repeats: many co-optimal alignments far from the diagonal
+        unit = bytes(rng.choice(list(alpha), int(rng.integers(2, 12))).tolist())
+        bb = (unit * (L // len(unit) + 1))[:L]
+    else:
+        bb = bytes(rng.choice(list(alpha), L).tolist())
+    seqs = [(bb, b"!" * L, 0, 0)]
+    for k in range(int(rng.integers(3, 14))):
+        full = rng.random() < 0.7
+        b0 = 0 if full else int(rng.integers(0, L // 3))
+        e0 = L - 1 if full else int(rng.integers(2 * L // 3, L))
+        src = bytearray(bb[b0:e0 + 1])
+        kind = rng.random()
+        if kind < 0.15:       # a long deletion
+            a = int(rng.integers(0, max(1, len(src) - 120))); del src[a:a + int(rng.integers(20, 120))]
+        elif kind < 0.30:     # a long insertion
+            a = int(rng.integers(0, len(src))); src[a:a] = bytes(rng.choice(list(alpha), int(rng.integers(20, 120))).tolist())
+        elif kind < 0.36:     # unrelated sequence
+            src = bytearray(rng.choice(list(alpha), len(src)).tolist())
+        rate = [0.02, 0.1, 0.25][int(rng.integers(0, 3))]
+        out = bytearray()
+        for ch in src:
+            r = rng.random()
+            if r < rate / 3:
+                continue
+            out.append(int(rng.choice(list(alpha))) if r < rate else ch)
+            if rng.random() < rate / 3:
+                out.append(int(rng.choice(list(alpha))))
+        if len(out) < 2:
+            out = bytearray(b"AC")
+        s = bytes(out[:639])
+        q = None if rng.random() < 0.3 else bytes((rng.integers(0, 25, len(s)) + 33).astype(np.uint8).tolist())
+        seqs.append((s, q, b0, e0))
+    return {"type": int(rng.integers(0, 2)), "seqs": seqs}
+
+
+def test_band_is_used_and_certified_on_ont_like_windows(oracle):
+    from racon_amd.engine import HipEngine
+    b = simulate_windows(150_000, 500, 30.0, 10000, seed=7001)
+    eng = HipEngine(3, -5, -4, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), "banded, cfg2-like")
+    st = eng.stats()
+    assert st["n_banded"] > 5000 and st["n_band_redone"] < 0.08 * st["n_banded"], (st["n_banded"], st["n_band_redone"], st["band_redo_why"])
+    assert st["dp_cells"] < 0.62 * st["dp_cells_full"]            # about half of every banded row is not evaluated
+
+
+@pytest.mark.parametrize("scores", [(3, -5, -4), (5, -4, -8), (1, -1, -1)])
+def test_band_redo_path(oracle, scores, monkeypatch):
+    """RCN_FORCE_BAND_FAIL: the banded pass runs, its certificate is discarded, every alignment is redone on full rows."""
+    from racon_amd.engine import HipEngine
+    monkeypatch.setenv("RCN_FORCE_BAND_FAIL", "1")
+    b = simulate_windows(40_000, 500, 25.0, 10000, seed=7002)
+    eng = HipEngine(*scores, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, *scores, True, 0), f"forced band redo {scores}")
+    st = eng.stats()
+    assert st["n_banded"] == 0 and st["n_band_redone"] > 1000 and st["dp_cells"] == st["dp_cells_full"]
+
+
+def test_band_off_switch(oracle, monkeypatch):
+    from racon_amd.engine import HipEngine
+    monkeypatch.setenv("RCN_NO_BAND", "1")
+    b = simulate_windows(40_000, 500, 25.0, 10000, seed=7003)
+    eng = HipEngine(3, -5, -4, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), "banding off")
+    st = eng.stats()
+    assert st["n_banded"] == 0 and st["n_band_redone"] == 0
+
+
+@pytest.mark.parametrize("seed,scores", [(1, (3, -5, -4)), (2, (5, -4, -8)), (3, (1, -1, -1)), (4, (2, -3, -2))])
+def test_band_on_long_pathological_windows(oracle, seed, scores):
+    from racon_amd.engine import HipEngine
+    rng = np.random.default_rng(7100 + seed)
+    b = WindowBatch.from_windows([long_window(rng, k) for k in range(160)])
+    eng = HipEngine(*scores, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, *scores, True, 0), f"long fuzz seed {seed} scores {scores}")
+    st = eng.stats()
+    assert st["n_banded"] + st["n_band_redone"] > 500
+
+
+@pytest.mark.parametrize("w,seed", [(300, 7201), (400, 7202), (600, 7203)])
+def test_band_window_lengths(oracle, w, seed):
+    """Window lengths around the banded range: 300 (window barely narrower than the row), 400, 600 (rows of up to ~640)."""
+    from racon_amd.engine import HipEngine
+    b = simulate_windows(60_000, w, 25.0, 10000, seed=seed)
+    eng = HipEngine(3, -5, -4, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), f"w {w}")
+    assert eng.stats()["n_banded"] > 0

@@ -33,7 +33,7 @@ def test_cfg2_full_size_properties(oracle):
     r2 = eng.run()
     assert r1.consensus == r2.consensus and (r1.polished == r2.polished).all()
     st = eng.stats()
-    assert st["n_retried"] == 0 and st["dp_cells"] > 2.0e10
+    assert st["n_retried"] == 0 and st["dp_cells_full"] > 2.0e10 and st["dp_cells"] <= st["dp_cells_full"]
     # shards: each rank's result is the slice of the full result
     parts = []
     for rank in range(3):
@@ -97,3 +97,62 @@ def test_batch_larger_than_the_resident_slots(oracle):
     b = simulate_windows(4_500_000, 500, 30.0, 10000, seed=20260927)
     assert b.n_windows == 9000
     _all_windows_vs_oracle(oracle, b, (3, -5, -4), "9000-window batch")
+
+
+def test_cfg5_fragment_correction_windows_against_the_oracle(oracle):
+    """BASELINE configs[4] (`-f`: the reads are the targets, dual overlaps, real backbone qualities) at 1/500 of its size:
+    200 reads of 10 kbp -> ~3900 windows of ~30 layers (the full configuration is 2 M windows of the same shape)."""
+    b = config_windows("cfg5", 0.002)
+    assert 3000 < b.n_windows < 5000 and int(b.seq_has_qual[b.win_seq_off[:-1]].min()) == 1     # backbones carry qualities
+    _all_windows_vs_oracle(oracle, b, (3, -5, -4), "cfg5 x 0.002")
+    _all_windows_vs_oracle(oracle, b, (1, -1, -1), "cfg5 x 0.002, scores 1/-1/-1 (the reference's fragment tests)")
+
+
+def _nccl_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from racon_amd import distributed as rd
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    b = simulate_windows(300_000, 500, 30.0, 10000, seed=20260922)
+    eng = HipEngine(3, -5, -4, True, device=rank)
+    out = rd.polish_sharded(b, eng.consensus, rank, world, device=torch.device("cuda", rank))
+    if rank == 0:
+        import hashlib
+        h = hashlib.sha256()
+        for c in out.consensus:
+            h.update(hashlib.md5(c).digest())
+        q.put((len(out.consensus), h.hexdigest()))
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+def test_two_ranks_two_gpus_rccl_gather():
+    """One process per GPU, shards polished independently, consensi gathered to rank 0 over RCCL (xGMI): the same bytes as
+    one GPU polishing everything.  Needs two devices: skipped on a one-GPU box."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n, digest = q.get(timeout=600)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    b = simulate_windows(300_000, 500, 30.0, 10000, seed=20260922)
+    one = HipEngine(3, -5, -4, True).consensus(b)
+    assert n == b.n_windows and digest == _digest(one.consensus)
