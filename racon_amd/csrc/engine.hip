@@ -84,8 +84,11 @@ struct rcn_engine {
     rcn_engine_config cfg{};
     hipStream_t stream = nullptr;                   // main stream: resident-batch launches, retry pass, result copies
     hipStream_t copy_stream = nullptr;              // H2D of a streamed batch (rcn_engine_polish)
-    static constexpr int kSubLaunches = 3;
-    hipStream_t sub_stream[kSubLaunches] = {nullptr, nullptr, nullptr};   // one per sub-launch of a streamed batch: they overlap
+    // sub-launches of a streamed batch: each on its own stream so that they overlap.  Two pieces, three streams in use
+    // (copy, piece 0, piece 1 = main): the device runs kernels of at most four hardware queues side by side, a third
+    // piece was observed to wait for the second one to finish
+    static constexpr int kSubLaunches = 2;
+    hipStream_t sub_stream[kSubLaunches] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
     int n_cu = 256;
@@ -363,7 +366,8 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     e->free_mem = fr;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    for (auto& st : e->sub_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->sub_stream[0], hipStreamNonBlocking));
+    e->sub_stream[rcn_engine::kSubLaunches - 1] = e->stream;                 // the last piece runs on the main stream
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
     for (auto& evs : e->sub_ev) for (auto& ev : evs) HIP_TRY(hipEventCreate(&ev));
@@ -386,7 +390,7 @@ void rcn_engine_destroy(rcn_engine* e) {
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (auto& evs : e->sub_ev) for (auto& ev : evs) if (ev) (void)hipEventDestroy(ev);
-    for (auto& st : e->sub_stream) if (st) (void)hipStreamDestroy(st);
+    for (auto& st : e->sub_stream) if (st && st != e->stream) (void)hipStreamDestroy(st);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -711,15 +715,13 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     HIP_TRY(hipMemcpyAsync(e->d_full.p, s_full, ns, hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_out_off.p, e->out_off.data(), 8ull * (nw + 1), hipMemcpyHostToDevice, cs));   // (pageable: small)
 
-    // ---- pieces: 1/8, 3/8, 1/2 of the bases, deepest windows first ----
-    uint32_t cut[rcn_engine::kSubLaunches + 1] = {0, 0, 0, nw};
+    // ---- pieces: the deepest windows that hold 1/8 of the bases, then the rest ----
+    uint32_t cut[rcn_engine::kSubLaunches + 1] = {0, 0, nw};
     {
-        const uint64_t q1 = nb / 8, q2 = nb / 2;
+        const uint64_t q1 = nb / 8;
         uint32_t k = 0;
         while (k < nw && win_base[k] < q1) ++k;
         cut[1] = std::min(std::max(k, 1u), nw);
-        while (k < nw && win_base[k] < q2) ++k;
-        cut[2] = std::min(std::max(k, cut[1]), nw);
     }
     const bool fast = !getenv("RCN_WIDE_ONLY");
     Launch L[rcn_engine::kSubLaunches];
@@ -759,7 +761,7 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
         HIP_TRY(hipMemcpyAsync(e->d_quals.as<uint8_t>() + b0, hs + o_quals + b0, b1 - b0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipEventRecord(e->sub_ev[c][0], cs));
         HIP_TRY(hipStreamWaitEvent(L[c].stream, e->sub_ev[c][0], 0));
-        HIP_TRY(hipStreamWaitEvent(L[c].stream, e->ev0, 0));
+        if (L[c].stream != e->stream) HIP_TRY(hipStreamWaitEvent(L[c].stream, e->ev0, 0));
         HIP_TRY(hipEventRecord(e->sub_ev[c][1], L[c].stream));
         if ((rc = launch_pass(e, L[c]))) return rc;
         HIP_TRY(hipEventRecord(e->sub_ev[c][2], L[c].stream));

@@ -98,7 +98,12 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 }
 
 // ---- the banded one-wave DP (wave 0 of the work-group) ----
-template <int NP, bool TAB>
+// ABL (profiling builds only, -DRCN_ABLATE=k): the pass is run an extra time before the real one with one piece compiled
+// out; the difference of the DP phase clocks against ABL = 0 (a plain second pass) is what that piece costs in situ.
+//   1 the six DPP steps of the prefix max, 2 the row store to HBM, 3 the LDS ring write, 4 the register-window update,
+//   5 the profile (LDS read / computation), 6 the row-class dispatch (every row treated as a chain row), 7 the sink branch,
+//   8 the row store goes to 16 L2-resident rows instead of the matrix, 9 only every other row is stored
+template <int NP, bool TAB, int ABL = 0>
 __device__ __noinline__ void dp2_rows_band() {
     constexpr int NTH = 64, WB = 128 * NP, LPC = 2 * NP;       // window columns, columns per lane
     const int t = threadIdx.x & 63, lane = t;
@@ -276,7 +281,7 @@ __device__ __noinline__ void dp2_rows_band() {
             for (int q = 0; q < NP; ++q) P[q] = Pn[q];
 
             uint32_t M[NP];
-            if (meta & (1 << 15)) {
+            if (ABL == 6 || __builtin_expect((meta & (1 << 15)) != 0, 1)) {
                 // ---- chain row: the only predecessor is the row just finished ----
 #pragma unroll
                 for (int q = 0; q < NP; ++q) M[q] = prev[q];
@@ -419,13 +424,15 @@ __device__ __noinline__ void dp2_rows_band() {
                 if (TAB) {
                     const uint32_t* src = ptab + (((sy >> 1) & 3) * NTH + t) * NP;
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) pw[q] = src[q];
+                    for (int q = 0; q < NP; ++q) pw[q] = ABL == 5 ? MG : src[q];
+                    if (ABL != 1) {
                     sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
                     sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
                     sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
                     sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
                     sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
                     sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
+                    }
                 } else {
 #define RCN_GAPB(o) do { __builtin_amdgcn_sched_barrier(0); dp2_gap_op<NP, (o)>(pw, sqx, symsym, ONE, XM, MG); \
                         dp2_gap_op<NP, (o) + 1>(pw, sqx, symsym, ONE, XM, MG); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -450,17 +457,20 @@ __device__ __noinline__ void dp2_rows_band() {
 
             {
                 RCN_G uint32_t* dst = hrow + t * NP;                           // absolute columns; woff + WB <= hstride
+                if (ABL == 8) dst = H + (1 + (i & 15)) * hs2 + t * NP;       // 8: the same store instruction into 16 rows that stay in the L2
+                if (ABL != 2 && !(ABL == 9 && (i & 1))) {                    // 9: every other row only
 #pragma unroll
                 for (int q = 0; q < NP; ++q) dst[q] = acc[q];
+                }
                 hrow += hs2;
             }
             uint32_t* rdst = ring + (slot * NTH + t) * NP;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) { rdst[q] = acc[q]; win[(i & (R - 1)) * NP + q] = acc[q]; prev[q] = acc[q]; }
+            for (int q = 0; q < NP; ++q) { if (ABL != 3) rdst[q] = acc[q]; if (ABL != 4) win[(i & (R - 1)) * NP + q] = acc[q]; prev[q] = acc[q]; }
             edgeR = pk_max(edgeR, acc[NP - 1]);                                // (a): lane 63's high half is the last window cell
             slot = (slot + 1 == K) ? 0 : slot + 1;
 
-            if ((meta & ((1 << 13) | 256)) == 256) {                           // sink rows are never "fast"
+            if (ABL != 7 && __builtin_expect((meta & ((1 << 13) | 256)) == 256, 0)) {       // sink rows are never "fast" (rare: kept off the row path)
                 if (own_in) {
                     uint32_t fv = acc[0];
 #pragma unroll

@@ -761,7 +761,7 @@ __device__ __noinline__ void dp2_rows() {
             if (WV > 1 && wv > 0) cwin = (lane == (i & 63)) ? cin : cwin;
             slot = (slot + 1 == K) ? 0 : slot + 1;
 
-            if ((meta & ((1 << 13) | 256)) == 256 && wv == own_wave) {      // sink rows are never "fast"
+            if (__builtin_expect((meta & ((1 << 13) | 256)) == 256 && wv == own_wave, 0)) {      // sink rows are never "fast"
                 uint32_t fv = acc[0];
 #pragma unroll
                 for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q];
@@ -1857,6 +1857,12 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             const int bnp = bcast0(ctx->band);
             if (bnp) {
                 // exact banded DP (poa_band.hpp); an alignment whose certificate fails is redone on full rows right below
+#ifdef RCN_ABLATE
+                if (wv == 0) {
+                    if (bcast0(ctx->tie_pad[1]) != 0) dp2_rows_band<2, true, RCN_ABLATE>(); else dp2_rows_band<2, false, RCN_ABLATE>();
+                }
+                Block4::sync();
+#endif
                 if (wv == 0) {
                     if (bcast0(ctx->tie_pad[1]) != 0) dp2_rows_band<2, true>(); else dp2_rows_band<2, false>();
                 }

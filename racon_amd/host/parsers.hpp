@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <functional>
 #include <string>
+#include <utility>
+#include <vector>
 
 namespace racon {
 namespace io {
@@ -25,6 +27,27 @@ void read_fastq(const std::string& path, const std::function<void(const SeqRecor
 void read_paf(const std::string& path, const std::function<void(const PafRecord&)>& cb);
 void read_mhap(const std::string& path, const std::function<void(const MhapRecord&)>& cb);
 void read_sam(const std::string& path, const std::function<void(const SamRecord&)>& cb);
+
+// ---- parallel ingest (the reference parses on the calling thread, src/polisher.cpp:200-349) ----
+// One thread inflates the file and frames whole records into batches of a few MiB of text; `threads` workers take the
+// batches (in any order) and call `work`: field parsing and object construction (upper-casing, quality checks, CIGAR
+// scans) leave the inflating thread.  Batch::number counts batches in file order and Batch::index0 is the ordinal of its
+// first record, so the caller can restore file order.  threads <= 1: everything on the calling thread, in order.
+// Exceptions thrown by `work` or by the reader are rethrown on the calling thread.
+enum class Format { kFasta, kFastq, kPaf, kMhap, kSam };
+struct Batch {
+    std::string text;
+    std::vector<std::pair<size_t, size_t>> recs;     // (offset, length) of every record in text, terminators stripped
+    uint64_t number = 0, index0 = 0;
+};
+void read_batches(const std::string& path, Format format, uint32_t threads, const std::function<void(Batch&)>& work);
+// One framed record -> fields.  `data` / `qual` receive the unwrapped lines of multi-line FASTA / FASTQ records and must
+// outlive `r`.  Throw std::runtime_error on malformed records (`path` only names the file in the message).
+void parse_seq(Format format, const char* s, size_t n, const std::string& path, std::string& data, std::string& qual, SeqRecord& r);
+void parse_paf(const char* s, size_t n, const std::string& path, PafRecord& r);
+void parse_mhap(const char* s, size_t n, const std::string& path, MhapRecord& r);
+bool parse_sam(const char* s, size_t n, const std::string& path, SamRecord& r);     // false: header line
+Format format_of(const std::string& path);          // by suffix; the caller has validated it
 
 bool has_suffix(const std::string& s, const std::string& suffix);
 bool is_fasta_path(const std::string& p);   // .fasta .fna .fa (+ .gz)

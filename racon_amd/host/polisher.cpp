@@ -108,25 +108,48 @@ Polisher::~Polisher() { logger_->total("[racon::Polisher::] total ="); }
 
 // ---------------------------------------------------------------- initialize
 namespace {
-void load_sequences(const std::string& path, std::vector<std::unique_ptr<Sequence>>& dst) {
-    auto take = [&](const io::SeqRecord& r) {
-        dst.emplace_back(r.qual ? new Sequence(r.name, r.name_len, r.data, r.data_len, r.qual, r.qual_len)
-                                : new Sequence(r.name, r.name_len, r.data, r.data_len));
-    };
+// Parallel ingest (reference src/polisher.cpp:200-349 parses on the calling thread): the inflating thread frames records,
+// `threads` workers build the objects (Sequence: upper-casing, quality scan; Overlap: field parsing, CIGAR extents); the
+// per-batch vectors are put back into file order afterwards.
+template <class T, class Make>
+void load_records(const std::string& path, uint32_t threads, std::vector<std::unique_ptr<T>>& dst, Make make) {
+    const io::Format format = io::format_of(path);
+    std::vector<std::vector<std::unique_ptr<T>>> parts;
+    std::mutex m;
     try {
-        if (io::is_fastq_path(path)) io::read_fastq(path, take); else io::read_fasta(path, take);
-    } catch (const std::runtime_error& e) { fatal(e.what()); }
+        io::read_batches(path, format, threads, [&](io::Batch& b) {
+            std::vector<std::unique_ptr<T>> local;
+            local.reserve(b.recs.size());
+            std::string data, qual;
+            for (const auto& rc : b.recs) make(format, b.text.data() + rc.first, rc.second, data, qual, local);
+            std::lock_guard<std::mutex> lock(m);
+            if (parts.size() <= b.number) parts.resize(b.number + 1);
+            parts[b.number] = std::move(local);
+        });
+    } catch (const FatalError&) { throw; } catch (const std::runtime_error& e) { fatal(e.what()); }
+    size_t n = 0;
+    for (const auto& p : parts) n += p.size();
+    dst.reserve(dst.size() + n);
+    for (auto& p : parts) for (auto& x : p) dst.emplace_back(std::move(x));
 }
 
-void load_overlaps(const std::string& path, std::vector<std::unique_ptr<Overlap>>& dst) {
-    try {
-        if (io::has_suffix(path, ".mhap") || io::has_suffix(path, ".mhap.gz"))
-            io::read_mhap(path, [&](const io::MhapRecord& r) { dst.emplace_back(new Overlap(r)); });
-        else if (io::has_suffix(path, ".paf") || io::has_suffix(path, ".paf.gz"))
-            io::read_paf(path, [&](const io::PafRecord& r) { dst.emplace_back(new Overlap(r)); });
-        else
-            io::read_sam(path, [&](const io::SamRecord& r) { dst.emplace_back(new Overlap(r)); });
-    } catch (const FatalError&) { throw; } catch (const std::runtime_error& e) { fatal(e.what()); }
+void load_sequences(const std::string& path, std::vector<std::unique_ptr<Sequence>>& dst, uint32_t threads) {
+    load_records<Sequence>(path, threads, dst, [&](io::Format f, const char* s, size_t n, std::string& data, std::string& qual,
+                                                   std::vector<std::unique_ptr<Sequence>>& out) {
+        io::SeqRecord r;
+        io::parse_seq(f, s, n, path, data, qual, r);
+        out.emplace_back(r.qual ? new Sequence(r.name, r.name_len, r.data, r.data_len, r.qual, r.qual_len)
+                                : new Sequence(r.name, r.name_len, r.data, r.data_len));
+    });
+}
+
+void load_overlaps(const std::string& path, std::vector<std::unique_ptr<Overlap>>& dst, uint32_t threads) {
+    load_records<Overlap>(path, threads, dst, [&](io::Format f, const char* s, size_t n, std::string&, std::string&,
+                                                  std::vector<std::unique_ptr<Overlap>>& out) {
+        if (f == io::Format::kMhap) { io::MhapRecord r; io::parse_mhap(s, n, path, r); out.emplace_back(new Overlap(r)); }
+        else if (f == io::Format::kPaf) { io::PafRecord r; io::parse_paf(s, n, path, r); out.emplace_back(new Overlap(r)); }
+        else { io::SamRecord r; if (io::parse_sam(s, n, path, r)) out.emplace_back(new Overlap(r)); }
+    });
 }
 }  // namespace
 
@@ -137,8 +160,23 @@ void Polisher::initialize() {
     }
     logger_->log();
 
+    // The three input files are read concurrently (one inflating thread each, num_threads_ parse workers shared out):
+    // their contents only meet below, in file order, when names are resolved.  RACON_HIP_SERIAL_INGEST=1: one file after
+    // the other on the calling thread (the reference's order of events, src/polisher.cpp:200-349).
+    const bool serial_ingest = getenv("RACON_HIP_SERIAL_INGEST") != nullptr || num_threads_ <= 1;
+    const uint32_t parse_threads = serial_ingest ? 1 : std::max<uint32_t>(2, num_threads_ / 2);
+    std::vector<std::unique_ptr<Sequence>> reads;
+    std::vector<std::unique_ptr<Overlap>> overlaps;
+    std::exception_ptr reads_error, overlaps_error;
+    std::thread reads_thread, overlaps_thread;
+    if (!serial_ingest) {
+        reads_thread = std::thread([&] { try { load_sequences(sequences_path_, reads, parse_threads); } catch (...) { reads_error = std::current_exception(); } });
+        overlaps_thread = std::thread([&] { try { load_overlaps(overlaps_path_, overlaps, parse_threads); } catch (...) { overlaps_error = std::current_exception(); } });
+    }
+    struct Joiner { std::thread& a; std::thread& b; ~Joiner() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } joiner{reads_thread, overlaps_thread};
+
     // ---- targets (reference src/polisher.cpp:200-221)
-    load_sequences(target_path_, sequences_);
+    load_sequences(target_path_, sequences_, parse_threads);
     const uint64_t targets_size = sequences_.size();
     if (targets_size == 0) fatal("[racon::Polisher::initialize] error: empty target sequences set!");
     std::unordered_map<std::string, uint64_t> name_to_id;     // "<name>t" / "<name>q" -> index in sequences_
@@ -150,8 +188,8 @@ void Polisher::initialize() {
     // ---- reads; a read that is also a target is stored once (reference src/polisher.cpp:223-278)
     uint64_t sequences_size = 0, total_sequences_length = 0;
     {
-        std::vector<std::unique_ptr<Sequence>> reads;
-        load_sequences(sequences_path_, reads);
+        if (serial_ingest) load_sequences(sequences_path_, reads, 1);
+        else { reads_thread.join(); if (reads_error) std::rethrow_exception(reads_error); }
         for (auto& read : reads) {
             total_sequences_length += read->data().size();
             const auto it = name_to_id.find(read->name() + "t");
@@ -169,6 +207,7 @@ void Polisher::initialize() {
             id_to_id[sequences_size << 1 | 0] = index;
             ++sequences_size;
         }
+        std::vector<std::unique_ptr<Sequence>>().swap(reads);
     }
     if (sequences_size == 0) fatal("[racon::Polisher::initialize] error: empty sequences set!");
     const WindowType window_type = static_cast<double>(total_sequences_length) / sequences_size <= 1000 ? WindowType::kNGS : WindowType::kTGS;
@@ -177,8 +216,8 @@ void Polisher::initialize() {
 
     // ---- overlaps: resolve ids, then filter each run of consecutive overlaps of one query
     //      (reference src/polisher.cpp:283-358)
-    std::vector<std::unique_ptr<Overlap>> overlaps;
-    load_overlaps(overlaps_path_, overlaps);
+    if (serial_ingest) load_overlaps(overlaps_path_, overlaps, 1);
+    else { overlaps_thread.join(); if (overlaps_error) std::rethrow_exception(overlaps_error); }
     auto filter_group = [&](uint64_t begin, uint64_t end) {
         for (uint64_t i = begin; i < end; ++i) {
             if (!overlaps[i]) continue;
