@@ -33,6 +33,18 @@
 namespace rcn {
 
 constexpr int kBandG = 32;            // window offsets are multiples of this many columns
+// How the rows of the matrix go to HBM (-DRCN_STORE_MODE, experiments): 0 one store per row as it is finished, 1 the same
+// non-temporal, 2 the eight rows of the register window at once every eighth row (a 4-8 KB burst per wave), 3 = 2 non-temporal
+#ifndef RCN_STORE_MODE
+#define RCN_STORE_MODE 0
+#endif
+template <bool NT>
+__device__ __forceinline__ void row_store2(RCN_G uint32_t* dst, uint32_t a, uint32_t b) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v = {a, b};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<RCN_G u32x2*>(dst));
+    else *reinterpret_cast<RCN_G u32x2*>(dst) = v;
+}
 constexpr int kBandSeq = 1536;        // LDS copy of the layer's bases (window shifts re-read their columns from it)
 
 // NP of the banded DP for a layer of `len` bases (0 = not banded).  The alive zone is about len / 3 wide
@@ -201,9 +213,22 @@ __device__ __noinline__ void dp2_rows_band() {
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
 
     // the window moves to new_off before row i is computed
+    constexpr bool kBatch = (RCN_STORE_MODE & 2) != 0 && NP == 2 && ABL == 0, kNT = (RCN_STORE_MODE & 1) != 0;
+    // batched row stores: rows [first, last] (all still in the register window, all written under the current window
+    // offset) go out back to back
+    auto flush_rows = [&](int first, int last) {
+#pragma unroll
+        for (int w = 0; w < R; ++w) {
+            const int r = (last & ~(R - 1)) + w - ((w > (last & (R - 1))) ? R : 0);     // the row held in slot w
+            if (r >= first && r <= last)
+                row_store2<kNT>(H + static_cast<int64_t>(r) * hs2 + (woff >> 1) + t * NP, win[w * NP], win[w * NP + 1]);
+        }
+    };
+    int flushed = 0;                            // rows <= flushed are in HBM (batched mode)
     auto shift_to = [&](int i_in, int new_off) {
         int i = i_in, Vs = V;
         asm volatile("; window shift (rare): nothing of it is carried in the row loop" : "+s"(i), "+s"(Vs));
+        if (kBatch) { flush_rows(flushed + 1, i - 1); flushed = i - 1; }
         flush_edge();
         const int delta = new_off - woff, dl = delta / LPC;
         {   // (b) dropped cells of the rows in the register window
@@ -458,7 +483,13 @@ __device__ __noinline__ void dp2_rows_band() {
             {
                 RCN_G uint32_t* dst = hrow + t * NP;                           // absolute columns; woff + WB <= hstride
                 if (ABL == 8) dst = H + (1 + (i & 15)) * hs2 + t * NP;       // 8: the same store instruction into 16 rows that stay in the L2
-                if (ABL != 2 && !(ABL == 9 && (i & 1))) {                    // 9: every other row only
+                if (ABL == 10) dst = H + (1 + (i & 255)) * hs2 + t * NP;     // 10: ... into 256 rows (256 KB per window: beyond L2 + MALL, few pages)
+                if (ABL == 11) dst = H + (1 + (i & 63)) * hs2 + t * NP;      // 11: ... into 64 rows (64 KB per window: beyond the L2, inside the MALL)
+                if (kBatch) {
+                    // stored from the register window, eight rows at a time (below)
+                } else if (NP == 2 && kNT && ABL == 0) {
+                    row_store2<true>(dst, acc[0], acc[1]);
+                } else if (ABL != 2 && !(ABL == 9 && (i & 1))) {             // 9: every other row only
 #pragma unroll
                 for (int q = 0; q < NP; ++q) dst[q] = acc[q];
                 }
@@ -469,6 +500,7 @@ __device__ __noinline__ void dp2_rows_band() {
             for (int q = 0; q < NP; ++q) { if (ABL != 3) rdst[q] = acc[q]; if (ABL != 4) win[(i & (R - 1)) * NP + q] = acc[q]; prev[q] = acc[q]; }
             edgeR = pk_max(edgeR, acc[NP - 1]);                                // (a): lane 63's high half is the last window cell
             slot = (slot + 1 == K) ? 0 : slot + 1;
+            if (kBatch && (i & (R - 1)) == R - 1) { flush_rows(flushed + 1, i); flushed = i; }
 
             if (ABL != 7 && __builtin_expect((meta & ((1 << 13) | 256)) == 256, 0)) {       // sink rows are never "fast" (rare: kept off the row path)
                 if (own_in) {
@@ -488,6 +520,7 @@ __device__ __noinline__ void dp2_rows_band() {
             }
         }
     }
+    if (kBatch && !bfail) flush_rows(flushed + 1, V);
     flush_edge();
     // ---- certificate: no recorded cell may be alive at T = the best end score found ----
     int ev = max(static_cast<int>(emaxV) >> 16, static_cast<int>(emaxV << 16) >> 16);
