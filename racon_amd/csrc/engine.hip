@@ -204,7 +204,7 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.heavy_ns = e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.force_tie = getenv("RCN_FORCE_TIE") ? atoi(getenv("RCN_FORCE_TIE")) : 0;
     P.force_slow_tb = getenv("RCN_FORCE_SLOW_TB") ? 1 : 0;
-    P.band = getenv("RCN_NO_BAND") ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : 1);
+    P.band = getenv("RCN_NO_BAND") ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : (getenv("RCN_BAND_SCORES") ? 3 : 1));
     P.scratch = e->d_scratch.as<uint8_t>() + L.scratch_off; P.slot_bytes = L.c.slot_bytes;
     P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride;
     P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_off = e->d_out_off.as<uint64_t>(); P.out_base = L.out_base;

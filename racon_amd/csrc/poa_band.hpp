@@ -115,8 +115,14 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 //   1 the six DPP steps of the prefix max, 2 the row store to HBM, 3 the LDS ring write, 4 the register-window update,
 //   5 the profile (LDS read / computation), 6 the row-class dispatch (every row treated as a chain row), 7 the sink branch,
 //   8 the row store goes to 16 L2-resident rows instead of the matrix, 9 only every other row is stored
-template <int NP, bool TAB, int ABL = 0>
+// CODE: instead of the row of scores the wave stores, per cell, what the traceback would find out from the scores (one
+// byte: bit 0 clear = a diagonal move reproduces the cell, bit 1 clear = a vertical one does, bits 2-4 / 5-7 = the first
+// predecessor in in-edge order that attains the predecessor maximum at the previous / at this column) -- see
+// phase_traceback_code.  A quarter of the bytes of the full int16 row, and the traceback neither re-reads scores nor
+// compares them.  Rows with more than six in-edges are left to the score-matrix path (band_fail).
+template <int NP, bool TAB, int ABL = 0, bool CODE = false>
 __device__ __noinline__ void dp2_rows_band() {
+    static_assert(!CODE || (NP == 2 && ABL == 0), "move codes: four cells per lane -> one dword per lane and row");
     constexpr int NTH = 64, WB = 128 * NP, LPC = 2 * NP;       // window columns, columns per lane
     const int t = threadIdx.x & 63, lane = t;
     const Ctx c = ctx_load<Block4>();
@@ -210,10 +216,14 @@ __device__ __noinline__ void dp2_rows_band() {
     unsigned int pred_rows = 0, not_chain = 0;
     int slot = 1 % K;
     RCN_G uint32_t* hrow = H + hs2;             // wave-uniform: row i of the matrix at the window's first column
+    // CODE: one byte per cell, absolute columns, row stride hs BYTES (same base as the score matrix it replaces)
+    RCN_G uint8_t* crow = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr()) + hs;
+    RCN_G int32_t* sinkz = g.path_node.ptr();   // CODE: end score (column len) of the sink rows, for phase_sink_tie_full
+    const uint32_t ZERO2 = 0u, TWO2 = 0x00020002u, FOUR2 = 0x00040004u, C32 = 0x00200020u;
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
 
     // the window moves to new_off before row i is computed
-    constexpr bool kBatch = (RCN_STORE_MODE & 2) != 0 && NP == 2 && ABL == 0, kNT = (RCN_STORE_MODE & 1) != 0;
+    constexpr bool kBatch = (RCN_STORE_MODE & 2) != 0 && NP == 2 && ABL == 0 && !CODE, kNT = (RCN_STORE_MODE & 1) != 0;
     // batched row stores: rows [first, last] (all still in the register window, all written under the current window
     // offset) go out back to back
     auto flush_rows = [&](int first, int last) {
@@ -251,9 +261,9 @@ __device__ __noinline__ void dp2_rows_band() {
                 prev[q] = keep ? v : NEGP;
             }
         }
-        // guards in HBM: the cell left of the window for every row still to come ...
-        for (int r = i + lane; r <= Vs; r += NTH) H16w[static_cast<int64_t>(r) * hs + new_off - 1] = static_cast<int16_t>(kNeg16);
-        {   // ... and the columns this shift adds, for the rows later rows can still name as predecessors
+        // guards in HBM (score matrix only): the cell left of the window for every row still to come ...
+        if (!CODE) for (int r = i + lane; r <= Vs; r += NTH) H16w[static_cast<int64_t>(r) * hs + new_off - 1] = static_cast<int16_t>(kNeg16);
+        if (!CODE) {   // ... and the columns this shift adds, for the rows later rows can still name as predecessors
             const int r0 = max(1, i - (K + 1)), dw = delta >> 1, n = (i - r0) * dw;
             for (int idx = lane; idx < n; idx += NTH) {
                 const int r = r0 + idx / dw, cw = idx % dw;
@@ -262,6 +272,7 @@ __device__ __noinline__ void dp2_rows_band() {
         }
         off2 = off1; s_row3 = s_row2; off1 = woff; s_row2 = s_row1; s_row1 = i; woff = new_off;
         hrow = H + static_cast<int64_t>(i) * hs2 + (woff >> 1);
+        crow = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr()) + static_cast<int64_t>(i) * hs + woff;
         set_columns();
     };
 
@@ -306,6 +317,20 @@ __device__ __noinline__ void dp2_rows_band() {
             for (int q = 0; q < NP; ++q) P[q] = Pn[q];
 
             uint32_t M[NP];
+            uint32_t Aq[NP];                        // CODE: per cell, the first predecessor (in-edge order) that attains M
+#pragma unroll
+            for (int q = 0; q < NP; ++q) Aq[q] = 0u;
+            bool multi = false;                     // CODE: the row has more than one predecessor
+            // running "first argmax": predecessor number e replaces the holder where it is strictly greater
+            auto arg_step = [&](const uint32_t (&zq)[NP], int e) {
+                const uint32_t Q = pack2(e, e);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const uint32_t d = pk_subs(zq[q], M[q]);
+                    const uint32_t gt = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, pk_max(d, ZERO2)), __builtin_bit_cast(s16x2, ONE)));
+                    Aq[q] = pk_mad(gt, pk_sub(Q, Aq[q]), Aq[q]);
+                }
+            };
             if (ABL == 6 || __builtin_expect((meta & (1 << 15)) != 0, 1)) {
                 // ---- chain row: the only predecessor is the row just finished ----
 #pragma unroll
@@ -325,9 +350,14 @@ __device__ __noinline__ void dp2_rows_band() {
                 for (int e = 1; e < npf; ++e) {
                     const int d = (dd >> (4 * e)) & 15;
                     const int wi = ((i - d) & (R - 1)) * NP;
+                    uint32_t zq[NP];
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], win[wi + q]);
+                    for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
+                    if (CODE) arg_step(zq, e);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
                 }
+                multi = npf > 1;
                 pred_rows += npf;
             } else if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
                 // ---- medium row whose predecessors all share this row's window: LDS ring, reads in flight together ----
@@ -342,8 +372,20 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) hp[e][q] = src[q];
                 }
+                if (CODE) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) M[q] = hp[0][q];
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) {           // unused slots repeat predecessor 0: never strictly greater
+                        arg_step(hp[e], e);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[e][q]);
+                    }
+                    multi = npf > 1;
+                } else {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
+                }
                 pred_rows += npf;
                 ++not_chain;
             } else {
@@ -354,6 +396,7 @@ __device__ __noinline__ void dp2_rows_band() {
                 const int er = __builtin_amdgcn_readlane(dl_er, k);
                 const int np = (meta >> 9) & 7;
                 bool first = true;
+                int nq = 0;                          // ordinal of the predecessor being combined (= its index in the descriptor)
                 auto combine = [&](int p) {
                     uint32_t hp[NP];
                     if (p == 0) {
@@ -397,10 +440,11 @@ __device__ __noinline__ void dp2_rows_band() {
                         for (int q = 0; q < NP; ++q) M[q] = hp[q];
                         first = false;
                     } else {
+                        if (CODE) { arg_step(hp, nq); multi = true; }
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[q]);
                     }
-                    ++pred_rows;
+                    ++pred_rows; ++nq;
                 };
                 combine(p0);
                 if (np > 1) {
@@ -410,6 +454,7 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll 1
                     for (int q = 1; q < np; ++q) combine(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
                 }
+                if (CODE && er >= 0) bfail |= 8;                  // move codes name at most six predecessors
                 for (int e = er; e >= 0; e = e_nin[e]) {          // more than six in-edges: the rest of the list
                     const int tl = e_tail[e];
                     if (sub && !inc[tl]) continue;
@@ -422,18 +467,20 @@ __device__ __noinline__ void dp2_rows_band() {
             // diagonal sources = the combined predecessor row shifted right by one column (lane 0: -inf, the cell left of the window)
             uint32_t mprev = mpv = __builtin_amdgcn_update_dpp(mpv, M[NP - 1], 0x138, 0xf, 0xf, false);
             uint32_t acc[NP];
+            uint32_t DPv[NP], Uv[NP];               // the diagonal / vertical candidates (CODE compares the finished cell with them)
             if (TAB) {
-                uint32_t D[NP], U[NP];
+                uint32_t D[NP];
 #pragma unroll
-                for (int q = 0; q < NP; ++q) { D[q] = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16); U[q] = pk_add(M[q], GG); }
+                for (int q = 0; q < NP; ++q) { D[q] = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16); Uv[q] = pk_add(M[q], GG); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) acc[q] = pk_max(pk_add(D[q], P[q]), U[q]);
+                for (int q = 0; q < NP; ++q) { DPv[q] = pk_add(D[q], P[q]); acc[q] = pk_max(DPv[q], Uv[q]); }
             } else {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
                     const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
-                    acc[q] = pk_max(pk_add(D, P[q]), pk_add(M[q], GG));
+                    DPv[q] = pk_add(D, P[q]); Uv[q] = pk_add(M[q], GG);
+                    acc[q] = pk_max(DPv[q], Uv[q]);
                 }
             }
 #pragma unroll
@@ -482,10 +529,32 @@ __device__ __noinline__ void dp2_rows_band() {
 
             {
                 RCN_G uint32_t* dst = hrow + t * NP;                           // absolute columns; woff + WB <= hstride
+                if (CODE) {
+                    // ---- move codes of this row ----
+                    uint32_t b[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const uint32_t nd = pk_minu(pk_sub(acc[q], DPv[q]), ONE), nu = pk_minu(pk_sub(acc[q], Uv[q]), ONE);
+                        b[q] = pk_mad(nu, TWO2, nd);
+                    }
+                    if (multi) {
+                        // the diagonal move comes from the previous column: the argmax one column to the left
+                        const uint32_t aprev = __builtin_amdgcn_update_dpp(0u, Aq[NP - 1], 0x138, 0xf, 0xf, true);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            const uint32_t ash = __builtin_amdgcn_alignbit(Aq[q], q == 0 ? aprev : Aq[q - 1], 16);
+                            b[q] = pk_mad(Aq[q], C32, pk_mad(ash, FOUR2, b[q]));
+                        }
+                    }
+                    const uint32_t word = __builtin_amdgcn_perm(b[1], b[0], 0x06040200u);
+                    __builtin_nontemporal_store(word, reinterpret_cast<RCN_G uint32_t*>(crow) + t);
+                    crow += hs;
+                }
                 if (ABL == 8) dst = H + (1 + (i & 15)) * hs2 + t * NP;       // 8: the same store instruction into 16 rows that stay in the L2
                 if (ABL == 10) dst = H + (1 + (i & 255)) * hs2 + t * NP;     // 10: ... into 256 rows (256 KB per window: beyond L2 + MALL, few pages)
                 if (ABL == 11) dst = H + (1 + (i & 63)) * hs2 + t * NP;      // 11: ... into 64 rows (64 KB per window: beyond the L2, inside the MALL)
-                if (kBatch) {
+                if (CODE) {
+                } else if (kBatch) {
                     // stored from the register window, eight rows at a time (below)
                 } else if (NP == 2 && kNT && ABL == 0) {
                     row_store2<true>(dst, acc[0], acc[1]);
@@ -509,13 +578,15 @@ __device__ __noinline__ void dp2_rows_band() {
                     for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q];
                     const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16);
                     const int val = __builtin_amdgcn_readlane(v16, own_lane);
+                    if (CODE && lane == 0) sinkz[i] = val;
                     if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
                     else if (best == val) {
                         if (tied < 8 && lane == 0) *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(tie_base + 4u * tied) = static_cast<uint32_t>(i);
                         ++tied;
                     }
                 } else if (lane == 0) {
-                    H16w[static_cast<int64_t>(i) * hs + len] = static_cast<int16_t>(kNeg16);   // never computed: the sink-tie code compares this cell
+                    // never computed: the sink-tie code compares this cell
+                    if (CODE) sinkz[i] = kNeg16; else H16w[static_cast<int64_t>(i) * hs + len] = static_cast<int16_t>(kNeg16);
                 }
             }
         }

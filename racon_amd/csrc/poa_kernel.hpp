@@ -40,8 +40,9 @@ struct KParams {
     int32_t heavy_ns;             // poa_window_kernel2: windows with at least this many sequences use the 4-wave DP (0 = none)
     int32_t force_tie;            // poa_window_kernel2, tests (env RCN_FORCE_TIE): 2 = every sink tie skips the id / backbone-position
                                   // rule (levels 2a/2b decide), 3 = every sink tie takes the full DFS (phase_sink_tie_full)
-    int32_t band;                 // poa_window_kernel2: 1 = exact banded DP where it applies (default), 0 = never (env RCN_NO_BAND),
-                                  // 2 = banded pass runs but every certificate is treated as failed (tests the redo path; RCN_FORCE_BAND_FAIL)
+    int32_t band;                 // poa_window_kernel2: 1 = exact banded DP where it applies, leaving move codes (default), 0 = never
+                                  // (env RCN_NO_BAND), 2 = banded pass runs but every certificate is treated as failed (tests the redo
+                                  // path; RCN_FORCE_BAND_FAIL), 3 = banded DP that stores the scores (RCN_BAND_SCORES)
     int32_t force_slow_tb;        // poa_window_kernel2, tests (env RCN_FORCE_SLOW_TB): every traceback step is the one-cell step
                                   // against HBM (traceback2_slow_step) instead of the box walk over the staged tile
     int32_t m, x, g, trim;
@@ -409,7 +410,7 @@ struct Ctx {
     int32_t tie_rows[8];          // rows of the sinks that share the best score (first 8)
     int32_t tie_why, tie_pad[3];   // tie_pad[0]: KParams::band, [1]: window is ACGT-only, [2]: KParams::force_slow_tb
     // exact banded DP (poa_band.hpp): NP of the window for the current alignment (0 = full rows), certificate verdict, counters
-    int32_t band, band_fail;
+    int32_t band, band_fail, coded;                // coded: the finished alignment left move codes, not scores (phase_traceback_code)
     unsigned long long cells_full, bytes_full;     // the full-matrix figures next to the evaluated ones (cells / bytes)
     unsigned int n_banded, n_band_fail;
     unsigned int band_why, band_whyn[8];            // reasons of the redos (bit k of dp2_rows_band's `why`), counted

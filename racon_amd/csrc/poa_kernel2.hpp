@@ -1223,7 +1223,8 @@ __device__ __noinline__ void phase_sink_tie_full() {
     const int nx = graph_toposort(g, g.rank_x.ptr(), sub, g.stack.ptr());
     for (int r = 0; r < nx; ++r) {
         const int row = nr[g.rank_x[r]] + 1;
-        if ((g.desc[row - 1].meta & 256) && H[static_cast<int64_t>(row) * hs + c.len] == c.best) { o->best_row = row; break; }
+        const int zend = c.coded ? g.path_node[row] : H[static_cast<int64_t>(row) * hs + c.len];    // coded: the DP kept the sinks' end scores
+        if ((g.desc[row - 1].meta & 256) && zend == c.best) { o->best_row = row; break; }
     }
     o->ties += 1;
 #ifdef RCN_PROF_WIN
@@ -1413,6 +1414,113 @@ __device__ __noinline__ void phase_traceback3() {
             if (lane == 0) { const long long tp2__ = clock64(); atomicAdd(&g_prof_out[4], (unsigned long long)(tp1__ - tp0__)); atomicAdd(&g_prof_out[5], (unsigned long long)(tp2__ - tp1__));
                              atomicAdd(&g_prof_out[6], 1ull); atomicAdd(&g_prof_out[7], (unsigned long long)nbox__); }
 #endif
+        }
+        Block4::sync();
+        i = bcast0(o->tb_i); j = bcast0(o->tb_j);
+        if (bcast0(o->overflow)) break;
+        Block4::sync();                                  // everyone has read the walk state before the next tile overwrites LDS
+    }
+    if (t == 0) { o->plen = -1; }
+    Block4::sync();
+}
+
+// ---- phase: traceback over move codes (the banded DP with CODE, poa_band.hpp) ----
+// The DP left one byte per cell: whether a diagonal / a vertical move reproduces the cell and which predecessor (first in
+// in-edge order) it comes from.  spoa's priority (diagonal over the in-edges, then vertical over the in-edges, then
+// horizontal) is then a table lookup: no score is read, nothing is compared.  Same organisation as phase_traceback3: the
+// four waves stage a tile (112 rows x 64 columns, now 64 BYTES per row: four rows per global_load_lds), the 64 lanes of wave 0
+// decode the successor of every cell of a 9 x 7 box at once and the walk inside the box is one v_readlane per step.
+constexpr int kTileCQuad = 272;        // LDS stride of FOUR tile rows in bytes (4 x 64 + 16: skews the banks)
+__device__ __forceinline__ int tilec_at(int trow, int tcol) { return (trow >> 2) * kTileCQuad + (trow & 3) * 64 + tcol; }
+static_assert((kTbRows / 4) * kTileCQuad + kTbRows * 32 + 64 <= kLdsBytes, "code tile + row descriptors must fit");
+
+__device__ __noinline__ void phase_traceback_code() {
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    const int len = c.len;
+    const int64_t hs = g.hstride;                    // row stride of the code matrix in bytes
+    RCN_G const uint8_t* __restrict__ C = reinterpret_cast<RCN_G const uint8_t*>(g.H.ptr());
+    Ctx* o = Block4::ctx();
+    if (t == 0) { o->tb_i = c.best_row; o->tb_j = len; o->tb_n = 0; }
+    Block4::sync();
+
+    uint8_t* tile = reinterpret_cast<uint8_t*>(Block4::work());                        // [kTbRows / 4][kTileCQuad]
+    int* tdesc = Block4::work() + (kTbRows / 4) * kTileCQuad / 4;                      // kTbRows x RowDesc (8 ints each)
+    RCN_G int32_t* __restrict__ prow = g.pos_t.ptr();
+    int i = bcast0(o->tb_i), j = bcast0(o->tb_j);
+    int overflow = g.overflow;
+    while (!(i == 0 && j == 0)) {
+        const int ti0 = i, j_stage = j;
+        int c0 = (j - 56) & ~7; if (c0 < 0) c0 = 0;
+        const int rmin = ti0 - (kTbRows - 1) > 0 ? ti0 - (kTbRows - 1) : 0;
+        {
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            constexpr int kQuadsPerWave = kTbRows / 4 / kWaves2;       // 7
+            static_assert(kQuadsPerWave * kWaves2 * 4 == kTbRows, "rows split evenly over the waves, four per load");
+#pragma unroll
+            for (int kk = 0; kk < kQuadsPerWave; ++kk) {
+                const int qd = kQuadsPerWave * wv + kk;            // tile rows 4 qd .. 4 qd + 3, sixteen lanes each
+                int r = ti0 - (4 * qd + (lane >> 4)); if (r < 1) r = 1;
+                RCN_G const uint8_t* src = C + r * hs + c0 + (lane & 15) * 4;
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(tile + qd * kTileCQuad), 4, 0, 0);
+            }
+            if (wv == 1 || wv == 2) {
+                const int k = (wv - 1) * 64 + lane;               // tile row whose descriptor this lane stages
+                if (k < kTbRows) {
+                    const int r = ti0 - k;
+                    int4 d0 = make_int4(0, -1, -1, -1), d1 = make_int4(-1, -1, -1, 1 << 9);
+                    if (r >= 1) { RCN_G const int4* dsrc = reinterpret_cast<RCN_G const int4*>(g.desc.ptr() + (r - 1)); d0 = dsrc[0]; d1 = dsrc[1]; }
+                    int4* ddst = reinterpret_cast<int4*>(tdesc + k * 8);
+                    ddst[0] = d0; ddst[1] = d1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wv == 0) {
+            const int a = lane / kBoxCols, b = lane % kBoxCols;
+            for (;;) {
+                if (i == 0 && j == 0) break;
+                const int ii = i - a, jj = j - b;
+                const bool inside = a < kBoxRows && ii >= rmin && ii >= 0 && jj >= c0 && jj >= 0;
+                const int trow = inside ? ti0 - ii : 0, tcol = inside ? jj - c0 : 0;
+                const int* dr = tdesc + trow * 8;
+                const int4 pa = *reinterpret_cast<const int4*>(dr);
+                const int2 pb = *reinterpret_cast<const int2*>(dr + 4);
+                const int code = tile[tilec_at(trow, tcol)];
+                int mv, q = 0;
+                if (ii == 0) mv = jj > 0 ? kMvLeft : kMvInvalid;
+                else if (jj > 0 && !(code & 1)) { mv = kMvDiag; q = (code >> 2) & 7; }
+                else if (!(code & 2)) { mv = kMvUp; q = code >> 5; }
+                else mv = jj > 0 ? kMvLeft : kMvInvalid;
+                int pi = q == 0 ? pa.x : q == 1 ? pa.y : q == 2 ? pa.z : q == 3 ? pa.w : q == 4 ? pb.x : pb.y;
+                if (!inside || q > 5 || (mv != kMvLeft && pi < 0)) mv = kMvInvalid;
+                const int ni = mv == kMvLeft ? ii : pi, nj = jj - (mv == kMvUp ? 0 : 1);
+                const int na = i - ni, nb = j - nj;
+                int nx;
+                if (mv == kMvInvalid) nx = kNxInvalid;
+                else if (ni == 0 && nj == 0) nx = kNxExit;
+                else if (na >= kBoxRows || nb >= kBoxCols) nx = kNxExit;
+                else nx = na * kBoxCols + nb;
+                int idx = 0, nxt;
+                unsigned long long vis = 0ull;
+                for (;;) {
+                    nxt = __builtin_amdgcn_readlane(nx, idx);
+                    if (nxt == kNxInvalid) break;
+                    vis |= 1ull << idx;
+                    if (nxt >= 64) break;
+                    idx = nxt;
+                }
+                if (((vis >> lane) & 1ull) && mv != kMvUp) prow[jj - 1] = (mv == kMvDiag) ? ii : -1;
+                bool stuck = false;
+                if (nxt == kNxInvalid) { stuck = idx == 0; i = __builtin_amdgcn_readlane(ii, idx); j = __builtin_amdgcn_readlane(jj, idx); }
+                else { i = __builtin_amdgcn_readlane(ni, idx); j = __builtin_amdgcn_readlane(nj, idx); }
+                if (stuck) break;
+            }
+            // a freshly anchored tile always holds the current cell: no progress means a corrupt code matrix
+            if (!(i == 0 && j == 0) && i == ti0 && j == j_stage) overflow = 4;
+            if (lane == 0) { o->tb_i = i; o->tb_j = j; o->overflow = overflow; }
         }
         Block4::sync();
         i = bcast0(o->tb_i); j = bcast0(o->tb_j);
@@ -1834,7 +1942,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 ctx->begin = static_cast<int32_t>(P.seq_begin[si]); ctx->end = static_cast<int32_t>(P.seq_end[si]);
                 ctx->V = ctx->n_nodes;
                 ctx->tb_j = 0;                 // phase_subgraph2: 0 = normal, 1 = closure query (marks only)
-                ctx->band = (P.band && !heavy) ? band_np(len) : 0; ctx->band_fail = 0;
+                ctx->band = (P.band && !heavy) ? band_np(len) : 0; ctx->band_fail = 0; ctx->coded = 0;
             }
             Block4::sync();
             if (partial) {
@@ -1863,11 +1971,16 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 }
                 Block4::sync();
 #endif
+                const bool coded = P.band != 3;
                 if (wv == 0) {
-                    if (bcast0(ctx->tie_pad[1]) != 0) dp2_rows_band<2, true>(); else dp2_rows_band<2, false>();
+                    const bool tab = bcast0(ctx->tie_pad[1]) != 0;
+                    if (coded) { if (tab) dp2_rows_band<2, true, 0, true>(); else dp2_rows_band<2, false, 0, true>(); }
+                    else { if (tab) dp2_rows_band<2, true>(); else dp2_rows_band<2, false>(); }
                 }
                 Block4::sync();
                 dp_done = bcast0(ctx->band_fail) == 0;
+                if (t == 0) ctx->coded = (dp_done && coded) ? 1 : 0;
+                Block4::sync();
                 if (!dp_done) {
                     Block4::sync();
                     if (t == 0) ctx->band = 0;
@@ -1942,7 +2055,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 }
                 if (st == 2) { if (wv == 0) phase_sink_tie_full(); Block4::sync(); }
             }
-            phase_traceback3();
+            if (bcast0(ctx->coded)) phase_traceback_code(); else phase_traceback3();
             RCN_PHASE2(3);
             overflow = bcast0(ctx->overflow);
             if (!overflow) {

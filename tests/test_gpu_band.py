@@ -103,3 +103,30 @@ def test_band_window_lengths(oracle, w, seed):
     eng = HipEngine(3, -5, -4, True)
     assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), f"w {w}")
     assert eng.stats()["n_banded"] > 0
+
+
+@pytest.mark.parametrize("seed,scores", [(5, (3, -5, -4)), (6, (5, -4, -8))])
+def test_band_that_keeps_the_scores(oracle, seed, scores, monkeypatch):
+    """RCN_BAND_SCORES: the banded pass stores the int16 scores of its window (and guard cells) instead of move codes, and the
+    score-reading traceback walks them -- the variant the move codes replaced, kept selectable."""
+    from racon_amd.engine import HipEngine
+    monkeypatch.setenv("RCN_BAND_SCORES", "1")
+    rng = np.random.default_rng(7300 + seed)
+    b = WindowBatch.from_windows([long_window(rng, k) for k in range(120)])
+    assert_same(HipEngine(*scores, True).consensus(b), oracle.consensus(b, *scores, True, 0), f"band with scores, long fuzz {seed}")
+    b2 = simulate_windows(40_000, 500, 25.0, 10000, seed=7300 + seed)
+    eng = HipEngine(*scores, True)
+    assert_same(eng.consensus(b2), oracle.consensus(b2, *scores, True, 0), f"band with scores, synthetic {seed}")
+    assert eng.stats()["n_banded"] > 1000
+
+
+@pytest.mark.parametrize("level", [2, 3])
+def test_band_with_forced_sink_tie_levels(oracle, level, monkeypatch):
+    """Sink ties after a coded alignment: the full-DFS level compares the end scores the DP kept aside (there is no score
+    matrix to read them from)."""
+    from racon_amd.engine import HipEngine
+    monkeypatch.setenv("RCN_FORCE_TIE", str(level))
+    rng = np.random.default_rng(7400 + level)
+    b = WindowBatch.from_windows([long_window(rng, k) for k in range(120)])
+    eng = HipEngine(3, -5, -4, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), f"coded band, forced tie level {level}")
