@@ -119,7 +119,8 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 // byte: bit 0 clear = a diagonal move reproduces the cell, bit 1 clear = a vertical one does, bits 2-4 / 5-7 = the first
 // predecessor in in-edge order that attains the predecessor maximum at the previous / at this column) -- see
 // phase_traceback_code.  A quarter of the bytes of the full int16 row, and the traceback neither re-reads scores nor
-// compares them.  Rows with more than six in-edges are left to the score-matrix path (band_fail).
+// compares them.  Rows with more than EIGHT in-edges (three bits name a predecessor) are left to the score-matrix path
+// (band_fail); the seventh and eighth are not in the row descriptor, the traceback finds them on the in-edge list.
 template <int NP, bool TAB, int ABL = 0, bool CODE = false>
 __device__ __noinline__ void dp2_rows_band() {
     static_assert(!CODE || (NP == 2 && ABL == 0), "move codes: four cells per lane -> one dword per lane and row");
@@ -454,12 +455,12 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll 1
                     for (int q = 1; q < np; ++q) combine(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
                 }
-                if (CODE && er >= 0) bfail |= 8;                  // move codes name at most six predecessors
                 for (int e = er; e >= 0; e = e_nin[e]) {          // more than six in-edges: the rest of the list
                     const int tl = e_tail[e];
                     if (sub && !inc[tl]) continue;
                     combine(nr[tl] + 1);
                 }
+                if (CODE && nq > 8) bfail |= 8;                   // move codes name predecessors 0..7 (three bits)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
             }

@@ -1448,6 +1448,11 @@ __device__ __noinline__ void phase_traceback_code() {
     uint8_t* tile = reinterpret_cast<uint8_t*>(Block4::work());                        // [kTbRows / 4][kTileCQuad]
     int* tdesc = Block4::work() + (kTbRows / 4) * kTileCQuad / 4;                      // kTbRows x RowDesc (8 ints each)
     RCN_G int32_t* __restrict__ prow = g.pos_t.ptr();
+    RCN_G const int32_t* nr = (c.sub ? g.n2r_x : g.n2r).ptr();
+    RCN_G const int32_t* e_nin = g.e_nin.ptr();
+    RCN_G const int32_t* e_tail = g.e_tail.ptr();
+    RCN_G const uint8_t* inc = g.inc.ptr();
+    const bool sub = c.sub != 0;
     int i = bcast0(o->tb_i), j = bcast0(o->tb_j);
     int overflow = g.overflow;
     while (!(i == 0 && j == 0)) {
@@ -1495,7 +1500,18 @@ __device__ __noinline__ void phase_traceback_code() {
                 else if (!(code & 2)) { mv = kMvUp; q = code >> 5; }
                 else mv = jj > 0 ? kMvLeft : kMvInvalid;
                 int pi = q == 0 ? pa.x : q == 1 ? pa.y : q == 2 ? pa.z : q == 3 ? pa.w : q == 4 ? pb.x : pb.y;
-                if (!inside || q > 5 || (mv != kMvLeft && pi < 0)) mv = kMvInvalid;
+                if (q > 5 && inside && mv != kMvLeft) {
+                    // seventh / eighth in-edge (rare): not in the descriptor, the q - 6 th included tail of the rest of the list
+                    pi = -1;
+                    int left = q - 6;
+                    for (int e = dr[6]; e >= 0; e = e_nin[e]) {
+                        const int tl = e_tail[e];
+                        if (sub && !inc[tl]) continue;
+                        if (left == 0) { pi = nr[tl] + 1; break; }
+                        --left;
+                    }
+                }
+                if (!inside || (mv != kMvLeft && pi < 0)) mv = kMvInvalid;
                 const int ni = mv == kMvLeft ? ii : pi, nj = jj - (mv == kMvUp ? 0 : 1);
                 const int na = i - ni, nb = j - nj;
                 int nx;

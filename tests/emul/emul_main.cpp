@@ -16,6 +16,8 @@ using namespace rcn;
 static int g_ties = 0, g_aligns = 0;
 static long long g_hist[8] = {0};   // pred distance: 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, >64
 static long long g_rows = 0, g_row0 = 0;
+static long long g_align_maxin[4] = {0};   // alignments whose widest row has <= 6, 7..8, > 8 in-edges; [3] = by window depth >= 40: 7+
+static int g_cur_maxin = 0;
 
 // scalar DP over `rank` (any valid topological order); returns the row of the best sink
 // and how many sinks tie at the best score.
@@ -41,11 +43,13 @@ static void host_dp(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int V, 
         const int np = (d.meta >> 9) & 15;
         ++g_rows;
         for (int q = 0; q < np; ++q) { dist(d.p[q]); acc(d.p[q]); }
+        int nin = np;
         for (int e = d.erest; e >= 0; e = g.e_nin[e]) {
             int t = g.e_tail[e];
             if (sub && !g.inc[t]) continue;
-            acc(nr[t] + 1);
+            acc(nr[t] + 1); ++nin;
         }
+        g_cur_maxin = std::max(g_cur_maxin, nin);
         for (int j = 1; j <= len; ++j) row[j] = std::max(row[j], row[j - 1] + gp);
         if (d.meta & 256) {
             if (!have || best < row[len]) { have = true; best = row[len]; best_row = r + 1; tied = 1; }
@@ -125,8 +129,11 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
                 rk = g.rank_sub.ptr(); nr = &g.n2r_x;
             }
             int best_row = 0, best = 0, tied = 0;
+            g_cur_maxin = 0;
             host_dp(g, rk, *nr, V, !full, sp(i), sl(i), m, x, gp, best_row, best, tied);
             ++g_aligns;
+            ++g_align_maxin[g_cur_maxin <= 6 ? 0 : g_cur_maxin <= 8 ? 1 : 2];
+            if (ns >= 40 && g_cur_maxin > 6) ++g_align_maxin[3];
             if (tied > 1) {       // spoa picks the first best sink in ITS rank order: run the exact DFS
                 ++g_ties;
                 int nx = graph_toposort(g, g.rank_x.ptr(), !full, g.stack.ptr());
@@ -162,6 +169,6 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
         polished[w] = 1;
     }
     cons_off[b->n_windows] = out;
-    if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] alignments %d, sink ties %d rows %lld row0 %lld hist", g_aligns, g_ties, g_rows, g_row0); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_hist[i]); fprintf(stderr, "\n"); }
+    if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] alignments %d, sink ties %d rows %lld row0 %lld hist", g_aligns, g_ties, g_rows, g_row0); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_hist[i]); fprintf(stderr, " | alignments by widest row: <=6 in-edges %lld, 7-8 %lld, >8 %lld (7+ in windows of >= 40 sequences: %lld)\n", g_align_maxin[0], g_align_maxin[1], g_align_maxin[2], g_align_maxin[3]); }
     return 0;
 }

@@ -130,3 +130,47 @@ def test_band_with_forced_sink_tie_levels(oracle, level, monkeypatch):
     b = WindowBatch.from_windows([long_window(rng, k) for k in range(120)])
     eng = HipEngine(3, -5, -4, True)
     assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), f"coded band, forced tie level {level}")
+
+
+def fan_in_window(rng, n_variants):
+    """A deep window in which the node after every hot spot collects `n_variants` + 1 in-edges (backbone edge + one per
+    local variant: inserted bases, deletions of 1..3 bases, substitutions of the base in front): rows with seven and
+    eight predecessors, which the move codes name from the in-edge list, and with more, which fall back to full rows."""
+    L = 420
+    bb = bytearray(rng.choice(list(b"ACGT"), L).tolist())
+    spots = [60, 150, 240, 330]
+    for p in spots:                       # fixed context so that every variant is a distinct, unambiguous edit
+        bb[p - 4:p + 2] = b"ACGTCA"
+    bb = bytes(bb)
+    variants = [("ins", b"G"), ("del", 1), ("sub", b"A"), ("ins", b"TT"), ("del", 2), ("sub", b"C"), ("ins", b"A"), ("del", 3),
+                ("sub", b"G"), ("ins", b"CC")][:n_variants]
+    seqs = [(bb, b"!" * L, 0, 0)]
+    for k in range(4 * len(variants) + 6):
+        s = bytearray(bb)
+        if k < 4 * len(variants):
+            kind, arg = variants[k % len(variants)]
+            for p in reversed(spots):
+                if kind == "ins": s[p:p] = arg
+                elif kind == "del": del s[p - arg:p]
+                else: s[p - 1:p] = arg
+        s = bytes(s)
+        seqs.append((s, bytes([33 + int(rng.integers(5, 40))]) * len(s), 0, L - 1))
+    return {"type": 1, "seqs": seqs}
+
+
+@pytest.mark.parametrize("n_variants,scores", [(8, (3, -5, -4)), (9, (3, -5, -4)), (9, (5, -4, -8)), (10, (3, -5, -4))])
+def test_band_rows_with_seven_and_eight_in_edges(oracle, n_variants, scores):
+    from racon_amd.engine import HipEngine
+    rng = np.random.default_rng(7500 + n_variants)
+    b = WindowBatch.from_windows([fan_in_window(rng, n_variants) for _ in range(24)])
+    eng = HipEngine(*scores, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, *scores, True, 0), f"fan-in {n_variants} {scores}")
+    st = eng.stats()
+    assert st["n_banded"] > 0
+    # (tests/emul with RCN_EMUL_VERBOSE counts them: 8 / 9 variants -> widest row has 7-8 in-edges in most alignments, 10 -> more)
+    if scores != (3, -5, -4):
+        return                            # other scores align the variants differently: in-edge counts not checked
+    if n_variants <= 9:                   # at most eight in-edges: no alignment is sent back for that reason
+        assert st["band_redo_why"][3] == 0, st["band_redo_why"]
+    else:
+        assert st["band_redo_why"][3] > 0, st["band_redo_why"]
