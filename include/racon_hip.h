@@ -199,6 +199,45 @@ int  rcn_engine_build_windows_from_cigars(rcn_engine* e, const rcn_read_set* rea
                                           uint32_t window_length, double quality_threshold, uint8_t window_type);
 int  rcn_engine_build_stats(rcn_engine* e, rcn_build_stats* out);
 
+/* --- exact pairwise alignment on the device ------------
+ * Replaces the host call of Overlap::find_breaking_points for overlaps that come without a CIGAR (PAF / MHAP):
+ *   edlibAlign(q, ql, t, tl, edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_PATH, NULL, 0)) + edlibAlignmentToCigar
+ * (reference src/overlap.cpp:205-224; the reference's own batched device aligner is src/cuda/cudaaligner.cpp:51-102).
+ * Global unit-cost alignment of the query segment (reverse-complemented when strand = 1, src/overlap.cpp:193-195)
+ * against the target segment, and THE SAME co-optimal path edlib 1.2.7 returns (plain traceback
+ * preferring insertion, deletion, then (mis)match below 1 MiB of traceback state, Hirschberg on the target axis with the
+ * smallest optimal query split above) -- byte-identical CIGARs, hence byte-identical breaking points and windows.      */
+typedef struct rcn_pair_set {
+    uint64_t n_pairs;
+    const uint32_t* q_id;          /* [n_pairs] index into the read set                                            */
+    const uint32_t* t_id;          /* [n_pairs] target index (< n_targets)                                         */
+    const uint8_t*  strand;        /* [n_pairs] 1 = the query segment is reverse-complemented                      */
+    const uint32_t* q_begin;       /* [n_pairs] Overlap::q_begin_ / q_end_: the segment on the FORWARD read        */
+    const uint32_t* q_end;
+    const uint32_t* t_begin;       /* [n_pairs] Overlap::t_begin_ / t_end_                                         */
+    const uint32_t* t_end;
+} rcn_pair_set;
+
+typedef struct rcn_align_stats {
+    double   h2d_ms;               /* reads + pair table to HBM (0 when the reads were resident)                   */
+    double   kernel_ms;            /* the alignment kernel, HIP events                                            */
+    uint64_t n_pairs;
+    uint64_t cells;                /* sum of rows x columns: the cells of the full matrices                        */
+    uint64_t ops_bytes;            /* path positions written (sum of rows + columns)                               */
+    uint32_t slots;                /* resident wavefronts (one overlap each)                                       */
+} rcn_align_stats;
+
+/* Aligns every pair; the paths stay in HBM (one op byte per path position).  `reads` as in rcn_engine_build_windows. */
+int  rcn_engine_align_pairs(rcn_engine* e, const rcn_read_set* reads, const rcn_pair_set* pairs);
+/* The alignments of the last rcn_engine_align_pairs as CIGAR strings (run-length encoded on the host after one D2H copy)
+ * and edit distances.  cigar_off: [n_pairs + 1]; `cigar` may be NULL or `cap` too small: *need receives the total bytes. */
+int  rcn_engine_alignment_cigars(rcn_engine* e, uint64_t* cigar_off, char* cigar, uint64_t cap, uint64_t* need, int32_t* distance);
+int  rcn_engine_align_stats(rcn_engine* e, rcn_align_stats* out);
+/* Alignment, breaking points and window construction in one go: reads and the pair table go to HBM once, nothing of the
+ * alignments comes back to the host (reference src/overlap.cpp:176-292 + src/polisher.cpp:388-461).                  */
+int  rcn_engine_build_windows_from_pairs(rcn_engine* e, const rcn_read_set* reads, const rcn_pair_set* pairs,
+                                         uint32_t window_length, double quality_threshold, uint8_t window_type);
+
 /* Dimensions and a copy (D2H) of the resident batch, uploaded or built; any output pointer may be NULL. */
 typedef struct rcn_batch_dims { uint32_t n_windows, n_seqs; uint64_t n_bases; } rcn_batch_dims;
 int  rcn_engine_batch_dims(rcn_engine* e, rcn_batch_dims* out);

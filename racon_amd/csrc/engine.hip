@@ -8,6 +8,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,15 +73,62 @@ struct EventPair {
     ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
 
+// Host worker threads shared by every engine of the process: creating threads per call costs more (~40 us each) than the
+// packing work of a small piece.  Chunks of different callers interleave on one queue; a caller runs one chunk itself and
+// then helps with whatever is queued until its own chunks are done.
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    unsigned workers() const { return static_cast<unsigned>(threads_.size()); }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(f)); }
+        cv_.notify_one();
+    }
+    bool run_one() {                     // a queued chunk on the calling thread; false if the queue is empty
+        std::function<void()> f;
+        { std::lock_guard<std::mutex> g(m_); if (q_.empty()) return false; f = std::move(q_.front()); q_.pop_front(); }
+        f();
+        return true;
+    }
+private:
+    HostPool() {
+        const unsigned n = std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
+        for (unsigned t = 0; t < n; ++t) threads_.emplace_back([this]() { loop(); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& th : threads_) th.join();
+    }
+    void loop() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this]() { return stop_ || !q_.empty(); });
+                if (q_.empty()) { if (stop_) return; continue; }
+                f = std::move(q_.front()); q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::mutex m_; std::condition_variable cv_; std::deque<std::function<void()>> q_; std::vector<std::thread> threads_; bool stop_ = false;
+};
+
 // Runs fn(i) for i in [0, n) on up to `threads` host threads (contiguous blocks); exceptions are not expected from fn.
 template <class F>
 void host_parallel(size_t n, unsigned threads, F fn) {
-    threads = static_cast<unsigned>(std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, n)));
+    HostPool& pool = HostPool::get();
+    threads = static_cast<unsigned>(std::min<size_t>(std::min(std::max(1u, threads), pool.workers() + 1u), std::max<size_t>(1, n)));
     if (threads <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t)
-        pool.emplace_back([=]() { for (size_t i = n * t / threads; i < n * (t + 1) / threads; ++i) fn(i); });
-    for (auto& th : pool) th.join();
+    std::atomic<unsigned> left{threads - 1};
+    for (unsigned t = 1; t < threads; ++t)
+        pool.submit([&fn, &left, n, t, threads]() {
+            for (size_t i = n * t / threads; i < n * (t + 1) / threads; ++i) fn(i);
+            left.fetch_sub(1, std::memory_order_release);
+        });
+    for (size_t i = 0; i < n / threads; ++i) fn(i);                      // chunk 0 here
+    while (left.load(std::memory_order_acquire) != 0) { if (!pool.run_one()) std::this_thread::yield(); }
 }
 
 }  // namespace
@@ -116,6 +169,10 @@ struct rcn_engine {
     rcn_run_stats stats{};
     rcn_build_stats bstats{};
     DevBuf d_build[24];                 // rcn_engine_build_windows: resident reads / overlaps / work arrays
+    DevBuf d_align[12];                 // rcn_engine_align_pairs: pair table, op bytes, distances, scratch
+    rcn_align_stats astats{};
+    uint64_t a_n_pairs = 0;             // pairs of the last alignment run (their op bytes are resident)
+    std::vector<uint64_t> a_ops_off;
 
     // incremental builder (addWindow form)
     std::vector<uint32_t> b_win_seq_off{0};
@@ -248,8 +305,20 @@ int run_pass(rcn_engine* e, const Caps& c, const uint32_t* d_ids, uint32_t n_wor
 // symbol count `nsym_all`.
 struct HostPrep { std::vector<uint32_t> order; std::vector<uint8_t> full, wflags; };
 
+// symbols of one window's sequences: how many distinct byte values, and whether they are all A/C/G/T
+inline void scan_symbols(const uint8_t* bases, uint64_t a, uint64_t z, int32_t& nsym, uint8_t& acgt_only) {
+    uint64_t present[4] = {0, 0, 0, 0};
+    for (uint64_t k = a; k < z; ++k) present[bases[k] >> 6] |= 1ull << (bases[k] & 63);
+    nsym = 0;
+    for (uint64_t p : present) nsym += __builtin_popcountll(p);
+    const uint64_t acgt = (1ull << ('A' & 63)) | (1ull << ('C' & 63)) | (1ull << ('G' & 63)) | (1ull << ('T' & 63));
+    acgt_only = (present[0] == 0 && present[2] == 0 && present[3] == 0 && (present[1] & ~acgt) == 0) ? 1 : 0;
+}
+
+// `scan` = false (streamed upload): the symbol statistics (shapes[].nsym, wflags) are left for the caller, which reads
+// the bases anyway when it packs a piece.
 int prepare_host(rcn_engine* e, HostPrep& hp, uint32_t nw, uint32_t ns, const uint32_t* win_seq_off, const uint64_t* seq_off,
-                 const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all, bool acgt_all) {
+                 const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all, bool acgt_all, bool scan = true) {
     hp.wflags.assign(nw, 0); hp.order.resize(ns); hp.full.assign(ns, 0);
     e->h_win_seq_off.assign(win_seq_off, win_seq_off + nw + 1);
     e->shapes.resize(nw);
@@ -266,7 +335,6 @@ int prepare_host(rcn_engine* e, HostPrep& hp, uint32_t nw, uint32_t ns, const ui
         const uint32_t L = static_cast<uint32_t>(seq_off[s0 + 1] - seq_off[s0]);
         if (L == 0) { bad[w] = 1; return; }                   // createWindow rejects empty backbones (window.cpp:19-23)
         const uint32_t offset = static_cast<uint32_t>(0.01 * L);
-        uint64_t present[4] = {0, 0, 0, 0};
         WinShape sh{static_cast<int32_t>(L), 0, 0, 0};
         for (uint32_t i = 0; i < n; ++i) {
             hp.order[s0 + i] = rank[i];
@@ -279,13 +347,9 @@ int prepare_host(rcn_engine* e, HostPrep& hp, uint32_t nw, uint32_t ns, const ui
                 sh.sum_l += static_cast<int32_t>(z - a);
                 sh.lmax = std::max<int32_t>(sh.lmax, static_cast<int32_t>(z - a));
             }
-            if (bases) for (uint64_t k = a; k < z; ++k) present[bases[k] >> 6] |= 1ull << (bases[k] & 63);
         }
-        if (bases) {
-            for (uint64_t p : present) sh.nsym += __builtin_popcountll(p);
-            const uint64_t acgt = (1ull << ('A' & 63)) | (1ull << ('C' & 63)) | (1ull << ('G' & 63)) | (1ull << ('T' & 63));
-            hp.wflags[w] = (present[0] == 0 && present[2] == 0 && present[3] == 0 && (present[1] & ~acgt) == 0) ? 1 : 0;
-        } else { sh.nsym = nsym_all; hp.wflags[w] = acgt_all ? 1 : 0; }
+        if (bases && scan) scan_symbols(bases, seq_off[s0], seq_off[s0 + n], sh.nsym, hp.wflags[w]);
+        else if (!bases) { sh.nsym = nsym_all; hp.wflags[w] = acgt_all ? 1 : 0; }
         e->shapes[w] = sh;
     });
     for (uint32_t w = 0; w < nw; ++w) if (bad[w]) return RCN_E_ARG;
@@ -322,6 +386,7 @@ int prepare_resident(rcn_engine* e, uint32_t nw, uint32_t ns, const uint32_t* wi
     return RCN_OK;
 }
 
+#include "pair_align.hpp"
 #include "window_build.hpp"
 
 extern "C" {
@@ -386,6 +451,7 @@ void rcn_engine_destroy(rcn_engine* e) {
                       &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_out_off, &e->d_ctr})
         d->release();
     for (DevBuf& d : e->d_build) d.release();
+    for (DevBuf& d : e->d_align) d.release();
     e->h_out.release(); e->h_stage.release();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -451,6 +517,53 @@ int rcn_engine_build_windows_from_cigars(rcn_engine* e, const rcn_read_set* read
                                          uint32_t window_length, double quality_threshold, uint8_t window_type) {
     if (!e || !reads || !al || window_length == 0) return RCN_E_ARG;
     return rcn::build_windows_from_cigars(e, *reads, *al, window_length, quality_threshold, window_type);
+}
+
+int rcn_engine_align_pairs(rcn_engine* e, const rcn_read_set* reads, const rcn_pair_set* pairs) {
+    if (!e || !reads || !pairs) return RCN_E_ARG;
+    return rcn::align_pairs(e, *reads, *pairs, false);
+}
+
+int rcn_engine_build_windows_from_pairs(rcn_engine* e, const rcn_read_set* reads, const rcn_pair_set* pairs,
+                                        uint32_t window_length, double quality_threshold, uint8_t window_type) {
+    if (!e || !reads || !pairs || window_length == 0) return RCN_E_ARG;
+    return rcn::build_windows_from_pairs(e, *reads, *pairs, window_length, quality_threshold, window_type);
+}
+
+int rcn_engine_align_stats(rcn_engine* e, rcn_align_stats* out) {
+    if (!e || !out) return RCN_E_ARG;
+    *out = e->astats;
+    return RCN_OK;
+}
+
+// Op bytes -> CIGAR text (edlibAlignmentToCigar, EDLIB_CIGAR_STANDARD: M / I / D runs), on the host after one D2H copy.
+int rcn_engine_alignment_cigars(rcn_engine* e, uint64_t* cigar_off, char* cigar, uint64_t cap, uint64_t* need, int32_t* distance) {
+    if (!e || !cigar_off) return RCN_E_ARG;
+    if (e->a_ops_off.empty() || e->a_ops_off.size() != e->a_n_pairs + 1) return RCN_E_STATE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint64_t n = e->a_n_pairs, bytes = e->a_ops_off[n];
+    std::vector<uint8_t> ops(bytes + 1);
+    if (bytes) HIP_TRY(hipMemcpy(ops.data(), e->d_align[rcn::kAOps].p, bytes, hipMemcpyDeviceToHost));
+    if (distance && n) HIP_TRY(hipMemcpy(distance, e->d_align[rcn::kADist].p, 4 * n, hipMemcpyDeviceToHost));
+    std::string all;
+    cigar_off[0] = 0;
+    for (uint64_t o = 0; o < n; ++o) {
+        const uint64_t a = e->a_ops_off[o], z = e->a_ops_off[o + 1];
+        uint8_t run_op = 0; uint64_t run = 0;
+        for (uint64_t p = a; p < z; ++p) {
+            const uint8_t op = ops[p];
+            if (!op) continue;
+            if (op == run_op) { ++run; continue; }
+            if (run) { all += std::to_string(run); all += static_cast<char>(run_op); }
+            run_op = op; run = 1;
+        }
+        if (run) { all += std::to_string(run); all += static_cast<char>(run_op); }
+        cigar_off[o + 1] = all.size();
+    }
+    if (need) *need = all.size();
+    if (!cigar || cap < all.size()) return cigar ? RCN_E_CAPACITY : RCN_OK;
+    std::memcpy(cigar, all.data(), all.size());
+    return RCN_OK;
 }
 
 int rcn_engine_build_stats(rcn_engine* e, rcn_build_stats* out) {
@@ -657,14 +770,18 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     }
     e->uploaded = false; e->ran = false;
     e->n_windows = nw; e->n_seqs = ns; e->n_bases = b->seq_off[ns];
+    const bool dbg = getenv("RCN_DEBUG") != nullptr;
+    const auto h0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count(); };
     EventPair t;
     if (t.create()) return RCN_E_HIP;
     HIP_TRY(hipEventRecord(t.a, e->copy_stream));
     HostPrep hp;
-    int rc = prepare_host(e, hp, nw, ns, b->win_seq_off, b->seq_off, b->seq_begin, b->seq_end, b->bases, 0, false);
+    int rc = prepare_host(e, hp, nw, ns, b->win_seq_off, b->seq_off, b->seq_begin, b->seq_end, b->bases, 0, false, /*scan=*/false);
     if (rc) return rc;
     e->lpt_layout = true;
     e->stats = rcn_run_stats{};
+    if (dbg) fprintf(stderr, "[racon_hip] polish: host preparation done at %.2f ms\n", since());
     if ((rc = begin_run(e))) return rc;
 
     // ---- device layout: window k of the device arrays = work item k = caller window lpt[k] ----
@@ -686,7 +803,7 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
         const uint32_t w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
         s_wso[k + 1] = s_wso[k] + n;
         win_base[k + 1] = win_base[k] + (b->seq_off[s0 + n] - b->seq_off[s0]);
-        s_type[k] = b->win_type[w]; s_flags[k] = hp.wflags[w];
+        s_type[k] = b->win_type[w];
     }
     const unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     host_parallel(nw, threads, [&](size_t k) {
@@ -706,7 +823,6 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     hipStream_t cs = e->copy_stream;
     HIP_TRY(hipMemcpyAsync(e->d_win_seq_off.p, s_wso, 4ull * (nw + 1), hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_win_type.p, s_type, nw, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_win_flags.p, s_flags, nw, hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_seq_off.p, s_so, 8ull * (ns + 1), hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_has_qual.p, s_hq, ns, hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_begin.p, s_bg, 4ull * ns, hipMemcpyHostToDevice, cs));
@@ -715,48 +831,64 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     HIP_TRY(hipMemcpyAsync(e->d_full.p, s_full, ns, hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_out_off.p, e->out_off.data(), 8ull * (nw + 1), hipMemcpyHostToDevice, cs));   // (pageable: small)
 
-    // ---- pieces: the deepest windows that hold 1/8 of the bases, then the rest ----
+    // ---- pieces: the deepest windows that hold 1/24 of the bases (they decide when the batch ends and must start first;
+    //      the fewer there are, the sooner the first launch is under way), then the rest ----
     uint32_t cut[rcn_engine::kSubLaunches + 1] = {0, 0, nw};
     {
-        const uint64_t q1 = nb / 8;
+        const uint64_t q1 = nb / 24;
         uint32_t k = 0;
         while (k < nw && win_base[k] < q1) ++k;
         cut[1] = std::min(std::max(k, 1u), nw);
     }
     const bool fast = !getenv("RCN_WIDE_ONLY");
     Launch L[rcn_engine::kSubLaunches];
+    // Scratch of the pieces side by side.  The symbol count of a window (it sizes the aligned rings) is only known once
+    // its bases have been read, which happens while its piece is packed: every piece is sized after its own scan and
+    // placed behind the previous one.
     uint64_t scratch_total = 0;
     std::vector<WinShape> sub_shapes;
+    {   // reserve for the usual alphabet (A, C, G, T and one more symbol) before anything runs; a piece that needs more
+        // grows the buffer below, behind a synchronisation
+        uint64_t est = 0;
+        for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
+            if (cut[c + 1] == cut[c]) continue;
+            sub_shapes.clear();
+            for (uint32_t k = cut[c]; k < cut[c + 1]; ++k) { WinShape sh = e->shapes[e->lpt[k]]; sh.nsym = 5; sub_shapes.push_back(sh); }
+            est += static_cast<uint64_t>(cut[c + 1] - cut[c]) * first_pass_caps(sub_shapes.begin(), sub_shapes.end(), fast).slot_bytes;
+        }
+        if (est <= scratch_budget(e) && (rc = e->d_scratch.reserve(est))) return rc;
+    }
+    // the main stream zeroed the counters (begin_run): the sub-launches must not start before that
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
     for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
         const uint32_t k0 = cut[c], k1 = cut[c + 1];
         L[c].n_work = k1 - k0; L[c].work_base = k0; L[c].out_base = k0; L[c].ctr = c; L[c].stream = e->sub_stream[c];
         if (k1 == k0) continue;
+        const uint64_t b0 = win_base[k0], b1 = win_base[k1];
+        // pack the piece into pinned staging and collect its symbol statistics in the same pass over the bases
+        host_parallel(k1 - k0, threads, [&](size_t kk) {
+            const uint32_t k = k0 + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
+            const uint64_t src0 = b->seq_off[s0], len = b->seq_off[s0 + n] - src0;
+            scan_symbols(b->bases, src0, src0 + len, e->shapes[w].nsym, s_flags[k]);
+            std::memcpy(hs + o_bases + win_base[k], b->bases + src0, len);
+            std::memcpy(hs + o_quals + win_base[k], b->quals + src0, len);
+        });
         sub_shapes.clear();
         for (uint32_t k = k0; k < k1; ++k) sub_shapes.push_back(e->shapes[e->lpt[k]]);
         L[c].c = first_pass_caps(sub_shapes.begin(), sub_shapes.end(), fast);
         L[c].slots = L[c].n_work;                                  // one resident slot per window (nw <= max_slots)
         L[c].scratch_off = scratch_total;
         scratch_total += static_cast<uint64_t>(L[c].slots) * L[c].c.slot_bytes;
-    }
-    if (scratch_total > scratch_budget(e)) {
-        // does not fit next to each other: the plain path shares the slots
-        HIP_TRY(hipStreamSynchronize(cs));
-        const int rc2 = rcn_engine_upload(e, b);
-        return rc2 ? rc2 : rcn_engine_run(e);
-    }
-    if ((rc = e->d_scratch.reserve(scratch_total))) return rc;
-    // the main stream zeroed the counters (begin_run): the sub-launches must not start before that
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
-        const uint32_t k0 = cut[c], k1 = cut[c + 1];
-        if (k1 == k0) continue;
-        const uint64_t b0 = win_base[k0], b1 = win_base[k1];
-        host_parallel(k1 - k0, threads, [&](size_t kk) {
-            const uint32_t k = k0 + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
-            const uint64_t src0 = b->seq_off[s0], len = b->seq_off[s0 + n] - src0;
-            std::memcpy(hs + o_bases + win_base[k], b->bases + src0, len);
-            std::memcpy(hs + o_quals + win_base[k], b->quals + src0, len);
-        });
+        if (scratch_total > scratch_budget(e)) {
+            // does not fit next to each other: the plain path shares the slots (launches already made finish first)
+            HIP_TRY(hipDeviceSynchronize());
+            const int rc2 = rcn_engine_upload(e, b);
+            return rc2 ? rc2 : rcn_engine_run(e);
+        }
+        // growing the scratch buffer would move it under a running launch: the pieces before this one must be done
+        if (scratch_total > e->d_scratch.cap && c > 0) HIP_TRY(hipDeviceSynchronize());
+        if ((rc = e->d_scratch.reserve(scratch_total))) return rc;
+        HIP_TRY(hipMemcpyAsync(e->d_win_flags.as<uint8_t>() + k0, s_flags + k0, k1 - k0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync(e->d_bases.as<uint8_t>() + b0, hs + o_bases + b0, b1 - b0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync(e->d_quals.as<uint8_t>() + b0, hs + o_quals + b0, b1 - b0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipEventRecord(e->sub_ev[c][0], cs));
@@ -765,6 +897,7 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
         HIP_TRY(hipEventRecord(e->sub_ev[c][1], L[c].stream));
         if ((rc = launch_pass(e, L[c]))) return rc;
         HIP_TRY(hipEventRecord(e->sub_ev[c][2], L[c].stream));
+        if (dbg) fprintf(stderr, "[racon_hip] polish: piece %d enqueued at %.2f ms (host clock)\n", c, since());
     }
     HIP_TRY(hipEventRecord(t.b, cs));
     float span0 = 0, span1 = 0;
@@ -788,7 +921,9 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     e->stats.h2d_ms = ms;
     e->stats.bytes_in = 2 * nb + 17ull * ns + 5ull * nw;
     e->uploaded = true;
-    return collect(e);
+    rc = collect(e);
+    if (dbg) fprintf(stderr, "[racon_hip] polish: results collected at %.2f ms (host clock)\n", since());
+    return rc;
 }
 
 int rcn_engine_result(rcn_engine* e, rcn_result* out) {

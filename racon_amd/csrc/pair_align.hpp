@@ -1,0 +1,419 @@
+// pair_align.hpp — exact global pairwise alignment WITH PATH on the device (included from engine.hip).
+//
+// What it replaces: Overlap::find_breaking_points' call of
+//   edlibAlign(q, ql, t, tl, edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_PATH, NULL, 0)) + edlibAlignmentToCigar
+// (reference src/overlap.cpp:205-224; shape model of a batched device aligner: src/cuda/cudaaligner.cpp:51-102), i.e. what
+// racon_amd/host/nw_path.cpp computes on the host.  edlib 1.2.7 is not vendored in the reference; WHICH co-optimal path it
+// returns is specified in SURVEY.md Appendix B (validated there against the PAF / MHAP goldens) and restated here:
+//   obtain(q, t, best):  |q| == 0 -> |t| x D;  |t| == 0 -> |q| x I;
+//     blocks = ceil(|q| / 64); if 20 * blocks * |t| + 8 * |t| < 2^20: plain traceback from the bottom-right cell, at each
+//       cell preferring up (I), then left (D), else diagonal (M);
+//     else Hirschberg on the target axis: lw = |t| / 2, left[h] = ED(q[:h], t[:lw]), right[k] = ED(q[|q|-k:], t[lw:]),
+//       the smallest h in 1..|q|-1 with left[h] + right[|q|-h] == best, else h = 0, else h = |q|; recurse on both sides.
+//
+// How: Myers' bit-vector recurrence, one 64-row word per lane, the 64 lanes of a wave on an anti-diagonal of
+// (word, column) cells: lane k works on column s - k at step s, its horizontal carry-out is the carry-in of lane k + 1
+// at the next step (one DPP shift), so a step advances 64 words x 64 rows = 4096 cells with ~45 instructions and no
+// serial carry chain.  Queries longer than 4096 rows take several passes (the carries of a pass's last word go through
+// a byte per column in HBM).  The query is held as bit planes of a dense symbol code (3 planes: up to 7 distinct query
+// symbols; 8 planes of the raw byte otherwise), Eq = "all planes agree with the column's symbol": no per-symbol table,
+// any byte alphabet.  One wave owns an overlap from start to end: the Hirschberg recursion is an explicit stack in LDS,
+// the two last-column vectors of a split live in the wave's HBM scratch, a leaf stores the vertical / horizontal delta
+// words (Pv, Ph) of its cells (at most ~0.8 MiB + skew padding, the same bound edlib's own traceback state has) and the
+// walk tests one bit per move.  The path is written as one op byte per (row + column) position of the move's start
+// cell -- positions are unique along a monotone path, sub-problems own disjoint ranges, so pieces land in place in any
+// order -- and either run-length encoded on the host (tests, rcn_engine_alignment_cigars) or walked on the device into
+// breaking points (k_ops_breaking_points) without leaving HBM.
+#pragma once
+
+namespace rcn {
+
+struct PairParams {
+    const uint8_t* bases;            // resident read set (forward strand)
+    const uint64_t* q_pos;           // [n] byte offset of the first base of the query segment (forward storage)
+    const uint64_t* t_pos;           // [n] ... of the target segment
+    const uint32_t* q_len;           // [n] rows
+    const uint32_t* t_len;           // [n] columns
+    const uint8_t* q_rc;             // [n] 1: the rows are the reverse complement of the stored segment
+    const uint32_t* order;           // [n] work order (largest problems first)
+    uint32_t n_pairs;
+    unsigned int* next;              // work queue counter
+    uint8_t* ops;                    // op bytes ('M' 'I' 'D', 0 = no move starts here), zeroed
+    const uint64_t* ops_off;         // [n + 1]
+    int32_t* dist;                   // [n] edit distance
+    uint8_t* scratch; uint64_t slot_bytes;
+    uint32_t m_cap, n_cap;           // largest rows / columns of the batch (scratch layout)
+    uint64_t leaf_bytes;             // leaf store per slot
+    uint32_t* err;                   // [0] != 0: internal error (no optimal split found / stack overflow)
+};
+
+constexpr int kPairStack = 64;       // Hirschberg tasks pending per overlap (depth ~ log2 columns, two pushes per level)
+
+struct PairView {                    // a sequence read forwards, or backwards and complemented
+    const uint8_t* p; bool rc;
+    int64_t n;
+};
+__device__ __forceinline__ uint32_t pair_comp(uint32_t c) {    // Sequence::create_reverse_complement (reference src/sequence.cpp:49-84)
+    return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+}
+__device__ __forceinline__ uint32_t pv_at(const PairView& v, int64_t i) {
+    return v.rc ? pair_comp(v.p[v.n - 1 - i]) : static_cast<uint32_t>(v.p[i]);
+}
+
+// leaf rule of the reference aligner (see the header)
+__host__ __device__ __forceinline__ bool pair_is_leaf(int64_t m, int64_t n) {
+    const int64_t blocks = (m + 63) / 64;
+    return (2 * 8 + 4) * blocks * n + 2 * 4 * n < 1024 * 1024;
+}
+// bytes of the (Pv, Ph) store of the largest leaf a query of at most m_cap rows can produce: 16 B per (word, column)
+// cell plus the skew padding of every 64-word pass
+__host__ __device__ __forceinline__ uint64_t pair_leaf_bytes(uint64_t m_cap) {
+    const uint64_t nb = (m_cap + 63) / 64;
+    return 16ull * (52429ull + 64ull * (nb + 64)) + 4096;
+}
+
+template <int NPL>
+struct PairLane {                    // what a lane keeps of its word between the steps of a pass
+    unsigned long long plane[NPL];
+    unsigned long long valid;
+    unsigned long long Pv, Mv;
+};
+
+__device__ __forceinline__ int pair_shr1(int fill, int v) {      // lane l <- lane l - 1, lane 0 <- fill
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+
+// One pass of the recurrence: words [w0, w0 + nwp) of the rows, all n columns.
+//   rows: logical row r of this sub-problem = Q[q0 + r], or Q[q0 + m - 1 - r] when flipped (the backward half of a split)
+//   columns likewise.  hin_buf / hout_buf: carries of the word above / for the word below (one byte per column:
+//   bit 0 = +1, bit 1 = -1); hin_buf == nullptr: the top boundary (+1 per column).  store != nullptr: leaf, (Pv, Ph)
+//   of the cell of lane l at step s goes to store[s * nwp + l].
+template <int NPL>
+__device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
+                                          int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
+                                          ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out) {
+    const int lane = threadIdx.x & 63;
+    PairLane<NPL> L;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) L.plane[k] = 0ull;
+    L.valid = 0ull; L.Pv = ~0ull; L.Mv = 0ull;
+    if (lane < nwp) {
+        const int64_t r0 = static_cast<int64_t>(w0 + lane) * 64;
+        for (int r = 0; r < 64; ++r) {
+            const int64_t row = r0 + r;
+            if (row >= m) break;
+            const uint32_t c = pv_at(Q, qflip ? q0 + m - 1 - row : q0 + row);
+            const uint32_t code = NPL == 8 ? c : codes[c];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) L.plane[k] |= static_cast<unsigned long long>((code >> k) & 1u) << r;
+            L.valid |= 1ull << r;
+        }
+    }
+    int tbuf = 0, hbuf = 0;          // columns s0 .. s0 + 63: symbol code / carry-in of the top word, one per lane
+    int tc = 0, hc = 0;              // this lane's column symbol; carry pair of the lane above from the previous step
+    const int steps = n + nwp - 1;
+    for (int s = 0; s < steps; ++s) {
+        if ((s & 63) == 0) {
+            const int col = s + lane;
+            int tv = 7, hv = 1;
+            if (col < n) {
+                const uint32_t c = pv_at(T, tflip ? t0 + n - 1 - col : t0 + col);
+                tv = NPL == 8 ? static_cast<int>(c) : static_cast<int>(codes[c]);
+                if (hin_buf) hv = hin_buf[col];
+            }
+            tbuf = tv; hbuf = hv;
+        }
+        // lane l takes over the column lane l - 1 had; lane 0 starts column s
+        const int t_new = __builtin_amdgcn_readlane(tbuf, s & 63), h_new = __builtin_amdgcn_readlane(hbuf, s & 63);
+        tc = pair_shr1(t_new, tc);
+        const int hin = pair_shr1(h_new, hc);
+        const int j = s - lane;
+        int hout = 0;
+        if (lane < nwp && j >= 0 && j < n) {
+            // Eq: rows whose code agrees with the column's in every plane (32-bit halves: one sign-extended bit-field
+            // extract per plane makes the 0 / ~0 mask of both halves)
+            uint32_t dlo = 0u, dhi = 0u;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const uint32_t mk = static_cast<uint32_t>((tc << (31 - k)) >> 31);
+                dlo |= static_cast<uint32_t>(L.plane[k]) ^ mk; dhi |= static_cast<uint32_t>(L.plane[k] >> 32) ^ mk;
+            }
+            unsigned long long Eq = ~((static_cast<unsigned long long>(dhi) << 32) | dlo) & L.valid;
+            const unsigned long long hin_p = static_cast<unsigned long long>(hin & 1), hin_n = static_cast<unsigned long long>((hin >> 1) & 1);
+            const unsigned long long Xv = Eq | L.Mv;
+            Eq |= hin_n;
+            const unsigned long long Xh = (((Eq & L.Pv) + L.Pv) ^ L.Pv) | Eq;
+            unsigned long long Ph = L.Mv | ~(Xh | L.Pv);
+            unsigned long long Mh = L.Pv & Xh;
+            hout = static_cast<int>(Ph >> 63) | (static_cast<int>(Mh >> 63) << 1);
+            const unsigned long long Ph0 = Ph;
+            Ph = (Ph << 1) | hin_p; Mh = (Mh << 1) | hin_n;
+            L.Pv = Mh | ~(Xv | Ph);
+            L.Mv = Ph & Xv;
+            if (store) { ulonglong2 v; v.x = L.Pv; v.y = Ph0; store[static_cast<int64_t>(s) * nwp + lane] = v; }
+            if (hout_buf && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(hout);
+        }
+        hc = hout;
+    }
+    Pv_out = L.Pv; Mv_out = L.Mv;
+}
+
+// Last column of the sub-problem's matrix: out[i] = ED(rows[:i], all columns), i = 0 .. m.  Returns out[m].
+template <int NPL>
+__device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
+                                            const uint8_t* codes, uint8_t* hbuf0, uint8_t* hbuf1, int32_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int nb = (m + 63) / 64;
+    int carry = n;                                   // score at the last row of the words done so far
+    if (lane == 0) out[0] = n;
+    for (int w0 = 0, pass = 0; w0 < nb; w0 += 64, ++pass) {
+        const int nwp = min(64, nb - w0);
+        const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
+        uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
+        unsigned long long Pv, Mv;
+        pair_pass<NPL>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv);
+        __threadfence();                               // the carries of this pass are read (by other lanes) in the next one
+        // scores of this pass's rows: running sum of the vertical deltas down the last column
+        const int rows_here = lane < nwp ? min(64, m - (w0 + lane) * 64) : 0;
+        const unsigned long long vmask = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+        int delta = __popcll(Pv & vmask) - __popcll(Mv & vmask);
+        int incl = delta;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        int acc = carry + incl - delta;
+        const int64_t r0 = static_cast<int64_t>(w0 + lane) * 64;
+        for (int r = 0; r < rows_here; ++r) {
+            acc += static_cast<int>((Pv >> r) & 1ull) - static_cast<int>((Mv >> r) & 1ull);
+            out[r0 + r + 1] = acc;
+        }
+        carry += __shfl(incl, 63);
+    }
+    __threadfence();                                   // out[] is read by other lanes than the ones that wrote it
+    return carry;
+}
+
+// plain traceback of a leaf (up, then left, else diagonal) over the stored delta words
+template <int NPL>
+__device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, const PairView& T, int64_t t0, int n, const uint8_t* codes,
+                                          uint8_t* hbuf0, uint8_t* hbuf1, ulonglong2* store, uint8_t* ops) {
+    const int lane = threadIdx.x & 63;
+    const int nb = (m + 63) / 64;
+    // forward passes with the (Pv, Ph) store; pass p starts at store + pass_off(p)
+    {
+        int64_t off = 0;
+        for (int w0 = 0, pass = 0; w0 < nb; w0 += 64, ++pass) {
+            const int nwp = min(64, nb - w0);
+            const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
+            uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
+            unsigned long long Pv, Mv;
+            pair_pass<NPL>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv);
+            __threadfence();
+            off += static_cast<int64_t>(n + nwp - 1) * nwp;
+        }
+    }
+    // every full pass has 64 words: pass p starts at p * (n + 63) * 64
+    const int64_t pass_stride = static_cast<int64_t>(n + 63) * 64;
+    int i = m, j = n;                                 // current cell (rows 1..m, columns 1..n; 0 = boundary)
+    int cw = -1, cj0 = -1;                            // cache: lane c holds cell (word cw, column cj0 - c)
+    uint32_t pv_lo = 0, pv_hi = 0, ph_lo = 0, ph_hi = 0;
+    const int64_t base = q0 + t0;
+    while (i > 0 && j > 0) {
+        const int w = (i - 1) >> 6, b = (i - 1) & 63;
+        if (w != cw || j > cj0 || j <= cj0 - 64) {
+            cw = w; cj0 = j;
+            const int jc = j - lane;
+            unsigned long long a = 0ull, h = 0ull;
+            if (jc >= 1) {
+                const int p = w >> 6, l = w & 63, nwp = min(64, nb - (p << 6));
+                const ulonglong2 v = store[p * pass_stride + static_cast<int64_t>(jc - 1 + l) * nwp + l];
+                a = v.x; h = v.y;
+            }
+            pv_lo = static_cast<uint32_t>(a); pv_hi = static_cast<uint32_t>(a >> 32);
+            ph_lo = static_cast<uint32_t>(h); ph_hi = static_cast<uint32_t>(h >> 32);
+        }
+        const int c = cj0 - j;
+        const uint32_t pvw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b < 32 ? pv_lo : pv_hi), c));
+        const uint32_t phw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b < 32 ? ph_lo : ph_hi), c));
+        const bool up = (pvw >> (b & 31)) & 1u, left = (phw >> (b & 31)) & 1u;
+        uint8_t op; int64_t slot;
+        if (up) { op = 'I'; slot = base + (i - 1) + j; --i; }
+        else if (left) { op = 'D'; slot = base + i + (j - 1); --j; }
+        else { op = 'M'; slot = base + (i - 1) + (j - 1); --i; --j; }
+        if (lane == 0) ops[slot] = op;
+    }
+    for (int k = lane; k < i; k += 64) ops[base + k] = 'I';          // column 0: D[k][0] = k, only "up" is possible
+    for (int k = lane; k < j; k += 64) ops[base + k] = 'D';          // row 0
+}
+
+struct PairTask { int q0, m, t0, n, best; };
+
+template <int NPL>
+__device__ __forceinline__ int pair_align_one(const PairParams& P, const PairView& Q, const PairView& T, const uint8_t* codes, PairTask* stack,
+                                              uint8_t* slot, uint8_t* ops) {
+    const int lane = threadIdx.x & 63;
+    // scratch of this wave
+    int32_t* left = reinterpret_cast<int32_t*>(slot);
+    int32_t* right = left + (P.m_cap + 64);
+    uint8_t* hbuf0 = reinterpret_cast<uint8_t*>(right + (P.m_cap + 64));
+    uint8_t* hbuf1 = hbuf0 + (P.n_cap + 64);
+    ulonglong2* store = reinterpret_cast<ulonglong2*>(hbuf1 + (P.n_cap + 64));
+    int sp = 0, distance = -1;
+    if (lane == 0) stack[0] = PairTask{0, static_cast<int>(Q.n), 0, static_cast<int>(T.n), -1};
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        __builtin_amdgcn_wave_barrier();
+        const PairTask tk = stack[sp];
+        const int q0 = __builtin_amdgcn_readfirstlane(tk.q0), m = __builtin_amdgcn_readfirstlane(tk.m);
+        const int t0 = __builtin_amdgcn_readfirstlane(tk.t0), n = __builtin_amdgcn_readfirstlane(tk.n);
+        int best = __builtin_amdgcn_readfirstlane(tk.best);
+        const int64_t base = static_cast<int64_t>(q0) + t0;
+        if (m == 0) { for (int k = lane; k < n; k += 64) ops[base + k] = 'D'; if (best < 0) distance = n; continue; }
+        if (n == 0) { for (int k = lane; k < m; k += 64) ops[base + k] = 'I'; if (best < 0) distance = m; continue; }
+        if (pair_is_leaf(m, n)) {
+            if (best < 0) {
+                // a leaf at the root: the distance is not known from a split; one extra forward pass provides it
+                distance = pair_columns<NPL>(Q, q0, m, false, T, t0, n, false, codes, hbuf0, hbuf1, left);
+            }
+            pair_leaf<NPL>(Q, q0, m, T, t0, n, codes, hbuf0, hbuf1, store, ops);
+            continue;
+        }
+        const int lw = n / 2, rw = n - lw;
+        pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left);
+        pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right);
+        if (best < 0) {
+            // the root: best = min over all rows of left + right (every path crosses the middle column somewhere)
+            int mn = 0x7fffffff;
+            for (int h = lane; h <= m; h += 64) mn = min(mn, left[h] + right[m - h]);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mn = min(mn, __shfl_xor(mn, d));
+            best = mn; distance = mn;
+        }
+        int h = -1;
+        for (int h0 = 1; h0 < m && h < 0; h0 += 64) {
+            const int hh = h0 + lane;
+            const bool hit = hh < m && left[hh] + right[m - hh] == best;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) h = h0 + __builtin_ctzll(mask);
+        }
+        if (h < 0 && lw + right[m] == best) h = 0;
+        if (h < 0 && left[m] + rw == best) h = m;
+        if (h < 0) { if (lane == 0) atomicAdd(P.err, 1u); break; }
+        const int ls = h > 0 ? left[h] : lw, rs = h < m ? right[m - h] : rw;
+        if (sp + 2 > kPairStack) { if (lane == 0) atomicAdd(P.err, 1u); break; }
+        if (lane == 0) {
+            stack[sp] = PairTask{q0 + h, m - h, t0 + lw, rw, rs};
+            stack[sp + 1] = PairTask{q0, h, t0, lw, ls};
+        }
+        sp += 2;
+    }
+    return distance;
+}
+
+// One wave per overlap, persistent over the work queue.
+__global__ __launch_bounds__(64) void k_pair_align(PairParams P) {
+    __shared__ uint8_t codes[256];
+    __shared__ uint8_t present[256];
+    __shared__ PairTask stack[kPairStack];
+    __shared__ unsigned int s_work;
+    const int lane = threadIdx.x;
+    uint8_t* slot = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_work = atomicAdd(P.next, 1u);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned int wi = __builtin_amdgcn_readfirstlane(s_work);
+        if (wi >= P.n_pairs) break;
+        const uint32_t o = P.order[wi];
+        PairView Q{P.bases + P.q_pos[o], P.q_rc[o] != 0, static_cast<int64_t>(P.q_len[o])};
+        PairView T{P.bases + P.t_pos[o], false, static_cast<int64_t>(P.t_len[o])};
+        uint8_t* ops = P.ops + P.ops_off[o];
+        // dense codes of the query's symbols (in byte order); 7 = "not in the query" for target symbols
+        for (int k = lane; k < 256; k += 64) present[k] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t i = lane; i < Q.n; i += 64) present[pv_at(Q, i)] = 1;
+        __builtin_amdgcn_wave_barrier();
+        int nsym = 0;
+        {
+            // four symbols per lane, exclusive count across the wave
+            int cnt = 0;
+            for (int k = 0; k < 4; ++k) cnt += present[4 * lane + k];
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            nsym = __shfl(incl, 63);
+            int code = incl - cnt;
+            for (int k = 0; k < 4; ++k) { const int c = 4 * lane + k; codes[c] = present[c] ? static_cast<uint8_t>(min(code, 7)) : 7; code += present[c]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int d;
+        if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, slot, ops);
+        else d = pair_align_one<8>(P, Q, T, codes, stack, slot, ops);
+        if (lane == 0) P.dist[o] = d;
+    }
+}
+
+// ---- breaking points from the op bytes (Overlap::find_breaking_points' walk, reference src/overlap.cpp:226-292) ----
+// One wave per overlap, 64 path positions per step: two wave scans turn "consumes a target base" / "consumes a query
+// base" into positions; the match columns of a step that fall into one window are a contiguous lane range, its first
+// lane is the window's first candidate, its last lane the window's last.  Same slot convention as the CIGAR walk: one
+// slot per window end the overlap touches, a window counts once the walk has passed its end.
+struct OpsWalkParams {
+    const uint8_t* ops; const uint64_t* ops_off;      // [n + 1]
+    const uint32_t* q_start; const uint32_t* t_begin; const uint32_t* t_end;
+    const uint64_t* bp_off; uint32_t* bp_t; uint32_t* bp_q;
+    unsigned long long* first_key; unsigned long long* last_key;     // [slots]: ~0 / 0
+    uint64_t n_overlaps; uint64_t W;
+};
+
+__global__ __launch_bounds__(256) void k_ops_breaking_points(OpsWalkParams C) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t o = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (o >= C.n_overlaps) return;
+    const uint64_t W = C.W;
+    const uint64_t t_begin = C.t_begin[o], t_end = C.t_end[o];
+    const uint64_t slot0 = C.bp_off[o] / 2, n_slots = (C.bp_off[o + 1] - C.bp_off[o]) / 2;
+    const uint64_t wb = t_begin / W;
+    auto end_of = [&](uint64_t k) -> uint64_t { return k + 1 < n_slots ? (wb + 1 + k) * W - 1 : t_end - 1; };
+    const uint64_t a = C.ops_off[o], z = C.ops_off[o + 1];
+    uint64_t t_run = t_begin, q_run = C.q_start[o];
+    for (uint64_t p0 = a; p0 < z; p0 += 64) {
+        const uint64_t p = p0 + lane;
+        const uint32_t op = p < z ? C.ops[p] : 0;
+        const bool isM = op == 'M';
+        const unsigned int dt = (isM || op == 'D') ? 1u : 0u, dq = (isM || op == 'I') ? 1u : 0u;
+        unsigned int st = dt, sq = dq;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int vt = __shfl_up(st, d), vq = __shfl_up(sq, d);
+            if (lane >= d) { st += vt; sq += vq; }
+        }
+        const uint64_t ts = t_run + (st - dt), qs = q_run + (sq - dq);
+        const uint64_t k = isM ? ts / W - wb : 0;
+        unsigned long long rem = __ballot(isM);
+        while (rem) {
+            const int fl = __builtin_ctzll(rem);
+            const uint64_t kk = __shfl(k, fl);
+            const unsigned long long mk = __ballot(isM && k == kk);
+            const int ll = 63 - __builtin_clzll(mk);
+            const uint64_t ft = __shfl(ts, fl), fq = __shfl(qs, fl), lt = __shfl(ts, ll) + 1, lq = __shfl(qs, ll) + 1;
+            if (lane == 0 && kk < n_slots) {          // positions grow along the walk: min keeps the first, max the last
+                atomicMin(&C.first_key[slot0 + kk], (ft << 32) | fq);
+                atomicMax(&C.last_key[slot0 + kk], (lt << 32) | lq);
+            }
+            rem &= ~mk;
+        }
+        t_run += __shfl(st, 63); q_run += __shfl(sq, 63);
+    }
+    __threadfence();
+    for (uint64_t k = lane; k < n_slots; k += 64) {
+        const unsigned long long f = C.first_key[slot0 + k], l = C.last_key[slot0 + k];
+        if (l != 0 && f != ~0ull && end_of(k) + 1 <= t_run) {
+            const uint64_t out = C.bp_off[o] + 2 * k;
+            C.bp_t[out] = static_cast<uint32_t>(f >> 32); C.bp_q[out] = static_cast<uint32_t>(f);
+            C.bp_t[out + 1] = static_cast<uint32_t>(l >> 32); C.bp_q[out + 1] = static_cast<uint32_t>(l);
+        }
+    }
+}
+
+}  // namespace rcn

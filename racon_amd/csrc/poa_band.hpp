@@ -38,6 +38,9 @@ constexpr int kBandG = 32;            // window offsets are multiples of this ma
 #ifndef RCN_STORE_MODE
 #define RCN_STORE_MODE 0
 #endif
+#ifndef RCN_CODE_STORE
+#define RCN_CODE_STORE 0          // how the move codes of a row go to HBM (experiments, see dp2_rows_band)
+#endif
 template <bool NT>
 __device__ __forceinline__ void row_store2(RCN_G uint32_t* dst, uint32_t a, uint32_t b) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -548,7 +551,15 @@ __device__ __noinline__ void dp2_rows_band() {
                         }
                     }
                     const uint32_t word = __builtin_amdgcn_perm(b[1], b[0], 0x06040200u);
+#if RCN_CODE_STORE == 0
                     __builtin_nontemporal_store(word, reinterpret_cast<RCN_G uint32_t*>(crow) + t);
+#elif RCN_CODE_STORE == 1       // timing experiment: the codes are computed and dropped (results are wrong)
+                    asm volatile("" :: "v"(word));
+#elif RCN_CODE_STORE == 2       // plain store (L2 write-back policy)
+                    reinterpret_cast<RCN_G uint32_t*>(crow)[t] = word;
+#elif RCN_CODE_STORE == 3       // timing experiment: the same store into 16 rows that stay in the L2
+                    __builtin_nontemporal_store(word, reinterpret_cast<RCN_G uint32_t*>(g.H.ptr()) + (1 + (i & 15)) * (hs >> 2) + t);
+#endif
                     crow += hs;
                 }
                 if (ABL == 8) dst = H + (1 + (i & 15)) * hs2 + t * NP;       // 8: the same store instruction into 16 rows that stay in the L2

@@ -346,10 +346,26 @@ enum { kBReadOff, kBReadBases, kBReadQuals, kBReadHasQual, kBQid, kBTid, kBStran
 
 // `C` != nullptr: the breaking points are computed on the device from the alignments (O then only carries n_overlaps,
 // q_id, t_id, strand and a host vector of slot offsets in bp_off; its bp_t / bp_q are null).
+// alignments that are already in HBM as op bytes (pair_align.hpp); the extents are host arrays
+struct OpsSource {
+    const uint8_t* d_ops; const uint64_t* d_ops_off;
+    const uint32_t* q_start; const uint32_t* t_begin; const uint32_t* t_end;
+};
+
+inline int upload_reads(rcn_engine* e, const rcn_read_set& R, hipStream_t st) {
+    DevBuf* B = e->d_build;
+    const uint64_t read_bytes = R.seq_off[R.n_seqs];
+    int rc;
+    if ((rc = upload_vec(B[kBReadOff], R.seq_off, 8 * (R.n_seqs + 1), st)) || (rc = upload_vec(B[kBReadBases], R.bases, read_bytes, st)) ||
+        (rc = upload_vec(B[kBReadQuals], R.quals, read_bytes, st)) || (rc = upload_vec(B[kBReadHasQual], R.seq_has_qual, R.n_seqs, st))) return rc;
+    return RCN_OK;
+}
+
+// `S` != nullptr: as with `C`, but the alignments are op bytes resident in HBM; `reads_resident`: upload_reads was done.
 inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap_set& O, uint32_t W, double qthr, uint8_t window_type,
-                         const rcn_cigar_set* C = nullptr) {
+                         const rcn_cigar_set* C = nullptr, const OpsSource* S = nullptr, bool reads_resident = false) {
     if (R.n_seqs == 0 || R.n_targets == 0 || R.n_targets > R.n_seqs || !R.seq_off || !R.bases || !R.quals || !R.seq_has_qual) return RCN_E_ARG;
-    if (O.n_overlaps && (!O.q_id || !O.t_id || !O.strand || !O.bp_off || (!C && (!O.bp_t || !O.bp_q)))) return RCN_E_ARG;
+    if (O.n_overlaps && (!O.q_id || !O.t_id || !O.strand || !O.bp_off || (!C && !S && (!O.bp_t || !O.bp_q)))) return RCN_E_ARG;
     if (R.n_seqs > 0xfffffffeull || O.n_overlaps > 0xfffffffeull) return RCN_E_ARG;
     HIP_TRY(hipSetDevice(e->cfg.device));
     e->uploaded = false; e->ran = false;
@@ -376,12 +392,17 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     HIP_TRY(hipEventRecord(ev[0], st));
     int rc;
     DevBuf* B = e->d_build;
-    if ((rc = upload_vec(B[kBReadOff], R.seq_off, 8 * (R.n_seqs + 1), st)) || (rc = upload_vec(B[kBReadBases], R.bases, read_bytes, st)) ||
-        (rc = upload_vec(B[kBReadQuals], R.quals, read_bytes, st)) || (rc = upload_vec(B[kBReadHasQual], R.seq_has_qual, R.n_seqs, st)) ||
+    if ((!reads_resident && (rc = upload_reads(e, R, st))) ||
         (rc = upload_vec(B[kBQid], O.q_id, 4 * O.n_overlaps, st)) || (rc = upload_vec(B[kBTid], O.t_id, 4 * O.n_overlaps, st)) ||
         (rc = upload_vec(B[kBStrand], O.strand, O.n_overlaps, st)) || (rc = upload_vec(B[kBBpOff], O.bp_off ? O.bp_off : &n_points, 8 * (O.n_overlaps + 1), st)) ||
         (rc = upload_vec(B[kBFirstWin], first_window.data(), 4 * (R.n_targets + 1), st))) { drop_events(); return rc; }
-    if (!C) {
+    if (S) {
+        if ((rc = B[kBBpT].reserve(4 * n_points + 16)) || (rc = B[kBBpQ].reserve(4 * n_points + 16)) ||
+            (rc = upload_vec(B[kBQStart], S->q_start, 4 * O.n_overlaps, st)) || (rc = upload_vec(B[kBTBegin], S->t_begin, 4 * O.n_overlaps, st)) ||
+            (rc = upload_vec(B[kBTEnd], S->t_end, 4 * O.n_overlaps, st))) { drop_events(); return rc; }
+        HIP_TRY(hipMemsetAsync(B[kBBpT].p, 0, 4 * n_points + 16, st));
+        HIP_TRY(hipMemsetAsync(B[kBBpQ].p, 0, 4 * n_points + 16, st));
+    } else if (!C) {
         if ((rc = upload_vec(B[kBBpT], O.bp_t, 4 * n_points, st)) || (rc = upload_vec(B[kBBpQ], O.bp_q, 4 * n_points, st))) { drop_events(); return rc; }
     } else {
         const uint64_t cig_bytes = C->n_overlaps ? C->cigar_off[C->n_overlaps] : 0;
@@ -428,6 +449,18 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
             CigarWaveParams KW{K, B[kBKeyFirst].as<unsigned long long>(), B[kBKeyLast].as<unsigned long long>()};
             hipLaunchKernelGGL(k_cigar_breaking_points_wave, dim3(static_cast<uint32_t>((C->n_overlaps + 3) / 4)), dim3(256), 0, st, KW);
         }
+    }
+    if (S && O.n_overlaps) {
+        const uint64_t n_slots_all = n_points / 2;
+        if ((rc = B[kBKeyFirst].reserve(8 * n_slots_all + 16)) || (rc = B[kBKeyLast].reserve(8 * n_slots_all + 16))) { drop_events(); return rc; }
+        HIP_TRY(hipMemsetAsync(B[kBKeyFirst].p, 0xff, 8 * n_slots_all + 16, st));
+        HIP_TRY(hipMemsetAsync(B[kBKeyLast].p, 0, 8 * n_slots_all + 16, st));
+        OpsWalkParams K{};
+        K.ops = S->d_ops; K.ops_off = S->d_ops_off; K.q_start = B[kBQStart].as<uint32_t>(); K.t_begin = B[kBTBegin].as<uint32_t>();
+        K.t_end = B[kBTEnd].as<uint32_t>(); K.bp_off = P.bp_off; K.bp_t = B[kBBpT].as<uint32_t>(); K.bp_q = B[kBBpQ].as<uint32_t>();
+        K.first_key = B[kBKeyFirst].as<unsigned long long>(); K.last_key = B[kBKeyLast].as<unsigned long long>();
+        K.n_overlaps = O.n_overlaps; K.W = W;
+        hipLaunchKernelGGL(k_ops_breaking_points, dim3(static_cast<uint32_t>((O.n_overlaps + 3) / 4)), dim3(256), 0, st, K);
     }
     hipLaunchKernelGGL(k_symbols, dim3(static_cast<uint32_t>(std::min<uint64_t>(1024, (read_bytes + 1023) / 1024 + 1))), dim3(256), 0, st, P.bases, read_bytes, d_err + 1);
     if (n_pairs) hipLaunchKernelGGL(k_layer_filter, dim3(static_cast<uint32_t>((n_pairs + 3) / 4)), dim3(256), 0, st, P);
@@ -532,6 +565,121 @@ inline int build_windows_from_cigars(rcn_engine* e, const rcn_read_set& R, const
     rcn_overlap_set O{};
     O.n_overlaps = C.n_overlaps; O.q_id = C.q_id; O.t_id = C.t_id; O.strand = C.strand; O.bp_off = bp_off.data();
     return build_windows(e, R, O, W, qthr, window_type, &C);
+}
+
+// ---- exact pairwise alignment of overlaps without a CIGAR (pair_align.hpp) ----
+enum { kAQPos, kATPos, kAQLen, kATLen, kAQRc, kAOrder, kAOps, kAOpsOff, kADist, kAScratch, kACtr, kAlignSlots };
+
+// Aligns every pair; op bytes and distances stay resident (e->d_align).  `reads_resident`: upload_reads was done.
+inline int align_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set& S, bool reads_resident) {
+    if (R.n_seqs == 0 || !R.seq_off || !R.bases || !R.quals || !R.seq_has_qual) return RCN_E_ARG;
+    if (S.n_pairs && (!S.q_id || !S.t_id || !S.strand || !S.q_begin || !S.q_end || !S.t_begin || !S.t_end)) return RCN_E_ARG;
+    if (S.n_pairs > 0xfffffffeull) return RCN_E_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    const uint64_t n = S.n_pairs;
+    e->astats = rcn_align_stats{};
+    e->a_n_pairs = 0;
+    EventPair tc, tk;
+    if (tc.create() || tk.create()) return RCN_E_HIP;
+    std::vector<uint64_t> q_pos(n), t_pos(n);
+    std::vector<uint32_t> q_len(n), t_len(n), order(n);
+    e->a_ops_off.assign(n + 1, 0);
+    uint64_t m_cap = 1, n_cap = 1, cells = 0;
+    for (uint64_t o = 0; o < n; ++o) {
+        const uint64_t q = S.q_id[o], t = S.t_id[o];
+        if (q >= R.n_seqs || t >= R.n_seqs || S.q_end[o] < S.q_begin[o] || S.t_end[o] < S.t_begin[o]) return RCN_E_ARG;
+        const uint64_t ql = R.seq_off[q + 1] - R.seq_off[q], tl = R.seq_off[t + 1] - R.seq_off[t];
+        if (S.q_end[o] > ql || S.t_end[o] > tl) return RCN_E_ARG;
+        q_pos[o] = R.seq_off[q] + S.q_begin[o]; t_pos[o] = R.seq_off[t] + S.t_begin[o];
+        q_len[o] = S.q_end[o] - S.q_begin[o]; t_len[o] = S.t_end[o] - S.t_begin[o];
+        // (a one-column problem must be a leaf of the reference rule, or the target-axis split would not shrink it: 20 * ceil(rows / 64) + 8 < 2^20)
+        if (q_len[o] > 3000000u || t_len[o] > 0x3fffffffu) return RCN_E_CAPACITY;
+        e->a_ops_off[o + 1] = e->a_ops_off[o] + q_len[o] + t_len[o];
+        m_cap = std::max<uint64_t>(m_cap, q_len[o]); n_cap = std::max<uint64_t>(n_cap, t_len[o]);
+        cells += static_cast<uint64_t>(q_len[o]) * t_len[o];
+        order[o] = static_cast<uint32_t>(o);
+    }
+    // largest problems first: a launch ends with its slowest overlap
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return static_cast<uint64_t>(q_len[a]) * t_len[a] > static_cast<uint64_t>(q_len[b]) * t_len[b]; });
+    m_cap = (m_cap + 15) & ~uint64_t(15); n_cap = (n_cap + 15) & ~uint64_t(15);       // keeps the pieces of a slot 16-byte aligned
+    const uint64_t ops_bytes = e->a_ops_off[n];
+    // per-wave scratch: two last-column vectors, two carry buffers, the leaf store
+    const uint64_t leaf_bytes = rcn::pair_leaf_bytes(m_cap);
+    uint64_t slot_bytes = 2 * 4 * (m_cap + 64) + 2 * (n_cap + 64);
+    slot_bytes = ((slot_bytes + 15) & ~uint64_t(15)) + leaf_bytes;
+    slot_bytes = (slot_bytes + 255) & ~uint64_t(255);
+    DevBuf* A = e->d_align;
+    HIP_TRY(hipEventRecord(tc.a, st));
+    int rc;
+    if (!reads_resident && (rc = upload_reads(e, R, st))) return rc;
+    if ((rc = upload_vec(A[kAQPos], q_pos.data(), 8 * n, st)) || (rc = upload_vec(A[kATPos], t_pos.data(), 8 * n, st)) ||
+        (rc = upload_vec(A[kAQLen], q_len.data(), 4 * n, st)) || (rc = upload_vec(A[kATLen], t_len.data(), 4 * n, st)) ||
+        (rc = upload_vec(A[kAQRc], S.strand, n, st)) || (rc = upload_vec(A[kAOrder], order.data(), 4 * n, st)) ||
+        (rc = upload_vec(A[kAOpsOff], e->a_ops_off.data(), 8 * (n + 1), st)) || (rc = A[kAOps].reserve(ops_bytes + 256)) ||
+        (rc = A[kADist].reserve(4 * n + 16)) || (rc = A[kACtr].reserve(64))) return rc;
+    HIP_TRY(hipMemsetAsync(A[kAOps].p, 0, ops_bytes + 256, st));
+    HIP_TRY(hipMemsetAsync(A[kACtr].p, 0, 64, st));
+    size_t fr = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&fr, &tot));
+    const uint64_t budget = e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>((fr + A[kAScratch].cap) * 0.8);
+    uint64_t slots = std::min<uint64_t>(std::max<uint64_t>(n, 1), static_cast<uint64_t>(e->n_cu) * 16);
+    while (slots > 1 && slots * slot_bytes > budget) slots = (slots + 1) / 2;
+    if (slots * slot_bytes > budget) return RCN_E_CAPACITY;
+    if ((rc = A[kAScratch].reserve(slots * slot_bytes))) return rc;
+    HIP_TRY(hipEventRecord(tc.b, st));
+    if (n) {
+        rcn::PairParams P{};
+        P.bases = e->d_build[kBReadBases].as<uint8_t>();
+        P.q_pos = A[kAQPos].as<uint64_t>(); P.t_pos = A[kATPos].as<uint64_t>(); P.q_len = A[kAQLen].as<uint32_t>(); P.t_len = A[kATLen].as<uint32_t>();
+        P.q_rc = A[kAQRc].as<uint8_t>(); P.order = A[kAOrder].as<uint32_t>(); P.n_pairs = static_cast<uint32_t>(n);
+        P.next = A[kACtr].as<unsigned int>(); P.err = A[kACtr].as<uint32_t>() + 4;
+        P.ops = A[kAOps].as<uint8_t>(); P.ops_off = A[kAOpsOff].as<uint64_t>(); P.dist = A[kADist].as<int32_t>();
+        P.scratch = A[kAScratch].as<uint8_t>(); P.slot_bytes = slot_bytes;
+        P.m_cap = static_cast<uint32_t>(m_cap); P.n_cap = static_cast<uint32_t>(n_cap); P.leaf_bytes = leaf_bytes;
+        HIP_TRY(hipEventRecord(tk.a, st));
+        hipLaunchKernelGGL(rcn::k_pair_align, dim3(static_cast<uint32_t>(slots)), dim3(64), 0, st, P);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(tk.b, st));
+    }
+    uint32_t h_ctr[16] = {0};
+    HIP_TRY(hipMemcpyAsync(h_ctr, A[kACtr].p, 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_ctr[4]) { fprintf(stderr, "[racon_hip] pairwise alignment: internal error on %u overlap(s)\n", h_ctr[4]); return RCN_E_STATE; }
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, tc.a, tc.b)); e->astats.h2d_ms = ms;
+    if (n) { HIP_TRY(hipEventElapsedTime(&ms, tk.a, tk.b)); e->astats.kernel_ms = ms; }
+    e->astats.n_pairs = n; e->astats.cells = cells; e->astats.ops_bytes = ops_bytes; e->astats.slots = static_cast<uint32_t>(slots);
+    e->a_n_pairs = n;
+    return RCN_OK;
+}
+
+// Alignment + breaking points + window construction, all in HBM.
+inline int build_windows_from_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set& S, uint32_t W, double qthr, uint8_t window_type) {
+    if (W == 0) return RCN_E_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    int rc;
+    if (R.n_seqs == 0 || R.n_targets == 0 || R.n_targets > R.n_seqs || !R.seq_off || !R.bases || !R.quals || !R.seq_has_qual) return RCN_E_ARG;
+    if ((rc = upload_reads(e, R, e->stream))) return rc;
+    if ((rc = align_pairs(e, R, S, true))) return rc;
+    std::vector<uint64_t> bp_off(S.n_pairs + 1, 0);
+    std::vector<uint32_t> q_start(S.n_pairs);
+    for (uint64_t o = 0; o < S.n_pairs; ++o) {
+        const uint64_t tb = S.t_begin[o], te = S.t_end[o];
+        if (te <= tb) return RCN_E_ARG;
+        const uint64_t inside = (te - 1) / W - tb / W;
+        bp_off[o + 1] = bp_off[o] + 2 * (inside + 1);
+        const uint64_t ql = R.seq_off[S.q_id[o] + 1] - R.seq_off[S.q_id[o]];
+        q_start[o] = S.strand[o] ? static_cast<uint32_t>(ql - S.q_end[o]) : S.q_begin[o];          // reference src/overlap.cpp:241-242
+    }
+    rcn_overlap_set O{};
+    O.n_overlaps = S.n_pairs; O.q_id = S.q_id; O.t_id = S.t_id; O.strand = S.strand; O.bp_off = bp_off.data();
+    OpsSource src{e->d_align[kAOps].as<uint8_t>(), e->d_align[kAOpsOff].as<uint64_t>(), q_start.data(), S.t_begin, S.t_end};
+    const rcn_align_stats keep = e->astats;
+    rc = build_windows(e, R, O, W, qthr, window_type, nullptr, &src, true);
+    e->astats = keep;
+    return rc;
 }
 
 }  // namespace rcn

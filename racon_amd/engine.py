@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 
 from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
-from .layout import CigarSet, OverlapSet, RcnBatchDims, RcnBuildStats, RcnCigarSet, RcnOverlapSet, RcnReadSet, ReadSet
+from .layout import (CigarSet, OverlapSet, PairSet, RcnAlignStats, RcnBatchDims, RcnBuildStats, RcnCigarSet, RcnOverlapSet, RcnPairSet,
+                     RcnReadSet, ReadSet)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RACON_HIP_LIB: another build of the same ABI (profiling / experiment variants under racon_amd/csrc/), as in the host layer
@@ -44,7 +45,8 @@ class RcnWindowDesc(C.Structure):
 EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_engine_run", "rcn_engine_result",
            "rcn_engine_stats", "rcn_engine_set_trim", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
-           "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory"]
+           "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory",
+           "rcn_engine_align_pairs", "rcn_engine_alignment_cigars", "rcn_engine_align_stats", "rcn_engine_build_windows_from_pairs"]
 
 _lib = None
 
@@ -75,6 +77,10 @@ def load_library():
     lib.rcn_engine_build_windows.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnOverlapSet), C.c_uint32, C.c_double, C.c_uint8]
     lib.rcn_engine_build_windows_from_cigars.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnCigarSet), C.c_uint32, C.c_double, C.c_uint8]
     lib.rcn_engine_build_stats.argtypes = [C.c_void_p, C.POINTER(RcnBuildStats)]
+    lib.rcn_engine_align_pairs.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnPairSet)]
+    lib.rcn_engine_alignment_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    lib.rcn_engine_align_stats.argtypes = [C.c_void_p, C.POINTER(RcnAlignStats)]
+    lib.rcn_engine_build_windows_from_pairs.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnPairSet), C.c_uint32, C.c_double, C.c_uint8]
     lib.rcn_engine_batch_dims.argtypes = [C.c_void_p, C.POINTER(RcnBatchDims)]
     lib.rcn_engine_export_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     lib.rcn_strerror.restype = C.c_char_p
@@ -162,6 +168,40 @@ class HipEngine:
         self._keep = (reads, alignments, cr, ca)
         _check(self.lib.rcn_engine_build_windows_from_cigars(self.h, C.byref(cr), C.byref(ca), int(window_length), float(quality_threshold),
                                                              int(window_type)), "rcn_engine_build_windows_from_cigars")
+
+    # exact pairwise alignment on the device (reference src/overlap.cpp:205-224) ------
+    def align_pairs(self, reads: ReadSet, pairs: PairSet):
+        """Aligns every pair in HBM (the paths stay there); alignment_cigars() brings them back as CIGAR strings."""
+        cr, cp = reads.as_c(), pairs.as_c()
+        self._keep = (reads, pairs, cr, cp)
+        self._n_pairs = pairs.n_pairs
+        _check(self.lib.rcn_engine_align_pairs(self.h, C.byref(cr), C.byref(cp)), "rcn_engine_align_pairs")
+
+    def alignment_cigars(self):
+        """(list of CIGAR bytes, int32 array of edit distances) of the last align_pairs()."""
+        n = self._n_pairs
+        off = np.zeros(n + 1, np.uint64)
+        dist = np.zeros(max(n, 1), np.int32)
+        need = C.c_uint64(0)
+        _check(self.lib.rcn_engine_alignment_cigars(self.h, off.ctypes.data_as(C.c_void_p), None, 0, C.byref(need), dist.ctypes.data_as(C.c_void_p)),
+               "rcn_engine_alignment_cigars")
+        buf = np.zeros(max(int(need.value), 1), np.uint8)
+        _check(self.lib.rcn_engine_alignment_cigars(self.h, off.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), int(need.value),
+                                                    C.byref(need), dist.ctypes.data_as(C.c_void_p)), "rcn_engine_alignment_cigars")
+        return [buf[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)], dist[:n]
+
+    def align_stats(self) -> dict:
+        s = RcnAlignStats()
+        _check(self.lib.rcn_engine_align_stats(self.h, C.byref(s)), "rcn_engine_align_stats")
+        return {k: getattr(s, k) for k, _ in RcnAlignStats._fields_}
+
+    def build_windows_from_pairs(self, reads: ReadSet, pairs: PairSet, window_length: int, quality_threshold: float, window_type: int):
+        """Alignment (edlib-equivalent, byte-identical paths), breaking points and window construction, all in HBM."""
+        cr, cp = reads.as_c(), pairs.as_c()
+        self._keep = (reads, pairs, cr, cp)
+        self._n_pairs = pairs.n_pairs
+        _check(self.lib.rcn_engine_build_windows_from_pairs(self.h, C.byref(cr), C.byref(cp), int(window_length), float(quality_threshold),
+                                                            int(window_type)), "rcn_engine_build_windows_from_pairs")
 
     def build_stats(self) -> dict:
         s = RcnBuildStats()

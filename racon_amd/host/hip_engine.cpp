@@ -28,6 +28,7 @@ struct Abi {
     decltype(&rcn_engine_set_trim) set_trim = nullptr;
     decltype(&rcn_engine_build_windows) build_windows = nullptr;
     decltype(&rcn_engine_build_windows_from_cigars) build_windows_from_cigars = nullptr;
+    decltype(&rcn_engine_build_windows_from_pairs) build_windows_from_pairs = nullptr;
     decltype(&rcn_device_count) device_count = nullptr;
     decltype(&rcn_strerror) strerror_ = nullptr;
 };
@@ -63,6 +64,7 @@ const Abi& abi() {
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
         RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
         RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
+        RCN_BIND(build_windows_from_pairs, "rcn_engine_build_windows_from_pairs")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
 #undef RCN_BIND
     });
@@ -155,6 +157,16 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_cigar_set& alignm
     const Abi& a = abi();
     int rc = a.set_trim(handle_, trim ? 1 : 0);
     if (rc == RCN_OK) rc = a.build_windows_from_cigars(handle_, &reads, &alignments, window_length, quality_threshold, window_type);
+    if (rc == RCN_E_ARG) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
+    fetch(rc, consensus, polished, chimeric);
+}
+
+void HipEngine::consensus(const rcn_read_set& reads, const rcn_pair_set& pairs, uint32_t window_length, double quality_threshold,
+                          uint8_t window_type, bool trim, std::vector<std::string>* consensus,
+                          std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
+    const Abi& a = abi();
+    int rc = a.set_trim(handle_, trim ? 1 : 0);
+    if (rc == RCN_OK) rc = a.build_windows_from_pairs(handle_, &reads, &pairs, window_length, quality_threshold, window_type);
     if (rc == RCN_E_ARG) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
     fetch(rc, consensus, polished, chimeric);
 }

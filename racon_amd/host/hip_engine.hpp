@@ -60,6 +60,11 @@ public:
     void consensus(const rcn_read_set& reads, const rcn_cigar_set& alignments, uint32_t window_length, double quality_threshold,
                    uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                    std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    // ... and with the overlaps aligned on the device first (rcn_engine_build_windows_from_pairs: the edlib-equivalent of
+    // reference src/overlap.cpp:205-224, byte-identical paths)
+    void consensus(const rcn_read_set& reads, const rcn_pair_set& pairs, uint32_t window_length, double quality_threshold,
+                   uint8_t window_type, bool trim, std::vector<std::string>* consensus,
+                   std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
     double last_kernel_ms() const { return last_kernel_ms_; }
 
 private:

@@ -95,10 +95,11 @@ void Overlap::transmute(const std::vector<std::unique_ptr<Sequence>>& sequences,
     is_transmuted_ = true;
 }
 
-void Overlap::find_breaking_points(const std::vector<std::unique_ptr<Sequence>>& sequences, uint32_t window_length, bool keep_cigar, bool cigar_only) {
+void Overlap::find_breaking_points(const std::vector<std::unique_ptr<Sequence>>& sequences, uint32_t window_length, bool keep_cigar, bool cigar_only,
+                                   bool no_align) {
     if (!is_transmuted_) fatal("[racon::Overlap::find_breaking_points] error: overlap is not transmuted!");
     if (!breaking_points_.empty()) return;
-    if (cigar_.empty()) {
+    if (cigar_.empty() && !(cigar_only && no_align)) {
         const char* q = !strand_ ? &(sequences[q_id_]->data()[q_begin_])
                                  : &(sequences[q_id_]->reverse_complement()[q_length_ - q_end_]);
         const char* t = &(sequences[t_id_]->data()[t_begin_]);

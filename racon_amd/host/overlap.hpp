@@ -40,9 +40,12 @@ public:
                    const std::unordered_map<uint64_t, uint64_t>& id_to_id);
     // reference src/overlap.cpp:179-203
     void find_breaking_points(const std::vector<std::unique_ptr<Sequence>>& sequences, uint32_t window_length, bool keep_cigar = false,
-                              bool cigar_only = false);   // cigar_only: align if needed, leave the CIGAR walk to the device
+                              bool cigar_only = false,    // cigar_only: align if needed, leave the CIGAR walk to the device
+                              bool no_align = false);     // no_align (with cigar_only): an overlap without a CIGAR is aligned on the device too
     // first query position on the overlap's strand / target extent: what breaking_points_from_cigar starts from
     uint32_t q_start_on_strand() const { return strand_ ? (q_length_ - q_end_) : q_begin_; }
+    uint32_t q_begin() const { return q_begin_; }          // the aligned segment on the forward read
+    uint32_t q_end() const { return q_end_; }
     uint32_t t_begin() const { return t_begin_; }
     uint32_t t_end() const { return t_end_; }
 

@@ -253,7 +253,13 @@ void Polisher::initialize() {
 
     parallel_for(sequences_.size(), num_threads_, [&](uint64_t j) { sequences_[j]->transmute(has_name[j], has_data[j], has_reverse_data[j]); });
 
-    if (const char* dv = getenv("RACON_HIP_DEVICE_WINDOWS")) { if (dv[0] == '1' || dv[0] == '2') device_windows(true, dv[0] == '2'); }
+    if (const char* dv = getenv("RACON_HIP_DEVICE_WINDOWS")) { if (dv[0] >= '1' && dv[0] <= '3') device_windows(true, dv[0] == '2', dv[0] == '3'); }
+    if (device_align_) {
+        // all or nothing per overlap file: SAM records carry CIGARs (nothing to align), PAF / MHAP records do not
+        bool any_cigar = false;
+        for (const auto& o : overlaps) any_cigar = any_cigar || !o->cigar().empty();
+        if (any_cigar) device_align_ = false;
+    }
     find_overlap_breaking_points(overlaps);
     logger_->log();
 
@@ -285,6 +291,7 @@ void Polisher::initialize() {
             if (!device_cigars_) for (const auto& bp : o->breaking_points()) { layout_.bp_t.push_back(bp.first); layout_.bp_q.push_back(bp.second); }
             layout_.bp_off.push_back(layout_.bp_t.size());
             layout_.q_start.push_back(o->q_start_on_strand()); layout_.t_begin.push_back(o->t_begin()); layout_.t_end.push_back(o->t_end());
+            layout_.q_begin.push_back(o->q_begin()); layout_.q_end.push_back(o->q_end());
             layout_.cigar.insert(layout_.cigar.end(), o->cigar().begin(), o->cigar().end());
             layout_.cigar_off.push_back(layout_.cigar.size());
         }
@@ -340,8 +347,8 @@ void Polisher::initialize() {
 }
 
 void Polisher::find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>>& overlaps) {
-    parallel_for(overlaps.size(), num_threads_, [&](uint64_t j) { overlaps[j]->find_breaking_points(sequences_, window_length_, keep_layout_, device_cigars_); });
-    logger_->log("[racon::Polisher::initialize] aligned overlaps");
+    parallel_for(overlaps.size(), num_threads_, [&](uint64_t j) { overlaps[j]->find_breaking_points(sequences_, window_length_, keep_layout_, device_cigars_, device_align_); });
+    logger_->log(device_align_ ? "[racon::Polisher::initialize] left the overlaps to the device aligner" : "[racon::Polisher::initialize] aligned overlaps");
 }
 
 // ---------------------------------------------------------------- polish
@@ -409,7 +416,12 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         o.n_overlaps = layout_.q_id.size(); o.q_id = layout_.q_id.data(); o.t_id = layout_.t_id.data(); o.strand = layout_.strand.data();
         o.bp_off = layout_.bp_off.data(); o.bp_t = layout_.bp_t.data(); o.bp_q = layout_.bp_q.data();
         auto engine = HipEngine::Create(0, match_, mismatch_, gap_);
-        if (device_cigars_) {
+        if (device_align_) {
+            rcn_pair_set ps{};
+            ps.n_pairs = o.n_overlaps; ps.q_id = o.q_id; ps.t_id = o.t_id; ps.strand = o.strand;
+            ps.q_begin = layout_.q_begin.data(); ps.q_end = layout_.q_end.data(); ps.t_begin = layout_.t_begin.data(); ps.t_end = layout_.t_end.data();
+            engine->consensus(r, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &cons, &pol, &chim);
+        } else if (device_cigars_) {
             rcn_cigar_set a{};
             a.n_overlaps = o.n_overlaps; a.q_id = o.q_id; a.t_id = o.t_id; a.strand = o.strand;
             a.q_start = layout_.q_start.data(); a.t_begin = layout_.t_begin.data(); a.t_end = layout_.t_end.data();

@@ -74,6 +74,9 @@ public:
         std::vector<uint64_t> cigar_off{0};
         std::vector<uint8_t> cigar;
         std::vector<uint32_t> q_start, t_begin, t_end;
+        // the aligned query segment on the forward read (rcn_pair_set): what the device aligner needs of an overlap
+        // that came without a CIGAR
+        std::vector<uint32_t> q_begin, q_end;
         uint8_t window_type = 0;
     };
     void keep_layout(bool on) { keep_layout_ = on; }
@@ -81,7 +84,12 @@ public:
     // which polish() needs for the stitching) and records the layout instead.  Also switched on by RACON_HIP_DEVICE_WINDOWS=1.
     // cigars: the CIGAR walk (Overlap::find_breaking_points, reference src/overlap.cpp:226-292) runs on the device too
     // (rcn_engine_build_windows_from_cigars; RACON_HIP_DEVICE_WINDOWS=2).
-    void device_windows(bool on, bool cigars = false) { device_windows_ = on; device_cigars_ = on && cigars; if (on) keep_layout_ = true; }
+    // align: overlaps without a CIGAR (PAF / MHAP) are aligned on the device as well (rcn_engine_build_windows_from_pairs:
+    // the edlib-equivalent of reference src/overlap.cpp:205-224 in HBM; RACON_HIP_DEVICE_WINDOWS=3); files whose overlaps
+    // carry CIGARs (SAM) take the cigars path.
+    void device_windows(bool on, bool cigars = false, bool align = false) {
+        device_windows_ = on; device_cigars_ = on && (cigars || align); device_align_ = on && align; if (on) keep_layout_ = true;
+    }
     const Layout& layout() const { return layout_; }
     uint32_t window_length() const { return window_length_; }
     double quality_threshold() const { return quality_threshold_; }
@@ -118,6 +126,7 @@ protected:
     std::vector<std::shared_ptr<Window>> windows_;
     bool keep_layout_ = false;
     bool device_cigars_ = false;
+    bool device_align_ = false;     // overlaps without a CIGAR are aligned on the device (set back by initialize() when the file has CIGARs)
     bool device_windows_ = false;   // polish(): windows built in HBM (rcn_engine_build_windows) instead of packed from windows_
     Layout layout_;
     std::unique_ptr<Logger> logger_;

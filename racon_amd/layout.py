@@ -27,6 +27,17 @@ class RcnCigarSet(C.Structure):
                 ("t_end", C.POINTER(C.c_uint32)), ("cigar_off", C.POINTER(C.c_uint64)), ("cigar", C.POINTER(C.c_uint8))]
 
 
+class RcnPairSet(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("q_id", C.POINTER(C.c_uint32)), ("t_id", C.POINTER(C.c_uint32)),
+                ("strand", C.POINTER(C.c_uint8)), ("q_begin", C.POINTER(C.c_uint32)), ("q_end", C.POINTER(C.c_uint32)),
+                ("t_begin", C.POINTER(C.c_uint32)), ("t_end", C.POINTER(C.c_uint32))]
+
+
+class RcnAlignStats(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("n_pairs", C.c_uint64), ("cells", C.c_uint64),
+                ("ops_bytes", C.c_uint64), ("slots", C.c_uint32)]
+
+
 class RcnBuildStats(C.Structure):
     _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("n_pairs", C.c_uint64),
                 ("n_layers", C.c_uint64), ("gather_bytes", C.c_uint64)]
@@ -157,3 +168,34 @@ class CigarSet:
         col = lambda k, dt: np.array([a[k] for a in al], dt)
         return CigarSet(col(0, np.uint32), col(1, np.uint32), col(2, np.uint8), col(3, np.uint32), col(4, np.uint32), col(5, np.uint32),
                         off, np.frombuffer(b"".join(a[6] for a in al), np.uint8).copy())
+
+
+@dataclass
+class PairSet:
+    """Overlaps that come without an alignment (include/racon_hip.h: rcn_pair_set): what Overlap::find_breaking_points
+    hands to edlib (reference src/overlap.cpp:205-224) -- the query segment on the FORWARD read (reverse-complemented by
+    the aligner when strand = 1) and the target segment."""
+    q_id: np.ndarray           # uint32 [n_pairs]
+    t_id: np.ndarray
+    strand: np.ndarray         # uint8
+    q_begin: np.ndarray        # uint32
+    q_end: np.ndarray
+    t_begin: np.ndarray
+    t_end: np.ndarray
+
+    @property
+    def n_pairs(self) -> int:
+        return int(self.q_id.shape[0])
+
+    def as_c(self) -> RcnPairSet:
+        for name, dt in (("q_id", np.uint32), ("t_id", np.uint32), ("strand", np.uint8), ("q_begin", np.uint32), ("q_end", np.uint32),
+                         ("t_begin", np.uint32), ("t_end", np.uint32)):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name), dtype=dt))
+        return RcnPairSet(self.n_pairs, _ptr(self.q_id, C.c_uint32), _ptr(self.t_id, C.c_uint32), _ptr(self.strand, C.c_uint8),
+                          _ptr(self.q_begin, C.c_uint32), _ptr(self.q_end, C.c_uint32), _ptr(self.t_begin, C.c_uint32), _ptr(self.t_end, C.c_uint32))
+
+    @staticmethod
+    def from_lists(pairs) -> "PairSet":
+        """pairs: [(q_id, t_id, strand, q_begin, q_end, t_begin, t_end)]"""
+        col = lambda k, dt: np.array([p[k] for p in pairs], dt)
+        return PairSet(col(0, np.uint32), col(1, np.uint32), col(2, np.uint8), col(3, np.uint32), col(4, np.uint32), col(5, np.uint32), col(6, np.uint32))
