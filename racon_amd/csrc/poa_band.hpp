@@ -112,6 +112,11 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
     Block4::sync();
 }
 
+#ifdef RCN_PROF_ROWS
+// profiling build: clocks and counts of the banded DP's rows by class (0 chain, 1 / 2 / 3 = fast rows with one / two /
+// three or four predecessors, 4 medium, 5 general, 6 rows where the window moved, 7 sink rows), spread over 256 copies
+__device__ unsigned long long g_rowprof[256][16];
+#endif
 // ---- the banded one-wave DP (wave 0 of the work-group) ----
 // ABL (profiling builds only, -DRCN_ABLATE=k): the pass is run an extra time before the real one with one piece compiled
 // out; the difference of the DP phase clocks against ABL = 0 (a plain second pass) is what that piece costs in situ.
@@ -310,10 +315,18 @@ __device__ __noinline__ void dp2_rows_band() {
         for (int i = rbase + 1; i <= rend; ++i) {
             const int k = (i - 1) & 63;
             const int meta = meta_next;
+#ifdef RCN_PROF_ROWS
+            const long long row_t0 = clock64();
+            int row_cls = (meta & (1 << 15)) ? 0 : (meta & (1 << 13)) ? min(3, (meta >> 9) & 7) : ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) ? 4 : 5;
+            if ((meta & ((1 << 13) | 256)) == 256) row_cls = 7;
+#endif
             meta_next = __builtin_amdgcn_readlane(dl_meta, i & 63);
             if (__builtin_expect((meta & (1 << 12)) != 0, 0)) {
                 // special row: the window may move here (all on-chip state is re-based, the profile of this row redone)
                 const int new_off = __builtin_amdgcn_readlane(dl_off, k);
+#ifdef RCN_PROF_ROWS
+                if (new_off != woff) row_cls = 6;
+#endif
                 if (new_off != woff) { shift_to(i, new_off); profile_now(meta); }
             }
             uint32_t P[NP];
@@ -601,6 +614,13 @@ __device__ __noinline__ void dp2_rows_band() {
                     if (CODE) sinkz[i] = kNeg16; else H16w[static_cast<int64_t>(i) * hs + len] = static_cast<int16_t>(kNeg16);
                 }
             }
+#ifdef RCN_PROF_ROWS
+            if (CODE && lane == 0) {
+                const unsigned long long dt = static_cast<unsigned long long>(clock64() - row_t0);
+                atomicAdd(&g_rowprof[blockIdx.x & 255][row_cls], dt);
+                atomicAdd(&g_rowprof[blockIdx.x & 255][8 + row_cls], 1ull);
+            }
+#endif
         }
     }
     if (kBatch && !bfail) flush_rows(flushed + 1, V);
