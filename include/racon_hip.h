@@ -91,7 +91,7 @@ typedef struct rcn_run_stats {
     uint64_t n_banded;         /* alignments done by the banded pass (certificate held)               */
     uint64_t n_band_redone;    /* alignments redone on full rows because the certificate failed       */
     uint64_t band_redo_why[8]; /* redo reasons, counted: source row off the left edge, predecessor older than the LDS ring,
-                                  >2 window shifts inside the ring, >6 in-edges, (shift span), no end cell, alive last window
+                                  >2 window shifts inside the ring, >8 in-edges, (shift span), no end cell, alive last window
                                   cell, alive dropped cell                                                                   */
 } rcn_run_stats;
 

@@ -178,7 +178,11 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int j0 = woff + t * LPC + 2 * q, j1 = j0 + 1;
-            const int s0 = (j0 >= 1 && j0 <= len) ? lseq[j0 - 1] : 0x100, s1 = (j1 >= 1 && j1 <= len) ? lseq[j1 - 1] : 0x100;
+            // (loads at clamped indices + selects: no lane-dependent branch may sit inside the row loop, or the compiler
+            //  structurizes the whole loop body into flag-guarded blocks and every row pays for their taken branches)
+            int l0 = lseq[min(max(j0 - 1, 0), kBandSeq - 1)], l1 = lseq[min(max(j1 - 1, 0), kBandSeq - 1)];
+            asm volatile("" : "+v"(l0), "+v"(l1));
+            const int s0 = (j0 >= 1 && j0 <= len) ? l0 : 0x100, s1 = (j1 >= 1 && j1 <= len) ? l1 : 0x100;
             sqx[q] = pack2(s0, s1);
             thrv[q] = pack2(mg * j0, mg * j1);
         }
@@ -228,7 +232,7 @@ __device__ __noinline__ void dp2_rows_band() {
     // CODE: one byte per cell, absolute columns, row stride hs BYTES (same base as the score matrix it replaces)
     RCN_G uint8_t* crow = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr()) + hs;
     RCN_G int32_t* sinkz = g.path_node.ptr();   // CODE: end score (column len) of the sink rows, for phase_sink_tie_full
-    const uint32_t ZERO2 = 0u, TWO2 = 0x00020002u, FOUR2 = 0x00040004u, C32 = 0x00200020u;
+    const uint32_t TWO2 = 0x00020002u, FOUR2 = 0x00040004u, C32 = 0x00200020u;
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
 
     // the window moves to new_off before row i is computed
@@ -254,7 +258,11 @@ __device__ __noinline__ void dp2_rows_band() {
             uint32_t ev = pack2(-32768, -32768);
 #pragma unroll
             for (int k = 0; k < R * NP; ++k) ev = pk_max(ev, pk_subs(win[k], thrv[k % NP]));
-            if (lane < dl) emaxV = pk_max(emaxV, ev);
+            {
+                uint32_t cand = pk_max(emaxV, ev);
+                asm volatile("" : "+v"(cand));
+                emaxV = lane < dl ? cand : emaxV;
+            }
         }
         {   // re-base the register window: lane l <- lane l + dl
             const int srcl = ((lane + dl) & 63) * 4;
@@ -292,7 +300,17 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
             for (int q = 0; q < kInlinePreds; ++q) d.p[q] = 0;
             int ro = 0;
-            if (rbase + lane < V) { d = desc[rbase + lane]; ro = roff[rbase + lane]; }
+            {
+                // (loaded by every lane at a clamped index, then selected: a lane-dependent branch anywhere in the row
+                //  loops makes the compiler turn ALL their control flow into flag-guarded blocks)
+                const int rr = min(rbase + lane, V - 1);
+                RowDesc dd_ = desc[rr]; int ro_ = roff[rr];
+                asm volatile("" : "+v"(dd_.p[0]), "+v"(dd_.p[1]), "+v"(dd_.p[2]), "+v"(dd_.p[3]), "+v"(dd_.p[4]), "+v"(dd_.p[5]), "+v"(dd_.erest), "+v"(dd_.meta), "+v"(ro_));
+                const bool in = rbase + lane < V;
+#pragma unroll
+                for (int q = 0; q < kInlinePreds; ++q) d.p[q] = in ? dd_.p[q] : d.p[q];
+                d.erest = in ? dd_.erest : d.erest; d.meta = in ? dd_.meta : d.meta; ro = in ? ro_ : ro;
+            }
             dl_p0 = d.p[0]; dl_p1 = d.p[1]; dl_p2 = d.p[2]; dl_p3 = d.p[3]; dl_p4 = d.p[4]; dl_p5 = d.p[5]; dl_er = d.erest; dl_meta = d.meta; dl_off = ro;
             asm volatile("; row descriptors retired" : "+v"(dl_p0), "+v"(dl_p1), "+v"(dl_p2), "+v"(dl_p3), "+v"(dl_p4), "+v"(dl_p5), "+v"(dl_er), "+v"(dl_meta), "+v"(dl_off));
         }
@@ -315,6 +333,13 @@ __device__ __noinline__ void dp2_rows_band() {
         for (int i = rbase + 1; i <= rend; ++i) {
             const int k = (i - 1) & 63;
             const int meta = meta_next;
+            // the row just finished enters the register window here, at ONE place: the copies of the row tail below then
+            // only hand over `prev` (with the window written in each of them the compiler copies all sixteen registers
+            // per row to reconcile the copies)
+            if (!kBatch && ABL != 4) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) win[((i - 1) & (R - 1)) * NP + q] = prev[q];
+            }
 #ifdef RCN_PROF_ROWS
             const long long row_t0 = clock64();
             int row_cls = (meta & (1 << 15)) ? 0 : (meta & (1 << 13)) ? min(3, (meta >> 9) & 7) : ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) ? 4 : 5;
@@ -343,39 +368,48 @@ __device__ __noinline__ void dp2_rows_band() {
                 const uint32_t Q = pack2(e, e);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
-                    const uint32_t d = pk_subs(zq[q], M[q]);
-                    const uint32_t gt = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, pk_max(d, ZERO2)), __builtin_bit_cast(s16x2, ONE)));
+                    // strictly greater <=> the maximum grows: the difference (mod 2^16, at most 63000) is non-zero
+                    const uint32_t gt = pk_minu(pk_sub(pk_max(M[q], zq[q]), M[q]), ONE);
                     Aq[q] = pk_mad(gt, pk_sub(Q, Aq[q]), Aq[q]);
                 }
             };
-            if (ABL == 6 || __builtin_expect((meta & (1 << 15)) != 0, 1)) {
-                // ---- chain row: the only predecessor is the row just finished ----
-#pragma unroll
-                for (int q = 0; q < NP; ++q) M[q] = prev[q];
-            } else if (meta & (1 << 13)) {
-                ++not_chain;
-                // ---- fast row: predecessors in the register window (always in current coordinates) ----
-                const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
-                const int npf = (meta >> 9) & 7;
+            if (ABL == 6 || __builtin_expect_with_probability((meta & (1 << 13)) != 0, 1, 0.98)) {
+                // ---- chain and fast rows (98 % of the rows): every predecessor is in the register window (always in current
+                //      coordinates).  The first predecessor is one indexed register read whatever its distance (a chain row
+                //      has distance 1), a second one follows in line, only a third / fourth loop; rows with one predecessor
+                //      and rows with several each run through their own copy of the row tail ----
+                const unsigned int dd = ABL == 6 ? 1u : static_cast<unsigned int>(meta) >> 16;
+                const int npf = ABL == 6 ? 1 : (meta >> 9) & 7;
                 {
-                    const int d = dd & 15;
-                    const int wi = ((i - d) & (R - 1)) * NP;
+                    const int wi = ((i - static_cast<int>(dd & 15)) & (R - 1)) * NP;
 #pragma unroll
                     for (int q = 0; q < NP; ++q) M[q] = win[wi + q];
                 }
+                const unsigned int nonchain = ((static_cast<unsigned int>(meta) >> 15) & 1u) ^ 1u;
+                not_chain += nonchain;
+                pred_rows += nonchain ? static_cast<unsigned int>(npf) : 0u;
+                if (__builtin_expect(npf > 1, 0)) {      // (38 % of the rows; kept off the fall-through path of the other 60 %)
+                    {
+                        const int wi = ((i - static_cast<int>((dd >> 4) & 15)) & (R - 1)) * NP;
+                        uint32_t zq[NP];
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
+                        if (CODE) arg_step(zq, 1);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
+                    }
 #pragma unroll 1
-                for (int e = 1; e < npf; ++e) {
-                    const int d = (dd >> (4 * e)) & 15;
-                    const int wi = ((i - d) & (R - 1)) * NP;
-                    uint32_t zq[NP];
+                    for (int e = 2; e < npf; ++e) {
+                        const int wi = ((i - static_cast<int>((dd >> (4 * e)) & 15)) & (R - 1)) * NP;
+                        uint32_t zq[NP];
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
-                    if (CODE) arg_step(zq, e);
+                        for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
+                        if (CODE) arg_step(zq, e);
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
+                        for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
+                    }
+                    multi = true;
                 }
-                multi = npf > 1;
-                pred_rows += npf;
             } else if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
                 // ---- medium row whose predecessors all share this row's window: LDS ring, reads in flight together ----
                 const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
@@ -440,12 +474,20 @@ __device__ __noinline__ void dp2_rows_band() {
                             const uint32_t dthr = pack2(mg * delta, mg * delta);
                             uint32_t ev = pack2(-32768, -32768);
 #pragma unroll
-                            for (int q = 0; q < NP; ++q) ev = pk_max(ev, pk_subs(old[q], pk_sub(thrv[q], dthr)));
-                            if (lane < dlp) emaxV = pk_max(emaxV, ev);
+                            for (int q = 0; q < NP; ++q) {
+                                uint32_t ov = old[q];
+                                asm volatile("" : "+v"(ov));          // (loaded by every lane: no exec-masked region in the row loop)
+                                ev = pk_max(ev, pk_subs(ov, pk_sub(thrv[q], dthr)));
+                            }
+                            {
+                                uint32_t cand = pk_max(emaxV, ev);
+                                asm volatile("" : "+v"(cand));         // computed by every lane, then selected: no exec-masked region
+                                emaxV = lane < dlp ? cand : emaxV;
+                            }
                             const uint32_t* src = ring + (sp * NTH + min(t + dlp, 63)) * NP;
                             const bool keep = t + dlp < 64;
 #pragma unroll
-                            for (int q = 0; q < NP; ++q) { const uint32_t v = src[q]; hp[q] = keep ? v : NEGP; }
+                            for (int q = 0; q < NP; ++q) { uint32_t v = src[q]; asm volatile("" : "+v"(v)); hp[q] = keep ? v : NEGP; }
                         }
                     } else {
                         bfail |= 2;                                    // (d)
@@ -481,146 +523,13 @@ __device__ __noinline__ void dp2_rows_band() {
                 for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
             }
 
-            // diagonal sources = the combined predecessor row shifted right by one column (lane 0: -inf, the cell left of the window)
-            uint32_t mprev = mpv = __builtin_amdgcn_update_dpp(mpv, M[NP - 1], 0x138, 0xf, 0xf, false);
-            uint32_t acc[NP];
-            uint32_t DPv[NP], Uv[NP];               // the diagonal / vertical candidates (CODE compares the finished cell with them)
-            if (TAB) {
-                uint32_t D[NP];
-#pragma unroll
-                for (int q = 0; q < NP; ++q) { D[q] = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16); Uv[q] = pk_add(M[q], GG); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) { DPv[q] = pk_add(D[q], P[q]); acc[q] = pk_max(DPv[q], Uv[q]); }
-            } else {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
-                    DPv[q] = pk_add(D, P[q]); Uv[q] = pk_add(M[q], GG);
-                    acc[q] = pk_max(DPv[q], Uv[q]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NP; ++q) acc[q] = pk_chain_pair(acc[q]);
-#pragma unroll
-            for (int q = 1; q < NP; ++q) acc[q] = pk_max_bhi(acc[q], acc[q - 1]);
-            int sc = static_cast<int>(acc[NP - 1]) >> 16;
             {
-                constexpr int I = static_cast<int>(0x80000000u);
-                const uint32_t sy = meta_next & 255;
-                const uint32_t symsym = sy | (sy << 16);
-                uint32_t pw[NP];
-                if (TAB) {
-                    const uint32_t* src = ptab + (((sy >> 1) & 3) * NTH + t) * NP;
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) pw[q] = ABL == 5 ? MG : src[q];
-                    if (ABL != 1) {
-                    sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
-                    sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
-                    sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
-                    sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
-                    sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
-                    sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
-                    }
-                } else {
-#define RCN_GAPB(o) do { __builtin_amdgcn_sched_barrier(0); dp2_gap_op<NP, (o)>(pw, sqx, symsym, ONE, XM, MG); \
-                        dp2_gap_op<NP, (o) + 1>(pw, sqx, symsym, ONE, XM, MG); __builtin_amdgcn_sched_barrier(0); } while (0)
-                    RCN_GAPB(0);  sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
-                    RCN_GAPB(2);  sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
-                    RCN_GAPB(4);  sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
-                    RCN_GAPB(6);  sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
-                    RCN_GAPB(8);  sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
-                    RCN_GAPB(10); sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
-                    __builtin_amdgcn_sched_barrier(0);
-#undef RCN_GAPB
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(pw[q]));
-                }
-#pragma unroll
-                for (int q = 0; q < NP; ++q) Pn[q] = pw[q];
+#define RCN_TAIL_MULTI 2
+#define RCN_TAIL_SINK 1
+#include "poa_band_row_tail.inc"
+#undef RCN_TAIL_MULTI
+#undef RCN_TAIL_SINK
             }
-            zsh = dpp_or<0x138, 0xf>(zsh, sc);
-            const int zex = max(zsh, kNeg16);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
-
-            {
-                RCN_G uint32_t* dst = hrow + t * NP;                           // absolute columns; woff + WB <= hstride
-                if (CODE) {
-                    // ---- move codes of this row ----
-                    uint32_t b[NP];
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) {
-                        const uint32_t nd = pk_minu(pk_sub(acc[q], DPv[q]), ONE), nu = pk_minu(pk_sub(acc[q], Uv[q]), ONE);
-                        b[q] = pk_mad(nu, TWO2, nd);
-                    }
-                    if (multi) {
-                        // the diagonal move comes from the previous column: the argmax one column to the left
-                        const uint32_t aprev = __builtin_amdgcn_update_dpp(0u, Aq[NP - 1], 0x138, 0xf, 0xf, true);
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) {
-                            const uint32_t ash = __builtin_amdgcn_alignbit(Aq[q], q == 0 ? aprev : Aq[q - 1], 16);
-                            b[q] = pk_mad(Aq[q], C32, pk_mad(ash, FOUR2, b[q]));
-                        }
-                    }
-                    const uint32_t word = __builtin_amdgcn_perm(b[1], b[0], 0x06040200u);
-#if RCN_CODE_STORE == 0
-                    __builtin_nontemporal_store(word, reinterpret_cast<RCN_G uint32_t*>(crow) + t);
-#elif RCN_CODE_STORE == 1       // timing experiment: the codes are computed and dropped (results are wrong)
-                    asm volatile("" :: "v"(word));
-#elif RCN_CODE_STORE == 2       // plain store (L2 write-back policy)
-                    reinterpret_cast<RCN_G uint32_t*>(crow)[t] = word;
-#elif RCN_CODE_STORE == 3       // timing experiment: the same store into 16 rows that stay in the L2
-                    __builtin_nontemporal_store(word, reinterpret_cast<RCN_G uint32_t*>(g.H.ptr()) + (1 + (i & 15)) * (hs >> 2) + t);
-#endif
-                    crow += hs;
-                }
-                if (ABL == 8) dst = H + (1 + (i & 15)) * hs2 + t * NP;       // 8: the same store instruction into 16 rows that stay in the L2
-                if (ABL == 10) dst = H + (1 + (i & 255)) * hs2 + t * NP;     // 10: ... into 256 rows (256 KB per window: beyond L2 + MALL, few pages)
-                if (ABL == 11) dst = H + (1 + (i & 63)) * hs2 + t * NP;      // 11: ... into 64 rows (64 KB per window: beyond the L2, inside the MALL)
-                if (CODE) {
-                } else if (kBatch) {
-                    // stored from the register window, eight rows at a time (below)
-                } else if (NP == 2 && kNT && ABL == 0) {
-                    row_store2<true>(dst, acc[0], acc[1]);
-                } else if (ABL != 2 && !(ABL == 9 && (i & 1))) {             // 9: every other row only
-#pragma unroll
-                for (int q = 0; q < NP; ++q) dst[q] = acc[q];
-                }
-                hrow += hs2;
-            }
-            uint32_t* rdst = ring + (slot * NTH + t) * NP;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { if (ABL != 3) rdst[q] = acc[q]; if (ABL != 4) win[(i & (R - 1)) * NP + q] = acc[q]; prev[q] = acc[q]; }
-            edgeR = pk_max(edgeR, acc[NP - 1]);                                // (a): lane 63's high half is the last window cell
-            slot = (slot + 1 == K) ? 0 : slot + 1;
-            if (kBatch && (i & (R - 1)) == R - 1) { flush_rows(flushed + 1, i); flushed = i; }
-
-            if (ABL != 7 && __builtin_expect((meta & ((1 << 13) | 256)) == 256, 0)) {       // sink rows are never "fast" (rare: kept off the row path)
-                if (own_in) {
-                    uint32_t fv = acc[0];
-#pragma unroll
-                    for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q];
-                    const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16);
-                    const int val = __builtin_amdgcn_readlane(v16, own_lane);
-                    if (CODE && lane == 0) sinkz[i] = val;
-                    if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
-                    else if (best == val) {
-                        if (tied < 8 && lane == 0) *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(tie_base + 4u * tied) = static_cast<uint32_t>(i);
-                        ++tied;
-                    }
-                } else if (lane == 0) {
-                    // never computed: the sink-tie code compares this cell
-                    if (CODE) sinkz[i] = kNeg16; else H16w[static_cast<int64_t>(i) * hs + len] = static_cast<int16_t>(kNeg16);
-                }
-            }
-#ifdef RCN_PROF_ROWS
-            if (CODE && lane == 0) {
-                const unsigned long long dt = static_cast<unsigned long long>(clock64() - row_t0);
-                atomicAdd(&g_rowprof[blockIdx.x & 255][row_cls], dt);
-                atomicAdd(&g_rowprof[blockIdx.x & 255][8 + row_cls], 1ull);
-            }
-#endif
         }
     }
     if (kBatch && !bfail) flush_rows(flushed + 1, V);

@@ -415,20 +415,104 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         r.bases = layout_.bases.data(); r.quals = layout_.quals.data(); r.seq_has_qual = layout_.seq_has_qual.data();
         o.n_overlaps = layout_.q_id.size(); o.q_id = layout_.q_id.data(); o.t_id = layout_.t_id.data(); o.strand = layout_.strand.data();
         o.bp_off = layout_.bp_off.data(); o.bp_t = layout_.bp_t.data(); o.bp_q = layout_.bp_q.data();
-        auto engine = HipEngine::Create(0, match_, mismatch_, gap_);
-        if (device_align_) {
-            rcn_pair_set ps{};
-            ps.n_pairs = o.n_overlaps; ps.q_id = o.q_id; ps.t_id = o.t_id; ps.strand = o.strand;
-            ps.q_begin = layout_.q_begin.data(); ps.q_end = layout_.q_end.data(); ps.t_begin = layout_.t_begin.data(); ps.t_end = layout_.t_end.data();
-            engine->consensus(r, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &cons, &pol, &chim);
-        } else if (device_cigars_) {
-            rcn_cigar_set a{};
-            a.n_overlaps = o.n_overlaps; a.q_id = o.q_id; a.t_id = o.t_id; a.strand = o.strand;
-            a.q_start = layout_.q_start.data(); a.t_begin = layout_.t_begin.data(); a.t_end = layout_.t_end.data();
-            a.cigar_off = layout_.cigar_off.data(); a.cigar = layout_.cigar.data();
-            engine->consensus(r, a, window_length_, quality_threshold_, layout_.window_type, trim_, &cons, &pol, &chim);
-        } else
-        engine->consensus(r, o, window_length_, quality_threshold_, layout_.window_type, trim_, &cons, &pol, &chim);
+        // Shards: the window index space is cut into one contiguous range per device, balanced by the bases of the
+        // overlaps that fall into it (the reference's multi-device code hands window ranges to per-device batches the
+        // same way, src/cuda/cudapolisher.cpp:228-240).  A shard's engine gets every read (they are what overlaps
+        // point into) and the overlaps that touch its range -- an overlap across a boundary goes to both sides, the
+        // windows outside a shard's range come out as bare backbones there and are dropped.  RACON_HIP_DEVICE_SHARDS
+        // forces a shard count (tests: several shards on one device).
+        uint32_t n_shards = static_cast<uint32_t>(n_devices);
+        if (const char* sh = getenv("RACON_HIP_DEVICE_SHARDS")) n_shards = std::max(1, atoi(sh));
+        n_shards = static_cast<uint32_t>(std::min<uint64_t>(n_shards, std::max<uint64_t>(1, nw)));
+        std::vector<uint64_t> first_window(layout_.n_targets + 1, 0);
+        for (uint64_t t = 0; t < layout_.n_targets; ++t) {
+            const uint64_t len = layout_.seq_off[t + 1] - layout_.seq_off[t];
+            first_window[t + 1] = first_window[t] + (len + window_length_ - 1) / window_length_;
+        }
+        const uint64_t n_ovl = o.n_overlaps;
+        std::vector<uint64_t> w_lo(n_ovl), w_hi(n_ovl);          // windows [w_lo, w_hi] an overlap touches
+        std::vector<double> win_cost(nw + 1, 0.0);
+        for (uint64_t k = 0; k < n_ovl; ++k) {
+            const uint64_t tb = layout_.t_begin[k], te = std::max<uint64_t>(layout_.t_end[k], tb + 1);
+            w_lo[k] = first_window[o.t_id[k]] + tb / window_length_;
+            w_hi[k] = std::min<uint64_t>(first_window[o.t_id[k]] + (te - 1) / window_length_, nw - 1);
+            for (uint64_t w = w_lo[k]; w <= w_hi[k]; ++w) win_cost[w] += 1.0;
+        }
+        std::vector<uint64_t> cut(n_shards + 1, nw);
+        cut[0] = 0;
+        {
+            double total = 0; for (uint64_t w = 0; w < nw; ++w) total += win_cost[w] + 0.05;
+            double acc = 0; uint32_t sidx = 1;
+            for (uint64_t w = 0; w < nw && sidx < n_shards; ++w) {
+                acc += win_cost[w] + 0.05;
+                if (acc >= total * sidx / n_shards) cut[sidx++] = w + 1;
+            }
+        }
+        std::vector<std::string> shard_errors(n_shards);
+        auto run_shard = [&](uint32_t sidx) {
+            try {
+                const uint64_t wa = cut[sidx], wb = cut[sidx + 1];
+                if (wa >= wb) return;
+                std::vector<uint64_t> sel;
+                for (uint64_t k = 0; k < n_ovl; ++k) if (w_hi[k] >= wa && w_lo[k] < wb) sel.push_back(k);
+                const bool all = sel.size() == n_ovl;
+                // the selected overlaps' slices of the layout arrays
+                std::vector<uint32_t> q_id, t_id, bp_t, bp_q, q_start, t_begin, t_end, q_begin, q_end;
+                std::vector<uint8_t> strand, cigar;
+                std::vector<uint64_t> bp_off{0}, cigar_off{0};
+                if (!all) {
+                    for (uint64_t k : sel) {
+                        q_id.push_back(o.q_id[k]); t_id.push_back(o.t_id[k]); strand.push_back(o.strand[k]);
+                        q_start.push_back(layout_.q_start[k]); t_begin.push_back(layout_.t_begin[k]); t_end.push_back(layout_.t_end[k]);
+                        q_begin.push_back(layout_.q_begin[k]); q_end.push_back(layout_.q_end[k]);
+                        bp_t.insert(bp_t.end(), layout_.bp_t.begin() + layout_.bp_off[k], layout_.bp_t.begin() + layout_.bp_off[k + 1]);
+                        bp_q.insert(bp_q.end(), layout_.bp_q.begin() + layout_.bp_off[k], layout_.bp_q.begin() + layout_.bp_off[k + 1]);
+                        bp_off.push_back(bp_t.size());
+                        cigar.insert(cigar.end(), layout_.cigar.begin() + layout_.cigar_off[k], layout_.cigar.begin() + layout_.cigar_off[k + 1]);
+                        cigar_off.push_back(cigar.size());
+                    }
+                }
+                rcn_overlap_set so = o;
+                const uint32_t* p_q_start = layout_.q_start.data(); const uint32_t* p_t_begin = layout_.t_begin.data(); const uint32_t* p_t_end = layout_.t_end.data();
+                const uint32_t* p_q_begin = layout_.q_begin.data(); const uint32_t* p_q_end = layout_.q_end.data();
+                const uint64_t* p_cigar_off = layout_.cigar_off.data(); const uint8_t* p_cigar = layout_.cigar.data();
+                static const uint8_t kNoByte = 0; static const uint32_t kNoWord = 0;
+                if (!all) {
+                    so.n_overlaps = sel.size(); so.q_id = q_id.empty() ? &kNoWord : q_id.data(); so.t_id = t_id.empty() ? &kNoWord : t_id.data();
+                    so.strand = strand.empty() ? &kNoByte : strand.data(); so.bp_off = bp_off.data();
+                    so.bp_t = bp_t.empty() ? &kNoWord : bp_t.data(); so.bp_q = bp_q.empty() ? &kNoWord : bp_q.data();
+                    p_q_start = q_start.data(); p_t_begin = t_begin.data(); p_t_end = t_end.data(); p_q_begin = q_begin.data(); p_q_end = q_end.data();
+                    p_cigar_off = cigar_off.data(); p_cigar = cigar.empty() ? &kNoByte : cigar.data();
+                }
+                const int32_t device = static_cast<int32_t>(sidx % static_cast<uint32_t>(n_devices));
+                const uint32_t sharing = (n_shards + n_devices - 1) / n_devices;
+                auto engine = HipEngine::Create(device, match_, mismatch_, gap_, sharing > 1 ? static_cast<uint64_t>(HipEngine::FreeMemory(device) * 0.8 / sharing) : 0);
+                std::vector<std::string> c; std::vector<uint8_t> pl, ch;
+                if (device_align_) {
+                    rcn_pair_set ps{};
+                    ps.n_pairs = so.n_overlaps; ps.q_id = so.q_id; ps.t_id = so.t_id; ps.strand = so.strand;
+                    ps.q_begin = p_q_begin; ps.q_end = p_q_end; ps.t_begin = p_t_begin; ps.t_end = p_t_end;
+                    engine->consensus(r, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                } else if (device_cigars_) {
+                    rcn_cigar_set a{};
+                    a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
+                    a.q_start = p_q_start; a.t_begin = p_t_begin; a.t_end = p_t_end; a.cigar_off = p_cigar_off; a.cigar = p_cigar;
+                    engine->consensus(r, a, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                } else {
+                    engine->consensus(r, so, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                }
+                if (c.size() != nw) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
+                for (uint64_t w = wa; w < wb; ++w) { cons[w].swap(c[w]); pol[w] = pl[w]; chim[w] = ch[w]; }
+            } catch (const std::exception& ex) { shard_errors[sidx] = ex.what(); }
+        };
+        {
+            // one thread per device; the shards of one device run one after the other on it
+            std::vector<std::thread> pool;
+            const uint32_t lanes = std::min<uint32_t>(n_shards, static_cast<uint32_t>(n_devices));
+            for (uint32_t l = 0; l < lanes; ++l) pool.emplace_back([&, l]() { for (uint32_t sidx = l; sidx < n_shards; sidx += lanes) run_shard(sidx); });
+            for (auto& th : pool) th.join();
+        }
+        for (const auto& e : shard_errors) if (!e.empty()) fatal(e);
         if (cons.size() != nw) fatal("[racon::Polisher::polish] error: window count mismatch between host and device!");
         for (uint64_t i = 0; i < nw; ++i)
             if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",

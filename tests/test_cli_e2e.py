@@ -90,3 +90,18 @@ def test_cli_with_device_side_windows_matches_oracle(P, oracle, data, ovl, mode)
     out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
     assert out == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ovl,mode", [("sam", "1"), ("sam", "2"), ("paf", "2"), ("paf", "3")])
+def test_cli_device_windows_sharded(P, oracle, data, ovl, mode):
+    """RACON_HIP_DEVICE_SHARDS=3: the device-side construction cut into three window ranges (what the host layer does with
+    one range per device on a multi-GPU node; here the three shards share the one device): overlaps across a boundary go
+    to both sides, every window is taken from the shard that owns it -- same FASTA."""
+    paths, _ = data
+    ref, _ = _oracle_fasta(P, oracle, paths, ovl)
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    env = dict(os.environ, RACON_HIP_DEVICE_WINDOWS=mode, RACON_HIP_DEVICE_SHARDS="3")
+    out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
+    assert out == ref
