@@ -40,7 +40,7 @@ if has winprof; then
   RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_prof.so timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu > "$OUT/winprof_bench.json" 2> "$OUT/winprof.txt"
   grep -A6 "per-window clocks" "$OUT/winprof.txt" | tail -8
 fi
-BENCH_PROF="python bench.py --steps 3 --warmup 1 --no-cpu"
+BENCH_PROF="python bench.py --steps 3 --warmup 1 --no-cpu --no-upload-leg"
 if has prof; then
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- $BENCH_PROF > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
   echo "prof exit $?"; cat "$OUT/prof_bench.json"

@@ -3,7 +3,7 @@ import hashlib
 import os
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_FILES = ["poa_core.hpp", "poa_kernel.hpp", "poa_kernel2.hpp", "poa_band.hpp", "engine.hip"]
+_FILES = ["poa_core.hpp", "poa_kernel.hpp", "poa_kernel2.hpp", "poa_band.hpp", "poa_band_row_tail.inc", "engine.hip", "Makefile"]
 
 
 def kernel_source_hash() -> str:
