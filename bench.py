@@ -72,7 +72,7 @@ def main():
     m, x, g = [int(v) for v in a.scores.split(",")]
 
     from racon_amd.engine import HipEngine
-    from racon_amd.synth import config_windows, simulate_windows
+    from racon_amd.synth import config_windows, simulate_windows, simulate_windows_parallel
 
     if a.config:
         scaling, cfg_name = "weak", a.config
@@ -89,7 +89,11 @@ def main():
         contig, seed, scaling, cfg_name = 50_000_000 // world, 20260922 + rank, "strong", "cfg3 (50 Mbp / %d ranks)" % world
     a.contig = contig
     if not a.config:
-        batch = simulate_windows(contig, a.window, a.coverage, 10000, seed=seed)
+        # (long contigs are generated as 1 Mbp stretches in worker processes before any GPU work starts: the generator
+        #  is a Python loop per read, 8 s per Mbp; a 1 Mbp contig is exactly simulate_windows(...))
+        workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+        batch = simulate_windows_parallel(contig, a.window, a.coverage, 10000, seed=seed, workers=workers) if contig > 1_000_000 \
+            else simulate_windows(contig, a.window, a.coverage, 10000, seed=seed)
     eng = HipEngine(m, x, g, True, device=local_rank, max_slots=a.slots)
     eng.upload(batch)                                   # inputs resident in HBM from here on
 
@@ -187,8 +191,8 @@ def main():
                          "banded_alignments": st["n_banded"], "band_redone": st["n_band_redone"], "band_redo_why": st["band_redo_why"],
                          "phase_clocks": st["phase_clocks"]},
         }
-        if not a.no_cpu:
-            # CPU baseline on this box's host cores: the oracle's AVX2 int16 variant (the scheme of spoa's SIMD
+        if not a.no_cpu and world == 1:
+            # CPU baseline on this box's host cores (rank 0 at N = 1 only): the oracle's AVX2 int16 variant (the scheme of spoa's SIMD
             # engine: row vectors + log-step prefix max), all hardware threads, whole batch, best of 3.  The scalar
             # int32 oracle is timed next to it on a sample for reference.
             from oracle import oracle_lib

@@ -334,3 +334,27 @@ def simulate_layout(contig_lens=(30000, 12345), window_len: int = 500, coverage:
     if with_cigars:
         return ReadSet.from_sequences(seqs, len(targets)), OverlapSet.from_lists(ovl), window_type, CigarSet.from_lists(aligns)
     return ReadSet.from_sequences(seqs, len(targets)), OverlapSet.from_lists(ovl), window_type
+
+
+def _sim_piece(args):
+    contig_len, window_len, coverage, read_len, seed = args
+    return simulate_windows(contig_len, window_len, coverage, read_len, seed=seed)
+
+
+def simulate_windows_parallel(contig_len: int, window_len: int = 500, coverage: float = 30.0, read_len: int = 10000,
+                              seed: int = 20260921, piece: int = 1_000_000, workers: int = 16) -> WindowBatch:
+    """The windows of a long synthetic contig, generated as independent `piece`-bp stretches in worker processes (the
+    generator is a Python loop per read: 8 s per Mbp) and concatenated: reads do not span stretches, everything else --
+    depth distribution, error model, window shapes -- is the one-contig workload's.  A contig of at most one piece is
+    exactly simulate_windows(contig_len, ..., seed)."""
+    if contig_len <= piece:
+        return simulate_windows(contig_len, window_len, coverage, read_len, seed=seed)
+    sizes = [piece] * (contig_len // piece) + ([contig_len % piece] if contig_len % piece else [])
+    jobs = [(n, window_len, coverage, read_len, seed * 1000 + k) for k, n in enumerate(sizes)]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(max(1, min(workers, len(jobs)))) as pool:
+        parts = pool.map(_sim_piece, jobs)
+    out = parts[0]
+    for p in parts[1:]:
+        out = out.concat(p)
+    return out
