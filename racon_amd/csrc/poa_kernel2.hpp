@@ -1494,40 +1494,49 @@ __device__ __noinline__ void phase_traceback_code() {
                 const int4 pa = *reinterpret_cast<const int4*>(dr);
                 const int2 pb = *reinterpret_cast<const int2*>(dr + 4);
                 const int code = tile[tilec_at(trow, tcol)];
-                int mv, q = 0;
-                if (ii == 0) mv = jj > 0 ? kMvLeft : kMvInvalid;
-                else if (jj > 0 && !(code & 1)) { mv = kMvDiag; q = (code >> 2) & 7; }
-                else if (!(code & 2)) { mv = kMvUp; q = code >> 5; }
-                else mv = jj > 0 ? kMvLeft : kMvInvalid;
-                int pi = q == 0 ? pa.x : q == 1 ? pa.y : q == 2 ? pa.z : q == 3 ? pa.w : q == 4 ? pb.x : pb.y;
-                if (q > 5 && inside && mv != kMvLeft) {
-                    // seventh / eighth in-edge (rare): not in the descriptor, the q - 6 th included tail of the rest of the list
-                    pi = -1;
-                    int left = q - 6;
-                    for (int e = dr[6]; e >= 0; e = e_nin[e]) {
-                        const int tl = e_tail[e];
-                        if (sub && !inc[tl]) continue;
-                        if (left == 0) { pi = nr[tl] + 1; break; }
-                        --left;
+                // decode without branches (selects only: the lanes disagree on every one of these conditions, and as
+                // branches each of them is an exec-mask region of its own -- the box used to spend more instructions on
+                // entering and leaving those than on the decision)
+                const bool row0 = ii == 0, jpos = jj > 0;
+                const bool dg = !row0 && jpos && !(code & 1);
+                const bool up = !row0 && !dg && !(code & 2);
+                int mv = dg ? kMvDiag : up ? kMvUp : jpos ? kMvLeft : kMvInvalid;
+                const int q = dg ? ((code >> 2) & 7) : up ? (code >> 5) : 0;
+                // (the six predecessor rows are in registers before the choice: left to itself the compiler turns the
+                //  select back into six conditional LDS loads, each in an exec-mask region)
+                int p0_ = pa.x, p1_ = pa.y, p2_ = pa.z, p3_ = pa.w, p4_ = pb.x, p5_ = pb.y;
+                asm volatile("" : "+v"(p0_), "+v"(p1_), "+v"(p2_), "+v"(p3_), "+v"(p4_), "+v"(p5_));
+                const bool q1 = (q & 1) != 0, q2 = (q & 2) != 0, q4 = (q & 4) != 0;
+                const int a01 = q1 ? p1_ : p0_, a23 = q1 ? p3_ : p2_, a45 = q1 ? p5_ : p4_;
+                const int a03 = q2 ? a23 : a01;
+                int pi = q4 ? a45 : a03;
+                const bool far = q > 5 && inside && mv != kMvLeft;
+                if (__builtin_expect(__ballot(far) != 0ull, 0)) {
+                    if (far) {
+                        // seventh / eighth in-edge (rare): not in the descriptor, the q - 6 th included tail of the rest of the list
+                        pi = -1;
+                        int left = q - 6;
+                        for (int e = dr[6]; e >= 0; e = e_nin[e]) {
+                            const int tl = e_tail[e];
+                            if (sub && !inc[tl]) continue;
+                            if (left == 0) { pi = nr[tl] + 1; break; }
+                            --left;
+                        }
                     }
                 }
-                if (!inside || (mv != kMvLeft && pi < 0)) mv = kMvInvalid;
+                mv = (!inside || (mv != kMvLeft && pi < 0)) ? kMvInvalid : mv;
                 const int ni = mv == kMvLeft ? ii : pi, nj = jj - (mv == kMvUp ? 0 : 1);
                 const int na = i - ni, nb = j - nj;
-                int nx;
-                if (mv == kMvInvalid) nx = kNxInvalid;
-                else if (ni == 0 && nj == 0) nx = kNxExit;
-                else if (na >= kBoxRows || nb >= kBoxCols) nx = kNxExit;
-                else nx = na * kBoxCols + nb;
-                int idx = 0, nxt;
+                const bool leaves = (ni == 0 && nj == 0) || na >= kBoxRows || nb >= kBoxCols;
+                const int nx = mv == kMvInvalid ? kNxInvalid : leaves ? kNxExit : na * kBoxCols + nb;
+                // the walk inside the box: one readlane per step, four steps per loop iteration (a taken branch costs as
+                // much as eight instructions, the early exits in between are not taken)
+                int idx = 0, nxt = kNxInvalid;
                 unsigned long long vis = 0ull;
-                for (;;) {
-                    nxt = __builtin_amdgcn_readlane(nx, idx);
-                    if (nxt == kNxInvalid) break;
-                    vis |= 1ull << idx;
-                    if (nxt >= 64) break;
-                    idx = nxt;
-                }
+#define RCN_WALK_STEP { nxt = __builtin_amdgcn_readlane(nx, idx); if (nxt == kNxInvalid) goto walk_done; vis |= 1ull << idx; if (nxt >= 64) goto walk_done; idx = nxt; }
+                for (;;) { RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP }
+#undef RCN_WALK_STEP
+            walk_done:
                 if (((vis >> lane) & 1ull) && mv != kMvUp) prow[jj - 1] = (mv == kMvDiag) ? ii : -1;
                 bool stuck = false;
                 if (nxt == kNxInvalid) { stuck = idx == 0; i = __builtin_amdgcn_readlane(ii, idx); j = __builtin_amdgcn_readlane(jj, idx); }
