@@ -226,7 +226,7 @@ __device__ __noinline__ void dp2_rows_band() {
     };
 
     int best = 0, best_row = 0, have_best = 0, tied = 0;
-    unsigned int pred_rows = 0, not_chain = 0;
+    unsigned int pred_rows = 0;             // predecessor rows combined (statistics: the algorithmic bytes of this alignment)
     int slot = 1 % K;
     RCN_G uint32_t* hrow = H + hs2;             // wave-uniform: row i of the matrix at the window's first column
     // CODE: one byte per cell, absolute columns, row stride hs BYTES (same base as the score matrix it replaces)
@@ -311,6 +311,14 @@ __device__ __noinline__ void dp2_rows_band() {
                 for (int q = 0; q < kInlinePreds; ++q) d.p[q] = in ? dd_.p[q] : d.p[q];
                 d.erest = in ? dd_.erest : d.erest; d.meta = in ? dd_.meta : d.meta; ro = in ? ro_ : ro;
             }
+            {
+                // statistics off the row path: the predecessor counts of this block's chain / fast rows, summed once per
+                // 64 rows (the other classes count theirs as they go)
+                int npl = (rbase + lane < V && (d.meta & (1 << 13))) ? ((d.meta >> 9) & 7) : 0;
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) npl += __shfl_xor(npl, sh);
+                pred_rows += static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(npl));
+            }
             dl_p0 = d.p[0]; dl_p1 = d.p[1]; dl_p2 = d.p[2]; dl_p3 = d.p[3]; dl_p4 = d.p[4]; dl_p5 = d.p[5]; dl_er = d.erest; dl_meta = d.meta; dl_off = ro;
             asm volatile("; row descriptors retired" : "+v"(dl_p0), "+v"(dl_p1), "+v"(dl_p2), "+v"(dl_p3), "+v"(dl_p4), "+v"(dl_p5), "+v"(dl_er), "+v"(dl_meta), "+v"(dl_off));
         }
@@ -385,9 +393,6 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) M[q] = win[wi + q];
                 }
-                const unsigned int nonchain = ((static_cast<unsigned int>(meta) >> 15) & 1u) ^ 1u;
-                not_chain += nonchain;
-                pred_rows += nonchain ? static_cast<unsigned int>(npf) : 0u;
                 if (__builtin_expect(npf > 1, 0)) {      // (38 % of the rows; kept off the fall-through path of the other 60 %)
                     {
                         const int wi = ((i - static_cast<int>((dd >> 4) & 15)) & (R - 1)) * NP;
@@ -438,9 +443,7 @@ __device__ __noinline__ void dp2_rows_band() {
                 for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
                 }
                 pred_rows += npf;
-                ++not_chain;
             } else {
-                ++not_chain;
                 // ---- general row: any number of predecessors from the LDS ring, each in the coordinates it was
                 //      written in (window offsets of the last two shifts are kept) ----
                 const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
@@ -549,7 +552,6 @@ __device__ __noinline__ void dp2_rows_band() {
         o->best = best; o->best_row = best_row; o->tied = tied; o->band_fail = fail;
         if (!fail) {
             const int W = len + 1;
-            pred_rows += static_cast<unsigned int>(V) - not_chain;
             o->pred_rows = pred_rows;
             const unsigned long long wcols = static_cast<unsigned long long>(W < WB ? W : WB);
             o->cells += static_cast<unsigned long long>(V + 1) * wcols;

@@ -1372,13 +1372,10 @@ __device__ __noinline__ void phase_traceback3() {
                 // ---- walk: one v_readlane per step ----
                 int idx = 0, nxt;
                 unsigned long long vis = 0ull;
-                for (;;) {
-                    nxt = __builtin_amdgcn_readlane(nx, idx);
-                    if (nxt == kNxInvalid) break;
-                    vis |= 1ull << idx;
-                    if (nxt >= 64) break;
-                    idx = nxt;
-                }
+#define RCN_WALK_STEP { nxt = __builtin_amdgcn_readlane(nx, idx); if (nxt == kNxInvalid) goto walk3_done; vis |= 1ull << idx; if (nxt >= 64) goto walk3_done; idx = nxt; }
+                for (;;) { RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP }      // four steps per back-edge
+#undef RCN_WALK_STEP
+            walk3_done:
                 // emit the sequence positions consumed inside the box
                 if (((vis >> lane) & 1ull) && mv != kMvUp) prow[jj - 1] = (mv == kMvDiag) ? ii : -1;
                 bool stuck = false;

@@ -1,7 +1,12 @@
 #!/bin/bash
 set -u
-TAG=${1:-r02m}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"
+TAG=${1:-r02n}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 L=$PWD/racon_amd/csrc
 timeout 600 python -m pytest tests/test_gpu_band.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py -q -x --timeout 600 > "$OUT/tests.log" 2>&1; echo "tests exit $?" >> "$OUT/tests.log"; tail -3 "$OUT/tests.log"
 bash tools/ab.sh $TAG 3 "RACON_HIP_LIB=$L/libracon_hip_old.so" "RCN_X=0" | sed -e "s#RACON_HIP_LIB=$L/libracon_hip_##"
-for CFG in cfg4 w1000; do AB_ARGS="--config $CFG" bash tools/ab.sh ${TAG}_$CFG 1 "RACON_HIP_LIB=$L/libracon_hip_old.so" "RCN_X=0" | sed -e "s#RACON_HIP_LIB=$L/libracon_hip_##"; done
+python - "$OUT" <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/ab_*_1.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); r = j["roofline"]
+    print(f, "algorithmic bytes", r["algorithmic_bytes_per_launch"], "full", r["full_matrix"]["algorithmic_bytes_per_launch"])
+PY
