@@ -189,8 +189,8 @@ typedef struct rcn_build_stats {
 } rcn_build_stats;
 
 /* Builds the resident batch (every window of every target, in target order).  window_type: 0 kNGS,
- * 1 kTGS (src/polisher.cpp:277-278).  RCN_E_ARG when a layer violates the add_layer contract
- * (src/window.cpp:49-58), as the reference's fatal error would.                                   */
+ * 1 kTGS (src/polisher.cpp:277-278).  RCN_E_LAYER when a layer violates the add_layer contract
+ * (src/window.cpp:49-58), where the reference exits with its fatal error; RCN_E_ARG for malformed arguments. */
 int  rcn_engine_build_windows(rcn_engine* e, const rcn_read_set* reads, const rcn_overlap_set* overlaps,
                               uint32_t window_length, double quality_threshold, uint8_t window_type);
 /* The same from alignments: breaking points (reference src/overlap.cpp:226-292) + window construction, all in HBM.
@@ -259,6 +259,7 @@ const char* rcn_version(void);
 #define RCN_E_NOMEM       (-4)
 #define RCN_E_STATE       (-5)
 #define RCN_E_CAPACITY    (-6)
+#define RCN_E_LAYER       (-7)   /* a layer violates the Window::add_layer contract (src/window.cpp:49-58): the reference's fatal error */
 
 #ifdef __cplusplus
 }

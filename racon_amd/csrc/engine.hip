@@ -409,6 +409,7 @@ const char* rcn_strerror(int code) {
         case RCN_E_NOMEM: return "out of device memory";
         case RCN_E_STATE: return "call sequence error";
         case RCN_E_CAPACITY: return "window exceeds device scratch budget";
+        case RCN_E_LAYER: return "layer begin and end positions are invalid (Window::add_layer contract)";
         default: return "unknown";
     }
 }

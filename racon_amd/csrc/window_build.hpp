@@ -479,7 +479,7 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     HIP_TRY(hipMemcpyAsync(&ns, d_cnt + nw, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (h_err[0]) { drop_events(); return RCN_E_ARG; }       // "[racon::Window::add_layer] error: layer begin and end positions are invalid!"
+    if (h_err[0]) { drop_events(); return RCN_E_LAYER; }     // "[racon::Window::add_layer] error: layer begin and end positions are invalid!"
     const uint64_t n_layers = ns - nw;
 
     // sequence table + offsets

@@ -147,7 +147,7 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_overlap_set& over
     const Abi& a = abi();
     int rc = a.set_trim(handle_, trim ? 1 : 0);
     if (rc == RCN_OK) rc = a.build_windows(handle_, &reads, &overlaps, window_length, quality_threshold, window_type);
-    if (rc == RCN_E_ARG) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
+    if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
     fetch(rc, consensus, polished, chimeric);
 }
 
@@ -157,7 +157,7 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_cigar_set& alignm
     const Abi& a = abi();
     int rc = a.set_trim(handle_, trim ? 1 : 0);
     if (rc == RCN_OK) rc = a.build_windows_from_cigars(handle_, &reads, &alignments, window_length, quality_threshold, window_type);
-    if (rc == RCN_E_ARG) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
+    if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
     fetch(rc, consensus, polished, chimeric);
 }
 
@@ -167,7 +167,7 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_pair_set& pairs, 
     const Abi& a = abi();
     int rc = a.set_trim(handle_, trim ? 1 : 0);
     if (rc == RCN_OK) rc = a.build_windows_from_pairs(handle_, &reads, &pairs, window_length, quality_threshold, window_type);
-    if (rc == RCN_E_ARG) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
+    if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
     fetch(rc, consensus, polished, chimeric);
 }
 

@@ -315,6 +315,8 @@ void Polisher::initialize() {
     targets_coverages_.assign(targets_size, 0);
     if (device_windows_) {                      // the layers are cut on the device, from layout_ (polish())
         for (auto& o : overlaps) { ++targets_coverages_[o->t_id()]; o.reset(); }
+        // the reads now live in layout_ only (the targets stay: windows_ point into their backbones)
+        for (uint64_t i = targets_size; i < sequences_.size(); ++i) sequences_[i]->release_data();
         logger_->log("[racon::Polisher::initialize] transformed data into windows");
         return;
     }

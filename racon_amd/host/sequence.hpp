@@ -30,6 +30,9 @@ public:
 
     void create_reverse_complement();                                   // src/sequence.cpp:49-84
     void transmute(bool has_name, bool has_data, bool has_reverse_data); // src/sequence.cpp:86-103
+    // (not in the reference) drops bases and qualities of both strands: the device-windows path keeps the reads in its
+    // flattened layout only (Polisher::initialize)
+    void release_data() { std::string().swap(data_); std::string().swap(quality_); std::string().swap(reverse_complement_); std::string().swap(reverse_quality_); }
 
 private:
     std::string name_, data_, reverse_complement_, quality_, reverse_quality_;

@@ -45,6 +45,7 @@ def test_small_pairs_against_oracle_and_host(P):
     rng = np.random.default_rng(9100)
     pairs = [(b"A", b"A"), (b"A", b"C"), (b"ACGT", b"A"), (b"A", b"ACGT"), (b"ACGTACGT", b"ACGTACGT"), (b"AAAA", b"TTTT"),
              (b"ACGTNNACGT", b"ACGTACGT"), (b"GATTACA" * 30, b"GATACA" * 30)]
+    pairs += [(b"", b"ACGT"), (b"ACGTT", b"")]                       # an empty side: all deletions / all insertions
     for n in [2, 3, 63, 64, 65, 127, 128, 129, 200, 500, 900, 1500]:
         t = random_seq(rng, n)
         pairs.append((mutate(rng, t, float(rng.choice([0.02, 0.1, 0.3]))), t))
