@@ -76,3 +76,19 @@ def test_cost_balanced_shards_at_cfg3_size():
         assert per.max() / per.mean() < 1.02, (world, per / per.mean())
     equal = np.array([cost[r * nw // 8:(r + 1) * nw // 8].sum() for r in range(8)])
     assert equal.max() / equal.mean() > 1.2
+
+
+def test_parallel_generator_is_the_concatenation_of_its_pieces():
+    """bench.py's multi-rank default (cfg3: 50 Mbp / ranks) generates its windows as 1 Mbp stretches in worker processes:
+    the result must be exactly the concatenation of simulate_windows() over the pieces' sizes and seeds, and a contig of
+    one piece exactly simulate_windows() itself."""
+    from racon_amd.synth import simulate_windows, simulate_windows_parallel
+    b = simulate_windows_parallel(125_000, 500, 12.0, 4000, seed=77, piece=50_000, workers=3)
+    parts = [simulate_windows(n, 500, 12.0, 4000, seed=77 * 1000 + k) for k, n in enumerate([50_000, 50_000, 25_000])]
+    ref = parts[0].concat(parts[1]).concat(parts[2])
+    assert b.n_windows == ref.n_windows == 250
+    for name in ("win_seq_off", "win_type", "seq_off", "seq_has_qual", "seq_begin", "seq_end", "bases", "quals"):
+        assert np.array_equal(getattr(b, name), getattr(ref, name)), name
+    one = simulate_windows_parallel(40_000, 500, 12.0, 4000, seed=5, piece=50_000)
+    same = simulate_windows(40_000, 500, 12.0, 4000, seed=5)
+    assert np.array_equal(one.bases, same.bases) and np.array_equal(one.seq_off, same.seq_off)
