@@ -45,11 +45,19 @@ __device__ __forceinline__ uint64_t last_le(const T* a, uint64_t n, T x) {
     return lo;
 }
 
+// which overlap a breaking-point pair belongs to: one thread per overlap writes its own pairs (a binary search over the
+// offsets per pair is ~15 dependent HBM loads in front of everything else the filter does: it was most of its time)
+__global__ __launch_bounds__(256) void k_pair_owner(BuildParams P) {
+    const uint64_t o = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (o >= P.n_overlaps) return;
+    for (uint64_t p = P.bp_off[o] / 2, e = P.bp_off[o + 1] / 2; p < e; ++p) P.pair_ovl[p] = static_cast<uint32_t>(o);
+}
+
 __global__ __launch_bounds__(256) void k_layer_filter(BuildParams P) {
     const int lane = threadIdx.x & 63;
     const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (p >= P.n_pairs) return;
-    const uint64_t o = last_le<uint64_t>(P.bp_off, P.n_overlaps + 1, 2 * p);
+    const uint64_t o = P.pair_ovl[p];
     const uint32_t t0 = P.bp_t[2 * p], t1 = P.bp_t[2 * p + 1], q0 = P.bp_q[2 * p], q1 = P.bp_q[2 * p + 1];
     const uint32_t qi = P.q_id[o], ti = P.t_id[o];
     const bool rev = P.strand[o] != 0;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void k_layer_filter(BuildParams P) {
     }
     if (lane == 0) {
         P.key[p] = keep ? wid : P.n_windows; P.val[p] = static_cast<uint32_t>(p);
-        P.pair_begin[p] = begin; P.pair_end[p] = end; P.pair_q0[p] = q0; P.pair_len[p] = dl; P.pair_ovl[p] = static_cast<uint32_t>(o);
+        P.pair_begin[p] = begin; P.pair_end[p] = end; P.pair_q0[p] = q0; P.pair_len[p] = dl;
         if (keep) atomicAdd(&P.win_cnt[wid], 1u);
     }
 }
@@ -169,12 +177,22 @@ __global__ __launch_bounds__(256) void k_symbols(const uint8_t* bases, uint64_t 
     if (threadIdx.x < 8) pres[threadIdx.x] = 0;
     __syncthreads();
     uint32_t acgt = 0;                                       // symbols 64..95, where ACGT live; anything else through LDS
-    for (uint64_t k = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; k < n; k += static_cast<uint64_t>(gridDim.x) * blockDim.x * 4) {
-        for (int j = 0; j < 4 && k + j < n; ++j) {
-            const uint32_t b = bases[k + j];
-            if ((b >> 5) == 2) acgt |= 1u << (b & 31); else atomicOr(&pres[b >> 5], 1u << (b & 31));
+    auto one = [&](uint32_t b) { if ((b >> 5) == 2) acgt |= 1u << (b & 31); else atomicOr(&pres[b >> 5], 1u << (b & 31)); };
+    // sixteen bytes per load (the buffer is 256-byte aligned and padded); a dword whose four bytes all lie in 64..95 -- all
+    // of them, for A/C/G/T reads -- costs four shifts, anything else goes byte by byte
+    const uint64_t n16 = n & ~15ull;
+    const uint4* v = reinterpret_cast<const uint4*>(bases);
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n16 / 16; k += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint4 q = v[k];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (((w[j] >> 5) & 0x07070707u) == 0x02020202u)
+                acgt |= (1u << (w[j] & 31)) | (1u << ((w[j] >> 8) & 31)) | (1u << ((w[j] >> 16) & 31)) | (1u << ((w[j] >> 24) & 31));
+            else { one(w[j] & 255); one((w[j] >> 8) & 255); one((w[j] >> 16) & 255); one(w[j] >> 24); }
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x < 16 && n16 + threadIdx.x < n) one(bases[n16 + threadIdx.x]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acgt |= __shfl_xor(acgt, d);
     if ((threadIdx.x & 63) == 0 && acgt) atomicOr(&pres[2], acgt);
@@ -463,7 +481,10 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
         hipLaunchKernelGGL(k_ops_breaking_points, dim3(static_cast<uint32_t>((O.n_overlaps + 3) / 4)), dim3(256), 0, st, K);
     }
     hipLaunchKernelGGL(k_symbols, dim3(static_cast<uint32_t>(std::min<uint64_t>(1024, (read_bytes + 1023) / 1024 + 1))), dim3(256), 0, st, P.bases, read_bytes, d_err + 1);
-    if (n_pairs) hipLaunchKernelGGL(k_layer_filter, dim3(static_cast<uint32_t>((n_pairs + 3) / 4)), dim3(256), 0, st, P);
+    if (n_pairs) {
+        hipLaunchKernelGGL(k_pair_owner, dim3(static_cast<uint32_t>((O.n_overlaps + 255) / 256)), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(k_layer_filter, dim3(static_cast<uint32_t>((n_pairs + 3) / 4)), dim3(256), 0, st, P);
+    }
     HIP_TRY(hipGetLastError());
 
     // stable sort of the pairs by window id (dropped pairs carry key nw and end up behind)
