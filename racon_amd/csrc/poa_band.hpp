@@ -230,7 +230,11 @@ __device__ __noinline__ void dp2_rows_band() {
     int slot = 1 % K;
     RCN_G uint32_t* hrow = H + hs2;             // wave-uniform: row i of the matrix at the window's first column
     // CODE: one byte per cell, absolute columns, row stride hs BYTES (same base as the score matrix it replaces)
-    RCN_G uint8_t* crow = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr()) + hs;
+    RCN_G uint8_t* cbase = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr());
+    // this lane's dword of the current code row as a 32-bit offset in a VGPR: one vector add per row instead of a 64-bit
+    // scalar add plus the lane term rebuilt for every store (the slot is ~3 MB: 32 bits are plenty)
+    uint32_t coff = static_cast<uint32_t>(hs) + 4u * static_cast<uint32_t>(t);
+    asm volatile("" : "+v"(coff));
     RCN_G int32_t* sinkz = g.path_node.ptr();   // CODE: end score (column len) of the sink rows, for phase_sink_tie_full
     const uint32_t TWO2 = 0x00020002u, FOUR2 = 0x00040004u, C32 = 0x00200020u;
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
@@ -289,7 +293,7 @@ __device__ __noinline__ void dp2_rows_band() {
         }
         off2 = off1; s_row3 = s_row2; off1 = woff; s_row2 = s_row1; s_row1 = i; woff = new_off;
         hrow = H + static_cast<int64_t>(i) * hs2 + (woff >> 1);
-        crow = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr()) + static_cast<int64_t>(i) * hs + woff;
+        coff = static_cast<uint32_t>(i) * static_cast<uint32_t>(hs) + static_cast<uint32_t>(woff) + 4u * static_cast<uint32_t>(t);
         set_columns();
     };
 
@@ -345,8 +349,10 @@ __device__ __noinline__ void dp2_rows_band() {
             // only hand over `prev` (with the window written in each of them the compiler copies all sixteen registers
             // per row to reconcile the copies)
             if (!kBatch && ABL != 4) {
+                __builtin_amdgcn_sched_barrier(0);       // (the two indexed writes back to back: one register-index mode region, not two)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) win[((i - 1) & (R - 1)) * NP + q] = prev[q];
+                __builtin_amdgcn_sched_barrier(0);
             }
 #ifdef RCN_PROF_ROWS
             const long long row_t0 = clock64();
@@ -397,8 +403,10 @@ __device__ __noinline__ void dp2_rows_band() {
                     {
                         const int wi = ((i - static_cast<int>((dd >> 4) & 15)) & (R - 1)) * NP;
                         uint32_t zq[NP];
+                        __builtin_amdgcn_sched_barrier(0);   // (both indexed reads in one register-index mode region)
 #pragma unroll
                         for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
+                        __builtin_amdgcn_sched_barrier(0);
                         if (CODE) arg_step(zq, 1);
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
@@ -407,8 +415,10 @@ __device__ __noinline__ void dp2_rows_band() {
                     for (int e = 2; e < npf; ++e) {
                         const int wi = ((i - static_cast<int>((dd >> (4 * e)) & 15)) & (R - 1)) * NP;
                         uint32_t zq[NP];
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
+                        __builtin_amdgcn_sched_barrier(0);
                         if (CODE) arg_step(zq, e);
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
