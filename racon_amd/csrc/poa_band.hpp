@@ -157,6 +157,10 @@ __device__ __noinline__ void dp2_rows_band() {
     uint32_t* ptab = ring + KT * NTH * NP;                                    // [4][NTH][NP] (TAB)
     uint8_t* lseq = reinterpret_cast<uint8_t*>(ptab + kTab / 4);             // [kBandSeq]
     for (int k = t; k < len; k += NTH) lseq[k] = seq[k];
+    // this lane's slice of the profile table as an LDS byte address held in a VGPR: table slot -> address is one add
+    typedef __attribute__((address_space(3))) const uint32_t* lds_cu32;
+    uint32_t ptab_l = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ptab + t * NP));
+    asm volatile("" : "+v"(ptab_l));
 
     const int mg = c.m - c.gp, xg = c.x - c.gp;
     uint32_t MG = pack2(mg, mg), XM = pack2(xg - mg, xg - mg), ONE = 0x00010001u;
@@ -236,7 +240,6 @@ __device__ __noinline__ void dp2_rows_band() {
     uint32_t coff = static_cast<uint32_t>(hs) + 4u * static_cast<uint32_t>(t);
     asm volatile("" : "+v"(coff));
     RCN_G int32_t* sinkz = g.path_node.ptr();   // CODE: end score (column len) of the sink rows, for phase_sink_tie_full
-    const uint32_t TWO2 = 0x00020002u, FOUR2 = 0x00040004u, C32 = 0x00200020u;
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
 
     // the window moves to new_off before row i is computed
@@ -331,7 +334,7 @@ __device__ __noinline__ void dp2_rows_band() {
         uint32_t Pn[NP];
         auto profile_now = [&](int meta_) {
             if (TAB) {
-                const uint32_t* src = ptab + ((((meta_ & 255) >> 1) & 3) * NTH + t) * NP;
+                const lds_cu32 src = reinterpret_cast<lds_cu32>(ptab_l + (((meta_ & 255) >> 1) & 3) * (NTH * NP * 4));
 #pragma unroll
                 for (int q = 0; q < NP; ++q) Pn[q] = src[q];
             } else {
@@ -376,7 +379,6 @@ __device__ __noinline__ void dp2_rows_band() {
             uint32_t Aq[NP];                        // CODE: per cell, the first predecessor (in-edge order) that attains M
 #pragma unroll
             for (int q = 0; q < NP; ++q) Aq[q] = 0u;
-            bool multi = false;                     // CODE: the row has more than one predecessor
             // running "first argmax": predecessor number e replaces the holder where it is strictly greater
             auto arg_step = [&](const uint32_t (&zq)[NP], int e) {
                 const uint32_t Q = pack2(e, e);
@@ -423,7 +425,6 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
                     }
-                    multi = true;
                 }
             } else if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
                 // ---- medium row whose predecessors all share this row's window: LDS ring, reads in flight together ----
@@ -447,7 +448,6 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[e][q]);
                     }
-                    multi = npf > 1;
                 } else {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
@@ -512,7 +512,7 @@ __device__ __noinline__ void dp2_rows_band() {
                         for (int q = 0; q < NP; ++q) M[q] = hp[q];
                         first = false;
                     } else {
-                        if (CODE) { arg_step(hp, nq); multi = true; }
+                        if (CODE) arg_step(hp, nq);
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[q]);
                     }
