@@ -1454,6 +1454,9 @@ __device__ __noinline__ void phase_traceback_code() {
     int overflow = g.overflow;
     while (!(i == 0 && j == 0)) {
         const int ti0 = i, j_stage = j;
+#ifdef RCN_PROF_WIN
+        if (t == 0) o->dbg_tiles += 1;
+#endif
         int c0 = (j - 56) & ~7; if (c0 < 0) c0 = 0;
         const int rmin = ti0 - (kTbRows - 1) > 0 ? ti0 - (kTbRows - 1) : 0;
         {
@@ -1484,6 +1487,9 @@ __device__ __noinline__ void phase_traceback_code() {
             const int a = lane / kBoxCols, b = lane % kBoxCols;
             for (;;) {
                 if (i == 0 && j == 0) break;
+#ifdef RCN_PROF_WIN
+                if (lane == 0) o->dbg_boxes += 1;
+#endif
                 const int ii = i - a, jj = j - b;
                 const bool inside = a < kBoxRows && ii >= rmin && ii >= 0 && jj >= c0 && jj >= 0;
                 const int trow = inside ? ti0 - ii : 0, tcol = inside ? jj - c0 : 0;
