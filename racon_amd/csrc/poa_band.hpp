@@ -426,7 +426,16 @@ __device__ __noinline__ void dp2_rows_band() {
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
                     }
                 }
-            } else if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
+                {
+#define RCN_TAIL_MULTI 2
+#define RCN_TAIL_SINK 0
+#include "poa_band_row_tail.inc"
+#undef RCN_TAIL_MULTI
+#undef RCN_TAIL_SINK
+                }
+                continue;
+            }
+            if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
                 // ---- medium row whose predecessors all share this row's window: LDS ring, reads in flight together ----
                 const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
                 const int npf = (meta >> 9) & 7;
