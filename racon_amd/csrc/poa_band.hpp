@@ -171,14 +171,20 @@ __device__ __noinline__ void dp2_rows_band() {
     asm volatile("" : "+s"(tie_base));
 
     // ---- window state ----
-    int woff = 0;                               // first column of the window
-    int s_row1 = 0, s_row2 = 0, s_row3 = 0;     // rows >= s_row1 have offset woff, rows in [s_row2, s_row1) off1, [s_row3, s_row2) off2
-    int off1 = 0, off2 = 0;
+    // State that only the rare rows touch (window shifts, general rows) lives in LDS, behind the layer's bases: kept in
+    // registers it is loop-carried through the row loop, and the chain / fast rows pay for the copies that reconcile it.
+    //   woff: first column of the window; rows >= s_row1 have offset woff, rows in [s_row2, s_row1) off1, [s_row3, s_row2) off2
+    struct BandCold { int woff, s_row1, s_row2, s_row3, off1, off2; };
+    static_assert(kBandSeq >= 1024 + static_cast<int>(sizeof(BandCold)), "cold state sits behind the bases (a layer has at most 640)");
+    BandCold* cold = reinterpret_cast<BandCold*>(lseq + 1024);
+    { BandCold z = {0, 0, 0, 0, 0, 0}; *cold = z; }
+    auto cold_get = [&](const int* p_) { return __builtin_amdgcn_readfirstlane(*p_); };
     int bfail = 0;
     uint32_t sqx[NP], thrv[NP];                 // bases / alive thresholds (m - g) * column of this lane's columns
     int own_lane = 0, own_q = 0, own_in = 0;    // where column len lives (own_in: inside the window)
     const int own_hi = len & 1;
     auto set_columns = [&]() {
+        const int woff = cold_get(&cold->woff);
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int j0 = woff + t * LPC + 2 * q, j1 = j0 + 1;
@@ -221,6 +227,7 @@ __device__ __noinline__ void dp2_rows_band() {
     uint32_t emaxV = pack2(-32768, -32768), edgeR = NEGP;
     int edgeS = -(1 << 30);
     auto flush_edge = [&]() {
+        const int woff = cold_get(&cold->woff);
         const int lastcol = woff + WB - 1;
         if (lastcol < len) {
             const int zr = static_cast<int>(__builtin_amdgcn_readlane(static_cast<int>(edgeR), 63)) >> 16;
@@ -247,6 +254,7 @@ __device__ __noinline__ void dp2_rows_band() {
     // batched row stores: rows [first, last] (all still in the register window, all written under the current window
     // offset) go out back to back
     auto flush_rows = [&](int first, int last) {
+        const int woff = cold_get(&cold->woff);
 #pragma unroll
         for (int w = 0; w < R; ++w) {
             const int r = (last & ~(R - 1)) + w - ((w > (last & (R - 1))) ? R : 0);     // the row held in slot w
@@ -260,6 +268,7 @@ __device__ __noinline__ void dp2_rows_band() {
         asm volatile("; window shift (rare): nothing of it is carried in the row loop" : "+s"(i), "+s"(Vs));
         if (kBatch) { flush_rows(flushed + 1, i - 1); flushed = i - 1; }
         flush_edge();
+        const int woff = cold_get(&cold->woff);
         const int delta = new_off - woff, dl = delta / LPC;
         {   // (b) dropped cells of the rows in the register window
             uint32_t ev = pack2(-32768, -32768);
@@ -294,9 +303,13 @@ __device__ __noinline__ void dp2_rows_band() {
                 H[static_cast<int64_t>(r) * hs2 + ((woff + WB) >> 1) + cw] = NEGP;
             }
         }
-        off2 = off1; s_row3 = s_row2; off1 = woff; s_row2 = s_row1; s_row1 = i; woff = new_off;
-        hrow = H + static_cast<int64_t>(i) * hs2 + (woff >> 1);
-        coff = static_cast<uint32_t>(i) * static_cast<uint32_t>(hs) + static_cast<uint32_t>(woff) + 4u * static_cast<uint32_t>(t);
+        {
+            BandCold n_;
+            n_.off2 = cold_get(&cold->off1); n_.s_row3 = cold_get(&cold->s_row2); n_.off1 = woff; n_.s_row2 = cold_get(&cold->s_row1); n_.s_row1 = i; n_.woff = new_off;
+            *cold = n_;
+        }
+        hrow = H + static_cast<int64_t>(i) * hs2 + (new_off >> 1);
+        coff = static_cast<uint32_t>(i) * static_cast<uint32_t>(hs) + static_cast<uint32_t>(new_off) + 4u * static_cast<uint32_t>(t);
         set_columns();
     };
 
@@ -367,9 +380,9 @@ __device__ __noinline__ void dp2_rows_band() {
                 // special row: the window may move here (all on-chip state is re-based, the profile of this row redone)
                 const int new_off = __builtin_amdgcn_readlane(dl_off, k);
 #ifdef RCN_PROF_ROWS
-                if (new_off != woff) row_cls = 6;
+                if (new_off != cold_get(&cold->woff)) row_cls = 6;
 #endif
-                if (new_off != woff) { shift_to(i, new_off); profile_now(meta); }
+                if (new_off != cold_get(&cold->woff)) { shift_to(i, new_off); profile_now(meta); }
             }
             uint32_t P[NP];
 #pragma unroll
@@ -467,6 +480,8 @@ __device__ __noinline__ void dp2_rows_band() {
                 //      written in (window offsets of the last two shifts are kept) ----
                 const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
                 const int er = __builtin_amdgcn_readlane(dl_er, k);
+                const int woff = cold_get(&cold->woff), s_row1 = cold_get(&cold->s_row1), s_row2 = cold_get(&cold->s_row2), s_row3 = cold_get(&cold->s_row3);
+                const int off1 = cold_get(&cold->off1), off2 = cold_get(&cold->off2);
                 const int np = (meta >> 9) & 7;
                 bool first = true;
                 int nq = 0;                          // ordinal of the predecessor being combined (= its index in the descriptor)
