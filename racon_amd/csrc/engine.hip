@@ -145,6 +145,7 @@ struct rcn_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
     int n_cu = 256;
+    uint64_t t_max = 0, t_sum = 0;      // bases of the deepest window / of all windows of the prepared batch (wg_per_cu)
     size_t free_mem = 0;
 
     // resident batch
@@ -233,7 +234,26 @@ uint64_t scratch_budget(const rcn_engine* e) {
     return e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>(e->free_mem * 0.80);
 }
 uint32_t max_slots(const rcn_engine* e) {
-    return e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;    // 8 work-groups per CU (20 KiB LDS each)
+    return e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;    // 8 work-groups per CU (20 KiB LDS each) at most
+}
+
+// ---- how many work-groups of poa_window_kernel2 share a CU ----
+// Eight fit (20.5 KiB of LDS each, 32 wave slots), and eight is what a long queue wants: 142k windows/s at 8000 windows
+// against 119k with six and 92k with four (profiles/r02/f_occupancy.txt).  But a batch whose windows are all resident at
+// once lasts as long as its DEEPEST window, and that window is faster with fewer neighbours on its CU: its DP wave
+// shares a SIMD's VALU with at most one other (-11 % DP clocks at four per CU), its graph phases share the CU's memory
+// pipeline (-30 %).  The estimate below says which case a batch is: per-window time goes with the window's bases (sum of
+// its layers' lengths; measured ~ n_seqs^1.1), the launch is max(deepest window, all windows / slots), six per CU cost
+// 1.23 x the second term (6 / 8 of the slots at 0.925 of the clocks) and save ~4 % of the first.
+// Fewer than eight per CU is enforced by asking for more LDS per work-group (allocation granule 1280 B, 128 per CU).
+uint32_t wg_per_cu(const rcn_engine* e) {
+    if (const char* v = getenv("RCN_WG_PER_CU")) return static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));   // experiments
+    const double even = static_cast<double>(e->t_sum) / (8.0 * e->n_cu);           // bases per slot if all slots stayed busy
+    return static_cast<double>(e->t_max) > 1.25 * even ? 6u : 8u;
+}
+uint32_t lds_bytes_for(uint32_t per_cu) {
+    const uint32_t need = rcn::kLdsBytes + rcn::kCtxBytes;
+    return per_cu >= 8 ? need : std::max(need, (128u / per_cu) * 1280u);
 }
 
 struct Launch {
@@ -268,7 +288,9 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.out_len = e->d_out_len.as<uint32_t>(); P.out_flags = e->d_out_flags.as<uint8_t>();
     P.next = e->d_ctr.as<unsigned int>() + L.ctr;
     P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + kStatsOff);
-    if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), rcn::kLdsBytes + rcn::kCtxBytes, L.stream, P);
+    if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] pass of %u windows on %u slots, %u work-groups per CU (deepest window %llu bases, all %llu)\n", L.n_work, L.slots,
+                                     L.c.fast ? wg_per_cu(e) : 8u, (unsigned long long)e->t_max, (unsigned long long)e->t_sum);
+    if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(wg_per_cu(e)), L.stream, P);
     else hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(L.slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, L.stream, P);
     HIP_TRY(hipGetLastError());
     return RCN_OK;
@@ -276,7 +298,7 @@ int launch_pass(rcn_engine* e, const Launch& L) {
 
 // resident slots for a pass of n_work windows within the scratch budget (0: not even one slot fits)
 uint32_t slots_for(const rcn_engine* e, const Caps& c, uint32_t n_work, uint64_t budget) {
-    uint32_t slots = std::min(max_slots(e), n_work);
+    uint32_t slots = std::min(e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e), n_work);
     while (slots > 1 && static_cast<uint64_t>(slots) * c.slot_bytes > budget) slots = (slots + 1) / 2;
     return static_cast<uint64_t>(slots) * c.slot_bytes > budget ? 0 : slots;
 }
@@ -353,6 +375,11 @@ int prepare_host(rcn_engine* e, HostPrep& hp, uint32_t nw, uint32_t ns, const ui
         e->shapes[w] = sh;
     });
     for (uint32_t w = 0; w < nw; ++w) if (bad[w]) return RCN_E_ARG;
+    e->t_max = 0; e->t_sum = 0;                                   // wg_per_cu()
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint64_t tw = win_seq_off[w + 1] - win_seq_off[w] < 3 ? 0 : static_cast<uint64_t>(e->shapes[w].sum_l + e->shapes[w].L);
+        e->t_max = std::max(e->t_max, tw); e->t_sum += tw;
+    }
     // Longest processing time first: a window's cost grows with (layers x bases), and a launch ends with its
     // slowest window; when there are more windows than resident slots the deep ones must not start last.
     e->lpt.resize(nw);
@@ -691,6 +718,19 @@ static int collect(rcn_engine* e) {
       for (int k = 0; k < 8; ++k) if (cnt[k]) fprintf(stderr, "  %-16s rows %5.1f %%  clocks %5.1f %%  %7.0f clocks/row\n", names[k], 100.0 * cnt[k] / std::max(1ull, alln),
                                                          100.0 * clk[k] / std::max(1ull, allc), (double)clk[k] / cnt[k]);
       fprintf(stderr, "  all              rows %llu  %7.0f clocks/row\n", alln, (double)allc / std::max(1ull, alln)); }
+#endif
+#ifdef RCN_PROF_WIN
+    { static unsigned long long wt[4096][8]; HIP_TRY(hipMemcpyFromSymbol(wt, HIP_SYMBOL(rcn::g_wtb), sizeof(wt)));
+      unsigned long long dg[8] = {0}; for (int w = 0; w < 4096; ++w) for (int k = 0; k < 8; ++k) dg[k] += wt[w][k];
+      fprintf(stderr, "[racon_hip] code traceback, first 4096 work items since load: %llu tiles, clocks per tile: issue loads %.0f, wait + barrier %.0f, walk %.0f\n", dg[3],
+              (double)dg[0] / std::max(1ull, dg[3]), (double)dg[1] / std::max(1ull, dg[3]), (double)dg[2] / std::max(1ull, dg[3]));
+      fprintf(stderr, "[racon_hip]   %llu boxes, clocks per box: decode %.0f, walk %.0f, emit + next anchor %.0f\n", dg[7], (double)dg[4] / std::max(1ull, dg[7]),
+              (double)dg[5] / std::max(1ull, dg[7]), (double)dg[6] / std::max(1ull, dg[7]));
+      static unsigned long long w2[4096][8]; HIP_TRY(hipMemcpyFromSymbol(w2, HIP_SYMBOL(rcn::g_wtb2), sizeof(w2)));
+      unsigned long long ex[8] = {0}; for (int w = 0; w < 4096; ++w) for (int k = 0; k < 8; ++k) ex[k] += w2[w][k];
+      fprintf(stderr, "[racon_hip]   boxes left at: tile edge %.1f %%, origin %.1f %%, columns used up %.1f %%, a row jump of 1-2 boxes %.1f %%, 2-4 boxes %.1f %%, more %.1f %%; %.2f cells walked per box\n",
+              100.0 * ex[0] / std::max(1ull, dg[7]), 100.0 * ex[1] / std::max(1ull, dg[7]), 100.0 * ex[2] / std::max(1ull, dg[7]), 100.0 * ex[3] / std::max(1ull, dg[7]),
+              100.0 * ex[4] / std::max(1ull, dg[7]), 100.0 * ex[5] / std::max(1ull, dg[7]), (double)ex[6] / std::max(1ull, dg[7])); }
 #endif
 #ifdef RCN_PROF_WIN
     { static unsigned long long wc[4096][8]; HIP_TRY(hipMemcpyFromSymbol(wc, HIP_SYMBOL(rcn::g_wclk), sizeof(wc)));

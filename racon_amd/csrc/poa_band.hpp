@@ -438,9 +438,17 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
                     }
+                    {
+#define RCN_TAIL_MULTI 1
+#define RCN_TAIL_SINK 0
+#include "poa_band_row_tail.inc"
+#undef RCN_TAIL_MULTI
+#undef RCN_TAIL_SINK
+                    }
+                    continue;
                 }
                 {
-#define RCN_TAIL_MULTI 2
+#define RCN_TAIL_MULTI 0
 #define RCN_TAIL_SINK 0
 #include "poa_band_row_tail.inc"
 #undef RCN_TAIL_MULTI

@@ -408,6 +408,11 @@ __device__ unsigned long long g_prof_out[8];
 __device__ unsigned long long g_dbg[8];
 #endif
 #ifdef RCN_PROF_WIN
+#ifndef RCN_PROF_DP
+__device__ unsigned long long g_dbg[8];          // code traceback: clocks of a tile's load issue / wait / walk, tiles
+#endif
+__device__ unsigned long long g_wtb2[4096][8];   // ... boxes left because: tile edge, origin, columns used up, row jump < 2 boxes, < 4 boxes, more; cells walked
+__device__ unsigned long long g_wtb[4096][8];    // per work item, code traceback: clocks of tile load issue / wait / walk, tiles, box decode / walk / emit, boxes
 __device__ unsigned long long g_wclk[4096][8];   // per work item: phase clocks     // per wave: cycles in row bodies, cycles in barriers
 #endif
 // ---- phase: NW sequence-to-graph DP ----
@@ -834,7 +839,7 @@ constexpr int kTbRows = 112;
 constexpr int kTile2Cols = 64;         // int16 cells per tile row
 constexpr int kTile2Pair = 136;        // LDS stride of a row PAIR in cells (272 B: 4 banks of skew per pair)
 __device__ __forceinline__ int tile_at(int trow, int tcol) { return (trow >> 1) * kTile2Pair + (trow & 1) * kTile2Cols + tcol; }
-static_assert((kTbRows / 2) * kTile2Pair * 2 + kTbRows * 32 + kTile2Cols + 8 <= kLdsBytes, "tile + row descriptors + sequence slice must fit");
+static_assert((kTbRows / 2) * kTile2Pair * 2 + kTbRows * 32 + 68 + 64 * 4 <= kLdsBytes, "tile + row descriptors + sequence slice + the tile's pos_t must fit");
 
 __device__ __forceinline__ void traceback2_slow_step(Win& g, RCN_G const int32_t* nr, bool sub, RCN_G const uint8_t* seq,
                                                      int m, int x, int gp, int& i, int& j, int& n) {
@@ -1266,6 +1271,7 @@ __device__ __noinline__ void phase_traceback3() {
     int16_t* tile = reinterpret_cast<int16_t*>(Block4::work());                       // [kTbRows / 2][kTile2Pair]
     int* tdesc = Block4::work() + (kTbRows / 2) * kTile2Pair / 2;                      // kTbRows x RowDesc (8 ints each)
     uint8_t* tseq = reinterpret_cast<uint8_t*>(tdesc + kTbRows * (sizeof(RowDesc) / 4));   // seq[c0 - 1 + k], k in [0, 64]
+    int* tpos = reinterpret_cast<int*>(tseq + 68);                                          // pos_t of the tile's 64 columns, flushed once per tile
     RCN_G int32_t* __restrict__ prow = g.pos_t.ptr();
     int i = bcast0(o->tb_i), j = bcast0(o->tb_j);
     int overflow = g.overflow;
@@ -1372,12 +1378,13 @@ __device__ __noinline__ void phase_traceback3() {
                 // ---- walk: one v_readlane per step ----
                 int idx = 0, nxt;
                 unsigned long long vis = 0ull;
-#define RCN_WALK_STEP { nxt = __builtin_amdgcn_readlane(nx, idx); if (nxt == kNxInvalid) goto walk3_done; vis |= 1ull << idx; if (nxt >= 64) goto walk3_done; idx = nxt; }
-                for (;;) { RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP }      // four steps per back-edge
+#define RCN_WALK_STEP { nxt = __builtin_amdgcn_readlane(nx, idx); if (nxt >= 64) goto walk3_done; asm("s_bitset1_b64 %0, %1" : "+s"(vis) : "s"(idx)); idx = nxt; }
+                for (;;) { RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP }      // four steps per back-edge; see phase_traceback_code
 #undef RCN_WALK_STEP
             walk3_done:
+                if (nxt != kNxInvalid) vis |= 1ull << idx;
                 // emit the sequence positions consumed inside the box
-                if (((vis >> lane) & 1ull) && mv != kMvUp) prow[jj - 1] = (mv == kMvDiag) ? ii : -1;
+                if (((vis >> lane) & 1ull) && mv != kMvUp) tpos[jj - c0] = (mv == kMvDiag) ? ii : -1;     // (LDS, not HBM: see phase_traceback_code)
                 bool stuck = false;
                 if (nxt == kNxInvalid) { stuck = idx == 0; i = __builtin_amdgcn_readlane(ii, idx); j = __builtin_amdgcn_readlane(jj, idx); }
                 else { i = __builtin_amdgcn_readlane(ni, idx); j = __builtin_amdgcn_readlane(nj, idx); }
@@ -1392,6 +1399,7 @@ __device__ __noinline__ void phase_traceback3() {
 #endif
                 if (stuck) break;
             }
+            { const int jc = j + 1 + lane; if (jc <= j_stage) prow[jc - 1] = tpos[jc - c0]; }     // the columns consumed on this tile
             if (!(i == 0 && j == 0) && i == ti0 && j == j_stage) {
                 // no progress on a freshly anchored tile (predecessor beyond the tile's rows or > 6 in-edges): one
                 // step against HBM
@@ -1429,7 +1437,7 @@ __device__ __noinline__ void phase_traceback3() {
 // decode the successor of every cell of a 9 x 7 box at once and the walk inside the box is one v_readlane per step.
 constexpr int kTileCQuad = 272;        // LDS stride of FOUR tile rows in bytes (4 x 64 + 16: skews the banks)
 __device__ __forceinline__ int tilec_at(int trow, int tcol) { return (trow >> 2) * kTileCQuad + (trow & 3) * 64 + tcol; }
-static_assert((kTbRows / 4) * kTileCQuad + kTbRows * 32 + 64 <= kLdsBytes, "code tile + row descriptors must fit");
+static_assert((kTbRows / 4) * kTileCQuad + kTbRows * 32 + 64 * 4 <= kLdsBytes, "code tile + row descriptors + the tile's pos_t must fit");
 
 __device__ __noinline__ void phase_traceback_code() {
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1444,6 +1452,7 @@ __device__ __noinline__ void phase_traceback_code() {
 
     uint8_t* tile = reinterpret_cast<uint8_t*>(Block4::work());                        // [kTbRows / 4][kTileCQuad]
     int* tdesc = Block4::work() + (kTbRows / 4) * kTileCQuad / 4;                      // kTbRows x RowDesc (8 ints each)
+    int* tpos = tdesc + kTbRows * 8;                                                   // pos_t of the tile's 64 columns (see the flush below)
     RCN_G int32_t* __restrict__ prow = g.pos_t.ptr();
     RCN_G const int32_t* nr = (c.sub ? g.n2r_x : g.n2r).ptr();
     RCN_G const int32_t* e_nin = g.e_nin.ptr();
@@ -1452,7 +1461,14 @@ __device__ __noinline__ void phase_traceback_code() {
     const bool sub = c.sub != 0;
     int i = bcast0(o->tb_i), j = bcast0(o->tb_j);
     int overflow = g.overflow;
+#ifdef RCN_PROF_WIN
+    long long ac__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long ex__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     while (!(i == 0 && j == 0)) {
+#ifdef RCN_PROF_WIN
+        const long long tq0__ = clock64();
+#endif
         const int ti0 = i, j_stage = j;
 #ifdef RCN_PROF_WIN
         if (t == 0) o->dbg_tiles += 1;
@@ -1481,14 +1497,22 @@ __device__ __noinline__ void phase_traceback_code() {
                 }
             }
         }
+#ifdef RCN_PROF_WIN
+        const long long tq1__ = clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef RCN_PROF_WIN
+        const long long tq2__ = clock64();
+        long long bx0__ = 0, bx1__ = 0, bx2__ = 0, bxn__ = 0;
+#endif
         if (wv == 0) {
             const int a = lane / kBoxCols, b = lane % kBoxCols;
             for (;;) {
                 if (i == 0 && j == 0) break;
 #ifdef RCN_PROF_WIN
                 if (lane == 0) o->dbg_boxes += 1;
+                const long long tb0__ = clock64();
 #endif
                 const int ii = i - a, jj = j - b;
                 const bool inside = a < kBoxRows && ii >= rmin && ii >= 0 && jj >= c0 && jj >= 0;
@@ -1534,20 +1558,44 @@ __device__ __noinline__ void phase_traceback_code() {
                 const int nx = mv == kMvInvalid ? kNxInvalid : leaves ? kNxExit : na * kBoxCols + nb;
                 // the walk inside the box: one readlane per step, four steps per loop iteration (a taken branch costs as
                 // much as eight instructions, the early exits in between are not taken)
+#ifdef RCN_PROF_WIN
+                const long long tb1__ = clock64() + (nx & 0);
+#endif
                 int idx = 0, nxt = kNxInvalid;
                 unsigned long long vis = 0ull;
-#define RCN_WALK_STEP { nxt = __builtin_amdgcn_readlane(nx, idx); if (nxt == kNxInvalid) goto walk_done; vis |= 1ull << idx; if (nxt >= 64) goto walk_done; idx = nxt; }
+                // (one compare per step: both ways out of the box are >= 64; the bit of the cell the walk stops on is set
+                //  afterwards, unless its move is invalid.  s_bitset1_b64 takes the lane number, no 64-bit shift and or.)
+#define RCN_WALK_STEP { nxt = __builtin_amdgcn_readlane(nx, idx); if (nxt >= 64) goto walk_done; asm("s_bitset1_b64 %0, %1" : "+s"(vis) : "s"(idx)); idx = nxt; }
                 for (;;) { RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP RCN_WALK_STEP }
 #undef RCN_WALK_STEP
             walk_done:
-                if (((vis >> lane) & 1ull) && mv != kMvUp) prow[jj - 1] = (mv == kMvDiag) ? ii : -1;
+                if (nxt != kNxInvalid) vis |= 1ull << idx;
+#ifdef RCN_PROF_WIN
+                const long long tb2__ = clock64() + (nxt & 0);
+#endif
+                // (into LDS: a store to HBM here would be waited for by the next box -- the compiler puts an s_waitcnt vmcnt(0)
+                //  at the join after the rare seventh-in-edge loads -- and a write round trip is most of what a box then costs)
+                if (((vis >> lane) & 1ull) && mv != kMvUp) tpos[tcol] = (mv == kMvDiag) ? ii : -1;
                 bool stuck = false;
                 if (nxt == kNxInvalid) { stuck = idx == 0; i = __builtin_amdgcn_readlane(ii, idx); j = __builtin_amdgcn_readlane(jj, idx); }
                 else { i = __builtin_amdgcn_readlane(ni, idx); j = __builtin_amdgcn_readlane(nj, idx); }
+#ifdef RCN_PROF_WIN
+                { const long long tb3__ = clock64() + (i & 0); bx0__ += tb1__ - tb0__; bx1__ += tb2__ - tb1__; bx2__ += tb3__ - tb2__; bxn__ += 1;
+                  // why the walk left the box, and how many steps it made inside
+                  const int xa__ = __builtin_amdgcn_readlane(na, idx), xb__ = __builtin_amdgcn_readlane(nb, idx);
+                  const int why__ = nxt == kNxInvalid ? 0 : (i == 0 && j == 0) ? 1 : xb__ >= kBoxCols ? 2 : xa__ < 2 * kBoxRows ? 3 : xa__ < 4 * kBoxRows ? 4 : 5;
+                  ex__[why__] += 1; ex__[6] += __popcll(vis); }
+#endif
                 if (stuck) break;
             }
+            // the columns the walk consumed on this tile: (j, j_stage], at most 64 (j >= c0 - 1), one store
+            { const int jc = j + 1 + lane; if (jc <= j_stage) prow[jc - 1] = tpos[jc - c0]; }
             // a freshly anchored tile always holds the current cell: no progress means a corrupt code matrix
             if (!(i == 0 && j == 0) && i == ti0 && j == j_stage) overflow = 4;
+#ifdef RCN_PROF_WIN
+            { const long long tq3__ = clock64(); ac__[0] += tq1__ - tq0__; ac__[1] += tq2__ - tq1__; ac__[2] += tq3__ - tq2__; ac__[3] += 1;
+              ac__[4] += bx0__; ac__[5] += bx1__; ac__[6] += bx2__; ac__[7] += bxn__; }
+#endif
             if (lane == 0) { o->tb_i = i; o->tb_j = j; o->overflow = overflow; }
         }
         Block4::sync();
@@ -1556,6 +1604,9 @@ __device__ __noinline__ void phase_traceback_code() {
         Block4::sync();                                  // everyone has read the walk state before the next tile overwrites LDS
     }
     if (t == 0) { o->plen = -1; }
+#ifdef RCN_PROF_WIN
+    if (t == 0 && c.wi < 4096) for (int k = 0; k < 8; ++k) { g_wtb[c.wi][k] += (unsigned long long)ac__[k]; g_wtb2[c.wi][k] += (unsigned long long)ex__[k]; }
+#endif
     Block4::sync();
 }
 

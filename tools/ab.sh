@@ -17,7 +17,7 @@ try:
     pc = r.get("phase_clocks") or [0] * 8
     tot = float(sum(pc)) or 1.0
     print("%-34s %8.1f w/s (incl. upload %8.1f)  launch %.2f ms  banded %s redone %s why %s | phases %% sub %.1f desc %.1f dp %.1f tb %.1f add %.1f merge %.1f cons %.1f other %.1f | Gclk %.1f" % (
-        sys.argv[2] or "(default)", j["value"], j.get("value_incl_upload", 0), r["avg_launch_ms"], r.get("banded_alignments"), r.get("band_redone"), r.get("band_redo_why"),
+        sys.argv[2] or "(default)", j["value"], j.get("value_incl_upload") or 0.0, r["avg_launch_ms"], r.get("banded_alignments"), r.get("band_redone"), r.get("band_redo_why"),
         *[100.0 * v / tot for v in pc], tot / 1e9))
 except Exception as e:
     print(sys.argv[2], "no result:", e)
