@@ -189,7 +189,7 @@ def main():
                                          "achieved": (alg_bytes - st["dp_bytes"] + st["dp_bytes_full"]) / avg_launch_s / 1e9,
                                          "gcups": st["dp_cells_full"] / avg_launch_s / 1e9},
                          "banded_alignments": st["n_banded"], "band_redone": st["n_band_redone"], "band_redo_why": st["band_redo_why"],
-                         "phase_clocks": st["phase_clocks"]},
+                         "phase_clocks": st["phase_clocks"], "work_groups_per_cu": st["wg_per_cu"]},
         }
         if not a.no_cpu and world == 1:
             # CPU baseline on this box's host cores (rank 0 at N = 1 only): the oracle's AVX2 int16 variant (the scheme of spoa's SIMD

@@ -93,6 +93,9 @@ typedef struct rcn_run_stats {
     uint64_t band_redo_why[8]; /* redo reasons, counted: source row off the left edge, predecessor older than the LDS ring,
                                   >2 window shifts inside the ring, >8 in-edges, (shift span), no end cell, alive last window
                                   cell, alive dropped cell                                                                   */
+    uint32_t wg_per_cu;        /* work-groups of the consensus kernel per CU in the last launch: 8, or 6 when the batch is
+                                  resident all at once and lasts as long as its deepest window (engine.hip: wg_per_cu)     */
+    uint32_t reserved0;
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */

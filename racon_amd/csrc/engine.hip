@@ -290,6 +290,7 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + kStatsOff);
     if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] pass of %u windows on %u slots, %u work-groups per CU (deepest window %llu bases, all %llu)\n", L.n_work, L.slots,
                                      L.c.fast ? wg_per_cu(e) : 8u, (unsigned long long)e->t_max, (unsigned long long)e->t_sum);
+    if (L.c.fast) e->stats.wg_per_cu = wg_per_cu(e);
     if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(wg_per_cu(e)), L.stream, P);
     else hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(L.slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, L.stream, P);
     HIP_TRY(hipGetLastError());

@@ -33,7 +33,7 @@ class RcnRunStats(C.Structure):
                 ("dp_pred_cells", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
                 ("dp_bytes", C.c_uint64), ("phase_clocks", C.c_uint64 * 8), ("n_sink_ties", C.c_uint64),
                 ("dp_cells_full", C.c_uint64), ("dp_bytes_full", C.c_uint64), ("n_banded", C.c_uint64), ("n_band_redone", C.c_uint64),
-                ("band_redo_why", C.c_uint64 * 8)]
+                ("band_redo_why", C.c_uint64 * 8), ("wg_per_cu", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class RcnWindowDesc(C.Structure):

@@ -107,6 +107,30 @@ def test_slot_count_and_arena_do_not_change_results(Engine, oracle):
     assert_same(Engine(*sc, True, arena_bytes=64 << 20).consensus(b), ref, "small arena")
 
 
+def test_work_groups_per_cu_do_not_change_results(Engine, oracle, monkeypatch):
+    """The engine runs a batch that is resident all at once with six work-groups per CU instead of eight
+    (engine.hip: wg_per_cu); the choice, and any forced value, must not show in the output."""
+    b = simulate_windows(300_000, 500, 30.0, 10000, seed=77)             # 600 windows: all resident, the deepest one bounds the launch
+    eng = Engine(3, -5, -4, True)
+    base = eng.consensus(b)
+    assert eng.stats()["wg_per_cu"] == 6
+    perm = np.random.default_rng(5).permutation(b.n_windows)[:120]
+    assert_same(Engine(3, -5, -4, True).consensus(b.select(perm)), oracle.consensus(b.select(perm), 3, -5, -4, True, 0), "sample")
+    for n in (8, 7, 5, 4):
+        monkeypatch.setenv("RCN_WG_PER_CU", str(n))
+        e2 = Engine(3, -5, -4, True)
+        r = e2.consensus(b)
+        assert e2.stats()["wg_per_cu"] == n
+        assert r.consensus == base.consensus and list(r.polished) == list(base.polished), n
+    monkeypatch.delenv("RCN_WG_PER_CU")
+    # a long queue (more windows than slots, none much deeper than its share) keeps eight
+    big = b.select(list(range(b.n_windows)) * 8)
+    e3 = Engine(3, -5, -4, True)
+    r = e3.consensus(big)
+    assert e3.stats()["wg_per_cu"] == 8
+    assert r.consensus[:b.n_windows] == base.consensus and r.consensus[-b.n_windows:] == base.consensus
+
+
 def test_full_size_properties(Engine, oracle):
     """BASELINE.json configs[1] at full size (2000 windows): size-independent
     properties — idempotence, independence from batch composition / order, and a
