@@ -729,7 +729,7 @@ static int collect(rcn_engine* e) {
               (double)dg[5] / std::max(1ull, dg[7]), (double)dg[6] / std::max(1ull, dg[7]));
       static unsigned long long w2[4096][8]; HIP_TRY(hipMemcpyFromSymbol(w2, HIP_SYMBOL(rcn::g_wtb2), sizeof(w2)));
       unsigned long long ex[8] = {0}; for (int w = 0; w < 4096; ++w) for (int k = 0; k < 8; ++k) ex[k] += w2[w][k];
-      fprintf(stderr, "[racon_hip]   boxes left at: tile edge %.1f %%, origin %.1f %%, columns used up %.1f %%, a row jump of 1-2 boxes %.1f %%, 2-4 boxes %.1f %%, more %.1f %%; %.2f cells walked per box\n",
+      fprintf(stderr, "[racon_hip]   boxes left at: tile edge %.1f %%, origin %.1f %%, columns used up %.1f %%, climbed 1-2 box heights %.1f %%, below the skew line %.1f %%, climbed more %.1f %%; %.2f cells walked per box\n",
               100.0 * ex[0] / std::max(1ull, dg[7]), 100.0 * ex[1] / std::max(1ull, dg[7]), 100.0 * ex[2] / std::max(1ull, dg[7]), 100.0 * ex[3] / std::max(1ull, dg[7]),
               100.0 * ex[4] / std::max(1ull, dg[7]), 100.0 * ex[5] / std::max(1ull, dg[7]), (double)ex[6] / std::max(1ull, dg[7])); }
 #endif

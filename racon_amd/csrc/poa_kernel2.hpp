@@ -411,7 +411,7 @@ __device__ unsigned long long g_dbg[8];
 #ifndef RCN_PROF_DP
 __device__ unsigned long long g_dbg[8];          // code traceback: clocks of a tile's load issue / wait / walk, tiles
 #endif
-__device__ unsigned long long g_wtb2[4096][8];   // ... boxes left because: tile edge, origin, columns used up, row jump < 2 boxes, < 4 boxes, more; cells walked
+__device__ unsigned long long g_wtb2[4096][8];   // ... boxes left because: tile edge, origin, columns used up, climbed 1-2 box heights, fell below the skew line, climbed more; cells walked
 __device__ unsigned long long g_wtb[4096][8];    // per work item, code traceback: clocks of tile load issue / wait / walk, tiles, box decode / walk / emit, boxes
 __device__ unsigned long long g_wclk[4096][8];   // per work item: phase clocks     // per wave: cycles in row bodies, cycles in barriers
 #endif
@@ -1245,10 +1245,19 @@ __device__ __noinline__ void phase_sink_tie_full() {
 // LDS round trips and ballots.  Output: pos_t[pos] = DP row aligned to sequence position pos, or -1.
 constexpr int kMvDiag = 0, kMvUp = 1, kMvLeft = 2, kMvInvalid = 3;
 #ifndef RCN_BOX_ROWS
-#define RCN_BOX_ROWS 9
-#define RCN_BOX_COLS 7
+#define RCN_BOX_ROWS 8
+#define RCN_BOX_COLS 8
 #endif
 constexpr int kBoxRows = RCN_BOX_ROWS, kBoxCols = RCN_BOX_COLS;   // <= 64 cells; the path drops ~1.7 rows per column on a 30x graph
+// The box is a parallelogram: its column b (b columns left of the anchor) holds the kBoxRows rows from kBoxSkew * b rows above
+// the anchor's row upwards.  A diagonal step leaves its row for a predecessor, at least one row up, so with skew 1 only the
+// rows the path climbs BEYOND one per column count against the box's height: measured (profiles/r02, exit statistics of the
+// profiling build) a straight 9 x 7 box was left after 5 steps, in 61 % of the cases because the path had climbed 9 rows;
+// the skewed one is left because its columns are used up (69 %), and 8 x 8 holds one column more (boxes per alignment 114 -> ~90).
+#ifndef RCN_BOX_SKEW
+#define RCN_BOX_SKEW 1
+#endif
+constexpr int kBoxSkew = RCN_BOX_SKEW;
 constexpr int kNxExit = 64, kNxInvalid = 65;
 
 __device__ __noinline__ void phase_traceback3() {
@@ -1331,7 +1340,7 @@ __device__ __noinline__ void phase_traceback3() {
                 if (lane == 0) o->dbg_boxes += 1;
 #endif
                 // ---- move of every cell of the box anchored at (i, j): all LDS reads first, compares after ----
-                const int ii = i - a, jj = j - b;
+                const int ii = i - a - kBoxSkew * b, jj = j - b;
                 const bool inside = a < kBoxRows && ii >= rmin && ii >= 0 && jj >= c0 && jj >= 0 && !(jj > 0 && jj - 1 < c0);
                 const int trow = inside ? ti0 - ii : 0, tcol = inside ? jj - c0 : 1;
                 const int* dr = tdesc + trow * 8;
@@ -1369,11 +1378,11 @@ __device__ __noinline__ void phase_traceback3() {
                 if (!ok) mv = kMvInvalid;
                 // successor of this cell: a lane of the box, or one of the exits
                 const int ni = ii - (mv == kMvLeft ? 0 : dl), nj = jj - (mv == kMvUp ? 0 : 1);
-                const int na = i - ni, nb = j - nj;
+                const int nb = j - nj, na = i - ni - kBoxSkew * nb;
                 int nx;
                 if (mv == kMvInvalid) nx = kNxInvalid;
                 else if (ni == 0 && nj == 0) nx = kNxExit;
-                else if (na >= kBoxRows || nb >= kBoxCols) nx = kNxExit;
+                else if (na < 0 || na >= kBoxRows || nb >= kBoxCols) nx = kNxExit;
                 else nx = na * kBoxCols + nb;
                 // ---- walk: one v_readlane per step ----
                 int idx = 0, nxt;
@@ -1434,7 +1443,7 @@ __device__ __noinline__ void phase_traceback3() {
 // in-edge order) it comes from.  spoa's priority (diagonal over the in-edges, then vertical over the in-edges, then
 // horizontal) is then a table lookup: no score is read, nothing is compared.  Same organisation as phase_traceback3: the
 // four waves stage a tile (112 rows x 64 columns, now 64 BYTES per row: four rows per global_load_lds), the 64 lanes of wave 0
-// decode the successor of every cell of a 9 x 7 box at once and the walk inside the box is one v_readlane per step.
+// decode the successor of every cell of an 8 x 8 box at once and the walk inside the box is one v_readlane per step.
 constexpr int kTileCQuad = 272;        // LDS stride of FOUR tile rows in bytes (4 x 64 + 16: skews the banks)
 __device__ __forceinline__ int tilec_at(int trow, int tcol) { return (trow >> 2) * kTileCQuad + (trow & 3) * 64 + tcol; }
 static_assert((kTbRows / 4) * kTileCQuad + kTbRows * 32 + 64 * 4 <= kLdsBytes, "code tile + row descriptors + the tile's pos_t must fit");
@@ -1514,7 +1523,7 @@ __device__ __noinline__ void phase_traceback_code() {
                 if (lane == 0) o->dbg_boxes += 1;
                 const long long tb0__ = clock64();
 #endif
-                const int ii = i - a, jj = j - b;
+                const int ii = i - a - kBoxSkew * b, jj = j - b;
                 const bool inside = a < kBoxRows && ii >= rmin && ii >= 0 && jj >= c0 && jj >= 0;
                 const int trow = inside ? ti0 - ii : 0, tcol = inside ? jj - c0 : 0;
                 const int* dr = tdesc + trow * 8;
@@ -1553,8 +1562,8 @@ __device__ __noinline__ void phase_traceback_code() {
                 }
                 mv = (!inside || (mv != kMvLeft && pi < 0)) ? kMvInvalid : mv;
                 const int ni = mv == kMvLeft ? ii : pi, nj = jj - (mv == kMvUp ? 0 : 1);
-                const int na = i - ni, nb = j - nj;
-                const bool leaves = (ni == 0 && nj == 0) || na >= kBoxRows || nb >= kBoxCols;
+                const int nb = j - nj, na = i - ni - kBoxSkew * nb;
+                const bool leaves = (ni == 0 && nj == 0) || na < 0 || na >= kBoxRows || nb >= kBoxCols;
                 const int nx = mv == kMvInvalid ? kNxInvalid : leaves ? kNxExit : na * kBoxCols + nb;
                 // the walk inside the box: one readlane per step, four steps per loop iteration (a taken branch costs as
                 // much as eight instructions, the early exits in between are not taken)
@@ -1583,7 +1592,7 @@ __device__ __noinline__ void phase_traceback_code() {
                 { const long long tb3__ = clock64() + (i & 0); bx0__ += tb1__ - tb0__; bx1__ += tb2__ - tb1__; bx2__ += tb3__ - tb2__; bxn__ += 1;
                   // why the walk left the box, and how many steps it made inside
                   const int xa__ = __builtin_amdgcn_readlane(na, idx), xb__ = __builtin_amdgcn_readlane(nb, idx);
-                  const int why__ = nxt == kNxInvalid ? 0 : (i == 0 && j == 0) ? 1 : xb__ >= kBoxCols ? 2 : xa__ < 2 * kBoxRows ? 3 : xa__ < 4 * kBoxRows ? 4 : 5;
+                  const int why__ = nxt == kNxInvalid ? 0 : (i == 0 && j == 0) ? 1 : xb__ >= kBoxCols ? 2 : xa__ < 0 ? 4 : xa__ < 2 * kBoxRows ? 3 : 5;
                   ex__[why__] += 1; ex__[6] += __popcll(vis); }
 #endif
                 if (stuck) break;
