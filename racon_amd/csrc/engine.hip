@@ -721,6 +721,9 @@ static int collect(rcn_engine* e) {
       fprintf(stderr, "  all              rows %llu  %7.0f clocks/row\n", alln, (double)allc / std::max(1ull, alln)); }
 #endif
 #ifdef RCN_PROF_WIN
+    { unsigned long long ws[8]; HIP_TRY(hipMemcpyFromSymbol(ws, HIP_SYMBOL(rcn::g_wsub), sizeof(ws)));
+      if (ws[4]) fprintf(stderr, "[racon_hip] Subgraph sweep (every 16th window since load): %llu calls, clocks per call: set-up %.0f, pass A %.0f, pass B %.0f (%.1f chunks), pass C %.0f; %.0f ranks swept of %.0f nodes\n",
+                         ws[4], (double)ws[0] / ws[4], (double)ws[1] / ws[4], (double)ws[2] / ws[4], (double)ws[5] / ws[4], (double)ws[3] / ws[4], (double)ws[6] / ws[4], (double)ws[7] / ws[4]); }
     { static unsigned long long wt[4096][8]; HIP_TRY(hipMemcpyFromSymbol(wt, HIP_SYMBOL(rcn::g_wtb), sizeof(wt)));
       unsigned long long dg[8] = {0}; for (int w = 0; w < 4096; ++w) for (int k = 0; k < 8; ++k) dg[k] += wt[w][k];
       fprintf(stderr, "[racon_hip] code traceback, first 4096 work items since load: %llu tiles, clocks per tile: issue loads %.0f, wait + barrier %.0f, walk %.0f\n", dg[3],

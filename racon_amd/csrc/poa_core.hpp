@@ -53,6 +53,18 @@ struct Arr {
     RCN_HD RCN_G T* ptr() const { return reinterpret_cast<RCN_G T*>(base + off); }
 };
 
+// The first kInlinePreds in-edges of a node by TAIL NODE ID, in in-edge (creation) order, next to each other: what the row
+// descriptors and the Subgraph sweep need of a node's in-list comes with one 32-byte load instead of one dependent load
+// pair per edge (e_tail, e_nin).  Maintained wherever an in-list changes (add_node / add_edge / addp_create /
+// addp_edge_create and the backbone set-up of the kernels); node ids never change, so it never needs rebuilding.
+struct PredRec {
+    int32_t t[kInlinePreds];   // tails, -1 = none
+    int32_t erest;             // first in-edge beyond the inline ones (the list goes on through e_nin), -1 = none
+    int32_t k;                 // number of inline tails in use
+};
+static_assert(sizeof(PredRec) == 32, "one 32-byte record per node");
+RCN_HD PredRec pred_rec_empty() { PredRec p; for (int q = 0; q < kInlinePreds; ++q) p.t[q] = -1; p.erest = -1; p.k = 0; return p; }
+
 struct Win {
     // capacities
     int32_t ncap, ecap, ring;      // ring = max aligned-ring size - 1 per node slot count
@@ -63,6 +75,7 @@ struct Win {
     Arr<uint8_t> mark;             // [ncap] toposort marks (bits0-1) | ignored (bit2)
     Arr<uint8_t> inc;              // [ncap] subgraph inclusion mask
     Arr<int32_t> in_head, in_tail;       // [ncap] edge ids, -1 = none
+    Arr<PredRec> in6;                    // [ncap] the head of the in-list by tail node, inline
     Arr<int32_t> out_head, out_tail;     // [ncap]
     Arr<uint32_t> cov;             // [ncap] #sequences (len>=2) through node == |labels|
     Arr<int32_t> al_nodes;         // [ncap*ring]
@@ -95,11 +108,20 @@ struct Win {
     int32_t  overflow;             // set when a capacity is exceeded
 };
 
+// edge e (tail -> head) has just been appended to head's in-list
+RCN_HD void pred_rec_append(Win& g, int32_t head, int32_t tail, int32_t e) {
+    RCN_G int32_t* r = reinterpret_cast<RCN_G int32_t*>(&g.in6[head]);
+    const int32_t k = r[kInlinePreds + 1];
+    if (k < kInlinePreds) { r[k] = tail; r[kInlinePreds + 1] = k + 1; }
+    else if (r[kInlinePreds] < 0) r[kInlinePreds] = e;
+}
+
 RCN_HD int32_t add_node(Win& g, uint8_t c) {
     if (g.n_nodes >= g.ncap) { g.overflow = 1; return g.ncap - 1; }
     int32_t v = g.n_nodes++;
     g.code[v] = c; g.al_cnt[v] = 0;
     g.in_head[v] = g.in_tail[v] = g.out_head[v] = g.out_tail[v] = -1;
+    g.in6[v] = pred_rec_empty();
     g.cov[v] = 0;
     return v;
 }
@@ -115,6 +137,7 @@ RCN_HD void add_edge(Win& g, int32_t tail, int32_t head, int64_t w) {
     g.out_tail[tail] = e;
     if (g.in_tail[head] < 0) g.in_head[head] = e; else g.e_nin[g.in_tail[head]] = e;
     g.in_tail[head] = e;
+    pred_rec_append(g, head, tail, e);
 }
 
 RCN_HD uint32_t base_weight(RCN_G const uint8_t* qual, int32_t i) {
@@ -244,6 +267,7 @@ RCN_HD int32_t addp_classify(Win& g, RCN_G const uint8_t* seq, int32_t pos) {
 RCN_HD void addp_create(Win& g, RCN_G const uint8_t* seq, int32_t pos, int32_t kind, int32_t id, uint32_t count) {
     g.code[id] = seq[pos]; g.al_cnt[id] = 0;
     g.in_head[id] = g.in_tail[id] = g.out_head[id] = g.out_tail[id] = -1;
+    g.in6[id] = pred_rec_empty();
     g.cov[id] = 0;
     (void)count;
     if (kind == 2) {
@@ -279,6 +303,7 @@ RCN_HD void addp_edge_create(Win& g, RCN_G const uint8_t* qual, int32_t pos, int
     g.out_tail[tail] = e;
     if (g.in_tail[head] < 0) g.in_head[head] = e; else g.e_nin[g.in_tail[head]] = e;
     g.in_tail[head] = e;
+    pred_rec_append(g, head, tail, e);
 }
 
 // Serial reference of the order merge (the kernel does it wave-parallel):
@@ -486,6 +511,7 @@ RCN_HD uint64_t win_bind(Win& g, RCN_G uint8_t* base, int32_t ncap, int32_t ecap
     const uint64_t n = static_cast<uint64_t>(ncap), e = static_cast<uint64_t>(ecap);
     RCN_TAKE(code, n); RCN_TAKE(al_cnt, n); RCN_TAKE(mark, n); RCN_TAKE(inc, n);
     RCN_TAKE(in_head, 4 * n); RCN_TAKE(in_tail, 4 * n); RCN_TAKE(out_head, 4 * n); RCN_TAKE(out_tail, 4 * n);
+    RCN_TAKE(in6, sizeof(PredRec) * n);
     RCN_TAKE(cov, 4 * n); RCN_TAKE(al_nodes, 4 * n * ring);
     RCN_TAKE(rank_full, 4 * n); RCN_TAKE(rank_tmp, 4 * n); RCN_TAKE(rank_sub, 4 * n); RCN_TAKE(rank_x, 4 * n);
     RCN_TAKE(n2r, 4 * n); RCN_TAKE(n2r_x, 4 * n); RCN_TAKE(pred, 4 * (n + 1));

@@ -739,6 +739,7 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
             for (int i = lane; i < L; i += 64) {
                 g.code[i] = bb[i]; g.al_cnt[i] = 0;
                 g.in_head[i] = g.in_tail[i] = (i > 0) ? i - 1 : -1;
+                { PredRec pr = pred_rec_empty(); if (i > 0) { pr.t[0] = i - 1; pr.k = 1; } g.in6[i] = pr; }
                 g.out_head[i] = g.out_tail[i] = (i < L - 1) ? i : -1;
                 g.cov[i] = L >= 2 ? 1u : 0u;
                 g.rank_full[i] = i; g.n2r[i] = i;

@@ -168,6 +168,11 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
            static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), k));
 }
 
+__device__ __forceinline__ void block4_scan(int* xch, int wv, int lane, int cnt, int wmax, int& off, int& total, int& pmax, int& tmax);
+constexpr int kSubMaxNodes = kLdsBytes - 64;      // phase_subgraph2: one pending byte per rank in LDS + the words of a prefix count
+#ifdef RCN_PROF_WIN
+__device__ unsigned long long g_wsub[8];         // Subgraph sweep, all windows: clocks of set-up, pass A, pass B, pass C, calls, chunks of pass B, ranks swept
+#endif
 // returns false (through ctx->tb_i = 0) when a node has more than six in-edges: the caller then takes the
 // serial DFS of poa_kernel.hpp for this layer
 __device__ __noinline__ void phase_subgraph2() {
@@ -186,24 +191,37 @@ __device__ __noinline__ void phase_subgraph2() {
         top = bcast0(r);
     }
     if (t == 0) o->tb_i = 1;
+#ifdef RCN_PROF_WIN
+    const long long ts0__ = clock64();
+    long long nch__ = 0;
+#endif
     Block4::sync();
+#ifdef RCN_PROF_WIN
+    const long long ts1__ = clock64();
+#endif
     // ---- pass A ----
     for (int r = t; r < n; r += kThreads2) pend[r] = 0;
     bool wide = false;
+    // (three dependent loads per rank: node, its in-edge record and ring members, their ranks -- the in-list itself is
+    //  only walked by pass B, for the rare node with more than six in-edges)
     for (int r = t; r <= top; r += kThreads2) {
         const int v = g.rank_full[r];
-        SubRec e; e.erest = -1;
-        int k = 0;
+        const PredRec pr = g.in6[v];
+        const int na = g.al_cnt[v];
+        SubRec e; e.erest = pr.erest;
+        // (loads only where there is something to load: with eight windows per CU these phases queue at the CU's memory
+        //  pipeline, a wave-wide scattered load is 64 requests whether its result is used or not)
 #pragma unroll
         for (int q = 0; q < 6; ++q) e.tr[q] = -1;
-        for (int ed = g.in_head[v]; ed >= 0; ed = g.e_nin[ed]) {
-            if (k == 6) { e.erest = ed; break; }
-            e.tr[k++] = g.n2r[g.e_tail[ed]];
+        if (pr.k > 0) e.tr[0] = g.n2r[pr.t[0]];
+        if (pr.k > 1) e.tr[1] = g.n2r[pr.t[1]];
+        if (__ballot(pr.k > 2)) {                   // (a third in-edge is rare: most waves skip these altogether)
+#pragma unroll
+            for (int q = 2; q < 6; ++q) if (q < pr.k) e.tr[q] = g.n2r[pr.t[q]];
         }
         int rb = r;
-        const int na = g.al_cnt[v];
         for (int a = 0; a < na; ++a) rb = min(rb, g.n2r[g.al_nodes[v * g.ring + a]]);
-        e.info = (v >= c.begin ? 1 : 0) | (k << 4) | ((r - rb) << 8) | ((na + 1) << 16);
+        e.info = (v >= c.begin ? 1 : 0) | (pr.k << 4) | ((r - rb) << 8) | ((na + 1) << 16);
         rec[r] = e;
     }
     if (wide) o->tb_i = 0;
@@ -211,6 +229,9 @@ __device__ __noinline__ void phase_subgraph2() {
     if (bcast0(o->tb_i) == 0) return;
     if (t == 0) pend[g.n2r[c.end]] = 1;
     Block4::sync();
+#ifdef RCN_PROF_WIN
+    const long long ts2__ = clock64();
+#endif
     // ---- pass B ----
     if (wv == 0) {
         int hi = top, minpend = g.n2r[c.end];
@@ -238,19 +259,37 @@ __device__ __noinline__ void phase_subgraph2() {
             }
             if (!idok) own_t = 0ull;
             const unsigned long long own_b = idok ? (1ull << lane) : 0ull;
-            // per block, at its first lane: members with id >= begin, union of their tail masks
+            // per block, at its first lane: members with id >= begin, union of their tail masks (blocks are short: the
+            // loop goes as far as the longest block of the chunk)
             unsigned long long bmask = own_b, btmask = own_t;
-            for (int d = 1; d < 8; ++d) {
+            const int maxd = __ballot(mine && bsz >= 5) ? 8 : __ballot(mine && bsz >= 3) ? 4 : __ballot(mine && bsz >= 2) ? 2 : 1;
+            for (int d = 1; d < maxd; ++d) {
                 const unsigned long long mb = __shfl_down(own_b, d), mt = __shfl_down(own_t, d);
                 if (d < bsz && lane + d < 64) { bmask |= mb; btmask |= mt; }
             }
-            unsigned long long incmask = 0ull;
-            unsigned long long todo = __ballot(mine && off == 0);
-            while (todo) {
-                const int k = 63 - __builtin_clzll(todo);
-                todo &= ~(1ull << k);
-                const unsigned long long bm = readlane64(bmask, k);
-                if (bm & pendmask) { incmask |= bm; pendmask |= readlane64(btmask, k); }
+            // The sweep proper, highest rank first: a block is included when one of its members is pending, and then its
+            // members' tails are pending.  Only pending ranks are looked at (a block nobody points to is never visited),
+            // and a RUN of chain links -- one-rank blocks whose only tail inside the chunk is the rank right below --
+            // is taken in one step with mask arithmetic on the scalar unit: most of a graph is such runs, and a step that
+            // has to fetch a lane's masks (v_readlane into the scalar unit and back) costs ~100 clocks.
+            const unsigned long long linkmask = __ballot(idok && bsz == 1 && lane > lo_lane && own_t == (1ull << ((lane - 1) & 63)));
+            const int bstart = lane - off;
+            unsigned long long incmask = 0ull, done = lo_lane > 0 ? ((1ull << lo_lane) - 1ull) : 0ull;   // (lanes below the processed part)
+            for (;;) {
+                const unsigned long long cand = pendmask & ~done;
+                if (!cand) break;
+                const int p = 63 - __builtin_clzll(cand);
+                const unsigned long long upto = p == 63 ? ~0ull : ((2ull << p) - 1ull);
+                if ((linkmask >> p) & 1ull) {
+                    const int z = 63 - __builtin_clzll(~linkmask & upto);          // first rank below p that is not a link (>= lo_lane)
+                    const unsigned long long run = upto & ~((2ull << z) - 1ull);   // ranks z + 1 .. p
+                    incmask |= run; pendmask |= run >> 1; done |= run;
+                } else {
+                    const int k = __builtin_amdgcn_readlane(bstart, p);
+                    const unsigned long long bm = readlane64(bmask, k);
+                    if (bm & pendmask) { incmask |= bm; pendmask |= readlane64(btmask, k); }
+                    done |= bm | (1ull << p);
+                }
             }
             const bool inc = (incmask >> lane) & 1ull;
             // tails below the processed part become pending
@@ -274,9 +313,15 @@ __device__ __noinline__ void phase_subgraph2() {
             if (minpend >= lo_eff) minpend = 0x7fffffff;                   // it has just been processed
             minpend = min(minpend, lowest);
             hi = lo_eff - 1;
+#ifdef RCN_PROF_WIN
+            ++nch__;
+#endif
         }
     }
     Block4::sync();
+#ifdef RCN_PROF_WIN
+    const long long ts3__ = clock64();
+#endif
     // ---- pass C ----
     if (c.tb_j == 1) {
         // closure query (phase_sink_tie_*): only DFS marks, nothing of the current alignment is touched
@@ -284,23 +329,37 @@ __device__ __noinline__ void phase_subgraph2() {
         Block4::sync();
         return;
     }
-    for (int r = t; r < n; r += kThreads2) g.inc[g.rank_full[r]] = pend[r];
-    if (wv == 0) {
+    {
+        // inclusion flags by node and the subgraph's own order (rank_full filtered): 256 ranks per step, the positions are a
+        // prefix count across the four waves
+        int* xch = Block4::work() + kSubMaxNodes / 4;
         int nv = 0;
-        for (int b0 = 0; b0 < n; b0 += 64) {
-            const int r = b0 + lane;
+        for (int b0 = 0; b0 < n; b0 += kThreads2) {
+            const int r = b0 + t;
+            const int v = r < n ? g.rank_full[r] : 0;
             const bool in = r < n && pend[r] != 0;
             const unsigned long long mk = __ballot(in);
+            int off, total, pmax, tmax;
+            block4_scan(xch, wv, lane, __popcll(mk), 0, off, total, pmax, tmax);
+            if (r < n) g.inc[v] = in ? 1 : 0;
             if (in) {
-                const int v = g.rank_full[r];
-                const int pos = nv + __popcll(mk & ((1ull << lane) - 1ull));
+                const int pos = nv + off + __popcll(mk & ((1ull << lane) - 1ull));
                 g.rank_sub[pos] = v; g.n2r_x[v] = pos;
             }
-            nv += __popcll(mk);
+            nv += total;
         }
-        if (lane == 0) o->V = nv;
+        if (t == 0) o->V = nv;
     }
     Block4::sync();
+#ifdef RCN_PROF_WIN
+    if (t == 0 && (c.wi & 15) == 0) {            // (every sixteenth window: the atomics must not become the measurement)
+        const long long ts4__ = clock64();
+        atomicAdd(&g_wsub[0], (unsigned long long)(ts1__ - ts0__)); atomicAdd(&g_wsub[1], (unsigned long long)(ts2__ - ts1__));
+        atomicAdd(&g_wsub[2], (unsigned long long)(ts3__ - ts2__)); atomicAdd(&g_wsub[3], (unsigned long long)(ts4__ - ts3__));
+        atomicAdd(&g_wsub[4], 1ull); atomicAdd(&g_wsub[5], (unsigned long long)nch__); atomicAdd(&g_wsub[6], (unsigned long long)(top + 1));
+        atomicAdd(&g_wsub[7], (unsigned long long)n);
+    }
+#endif
 }
 
 __device__ __forceinline__ void block4_scan(int* xch, int wv, int lane, int cnt, int wmax, int& off, int& total, int& pmax, int& tmax);
@@ -323,11 +382,14 @@ __device__ __noinline__ void phase_desc2() {
     // the window moves or a predecessor outside the register window was written under another offset (meta bit 12)
     RCN_G const int32_t* roff = g.pred.ptr();
     if (c.band) band_row_offsets(c, g, rank);
-    // Every row is a chain of dependent HBM loads (rank -> in-edge head -> edge -> tail's rank ...).  For a
-    // full-graph alignment U rows per thread are walked in lock step, with static register indices only (a
-    // runtime index into the descriptors would send them to scratch memory), so that their loads are in flight
-    // together: the phase is pure latency.  Subgraph alignments (edges filtered by the mask) go row by row.
-    constexpr int U = 4;
+    // Every row is a chain of dependent HBM loads: rank -> node -> its in-edge record (PredRec: the first six tails next to
+    // each other, one 32-byte load instead of a load pair per edge) -> the tails' rows.  For a full-graph alignment U rows per
+    // thread are walked in lock step, with static register indices only (a runtime index into the descriptors would send
+    // them to scratch memory), so that their loads are in flight together: the phase is pure latency on cfg2 -- and a queue
+    // at the CU's memory pipeline on cfg4 (eight windows per CU, all in graph phases half of the time), where a wave-wide
+    // scattered load costs its 64 requests whether the result is used or not: tails are only loaded where there are tails, a
+    // third to sixth one only in waves that have a row with that many.  Subgraph alignments (tails filtered by the mask) go row by row.
+    constexpr int U = 2;
     const bool sub = c.sub != 0;
     auto finish = [&](RowDesc d, int r) {
         // "fast" rows: at most 4 predecessors, every one among the R rows right above (the DP keeps those in
@@ -361,38 +423,80 @@ __device__ __noinline__ void phase_desc2() {
         g.desc[r] = d;
     };
     if (sub) {
-        for (int r = t; r < c.V; r += kThreads2) finish(make_row_desc(g, nr, rank[r], true), r);
+        // the included ones of the (at most six) inline in-edge tails, in order; a node with more in-edges takes the list walk
+        for (int r = t; r < c.V; r += kThreads2) {
+            const int v = rank[r];
+            const PredRec pr = g.in6[v];
+            const int eo = g.out_head[v], code = g.code[v];
+            if (pr.erest >= 0) { finish(make_row_desc(g, nr, v, true), r); continue; }
+            int inq[kInlinePreds], rowq[kInlinePreds];
+#pragma unroll
+            for (int q = 0; q < kInlinePreds; ++q) { inq[q] = 0; rowq[q] = 0; }
+            if (pr.k > 0) { inq[0] = g.inc[pr.t[0]]; rowq[0] = nr[pr.t[0]]; }
+            if (pr.k > 1) { inq[1] = g.inc[pr.t[1]]; rowq[1] = nr[pr.t[1]]; }
+            if (__ballot(pr.k > 2)) {
+#pragma unroll
+                for (int q = 2; q < kInlinePreds; ++q) if (q < pr.k) { inq[q] = g.inc[pr.t[q]]; rowq[q] = nr[pr.t[q]]; }
+            }
+            const int h0 = eo >= 0 ? g.e_head[eo] : v;
+            int e1 = eo >= 0 ? g.e_nout[eo] : -1;
+            RowDesc d; d.erest = -1;
+#pragma unroll
+            for (int q = 0; q < kInlinePreds; ++q) d.p[q] = -1;
+            int k = 0;
+#pragma unroll
+            for (int q = 0; q < kInlinePreds; ++q) {
+                const bool take = q < pr.k && inq[q] != 0;
+#pragma unroll
+                for (int j = 0; j <= q; ++j) d.p[j] = (take && j == k) ? rowq[q] + 1 : d.p[j];       // (static indices: no scratch)
+                k += take ? 1 : 0;
+            }
+            if (k == 0) { d.p[0] = 0; k = 1; }
+            bool sink = true;
+            if (eo >= 0) {
+                if (g.inc[h0]) sink = false;
+                else for (; e1 >= 0; e1 = g.e_nout[e1]) if (g.inc[g.e_head[e1]]) { sink = false; break; }
+            }
+            d.meta = code | (sink ? 256 : 0) | (k << 9);
+            finish(d, r);
+        }
     } else {
         for (int r0 = t; r0 < c.V; r0 += kThreads2 * U) {
-            int v[U], e0[U], eo[U], code[U];
+            int v[U], eo[U], code[U];
+            PredRec pr[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { const int r = r0 + u * kThreads2; v[u] = r < c.V ? rank[r] : 0; }
 #pragma unroll
-            for (int u = 0; u < U; ++u) { e0[u] = g.in_head[v[u]]; eo[u] = g.out_head[v[u]]; code[u] = g.code[v[u]]; }
-            int t0[U], e1[U];
+            for (int u = 0; u < U; ++u) { pr[u] = g.in6[v[u]]; eo[u] = g.out_head[v[u]]; code[u] = g.code[v[u]]; }
+            int pq[U][kInlinePreds];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const int e = e0[u] >= 0 ? e0[u] : 0; t0[u] = g.e_tail[e]; e1[u] = e0[u] >= 0 ? g.e_nin[e] : -1; }
-            int t1[U], e2[U], p0[U];
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const int e = e1[u] >= 0 ? e1[u] : 0; t1[u] = g.e_tail[e]; e2[u] = e1[u] >= 0 ? g.e_nin[e] : -1; p0[u] = nr[t0[u]] + 1; }
-            int p1[U];
+                for (int q = 0; q < kInlinePreds; ++q) pq[u][q] = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) p1[u] = nr[t1[u]] + 1;
+            for (int u = 0; u < U; ++u) {
+                pq[u][0] = nr[pr[u].k > 0 ? pr[u].t[0] : v[u]];
+                if (pr[u].k > 1) pq[u][1] = nr[pr[u].t[1]];
+            }
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) more = more || pr[u].k > 2;
+            if (__ballot(more)) {                       // (a third in-edge is rare: most waves skip these altogether)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int q = 2; q < kInlinePreds; ++q) if (q < pr[u].k) pq[u][q] = nr[pr[u].t[q]];
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = r0 + u * kThreads2;
                 if (r >= c.V) continue;
-                RowDesc d; d.erest = -1;
-                d.p[0] = e0[u] >= 0 ? p0[u] : 0;
-                d.p[1] = e1[u] >= 0 ? p1[u] : -1;
-                d.p[2] = d.p[3] = d.p[4] = d.p[5] = -1;
-                int k = e0[u] < 0 ? 1 : (e1[u] < 0 ? 1 : 2);
-                int ed = e2[u];
+                RowDesc d;
 #pragma unroll
-                for (int q = 2; q < kInlinePreds; ++q) {       // third .. sixth in-edge (rare), static slots
-                    if (ed >= 0) { d.p[q] = nr[g.e_tail[ed]] + 1; ed = g.e_nin[ed]; k = q + 1; }
-                }
-                d.erest = ed;                                   // more than six: the DP / traceback walk the list
+                for (int q = 0; q < kInlinePreds; ++q) d.p[q] = q < pr[u].k ? pq[u][q] + 1 : -1;
+                int k = pr[u].k;
+                if (k == 0) { d.p[0] = 0; k = 1; }
+                d.erest = pr[u].erest;                          // more than six: the DP / traceback walk the list
                 d.meta = code[u] | (eo[u] < 0 ? 256 : 0) | (k << 9);
                 finish(d, r);
             }
@@ -1095,7 +1199,7 @@ __device__ __noinline__ void phase_sink_tie_rule() {
             if (key < bestkey) { bestkey = key; pick = v; }
         }
         if (classified) { o->best_row = nr[pick] + 1; status = 0; }
-        else if (g.n_nodes <= kLdsBytes) status = 1;
+        else if (g.n_nodes <= kSubMaxNodes) status = 1;
         else o->tie_why = 2;
     }
     o->tb_n = status;
@@ -2005,6 +2109,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             for (int i = t; i < L; i += kThreads2) {
                 g.code[i] = bb[i]; g.al_cnt[i] = 0;
                 g.in_head[i] = g.in_tail[i] = (i > 0) ? i - 1 : -1;
+                { PredRec pr = pred_rec_empty(); if (i > 0) { pr.t[0] = i - 1; pr.k = 1; } g.in6[i] = pr; }
                 g.out_head[i] = g.out_tail[i] = (i < L - 1) ? i : -1;
                 g.cov[i] = L >= 2 ? 1u : 0u;
                 g.rank_full[i] = i; g.n2r[i] = i;
@@ -2035,7 +2140,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             Block4::sync();
             if (partial) {
                 bool done = false;
-                if (bcast0(ctx->n_nodes) <= kLdsBytes) { phase_subgraph2(); done = bcast0(ctx->tb_i) != 0; }
+                if (bcast0(ctx->n_nodes) <= kSubMaxNodes) { phase_subgraph2(); done = bcast0(ctx->tb_i) != 0; }
                 if (!done) { if (wv == 0) phase_subgraph<Wave0Of4>(); Block4::sync(); }
             }
             RCN_PHASE2(0);
@@ -2105,7 +2210,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     // test switches: the cheaper levels' answers are discarded, a later level must reproduce them
                     // (more than eight tied sinks / graphs beyond the LDS sweep stay on the full DFS either way)
                     if (P.force_tie >= 3) { st = 2; if (t == 0) ctx->tie_why = 6; }
-                    else if (st == 0 && bcast0(ctx->n_nodes) <= kLdsBytes) st = 1;
+                    else if (st == 0 && bcast0(ctx->n_nodes) <= kSubMaxNodes) st = 1;
                     Block4::sync();
                 }
                 if (st == 1) {
