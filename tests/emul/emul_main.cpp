@@ -149,6 +149,19 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
             else nn = emul_parallel_add(g, plen, sp(i), qp(i), sl(i));
             if (g.overflow) { fprintf(stderr, "emul overflow %d\n", g.overflow); return -2; }
             order_merge_serial(g, n_old, nn);
+            // invariant of the in-edge records (PredRec): the first kInlinePreds tails of every in-list in list order, the
+            // first edge beyond them, kept up to date by both AddAlignment forms
+            for (int v = 0; v < g.n_nodes; ++v) {
+                const PredRec pr = g.in6[v];
+                int k = 0, rest = -1;
+                for (int e = g.in_head[v]; e >= 0; e = g.e_nin[e]) {
+                    if (k == kInlinePreds) { rest = e; break; }
+                    if (pr.t[k] != g.e_tail[e]) { fprintf(stderr, "emul: in-edge record of node %d, slot %d: %d, list says %d\n", v, k, pr.t[k], g.e_tail[e]); return -4; }
+                    ++k;
+                }
+                if (pr.k != k || pr.erest != rest) { fprintf(stderr, "emul: in-edge record of node %d: k %d erest %d, list says %d %d\n", v, pr.k, pr.erest, k, rest); return -4; }
+                for (int q = k; q < kInlinePreds; ++q) if (pr.t[q] != -1) return -4;
+            }
         }
         {
             int nr_ = graph_toposort(g, g.rank_x.ptr(), false, g.stack.ptr());

@@ -51,3 +51,14 @@ def test_emul_synthetic(emul, oracle, idx):
     got, pol = run_emul(emul, b, *sc)
     assert got == ref.consensus, name
     assert (pol == ref.polished).all()
+
+
+def test_emul_serial_add_keeps_in_edge_records(emul, oracle, monkeypatch):
+    """graph_add_alignment (add_node / add_edge) maintains the in-edge records as the per-position AddAlignment does:
+    the emulator checks them against the in-lists after every layer (rc -4 on a difference)."""
+    monkeypatch.setenv("RCN_EMUL_SERIAL_ADD", "1")
+    name, b, sc = synthetic_sets()[0]
+    b = b.select(range(min(b.n_windows, 6)))
+    ref = oracle.consensus(b, *sc, True, 4)
+    got, pol = run_emul(emul, b, *sc)
+    assert got == ref.consensus
