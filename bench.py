@@ -58,22 +58,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(a.dist_backend)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    if a.dist_backend != "nccl":
-        local_rank %= torch.cuda.device_count()          # several test ranks on one GPU
-    torch.cuda.set_device(local_rank)
-    red_dev = "cuda" if a.dist_backend == "nccl" else "cpu"
     m, x, g = [int(v) for v in a.scores.split(",")]
 
     from racon_amd.engine import HipEngine
     from racon_amd.synth import config_windows, simulate_windows, simulate_windows_parallel
 
+    # The synthetic input first: long contigs are generated in forked worker processes, and nothing of HIP / RCCL (contexts,
+    # helper threads) may exist in the parent when it forks.  Rank and world size come from the launcher's environment.
     if a.config:
         scaling, cfg_name = "weak", a.config
         if a.config.startswith("cfg5x"):
@@ -94,6 +85,17 @@ def main():
         workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
         batch = simulate_windows_parallel(contig, a.window, a.coverage, 10000, seed=seed, workers=workers) if contig > 1_000_000 \
             else simulate_windows(contig, a.window, a.coverage, 10000, seed=seed)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.dist_backend)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if a.dist_backend != "nccl":
+        local_rank %= torch.cuda.device_count()          # several test ranks on one GPU
+    torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if a.dist_backend == "nccl" else "cpu"
     eng = HipEngine(m, x, g, True, device=local_rank, max_slots=a.slots)
     eng.upload(batch)                                   # inputs resident in HBM from here on
 
