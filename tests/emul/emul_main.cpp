@@ -14,6 +14,7 @@
 using namespace rcn;
 
 static int g_ties = 0, g_aligns = 0;
+static long long g_sweeps = 0, g_sweep_chunks = 0, g_sweep_runs = 0;   // Subgraph sweeps compared with the DFS, their 64-rank chunks, chain runs taken
 static long long g_hist[8] = {0};   // pred distance: 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, >64
 static long long g_rows = 0, g_row0 = 0;
 static long long g_align_maxin[4] = {0};   // alignments whose widest row has <= 6, 7..8, > 8 in-edges; [3] = by window depth >= 40: 7+
@@ -88,6 +89,94 @@ static int emul_parallel_add(Win& g, int plen, const uint8_t* seq, const uint8_t
     return nn;
 }
 
+// The Subgraph sweep of the kernel (phase_subgraph2, racon_amd/csrc/poa_kernel2.hpp), restated lane by lane: per-rank records
+// from the in-edge records (pass A), then 64 ranks at a time from the top rank downwards -- ring blocks, lane masks, only
+// pending ranks visited, runs of chain links in one step (pass B).  Returns the inclusion flag per NODE; the caller compares
+// with graph_subgraph_mask (spoa's Subgraph as a DFS).  A 64-bit word per "lane" stands for the wave's ballots / readlanes.
+static void sweep_subgraph_mask(const Win& g, int begin, int end, std::vector<uint8_t>& inc_out) {
+    const int n = g.n_nodes;
+    int top = g.n2r[end];
+    for (int a = 0; a < g.al_cnt[end]; ++a) top = std::max(top, (int)g.n2r[g.al_nodes[end * g.ring + a]]);
+    struct Rec { int tr[6]; int erest; bool idok; int off, bsz; };
+    std::vector<Rec> rec(top + 1);
+    for (int r = 0; r <= top; ++r) {
+        const int v = g.rank_full[r];
+        const PredRec pr = g.in6[v];
+        Rec e; e.erest = pr.erest;
+        for (int q = 0; q < 6; ++q) e.tr[q] = q < pr.k ? (int)g.n2r[pr.t[q]] : -1;
+        int rb = r;
+        for (int a = 0; a < g.al_cnt[v]; ++a) rb = std::min(rb, (int)g.n2r[g.al_nodes[v * g.ring + a]]);
+        e.idok = v >= begin; e.off = r - rb; e.bsz = g.al_cnt[v] + 1;
+        rec[r] = e;
+    }
+    std::vector<uint8_t> pend(n, 0);
+    pend[g.n2r[end]] = 1;
+    typedef unsigned long long u64;
+    int hi = top, minpend = g.n2r[end];
+    ++g_sweeps;
+    while (hi >= 0 && minpend <= hi) {
+        ++g_sweep_chunks;
+        const int base = hi - 63;
+        bool mine[64]; u64 own_t[64], own_b[64], bmask[64], btmask[64]; int bstart[64];
+        int lo_lane = 64;
+        for (int l = 0; l < 64; ++l) { const int r = base + l; mine[l] = r >= 0 && r - rec[r].off >= base && r - rec[r].off >= 0; if (mine[l] && l < lo_lane) lo_lane = l; }
+        u64 pendmask = 0, linkmask = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int r = base + l;
+            own_t[l] = own_b[l] = 0; bstart[l] = 0;
+            if (!mine[l]) continue;
+            const Rec& e = rec[r];
+            if (pend[r]) pendmask |= 1ull << l;
+            bstart[l] = l - e.off;
+            if (!e.idok) continue;
+            own_b[l] = 1ull << l;
+            for (int q = 0; q < 6; ++q) { const int tl = e.tr[q] - base; if (e.tr[q] >= 0 && tl >= lo_lane) own_t[l] |= 1ull << tl; }
+            for (int ed = e.erest; ed >= 0; ed = g.e_nin[ed]) { const int tl = g.n2r[g.e_tail[ed]] - base; if (tl >= lo_lane) own_t[l] |= 1ull << tl; }
+            if (e.bsz == 1 && l > lo_lane && own_t[l] == (1ull << (l - 1))) linkmask |= 1ull << l;
+        }
+        for (int l = 0; l < 64; ++l) {
+            bmask[l] = own_b[l]; btmask[l] = own_t[l];
+            const int bsz = mine[l] ? rec[base + l].bsz : 0;
+            for (int d = 1; d < 8; ++d) if (d < bsz && l + d < 64) { bmask[l] |= own_b[l + d]; btmask[l] |= own_t[l + d]; }
+        }
+        u64 incmask = 0, done = lo_lane > 0 ? ((1ull << lo_lane) - 1ull) : 0ull;
+        for (;;) {
+            const u64 cand = pendmask & ~done;
+            if (!cand) break;
+            const int p = 63 - __builtin_clzll(cand);
+            const u64 upto = p == 63 ? ~0ull : ((2ull << p) - 1ull);
+            if ((linkmask >> p) & 1ull) {
+                const int z = 63 - __builtin_clzll(~linkmask & upto);
+                const u64 run = upto & ~((2ull << z) - 1ull);
+                incmask |= run; pendmask |= run >> 1; done |= run; ++g_sweep_runs;
+            } else {
+                const int k = bstart[p];
+                const u64 bm = bmask[k];
+                if (bm & pendmask) { incmask |= bm; pendmask |= btmask[k]; }
+                done |= bm | (1ull << p);
+            }
+        }
+        int lowest = 0x7fffffff;
+        for (int l = 0; l < 64; ++l) {
+            const int r = base + l;
+            if (!mine[l]) continue;
+            const bool inc = (incmask >> l) & 1ull;
+            if (inc) {
+                const Rec& e = rec[r];
+                for (int q = 0; q < 6; ++q) if (e.tr[q] >= 0 && e.tr[q] - base < lo_lane) { pend[e.tr[q]] = 1; lowest = std::min(lowest, e.tr[q]); }
+                for (int ed = e.erest; ed >= 0; ed = g.e_nin[ed]) { const int tr = g.n2r[g.e_tail[ed]]; if (tr - base < lo_lane) { pend[tr] = 1; lowest = std::min(lowest, tr); } }
+            }
+            pend[r] = inc ? 1 : 0;
+        }
+        const int lo_eff = base + lo_lane;
+        if (minpend >= lo_eff) minpend = 0x7fffffff;
+        minpend = std::min(minpend, lowest);
+        hi = lo_eff - 1;
+    }
+    inc_out.assign(n, 0);
+    for (int r = 0; r < n; ++r) inc_out[g.rank_full[r]] = pend[r];
+}
+
 extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int trim,
                                   uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint8_t* polished) {
     uint64_t out = 0;
@@ -124,6 +213,14 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
             const Arr<int32_t>* nr = &g.n2r;
             if (!full) {
                 graph_subgraph_mask(g, bg, en, g.stack.ptr());
+                {
+                    std::vector<uint8_t> swept;
+                    sweep_subgraph_mask(g, (int)bg, (int)en, swept);
+                    for (int v = 0; v < g.n_nodes; ++v) if ((swept[v] != 0) != (g.inc[v] != 0)) {
+                        fprintf(stderr, "emul: Subgraph sweep and DFS disagree on node %d (sweep %d, dfs %d), window %u layer %u [%u, %u]\n", v, swept[v], g.inc[v], w, j, bg, en);
+                        return -5;
+                    }
+                }
                 V = 0;
                 for (int r = 0; r < g.n_nodes; ++r) { int v = g.rank_full[r]; if (g.inc[v]) { g.rank_sub[V] = v; g.n2r_x[v] = V; ++V; } }
                 rk = g.rank_sub.ptr(); nr = &g.n2r_x;
@@ -182,6 +279,7 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
         polished[w] = 1;
     }
     cons_off[b->n_windows] = out;
+    if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] Subgraph sweeps checked against the DFS: %lld (%lld chunks, %lld chain runs)\n", g_sweeps, g_sweep_chunks, g_sweep_runs);
     if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] alignments %d, sink ties %d rows %lld row0 %lld hist", g_aligns, g_ties, g_rows, g_row0); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_hist[i]); fprintf(stderr, " | alignments by widest row: <=6 in-edges %lld, 7-8 %lld, >8 %lld (7+ in windows of >= 40 sequences: %lld)\n", g_align_maxin[0], g_align_maxin[1], g_align_maxin[2], g_align_maxin[3]); }
     return 0;
 }

@@ -1,7 +1,12 @@
 """The flat-array graph code the HIP kernel runs on one lane
 (racon_amd/csrc/poa_core.hpp), compiled for the CPU with a scalar DP
 (tests/emul/emul_main.cpp), against the oracle.  Catches logic errors in the
-device data structures without a GPU."""
+device data structures without a GPU.
+
+The harness also restates, lane by lane, the Subgraph sweep the kernel runs instead of spoa's DFS (in-edge records ->
+per-rank records -> 64-rank chunks with ring blocks, pending-rank visiting and chain runs) and compares its mask with the
+DFS's for every partial layer (rc -5 on a difference), and checks the in-edge records against the in-lists after every
+layer (rc -4)."""
 import ctypes as C
 import os
 import subprocess
