@@ -89,6 +89,58 @@ static int emul_parallel_add(Win& g, int plen, const uint8_t* seq, const uint8_t
     return nn;
 }
 
+// The move codes of the banded DP (poa_band_row_tail.inc) and the traceback over them (phase_traceback_code), restated on the
+// full score matrix of host_dp: per cell one byte -- bit 0 clear: a diagonal move reproduces the cell, bit 1 clear: a vertical
+// one does, bits 2-4 / 5-7: the first predecessor in in-edge order that attains the predecessor maximum at the previous / this
+// column -- and a walk that reads nothing but the codes.  The path must be nw_traceback's (spoa's priority: diagonal over the
+// in-edges, then vertical over the in-edges, then horizontal).  Rows with more than eight in-edges are not coded (the kernel
+// redoes such alignments on scores): returns -1 for them, else the path length; the path goes to node_out / pos_out.
+static long long g_code_paths = 0, g_code_skipped = 0;
+static int code_traceback(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int V, bool sub, const uint8_t* seq, int len,
+                          int best_row, int m, int x, int gp, std::vector<int>& node_out, std::vector<int>& pos_out) {
+    const int64_t W = g.hstride;
+    std::vector<std::vector<int>> preds(V + 1);
+    for (int r = 0; r < V; ++r) {
+        const RowDesc d = g.desc[r];
+        const int np = (d.meta >> 9) & 7;
+        for (int q = 0; q < np; ++q) preds[r + 1].push_back(d.p[q]);
+        for (int e = d.erest; e >= 0; e = g.e_nin[e]) { const int t = g.e_tail[e]; if (sub && !g.inc[t]) continue; preds[r + 1].push_back(nr[t] + 1); }
+        if (preds[r + 1].size() > 8) return -1;
+    }
+    std::vector<uint8_t> code((size_t)(V + 1) * (len + 1), 0);
+    for (int i = 1; i <= V; ++i) {
+        const int sym = g.desc[i - 1].meta & 255;
+        for (int j = 0; j <= len; ++j) {
+            // predecessor maxima at this column and at the previous one, with the first predecessor that attains them
+            int mu = kNeg, au = 0, md = kNeg, ad = 0;
+            for (size_t q = 0; q < preds[i].size(); ++q) {
+                const int32_t* hp = &g.H[(int64_t)preds[i][q] * W];
+                if (hp[j] > mu) { mu = hp[j]; au = (int)q; }
+                if (j > 0 && hp[j - 1] > md) { md = hp[j - 1]; ad = (int)q; }
+            }
+            const int acc = g.H[(int64_t)i * W + j];
+            const int dpv = j > 0 ? md + (sym == seq[j - 1] ? m : x) : kNeg, uv = mu + gp;
+            code[(size_t)i * (len + 1) + j] = (uint8_t)((acc != dpv ? 1 : 0) | (acc != uv ? 2 : 0) | (ad << 2) | (au << 5));
+        }
+    }
+    node_out.clear(); pos_out.clear();
+    int i = best_row, j = len;
+    while (!(i == 0 && j == 0)) {
+        int pi = i, pj = j;
+        if (i == 0) { pj = j - 1; }
+        else {
+            const int c = code[(size_t)i * (len + 1) + j];
+            if (j > 0 && !(c & 1)) { pi = preds[i][(c >> 2) & 7]; pj = j - 1; }
+            else if (!(c & 2)) { pi = preds[i][(c >> 5) & 7]; }
+            else { if (j == 0) return -2; pj = j - 1; }
+        }
+        node_out.push_back(i == pi ? -1 : rank[i - 1]);
+        pos_out.push_back(j == pj ? -1 : j - 1);
+        i = pi; j = pj;
+    }
+    return (int)node_out.size();
+}
+
 // The Subgraph sweep of the kernel (phase_subgraph2, racon_amd/csrc/poa_kernel2.hpp), restated lane by lane: per-rank records
 // from the in-edge records (pass A), then 64 ranks at a time from the top rank downwards -- ring blocks, lane masks, only
 // pending ranks visited, runs of chain links in one step (pass B).  Returns the inclusion flag per NODE; the caller compares
@@ -240,6 +292,17 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
                 }
             }
             int plen = nw_traceback(g, rk, *nr, !full, sp(i), sl(i), best_row, m, x, gp);
+            {
+                std::vector<int> cn_, cp_;
+                const int clen = code_traceback(g, rk, *nr, V, !full, sp(i), sl(i), best_row, m, x, gp, cn_, cp_);
+                if (clen == -1) ++g_code_skipped;
+                else {
+                    ++g_code_paths;
+                    bool same = clen == plen;
+                    for (int k = 0; same && k < plen; ++k) same = cn_[k] == g.path_node[k] && cp_[k] == g.path_pos[k];
+                    if (!same) { fprintf(stderr, "emul: the traceback over move codes and the one over scores disagree, window %u layer %u (lengths %d / %d)\n", w, j, clen, plen); return -6; }
+                }
+            }
             const int n_old = g.n_nodes;
             int nn;
             if (getenv("RCN_EMUL_SERIAL_ADD")) nn = graph_add_alignment(g, plen, sp(i), qp(i), sl(i));
@@ -279,6 +342,7 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
         polished[w] = 1;
     }
     cons_off[b->n_windows] = out;
+    if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] tracebacks over move codes checked against the ones over scores: %lld (%lld alignments with a row of more than eight in-edges not coded)\n", g_code_paths, g_code_skipped);
     if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] Subgraph sweeps checked against the DFS: %lld (%lld chunks, %lld chain runs)\n", g_sweeps, g_sweep_chunks, g_sweep_runs);
     if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] alignments %d, sink ties %d rows %lld row0 %lld hist", g_aligns, g_ties, g_rows, g_row0); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_hist[i]); fprintf(stderr, " | alignments by widest row: <=6 in-edges %lld, 7-8 %lld, >8 %lld (7+ in windows of >= 40 sequences: %lld)\n", g_align_maxin[0], g_align_maxin[1], g_align_maxin[2], g_align_maxin[3]); }
     return 0;

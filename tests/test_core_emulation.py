@@ -5,8 +5,10 @@ device data structures without a GPU.
 
 The harness also restates, lane by lane, the Subgraph sweep the kernel runs instead of spoa's DFS (in-edge records ->
 per-rank records -> 64-rank chunks with ring blocks, pending-rank visiting and chain runs) and compares its mask with the
-DFS's for every partial layer (rc -5 on a difference), and checks the in-edge records against the in-lists after every
-layer (rc -4)."""
+DFS's for every partial layer (rc -5 on a difference), checks the in-edge records against the in-lists after every
+layer (rc -4), and codes every alignment's cells as the banded DP does (one move byte per cell: first-argmax predecessors,
+"diagonal / vertical reproduces the cell" flags), walks the codes alone and compares the path with the score traceback's
+(rc -6)."""
 import ctypes as C
 import os
 import subprocess
