@@ -104,7 +104,10 @@ Polisher::Polisher(const std::string& sequences_path, const std::string& overlap
           hip_batches_(std::max<uint32_t>(1, hip_batches)), dummy_quality_(window_length, '!'),
           window_length_(window_length), logger_(new Logger()) {}
 
-Polisher::~Polisher() { logger_->total("[racon::Polisher::] total ="); }
+Polisher::~Polisher() {
+    if (device_warmup_.joinable()) device_warmup_.join();
+    logger_->total("[racon::Polisher::] total =");
+}
 
 // ---------------------------------------------------------------- initialize
 namespace {
@@ -159,6 +162,11 @@ void Polisher::initialize() {
         return;
     }
     logger_->log();
+    if (!device_warmup_.joinable() && getenv("RACON_HIP_NO_WARMUP") == nullptr)
+        device_warmup_ = std::thread([] {
+            const int32_t n = HipEngine::DeviceCount();              // (0 without the library or a device: polish() reports that)
+            for (int32_t d = 0; d < n; ++d) HipEngine::FreeMemory(d);
+        });
 
     // The three input files are read concurrently (one inflating thread each, num_threads_ parse workers shared out):
     // their contents only meet below, in file order, when names are resolved.  RACON_HIP_SERIAL_INGEST=1: one file after
@@ -386,6 +394,7 @@ void Polisher::assemble(const std::function<const std::string&(uint64_t)>& conse
 
 void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {
     logger_->log();
+    if (device_warmup_.joinable()) device_warmup_.join();
     const int32_t n_devices = HipEngine::DeviceCount();
     if (n_devices <= 0)
         fatal("[racon::Polisher::polish] error: no MI355X device / libracon_hip.so available (the consensus stage has no CPU fallback)!");

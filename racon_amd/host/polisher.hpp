@@ -14,6 +14,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "window.hpp"
@@ -130,6 +131,9 @@ protected:
     bool device_windows_ = false;   // polish(): windows built in HBM (rcn_engine_build_windows) instead of packed from windows_
     Layout layout_;
     std::unique_ptr<Logger> logger_;
+    // Started by initialize(): loads libracon_hip.so and brings up the HIP runtime and the devices' contexts while the input
+    // files are parsed (0.2 s that polish() would otherwise spend before its first launch); joined by polish() / the destructor.
+    std::thread device_warmup_;
 };
 
 }  // namespace racon
