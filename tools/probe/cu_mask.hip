@@ -40,6 +40,14 @@ int main() {
         char what[64]; snprintf(what, sizeof what, "first %d bits", n);
         run(what, s);
     }
+    for (int n : {96, 128}) {   // the complement of a prefix: bits n .. 255
+        std::vector<uint32_t> mask(8, 0u);
+        for (int b = n; b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+        hipStream_t s;
+        if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) { printf("mask of bits %d..255: stream creation failed\n", n); continue; }
+        char what[64]; snprintf(what, sizeof what, "bits %d..255", n);
+        run(what, s);
+    }
     {   // every fourth bit: does a sparse mask spread over the XCDs?
         std::vector<uint32_t> mask(8, 0x11111111u);
         hipStream_t s;
