@@ -12,9 +12,13 @@ configs[2] (cfg3): the 50 Mbp / 100 000-window job split evenly over the ranks
 are independent: there is no data-path collective, only the timing barrier /
 all-reduce.
 
-Next to `value` (inputs resident) the line carries `value_incl_upload`: the same
-windows through pack-to-pinned + H2D + kernel + D2H, what Polisher::polish() pays per
-batch (reference src/polisher.cpp:493 -> :539-543 brackets exactly that interval).
+Next to `value` (inputs resident) the line carries
+  value_incl_upload     the same windows through pack-to-pinned + H2D + kernel + D2H on a warm engine;
+  value_product_polish  THE PRODUCT: the same workload written as racon input files (FASTQ + SAM + FASTA), read by
+                        racon_amd/host's Polisher (include/racon_host.h), and the interval the reference's Logger
+                        brackets around Polisher::polish (reference src/polisher.cpp:493 -> :539-543) -- the interval
+                        SURVEY.md 8(d) defines "polished windows / second" on -- for cfg2's 2000 windows and for one
+                        GPU's share of cfg3 (6.25 Mbp, 12 500 windows); the FASTA is checked against the kernel leg.
 """
 from __future__ import annotations
 
@@ -32,6 +36,90 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CACHE = os.environ.get("RACON_AMD_CACHE", "/tmp/racon_amd_cache")
+
+
+def cached_windows(contig, window, coverage, read_len, seed, workers):
+    """simulate_windows_parallel, kept as .npz in a scratch directory keyed by its arguments: the generator is a Python
+    loop per read (8 s per Mbp), and the driver runs this file at N = 1, 2, 4, 8 back to back on one box."""
+    from racon_amd.batch import WindowBatch
+    from racon_amd.synth import simulate_windows, simulate_windows_parallel
+    key = os.path.join(CACHE, "win_%d_%d_%g_%d_%d.npz" % (contig, window, coverage, read_len, seed))
+    if os.path.exists(key):
+        try:
+            return WindowBatch.load(key)
+        except Exception:
+            pass
+    b = simulate_windows_parallel(contig, window, coverage, read_len, seed=seed, workers=workers) if contig > 1_000_000 \
+        else simulate_windows(contig, window, coverage, read_len, seed=seed)
+    if contig >= 1_000_000:
+        try:
+            os.makedirs(CACHE, exist_ok=True)
+            np.savez(key + ".tmp.npz", win_seq_off=b.win_seq_off, win_type=b.win_type, seq_off=b.seq_off, seq_has_qual=b.seq_has_qual,
+                     seq_begin=b.seq_begin, seq_end=b.seq_end, bases=b.bases, quals=b.quals)
+            os.replace(key + ".tmp.npz", key)
+        except Exception:
+            pass
+    return b
+
+
+def cpu_limits():
+    """What this process may use of the host: the numbers the CPU baseline's "all host cores" has to be read against."""
+    out = {"os_cpu_count": os.cpu_count(), "sched_affinity": len(os.sched_getaffinity(0))}
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
+        try:
+            out[f.rsplit("/", 1)[1]] = open(f).read().strip()
+        except Exception:
+            pass
+    try:
+        out["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except Exception:
+        pass
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        out["cpu_model"] = model[0] if model else None
+    except Exception:
+        pass
+    q = out.get("cpu.max", "max").split()
+    out["cgroup_cpus"] = (float(q[0]) / float(q[1])) if len(q) == 2 and q[0] != "max" else None
+    return out
+
+
+def product_files(contig, coverage, seed, workers):
+    """The workload as racon input files in the scratch cache (generated in forked workers: call before HIP exists)."""
+    from racon_amd.synth import simulate_window_files
+    d = os.path.join(CACHE, "files_%d_%g_%d" % (contig, coverage, seed))
+    t0 = time.perf_counter()
+    if not all(os.path.exists(os.path.join(d, n)) for n in ("targets.fasta", "reads.fastq", "overlaps.sam", ".done")):
+        simulate_window_files(d, contig, coverage, 10000, seed=seed, workers=workers)
+        open(os.path.join(d, ".done"), "w").close()
+    return {"targets": os.path.join(d, "targets.fasta"), "reads": os.path.join(d, "reads.fastq"), "sam": os.path.join(d, "overlaps.sam"),
+            "contig": contig, "files_s": round(time.perf_counter() - t0, 1)}
+
+
+def product_polish(paths, window, scores, threads, expect=None, reps=2):
+    """files -> racon_amd.host Polisher -> initialize() -> polish(); returns the Logger-bracketed polish() interval."""
+    from racon_amd.polisher import Polisher
+    m, x, g = scores
+    best, runs, nw, same = None, [], 0, None
+    for _ in range(reps):
+        p = Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", window, 10.0, 0.3, True, m, x, g, threads, 1)
+        t1 = time.perf_counter()
+        p.initialize()
+        t_init = time.perf_counter() - t1
+        nw = p.num_windows()
+        fasta = p.polish(True)
+        sec = p.polish_seconds()
+        p.close()
+        runs.append({"initialize_s": round(t_init, 3), "polish_s": round(sec, 5)})
+        best = sec if best is None else min(best, sec)
+        if expect is not None:
+            same = b"".join(fasta.split(b"\n")[1::2]) == expect
+    return {"windows": nw, "polish_s": best, "windows_per_s": nw / best, "runs": runs, "files_s": paths["files_s"],
+            "fasta_matches_kernel_leg": same,
+            "what": "racon_amd/host Polisher on %d bp of cfg-shaped files (FASTQ + SAM + FASTA), -t %d: the interval of reference "
+                    "src/polisher.cpp:493 -> :539-543 (rcnh_polisher_polish_seconds); best of %d createPolisher + initialize + polish rounds"
+                    % (paths["contig"], threads, reps)}
 
 
 def main():
@@ -40,17 +128,19 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--contig", type=int, default=0, help="contig bp per GPU (default: cfg2 = 1 Mbp at N=1; cfg3 = 50 Mbp / N at N>1)")
-    ap.add_argument("--config", default="", help="another named workload of SURVEY 8(d) instead (cfg4, cfg5x<scale>, w1000): profiling runs, "
+    ap.add_argument("--config", default="", help="another named workload of SURVEY 8(d) instead (cfg3, cfg4, cfg5x<scale>, w1000): profiling runs, "
                                                  "not the headline metric")
     ap.add_argument("--window", type=int, default=500)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--scores", default="3,-5,-4", help="match,mismatch,gap (racon CLI defaults, main.cpp:51-53)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
-    ap.add_argument("--cpu-threads", default="", help="comma list of thread counts for the CPU baseline sweep (default: 32,64,128,all)")
+    ap.add_argument("--cpu-threads", default="", help="comma list of thread counts for the CPU baseline sweep (default: 8,16,24,32,48,64,96,128,all)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the untimed pack + upload + run leg (value_incl_upload): the rocprofv3 passes "
                                                                  "use it so that every traced launch of the kernel is one of the timed whole-batch launches")
+    ap.add_argument("--no-product", action="store_true", help="skip the product leg (files -> Polisher::polish)")
+    ap.add_argument("--product-contig", type=int, default=6_250_000, help="second product job: contig bp (one GPU's share of cfg3)")
     ap.add_argument("--verify", action="store_true", help="also check every window against the oracle (untimed)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (code-path test with several ranks on ONE GPU)")
     a = ap.parse_args()
@@ -61,30 +151,41 @@ def main():
     m, x, g = [int(v) for v in a.scores.split(",")]
 
     from racon_amd.engine import HipEngine
-    from racon_amd.synth import config_windows, simulate_windows, simulate_windows_parallel
+    from racon_amd.synth import config_windows
 
     # The synthetic input first: long contigs are generated in forked worker processes, and nothing of HIP / RCCL (contexts,
     # helper threads) may exist in the parent when it forks.  Rank and world size come from the launcher's environment.
-    if a.config:
+    workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+    seed = None
+    if a.config and a.config != "cfg3":
         scaling, cfg_name = "weak", a.config
         if a.config.startswith("cfg5x"):
             batch = config_windows("cfg5", float(a.config[5:]))
+            what = "%s: fragment correction (-f), %g of 100 000 x 10 kbp ONT-error reads with dual overlaps, -w %d" % (a.config, float(a.config[5:]), 500)
         else:
             batch = config_windows(a.config)
+            what = {"cfg4": "cfg4: synthetic 1 Mbp contig, 60x of 150 bp short reads (0.3% sub, 0.05% ins, 0.05% del, phred 30), -w 200, kNGS",
+                    "w1000": "w1000: synthetic 1 Mbp contig, 30x ONT-error reads, -w 1000"}.get(a.config, a.config)
         contig = 0
-    elif a.contig:
-        contig, seed, scaling, cfg_name = a.contig, 20260921 + rank, "weak", "cfg2-shaped"
-    elif world == 1:
-        contig, seed, scaling, cfg_name = 1_000_000, 20260921, "weak", "cfg2"
     else:
-        contig, seed, scaling, cfg_name = 50_000_000 // world, 20260922 + rank, "strong", "cfg3 (50 Mbp / %d ranks)" % world
+        if a.config == "cfg3":          # the whole 100 000-window job on this rank's GPU (fits one MI355X: 3.1 GB packed)
+            contig, seed, scaling, cfg_name = 50_000_000, 20260922, "weak", "cfg3 (whole job on one GPU)"
+        elif a.contig:
+            contig, seed, scaling, cfg_name = a.contig, 20260921 + rank, "weak", "cfg2-shaped"
+        elif world == 1:
+            contig, seed, scaling, cfg_name = 1_000_000, 20260921, "weak", "cfg2"
+        else:
+            contig, seed, scaling, cfg_name = 50_000_000 // world, 20260922 + rank, "strong", "cfg3 (50 Mbp / %d ranks)" % world
+        batch = cached_windows(contig, a.window, a.coverage, 10000, seed, workers)
+        what = "%s: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d" % (cfg_name, contig, a.coverage, a.window)
     a.contig = contig
-    if not a.config:
-        # (long contigs are generated as 1 Mbp stretches in worker processes before any GPU work starts: the generator
-        #  is a Python loop per read, 8 s per Mbp; a 1 Mbp contig is exactly simulate_windows(...))
-        workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
-        batch = simulate_windows_parallel(contig, a.window, a.coverage, 10000, seed=seed, workers=workers) if contig > 1_000_000 \
-            else simulate_windows(contig, a.window, a.coverage, 10000, seed=seed)
+    # the product leg's input files (same seeds -> the same windows as the packed batches; generated in forked workers too)
+    do_product = not a.no_product and world == 1 and not a.config and contig == 1_000_000 and a.window == 500
+    pfiles = []
+    if do_product:
+        pfiles.append(("cfg2", product_files(1_000_000, a.coverage, 20260921, workers)))
+        if a.product_contig > 1_000_000:
+            pfiles.append(("cfg3_share", product_files(a.product_contig, a.coverage, 20260922, workers)))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.dist_backend == "nccl":
@@ -109,13 +210,13 @@ def main():
         eng.run_only()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = 0.0
-    launches = 0
+    kernel_ms, launches, launch_ms = 0.0, 0, [0.0, 0.0]
     for _ in range(a.steps):
         eng.run_only()                                  # kernel(s) + D2H of consensi; syncs its own stream
         st = eng.stats()
-        kernel_ms += st["kernel_ms"]
+        kernel_ms += st["kernel_ms"]                    # the interval the (one, or two concurrent) launches of a step cover
         launches += st["n_launches"]
+        launch_ms = [launch_ms[k] + st["launch_ms"][k] for k in range(2)]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -130,7 +231,7 @@ def main():
 
     res = eng.result()
     st = eng.stats()
-    # the same windows including pack + upload (what the product's polish() pays per batch); outside the timed region above
+    # the same windows including pack + upload (a warm engine's polish call); outside the timed region above
     dt_up = float("nan")
     if not a.no_upload_leg:
         eng.consensus(batch)
@@ -146,16 +247,21 @@ def main():
         dt_up = float(t.item())
     st_up = eng.stats()
     if rank == 0:
-        # --- roofline of the dominant (only) kernel: algorithmic bytes per launch / launch duration
+        # --- roofline of the dominant (only) kernel: algorithmic bytes per step / the interval its launches cover.
+        # A step is ONE launch of poa_window_kernel2, or -- split launch, rcn_run_stats.split_deep > 0 -- TWO CONCURRENT
+        # launches of it on disjoint CU sets (deepest windows / all others): `step_kernel_ms` is the interval they
+        # cover together (HIP events, first begin to last end), `launch_ms` their individual durations (what rocprofv3's
+        # per-dispatch statistics average over); the bytes are the step's, so achieved = bytes per step / step interval.
         alg_bytes = st["dp_bytes"] + 2 * int(batch.bases.size) + 5 * sum(len(c) for c in res.consensus)
-        avg_launch_s = (kernel_ms / max(1, launches)) / 1e3
-        # measured HBM bytes per launch: PMC counters cannot be read from inside this process; the number comes
+        step_s = (kernel_ms / a.steps) / 1e3
+        per_launch_ms = [v / a.steps for v in launch_ms] if st["split_deep"] else [kernel_ms / max(1, launches)]
+        # measured HBM bytes per step: PMC counters cannot be read from inside this process; the number comes
         # from the rocprofv3 --pmc passes of THIS command (tools/gpu_round.sh -> tools/pmc_summary.py), committed as
         # profiles/traffic.json and stamped with the hash of the kernel sources it was measured on: a stale file
         # (sources changed since) is reported as null, not quoted
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and world == 1 and a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0:
+        if os.path.exists(tf) and world == 1 and not a.config and a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0:
             try:
                 tj = json.load(open(tf))
                 from tools.srchash import kernel_source_hash
@@ -165,7 +271,7 @@ def main():
                     traffic_src = "profiles/traffic.json is stale (kernel sources changed since it was measured)"
             except Exception:
                 traffic = None
-        achieved = alg_bytes / avg_launch_s / 1e9
+        achieved = alg_bytes / step_s / 1e9
         out = {
             "metric": "polished windows/sec (500 bp, 30x cov)",
             "value": total_windows * a.steps / dt,
@@ -177,37 +283,53 @@ def main():
             "value_incl_upload": None if a.no_upload_leg else total_windows * a.steps / dt_up,
             "ms_per_step_incl_upload": None if a.no_upload_leg else dt_up / a.steps * 1e3,
             "upload": {"h2d_ms": st_up["h2d_ms"], "d2h_ms": st_up["d2h_ms"], "bytes_in": st_up["bytes_in"]},
-            "config": {"workload": "%s: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d, "
-                                   "scores %s, %d windows/GPU" % (cfg_name, a.contig, a.coverage, a.window, a.scores, batch.n_windows),
+            "config": {"workload": "%s, scores %s, %d windows/GPU" % (what, a.scores, batch.n_windows),
                        "windows_per_gpu": batch.n_windows, "parallelism": "windows sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "poa_window_kernel2", "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel": "poa_window_kernel2", "step_kernel_ms": step_s * 1e3, "avg_launch_ms": sum(per_launch_ms) / len(per_launch_ms),
+                         "launches_per_step": len(per_launch_ms), "launch_ms": per_launch_ms,
+                         "split_launch": None if not st["split_deep"] else
+                             {"deep_windows": st["split_deep"], "deep_cus": st["split_cus"], "deep_work_groups_per_cu": st["split_deep_per_cu"],
+                              "note": "two concurrent launches on disjoint CU sets; bytes and interval are the step's"},
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "gcups": st["dp_cells"] / avg_launch_s / 1e9,
+                         "gcups": st["dp_cells"] / step_s / 1e9,
                          # exact banded DP ("cells counts the cells actually evaluated and the full-matrix figure
                          # is reported alongside"): the figures an unbanded pass over the same alignments has
                          "full_matrix": {"algorithmic_bytes_per_launch": alg_bytes - st["dp_bytes"] + st["dp_bytes_full"],
-                                         "achieved": (alg_bytes - st["dp_bytes"] + st["dp_bytes_full"]) / avg_launch_s / 1e9,
-                                         "gcups": st["dp_cells_full"] / avg_launch_s / 1e9},
+                                         "achieved": (alg_bytes - st["dp_bytes"] + st["dp_bytes_full"]) / step_s / 1e9,
+                                         "gcups": st["dp_cells_full"] / step_s / 1e9},
                          "banded_alignments": st["n_banded"], "band_redone": st["n_band_redone"], "band_redo_why": st["band_redo_why"],
                          "phase_clocks": st["phase_clocks"], "work_groups_per_cu": st["wg_per_cu"]},
         }
+        if do_product:
+            # the product on the same workload (same seed -> the same windows, tests/test_synth_files.py)
+            try:
+                th = max(1, min(32, len(os.sched_getaffinity(0))))
+                out["product_polish"] = {}
+                for name, paths in pfiles:
+                    out["product_polish"][name] = product_polish(paths, a.window, (m, x, g), th, expect=b"".join(res.consensus) if name == "cfg2" else None)
+                out["value_product_polish"] = out["product_polish"]["cfg2"]["windows_per_s"]
+                if "cfg3_share" in out["product_polish"]:
+                    out["value_product_polish_12k"] = out["product_polish"]["cfg3_share"]["windows_per_s"]
+            except Exception as e:                       # the headline line must not die with the product leg
+                out["product_polish"] = {"error": repr(e)}
         if not a.no_cpu and world == 1:
             # CPU baseline on this box's host cores (rank 0 at N = 1 only): the oracle's AVX2 int16 variant (the scheme of spoa's SIMD
-            # engine: row vectors + log-step prefix max), all hardware threads, whole batch, best of 3.  The scalar
-            # int32 oracle is timed next to it on a sample for reference.
+            # engine: row vectors + log-step prefix max), whole batch; the thread count is swept and the box's best is what the
+            # GPU is compared with.  The scalar int32 oracle is timed next to it on a sample for reference.
             from oracle import oracle_lib
-            ncpu = os.cpu_count() or 1
+            lim = cpu_limits()
+            ncpu = lim["sched_affinity"] or (os.cpu_count() or 1)
             # bounded sample of the same workload: at most 2000 windows (all of cfg2)
             cb = batch if batch.n_windows <= 2000 else batch.select(range(2000))
-            want = [int(v) for v in a.cpu_threads.split(",") if v] or [32, 64, 128, ncpu]
+            want = [int(v) for v in a.cpu_threads.split(",") if v] or [8, 16, 24, 32, 48, 64, 96, 128, ncpu]
             sweep_threads = sorted({min(max(1, v), ncpu) for v in want})
-            oracle_lib.consensus(cb.select(range(min(64, cb.n_windows))), m, x, g, True, ncpu, simd=True)   # warm up
+            oracle_lib.consensus(cb.select(range(min(64, cb.n_windows))), m, x, g, True, min(ncpu, 32), simd=True)   # warm up
             sweep, best_dt, ref, cores = {}, None, None, ncpu
-            for th in sweep_threads:                       # the box's best thread count is what the GPU is compared with
+            for th in sweep_threads:
                 bt = None
-                for _ in range(3):
+                for _ in range(2):
                     tc = time.perf_counter()
                     ref = oracle_lib.consensus(cb, m, x, g, True, th, simd=True)
                     dtc = time.perf_counter() - tc
@@ -216,22 +338,23 @@ def main():
                 if best_dt is None or bt < best_dt:
                     best_dt, cores = bt, th
             ok = ref.consensus == res.consensus[:cb.n_windows]
-            n_s = a.cpu_sample or min(cb.n_windows, max(64, 4 * ncpu))
+            n_s = a.cpu_sample or min(cb.n_windows, max(64, 4 * min(ncpu, 64)))
             sample = cb.select(range(n_s))
             tc = time.perf_counter()
-            oracle_lib.consensus(sample, m, x, g, True, ncpu)
+            oracle_lib.consensus(sample, m, x, g, True, min(ncpu, cores))
             dts = time.perf_counter() - tc
             out["cpu_baseline"] = {"value": cb.n_windows / best_dt, "unit": "windows/s", "cores": cores, "kind": "port",
                                    "sample": "%d windows of the same workload, oracle/poa_oracle.cpp AVX2 int16 variant, best thread "
-                                             "count of the sweep (%d of %d hardware threads), best of 3 (%.2f s); scalar int32 oracle "
-                                             "on the first %d windows, all threads: %.0f windows/s"
-                                             % (cb.n_windows, cores, ncpu, best_dt, n_s, n_s / dts),
-                                   "thread_sweep_windows_per_s": sweep,
+                                             "count of the sweep (%d; the process may run on %d logical CPUs, cgroup quota %s), best of 2 (%.2f s); "
+                                             "scalar int32 oracle on the first %d windows, %d threads: %.0f windows/s"
+                                             % (cb.n_windows, cores, ncpu, lim.get("cgroup_cpus"), best_dt, n_s, min(ncpu, cores), n_s / dts),
+                                   "thread_sweep_windows_per_s": sweep, "host": lim,
                                    "matches_gpu": bool(ok)}
         if a.verify:
             from oracle import oracle_lib
-            ref = oracle_lib.consensus(batch, m, x, g, True, 0)
+            ref = oracle_lib.consensus(batch, m, x, g, True, 0, simd=True)
             out["verified_windows"] = int(sum(ref.consensus[i] == res.consensus[i] for i in range(batch.n_windows)))
+            out["verified_flags"] = bool((ref.polished == res.polished).all() and (ref.chimeric == res.chimeric).all())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

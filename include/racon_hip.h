@@ -95,7 +95,11 @@ typedef struct rcn_run_stats {
                                   cell, alive dropped cell                                                                   */
     uint32_t wg_per_cu;        /* work-groups of the consensus kernel per CU in the last launch: 8, or 6 when the batch is
                                   resident all at once and lasts as long as its deepest window (engine.hip: wg_per_cu)     */
-    uint32_t reserved0;
+    uint32_t split_deep;       /* split launch (engine.hip: split_plan): windows of the deep launch, 0 = one uniform launch */
+    uint32_t split_cus;        /* CUs the deep launch ran on (the other launch: all the others)                            */
+    uint32_t split_deep_per_cu;/* work-groups per CU of the deep launch                                                    */
+    double   launch_ms[2];     /* HIP-event durations of the (up to two, concurrent) launches of the first pass; kernel_ms is
+                                  the interval they cover together                                                         */
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */
@@ -114,6 +118,45 @@ int  rcn_engine_run(rcn_engine* e);
  * soon as it has arrived.  Results and statistics as after rcn_engine_upload + rcn_engine_run; the batch stays
  * resident (rcn_engine_run may follow).                                                                               */
 int  rcn_engine_polish(rcn_engine* e, const rcn_batch* b);
+
+/* The same batch as BORROWED POINTERS, the form a racon::Window holds its sequences in (reference src/window.hpp:71-73:
+ * `(const char*, uint32_t)` pairs into Polisher::sequences_; what CUDABatchProcessor::addWindow reads,
+ * src/cuda/cudabatch.cpp:80-122).  rcn_engine_polish_refs packs straight from these pointers into the engine's pinned
+ * staging (host threads, deepest window first) -- one host copy of the bases instead of two -- and otherwise does what
+ * rcn_engine_polish does.  Nothing is retained after the call returns.                                               */
+typedef struct rcn_window_refs {
+    uint32_t n_windows;
+    uint32_t n_seqs;                 /* == win_seq_off[n_windows]                                   */
+    const uint32_t* win_seq_off;     /* [n_windows+1]                                               */
+    const uint8_t*  win_type;        /* [n_windows]  0 = kNGS, 1 = kTGS                              */
+    const uint8_t* const* seq;       /* [n_seqs] Window::sequences_[i].first                         */
+    const uint8_t* const* qual;      /* [n_seqs] Window::qualities_[i].first; NULL = no quality      */
+    const uint32_t* seq_len;         /* [n_seqs] Window::sequences_[i].second                        */
+    const uint32_t* seq_begin;       /* [n_seqs] positions_.first  (backbone: 0)                     */
+    const uint32_t* seq_end;         /* [n_seqs] positions_.second (backbone: 0)                     */
+    uint32_t flags;                  /* RCN_REFS_*                                                   */
+} rcn_window_refs;
+#define RCN_REFS_QUEUED  1u          /* this batch is one of several that the caller keeps in flight on the device (two
+                                        engines alternating): run it at full residency (eight work-groups per CU) even
+                                        when its own deepest window would otherwise rule the launch                  */
+int  rcn_engine_polish_refs(rcn_engine* e, const rcn_window_refs* w);
+
+/* Allocation ahead of the first batch (the role of spoa::AlignmentEngine::Prealloc(window_length, 5), reference
+ * src/polisher.cpp:180-182, and of createCUDABatch's up-front device allocation, src/cuda/cudabatch.cpp:24-75):
+ * device input arrays, the per-slot scratch arena, pinned staging for inputs and results, and the first use of the
+ * code object and the copy engines, so that the first rcn_engine_polish* call pays none of it.  Every figure is a
+ * hint: a batch that needs more grows the buffers as before.                                                      */
+typedef struct rcn_reserve_hint {
+    uint32_t n_windows;              /* windows per batch                                            */
+    uint32_t n_seqs;                 /* sequences (backbones + layers) per batch                     */
+    uint64_t n_bases;                /* bases per batch                                              */
+    uint32_t window_length;          /* backbone length (-w)                                         */
+    uint32_t max_layer_length;       /* longest layer; 0 = 1.3 x window_length                       */
+    uint64_t max_window_bases;       /* bases of the deepest window, backbone included (it sizes a resident window's
+                                        scratch slot); 0 = n_bases / n_windows                        */
+} rcn_reserve_hint;
+int  rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* hint);
+
 int  rcn_engine_result(rcn_engine* e, rcn_result* out);
 int  rcn_engine_stats(rcn_engine* e, rcn_run_stats* out);
 /* Changes the trim flag (Window::generate_consensus takes it per call, reference

@@ -59,6 +59,11 @@ int  rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* results, int dro
                             const char** fasta, uint64_t* fasta_length);
 /* Polisher::polish on the MI355X (loads libracon_hip.so; fails without a device) + FASTA text. */
 int  rcnh_polisher_polish(rcnh_polisher* p, int drop_unpolished_sequences, const char** fasta, uint64_t* fasta_length);
+/* Seconds of the last rcnh_polisher_polish: the interval the reference's Logger brackets around Polisher::polish
+ * (reference src/polisher.cpp:493 -> :539-543, "[racon::Polisher::polish] generated consensus") -- the interval
+ * "polished windows / second" is defined on.  Window count of the job alongside.               */
+double   rcnh_polisher_polish_seconds(rcnh_polisher* p);
+uint64_t rcnh_polisher_num_windows(rcnh_polisher* p);     /* valid between initialize and polish/assemble */
 void rcnh_polisher_destroy(rcnh_polisher* p);
 
 /* Pairwise global alignment used for overlaps without CIGAR (reference src/overlap.cpp:205-224).

@@ -142,10 +142,17 @@ struct rcn_engine {
     // piece was observed to wait for the second one to finish
     static constexpr int kSubLaunches = 2;
     hipStream_t sub_stream[kSubLaunches] = {nullptr, nullptr};
+    // CU-masked pair for the split launch of a batch that is resident all at once (split_plan): the deepest windows on
+    // `deep_stream` (the first split_cus bits of the mask = an even slice of every XCD, tools/probe/cu_mask.hip) with few
+    // work-groups per CU, all the others on `rest_stream` (the complement).  Null when the runtime refused the masks.
+    hipStream_t deep_stream = nullptr, rest_stream = nullptr;
+    int split_cus = 0;
+    bool warmed = false;                            // rcn_engine_reserve ran its warm-up launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
     int n_cu = 256;
     uint64_t t_max = 0, t_sum = 0;      // bases of the deepest window / of all windows of the prepared batch (wg_per_cu)
+    bool queued = false;                // RCN_REFS_QUEUED: the caller keeps several batches in flight (wg_per_cu: eight)
     size_t free_mem = 0;
 
     // resident batch
@@ -246,20 +253,56 @@ uint32_t max_slots(const rcn_engine* e) {
 // its layers' lengths; measured ~ n_seqs^1.1), the launch is max(deepest window, all windows / slots), six per CU cost
 // 1.23 x the second term (6 / 8 of the slots at 0.925 of the clocks) and save ~4 % of the first.
 // Fewer than eight per CU is enforced by asking for more LDS per work-group (allocation granule 1280 B, 128 per CU).
+// deepest window against an even share of all windows: does one window's serial chain rule the launch?
+bool deepest_rules(const rcn_engine* e) {
+    const double even = static_cast<double>(e->t_sum) / (8.0 * e->n_cu);           // bases per slot if all slots stayed busy
+    return static_cast<double>(e->t_max) > 1.25 * even;
+}
 uint32_t wg_per_cu(const rcn_engine* e) {
     if (const char* v = getenv("RCN_WG_PER_CU")) return static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));   // experiments
-    const double even = static_cast<double>(e->t_sum) / (8.0 * e->n_cu);           // bases per slot if all slots stayed busy
-    return static_cast<double>(e->t_max) > 1.25 * even ? 6u : 8u;
+    if (e->queued) return 8u;                       // the caller keeps the device busy with further batches: a long queue
+    return deepest_rules(e) ? 6u : 8u;
 }
 uint32_t lds_bytes_for(uint32_t per_cu) {
     const uint32_t need = rcn::kLdsBytes + rcn::kCtxBytes;
-    return per_cu >= 8 ? need : std::max(need, (128u / per_cu) * 1280u);
+    return per_cu >= 8 ? need : std::max(need, (128u / std::max(1u, per_cu)) * 1280u);
+}
+
+// ---- split launch: the deepest windows on CUs of their own ----
+// A batch that is resident all at once ends with its deepest window (cfg2: 53 layers against a median of 30, ~45 % of
+// the slot-time of a uniform launch is tail), and a window runs faster the fewer neighbours share its CU: -11 % DP
+// clocks and -30 % in the four-wave graph phases at four work-groups per CU instead of eight
+// (profiles/r02/f_occupancy.txt).  Uniform residency cannot use that, two launches on two CU-masked streams can
+// (hipExtStreamCreateWithCUMask; tools/probe/cu_mask.hip: the first N mask bits are N/8 CUs of every XCD, the
+// complement is honoured): the `n_deep` deepest windows -- the layer chains that cannot be reordered, reference
+// src/window.cpp:88-119 -- at `deep_per_cu` work-groups per CU on `split_cus` CUs, all the others at eight per CU on the
+// rest of the chip, persistent over their queue.  Same kernel, same results; the decision uses the cost proxy of
+// wg_per_cu.  RCN_SPLIT=0 switches it off, RCN_SPLIT=1 forces it (tests), RCN_SPLIT_DEEP / RCN_SPLIT_DEEP_PER_CU /
+// RCN_SPLIT_REST_PER_CU override the plan (experiments).
+struct SplitPlan { bool on = false; uint32_t n_deep = 0, deep_per_cu = 1, rest_per_cu = 8; };
+SplitPlan split_plan(const rcn_engine* e, uint32_t nw, bool fast) {
+    SplitPlan sp;
+    const char* sw = getenv("RCN_SPLIT");
+    if (!fast || !e->deep_stream || !e->rest_stream || e->cfg.max_slots || (sw && atoi(sw) == 0)) return sp;
+    const bool forced = sw && atoi(sw) == 1;
+    const uint32_t cus = static_cast<uint32_t>(e->split_cus);
+    if (!forced && (e->queued || !deepest_rules(e) || nw < 4 * cus || nw > static_cast<uint32_t>(e->n_cu) * 8u)) return sp;
+    if (nw < 2) return sp;
+    sp.on = true;
+    sp.deep_per_cu = 1; sp.rest_per_cu = 8;
+    if (const char* v = getenv("RCN_SPLIT_DEEP_PER_CU")) sp.deep_per_cu = static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));
+    if (const char* v = getenv("RCN_SPLIT_REST_PER_CU")) sp.rest_per_cu = static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));
+    sp.n_deep = cus * sp.deep_per_cu;
+    if (const char* v = getenv("RCN_SPLIT_DEEP")) sp.n_deep = static_cast<uint32_t>(std::max(1, atoi(v)));
+    sp.n_deep = std::min(sp.n_deep, nw - 1);
+    return sp;
 }
 
 struct Launch {
     Caps c;
     const uint32_t* d_ids = nullptr;    // work item -> device window, or nullptr: work_base + work item
     uint32_t n_work = 0, work_base = 0, out_base = 0, slots = 0;
+    uint32_t per_cu = 0;                // work-groups per CU of the fast kernel (0: wg_per_cu)
     uint64_t scratch_off = 0;
     int ctr = 0;                        // which work-queue counter of d_ctr
     hipStream_t stream = nullptr;
@@ -288,10 +331,11 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.out_len = e->d_out_len.as<uint32_t>(); P.out_flags = e->d_out_flags.as<uint8_t>();
     P.next = e->d_ctr.as<unsigned int>() + L.ctr;
     P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + kStatsOff);
+    const uint32_t per_cu = L.per_cu ? L.per_cu : wg_per_cu(e);
     if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] pass of %u windows on %u slots, %u work-groups per CU (deepest window %llu bases, all %llu)\n", L.n_work, L.slots,
-                                     L.c.fast ? wg_per_cu(e) : 8u, (unsigned long long)e->t_max, (unsigned long long)e->t_sum);
-    if (L.c.fast) e->stats.wg_per_cu = wg_per_cu(e);
-    if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(wg_per_cu(e)), L.stream, P);
+                                     L.c.fast ? per_cu : 8u, (unsigned long long)e->t_max, (unsigned long long)e->t_sum);
+    if (L.c.fast) e->stats.wg_per_cu = per_cu;
+    if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(per_cu), L.stream, P);
     else hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(L.slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, L.stream, P);
     HIP_TRY(hipGetLastError());
     return RCN_OK;
@@ -465,6 +509,26 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
     for (auto& evs : e->sub_ev) for (auto& ev : evs) HIP_TRY(hipEventCreate(&ev));
+    {
+        // the CU-masked stream pair of the split launch (split_plan); a runtime that refuses masks leaves them null
+        int cus = 96;
+        if (const char* v = getenv("RCN_SPLIT_CUS")) cus = atoi(v);
+        cus = (cus / 8) * 8;                                   // an even slice of the eight XCDs
+        const char* sw = getenv("RCN_SPLIT");
+        if (cus >= 8 && cus <= e->n_cu - 8 && e->n_cu <= 256 && !(sw && atoi(sw) == 0)) {
+            uint32_t deep[8] = {0}, rest[8] = {0};
+            for (int b = 0; b < e->n_cu; ++b) (b < cus ? deep : rest)[b >> 5] |= 1u << (b & 31);
+            const uint32_t words = static_cast<uint32_t>((e->n_cu + 31) / 32);
+            if (hipExtStreamCreateWithCUMask(&e->deep_stream, words, deep) != hipSuccess) e->deep_stream = nullptr;
+            if (e->deep_stream && hipExtStreamCreateWithCUMask(&e->rest_stream, words, rest) != hipSuccess) e->rest_stream = nullptr;
+            if (!e->rest_stream && e->deep_stream) { (void)hipStreamDestroy(e->deep_stream); e->deep_stream = nullptr; }
+            (void)hipGetLastError();
+            e->split_cus = e->deep_stream ? cus : 0;
+        }
+        // fewer than eight work-groups per CU are enforced through the LDS request (lds_bytes_for): up to the whole LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
     int rc = e->d_ctr.reserve(kCtrBytes);
     if (rc) return rc;
     guard.e = nullptr;
@@ -486,6 +550,8 @@ void rcn_engine_destroy(rcn_engine* e) {
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (auto& evs : e->sub_ev) for (auto& ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (auto& st : e->sub_stream) if (st && st != e->stream) (void)hipStreamDestroy(st);
+    if (e->deep_stream) (void)hipStreamDestroy(e->deep_stream);
+    if (e->rest_stream) (void)hipStreamDestroy(e->rest_stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -515,7 +581,7 @@ int rcn_engine_upload(rcn_engine* e, const rcn_batch* b) {
     HIP_TRY(hipEventRecord(t.a, e->stream));
     const uint32_t nw = b->n_windows, ns = b->n_seqs;
     e->n_windows = nw; e->n_seqs = ns; e->n_bases = ns ? b->seq_off[ns] : 0;
-    e->uploaded = false; e->ran = false;
+    e->uploaded = false; e->ran = false; e->queued = false;
     int rc;
     if ((rc = prepare_resident(e, nw, ns, b->win_seq_off, b->seq_off, b->seq_begin, b->seq_end, b->bases, 0))) return rc;
     if ((rc = upload_vec(e->d_win_seq_off, b->win_seq_off, 4ull * (nw + 1), e->stream))) return rc;
@@ -619,14 +685,47 @@ int rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_t
         return RCN_OK;
     };
     int rc;
-    if ((rc = get(win_seq_off, e->d_win_seq_off, 4 * (nw + 1)))) return rc;
-    if ((rc = get(win_type, e->d_win_type, nw))) return rc;
-    if ((rc = get(seq_off, e->d_seq_off, 8 * (ns + 1)))) return rc;
-    if ((rc = get(seq_has_qual, e->d_has_qual, ns))) return rc;
-    if ((rc = get(seq_begin, e->d_begin, 4 * ns))) return rc;
-    if ((rc = get(seq_end, e->d_end, 4 * ns))) return rc;
-    if ((rc = get(bases, e->d_bases, e->n_bases))) return rc;
-    if ((rc = get(quals, e->d_quals, e->n_bases))) return rc;
+    if (!e->lpt_layout) {
+        if ((rc = get(win_seq_off, e->d_win_seq_off, 4 * (nw + 1)))) return rc;
+        if ((rc = get(win_type, e->d_win_type, nw))) return rc;
+        if ((rc = get(seq_off, e->d_seq_off, 8 * (ns + 1)))) return rc;
+        if ((rc = get(seq_has_qual, e->d_has_qual, ns))) return rc;
+        if ((rc = get(seq_begin, e->d_begin, 4 * ns))) return rc;
+        if ((rc = get(seq_end, e->d_end, 4 * ns))) return rc;
+        if ((rc = get(bases, e->d_bases, e->n_bases))) return rc;
+        if ((rc = get(quals, e->d_quals, e->n_bases))) return rc;
+        return RCN_OK;
+    }
+    // streamed batches (rcn_engine_polish*) are resident deepest first: device window k is caller window lpt[k].  The
+    // copy handed out is in CALLER order, like every other view of the batch.
+    std::vector<uint32_t> d_wso(nw + 1), d_bg(ns), d_en(ns);
+    std::vector<uint64_t> d_so(ns + 1);
+    std::vector<uint8_t> d_type(nw), d_hq(ns), d_b(bases ? e->n_bases : 0), d_q(quals ? e->n_bases : 0);
+    if ((rc = get(d_wso.data(), e->d_win_seq_off, 4 * (nw + 1))) || (rc = get(d_type.data(), e->d_win_type, nw)) ||
+        (rc = get(d_so.data(), e->d_seq_off, 8 * (ns + 1))) || (rc = get(d_hq.data(), e->d_has_qual, ns)) ||
+        (rc = get(d_bg.data(), e->d_begin, 4 * ns)) || (rc = get(d_en.data(), e->d_end, 4 * ns)) ||
+        (rc = get(d_b.data(), e->d_bases, d_b.size())) || (rc = get(d_q.data(), e->d_quals, d_q.size())))
+        return rc;
+    std::vector<uint32_t> item_of(nw);
+    for (uint32_t k = 0; k < nw; ++k) item_of[e->lpt[k]] = k;
+    uint32_t so = 0; uint64_t bo = 0;
+    if (win_seq_off) win_seq_off[0] = 0;
+    if (seq_off) seq_off[0] = 0;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t k = item_of[w], s0 = d_wso[k], n = d_wso[k + 1] - s0;
+        if (win_type) win_type[w] = d_type[k];
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t a = d_so[s0 + i], len = d_so[s0 + i + 1] - a;
+            if (seq_has_qual) seq_has_qual[so] = d_hq[s0 + i];
+            if (seq_begin) seq_begin[so] = d_bg[s0 + i];
+            if (seq_end) seq_end[so] = d_en[s0 + i];
+            if (bases && len) std::memcpy(bases + bo, d_b.data() + a, len);
+            if (quals && len) std::memcpy(quals + bo, d_q.data() + a, len);
+            bo += len; ++so;
+            if (seq_off) seq_off[so] = bo;
+        }
+        if (win_seq_off) win_seq_off[w + 1] = so;
+    }
     return RCN_OK;
 }
 
@@ -793,6 +892,91 @@ static int begin_run(rcn_engine* e) {
     return RCN_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Internal view of a batch: one pointer per sequence.  rcn_batch (contiguous bytes) and rcn_window_refs (borrowed
+// pointers, what a racon::Window holds) both map onto it.
+struct SrcView {
+    uint32_t nw = 0, ns = 0, flags = 0;
+    const uint32_t* win_seq_off = nullptr; const uint8_t* win_type = nullptr;
+    const uint64_t* seq_off = nullptr;                  // [ns + 1] prefix sums of the sequence lengths
+    const uint8_t* const* seq = nullptr;                // [ns]
+    const uint8_t* const* qual = nullptr;               // [ns] nullptr = no quality
+    const uint32_t* begin = nullptr; const uint32_t* end = nullptr;
+};
+
+// contiguous copy of a view (the plain upload path of a batch that came as pointers)
+struct HostBatch { std::vector<uint8_t> has_qual, bases, quals; rcn_batch b{}; };
+void materialize(const SrcView& v, HostBatch& h) {
+    const uint64_t nb = v.ns ? v.seq_off[v.ns] : 0;
+    h.has_qual.resize(std::max<size_t>(1, v.ns)); h.bases.resize(nb + 1); h.quals.resize(nb + 1);
+    for (uint32_t i = 0; i < v.ns; ++i) {
+        const uint64_t a = v.seq_off[i], len = v.seq_off[i + 1] - a;
+        if (len) std::memcpy(h.bases.data() + a, v.seq[i], len);
+        h.has_qual[i] = v.qual[i] ? 1 : 0;
+        if (!len) continue;
+        if (v.qual[i]) std::memcpy(h.quals.data() + a, v.qual[i], len); else std::memset(h.quals.data() + a, '!', len);
+    }
+    h.b.n_windows = v.nw; h.b.n_seqs = v.ns; h.b.win_seq_off = v.win_seq_off; h.b.win_type = v.win_type; h.b.seq_off = v.seq_off;
+    h.b.seq_has_qual = h.has_qual.data(); h.b.seq_begin = v.begin; h.b.seq_end = v.end; h.b.bases = h.bases.data(); h.b.quals = h.quals.data();
+}
+
+// The launches of a first pass: cut[c] .. cut[c + 1] are the work items of piece c (deepest first).  Fills the Launch
+// records (capacities from the pieces' own shapes, slots, scratch placement); false when the scratch does not fit.
+struct PassPlan { int n = 0; uint32_t cut[rcn_engine::kSubLaunches + 1] = {}; Launch L[rcn_engine::kSubLaunches]; uint64_t scratch = 0; bool split = false, copied = false; };
+
+void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fast, uint32_t slots_left) {
+    std::vector<WinShape> sh;
+    sh.reserve(pp.cut[c + 1] - pp.cut[c]);
+    for (uint32_t k = pp.cut[c]; k < pp.cut[c + 1]; ++k) sh.push_back(e->shapes[e->lpt[k]]);
+    Launch& L = pp.L[c];
+    L.c = first_pass_caps(sh.begin(), sh.end(), fast);
+    L.n_work = pp.cut[c + 1] - pp.cut[c]; L.work_base = pp.cut[c]; L.out_base = pp.cut[c]; L.ctr = c;
+    if (sp.on) {
+        L.stream = c == 0 ? e->deep_stream : e->rest_stream;
+        L.per_cu = c == 0 ? sp.deep_per_cu : sp.rest_per_cu;
+        const uint32_t cus = c == 0 ? static_cast<uint32_t>(e->split_cus) : static_cast<uint32_t>(e->n_cu - e->split_cus);
+        L.slots = std::min(L.n_work, cus * L.per_cu);
+    } else {
+        L.stream = e->sub_stream[c]; L.per_cu = 0;
+        L.slots = std::min(L.n_work, slots_left);
+    }
+    L.scratch_off = pp.scratch;
+    pp.scratch += static_cast<uint64_t>(L.slots) * L.c.slot_bytes;
+}
+
+// kernel begin / end events of the pieces -> run statistics (the overlapping launches as one interval)
+int finish_pieces(rcn_engine* e, const PassPlan& pp, hipEvent_t ref) {
+    float span0 = 0, span1 = 0;
+    bool have = false;
+    for (int c = 0; c < pp.n; ++c) {
+        if (pp.L[c].n_work == 0) continue;
+        HIP_TRY(hipEventSynchronize(e->sub_ev[c][2]));
+        float a0 = 0, a1 = 0;       // begin / end of this launch relative to `ref`
+        HIP_TRY(hipEventElapsedTime(&a0, ref, e->sub_ev[c][1]));
+        HIP_TRY(hipEventElapsedTime(&a1, ref, e->sub_ev[c][2]));
+        if (!have) { span0 = a0; span1 = a1; have = true; } else { span0 = std::min(span0, a0); span1 = std::max(span1, a1); }
+        if (getenv("RCN_DEBUG")) {
+            float cp = 0; if (pp.copied) (void)hipEventElapsedTime(&cp, ref, e->sub_ev[c][0]);
+            fprintf(stderr, "[racon_hip] piece %d: work items [%u, %u) slots %u (%u per CU) ncap %d lmax %d | copy done %.2f ms, kernel %.2f .. %.2f ms\n",
+                    c, pp.cut[c], pp.cut[c + 1], pp.L[c].slots, pp.L[c].per_cu, pp.L[c].c.ncap, pp.L[c].c.lmax, cp, a0, a1);
+        }
+        e->stats.launch_ms[c] = a1 - a0;
+        e->stats.n_launches += 1;
+    }
+    e->stats.kernel_ms += span1 - span0;
+    e->stats.split_deep = pp.split ? pp.L[0].n_work : 0;
+    e->stats.split_cus = pp.split ? static_cast<uint32_t>(e->split_cus) : 0;
+    e->stats.split_deep_per_cu = pp.split ? pp.L[0].per_cu : 0;
+    return RCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int rcn_engine_run(rcn_engine* e) {
     if (!e) return RCN_E_ARG;
     if (!e->uploaded) return RCN_E_STATE;
@@ -805,27 +989,67 @@ int rcn_engine_run(rcn_engine* e) {
     }
     int rc;
     if ((rc = begin_run(e))) return rc;
-    const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), !getenv("RCN_WIDE_ONLY"));
-    if ((rc = run_pass(e, c1, e->lpt_layout ? nullptr : e->d_lpt_ids.as<uint32_t>(), nw))) return rc;
+    const bool fast = !getenv("RCN_WIDE_ONLY");
+    const uint32_t* ids = e->lpt_layout ? nullptr : e->d_lpt_ids.as<uint32_t>();
+    const SplitPlan sp = split_plan(e, nw, fast);
+    if (sp.on) {
+        // the split pair: deepest windows on their own CUs, everything else on the rest of the chip
+        PassPlan pp; pp.n = 2; pp.split = true; pp.cut[0] = 0; pp.cut[1] = sp.n_deep; pp.cut[2] = nw;
+        for (int c = 0; c < 2; ++c) { plan_piece(e, pp, c, sp, fast, 0); pp.L[c].d_ids = ids ? ids + pp.cut[c] : nullptr; }
+        if (pp.scratch <= scratch_budget(e)) {
+            if ((rc = e->d_scratch.reserve(pp.scratch))) return rc;
+            HIP_TRY(hipEventRecord(e->ev0, e->stream));             // the counters were zeroed on the main stream (begin_run)
+            for (int c = 0; c < 2; ++c) {
+                HIP_TRY(hipStreamWaitEvent(pp.L[c].stream, e->ev0, 0));
+                HIP_TRY(hipEventRecord(e->sub_ev[c][1], pp.L[c].stream));
+                if ((rc = launch_pass(e, pp.L[c]))) return rc;
+                HIP_TRY(hipEventRecord(e->sub_ev[c][2], pp.L[c].stream));
+            }
+            if ((rc = finish_pieces(e, pp, e->ev0))) return rc;
+            return collect(e);
+        }
+    }
+    const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), fast);
+    if ((rc = run_pass(e, c1, ids, nw))) return rc;
     return collect(e);
+}
+
+}  // extern "C"
+
+namespace {
+
+inline void symbols_add(uint64_t present[4], const uint8_t* p, uint64_t n) {
+    for (uint64_t k = 0; k < n; ++k) present[p[k] >> 6] |= 1ull << (p[k] & 63);
+}
+inline void symbols_finish(const uint64_t present[4], int32_t& nsym, uint8_t& acgt_only) {
+    nsym = 0;
+    for (int k = 0; k < 4; ++k) nsym += __builtin_popcountll(present[k]);
+    const uint64_t acgt = (1ull << ('A' & 63)) | (1ull << ('C' & 63)) | (1ull << ('G' & 63)) | (1ull << ('T' & 63));
+    acgt_only = (present[0] == 0 && present[2] == 0 && present[3] == 0 && (present[1] & ~acgt) == 0) ? 1 : 0;
 }
 
 // Upload + run of one batch with the copy hidden behind the kernel (what Polisher::polish pays per batch; reference
 // src/cuda/cudapolisher.cpp:254-333 fills and runs a batch strictly one after the other).  The windows are packed
-// DEEPEST FIRST into pinned staging by host threads, go to HBM in kSubLaunches pieces on a copy stream, and every piece is
-// polished by its own launch on its own stream as soon as it has arrived: the launches overlap on the device, the deepest
-// windows (which decide when the batch ends) start after the first, small piece.  Same results as upload + run.
-// Batches with more windows than resident slots take the plain path (their caller overlaps batches with two engines).
-int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
-    if (!e || !b || check_batch(b)) return RCN_E_ARG;
-    const uint32_t nw = b->n_windows, ns = b->n_seqs;
+// DEEPEST FIRST into pinned staging by host threads -- straight from the caller's per-sequence pointers --, go to HBM in
+// kSubLaunches pieces on a copy stream, and every piece is polished by its own launch on its own stream as soon as it
+// has arrived: the launches overlap on the device, the deepest windows (which decide when the batch ends) start after
+// the first, small piece.  With the split plan the first piece is the deep launch on its own CUs.  A batch with more
+// windows than resident slots runs the same way, its launches persistent over their queues.  Same results as
+// upload + run.
+int polish_view(rcn_engine* e, const SrcView& v) {
+    const uint32_t nw = v.nw, ns = v.ns;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    if (nw < 64 || nw > max_slots(e) || getenv("RCN_NO_STREAM")) {
-        const int rc = rcn_engine_upload(e, b);
+    e->queued = (v.flags & RCN_REFS_QUEUED) != 0;
+    auto plain = [&]() -> int {
+        HostBatch hb; materialize(v, hb);
+        const int rc = rcn_engine_upload(e, &hb.b);
+        e->queued = (v.flags & RCN_REFS_QUEUED) != 0;
         return rc ? rc : rcn_engine_run(e);
-    }
+    };
+    const bool fast = !getenv("RCN_WIDE_ONLY");
+    if (nw < 64 || getenv("RCN_NO_STREAM")) return plain();
     e->uploaded = false; e->ran = false;
-    e->n_windows = nw; e->n_seqs = ns; e->n_bases = b->seq_off[ns];
+    e->n_windows = nw; e->n_seqs = ns; e->n_bases = v.seq_off[ns];
     const bool dbg = getenv("RCN_DEBUG") != nullptr;
     const auto h0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count(); };
@@ -833,7 +1057,7 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     if (t.create()) return RCN_E_HIP;
     HIP_TRY(hipEventRecord(t.a, e->copy_stream));
     HostPrep hp;
-    int rc = prepare_host(e, hp, nw, ns, b->win_seq_off, b->seq_off, b->seq_begin, b->seq_end, b->bases, 0, false, /*scan=*/false);
+    int rc = prepare_host(e, hp, nw, ns, v.win_seq_off, v.seq_off, v.begin, v.end, nullptr, 0, false, /*scan=*/false);
     if (rc) return rc;
     e->lpt_layout = true;
     e->stats = rcn_run_stats{};
@@ -856,18 +1080,18 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     std::vector<uint64_t> win_base(nw + 1, 0);         // first byte of device window k in the packed bases
     s_wso[0] = 0; s_so[0] = 0;
     for (uint32_t k = 0; k < nw; ++k) {
-        const uint32_t w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
+        const uint32_t w = e->lpt[k], s0 = v.win_seq_off[w], n = v.win_seq_off[w + 1] - s0;
         s_wso[k + 1] = s_wso[k] + n;
-        win_base[k + 1] = win_base[k] + (b->seq_off[s0 + n] - b->seq_off[s0]);
-        s_type[k] = b->win_type[w];
+        win_base[k + 1] = win_base[k] + (v.seq_off[s0 + n] - v.seq_off[s0]);
+        s_type[k] = v.win_type[w];
     }
     const unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     host_parallel(nw, threads, [&](size_t k) {
-        const uint32_t w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0, d0 = s_wso[k];
-        const uint64_t src0 = b->seq_off[s0];
+        const uint32_t w = e->lpt[k], s0 = v.win_seq_off[w], n = v.win_seq_off[w + 1] - s0, d0 = s_wso[k];
+        const uint64_t src0 = v.seq_off[s0];
         for (uint32_t i = 0; i < n; ++i) {
-            s_so[d0 + i + 1] = win_base[k] + (b->seq_off[s0 + i + 1] - src0);
-            s_hq[d0 + i] = b->seq_has_qual[s0 + i]; s_bg[d0 + i] = b->seq_begin[s0 + i]; s_en[d0 + i] = b->seq_end[s0 + i];
+            s_so[d0 + i + 1] = win_base[k] + (v.seq_off[s0 + i + 1] - src0);
+            s_hq[d0 + i] = v.qual[s0 + i] ? 1 : 0; s_bg[d0 + i] = v.begin[s0 + i]; s_en[d0 + i] = v.end[s0 + i];
             s_ord[d0 + i] = hp.order[s0 + i]; s_full[d0 + i] = hp.full[s0 + i];
         }
     });
@@ -887,92 +1111,79 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     HIP_TRY(hipMemcpyAsync(e->d_full.p, s_full, ns, hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_out_off.p, e->out_off.data(), 8ull * (nw + 1), hipMemcpyHostToDevice, cs));   // (pageable: small)
 
-    // ---- pieces: the deepest windows that hold 1/24 of the bases (they decide when the batch ends and must start first;
-    //      the fewer there are, the sooner the first launch is under way), then the rest ----
-    uint32_t cut[rcn_engine::kSubLaunches + 1] = {0, 0, nw};
-    {
+    // ---- pieces ----
+    // split plan: the deep launch's windows, then the rest.  Otherwise: the deepest windows that hold 1/24 of the bases
+    // (they decide when the batch ends and must start first; the fewer there are, the sooner the first launch is under
+    // way), then the rest.
+    const SplitPlan sp = split_plan(e, nw, fast);
+    const uint32_t slots_total = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e);
+    if (slots_total < 2) { HIP_TRY(hipStreamSynchronize(cs)); return plain(); }
+    PassPlan pp; pp.n = rcn_engine::kSubLaunches; pp.split = sp.on; pp.copied = true;
+    pp.cut[0] = 0; pp.cut[2] = nw;
+    if (sp.on) pp.cut[1] = sp.n_deep;
+    else {
         const uint64_t q1 = nb / 24;
         uint32_t k = 0;
         while (k < nw && win_base[k] < q1) ++k;
-        cut[1] = std::min(std::max(k, 1u), nw);
+        pp.cut[1] = std::min(std::min(std::max(k, 1u), nw), std::max(1u, slots_total / 2));
     }
-    const bool fast = !getenv("RCN_WIDE_ONLY");
-    Launch L[rcn_engine::kSubLaunches];
-    // Scratch of the pieces side by side.  The symbol count of a window (it sizes the aligned rings) is only known once
-    // its bases have been read, which happens while its piece is packed: every piece is sized after its own scan and
-    // placed behind the previous one.
-    uint64_t scratch_total = 0;
-    std::vector<WinShape> sub_shapes;
-    {   // reserve for the usual alphabet (A, C, G, T and one more symbol) before anything runs; a piece that needs more
-        // grows the buffer below, behind a synchronisation
-        uint64_t est = 0;
-        for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
-            if (cut[c + 1] == cut[c]) continue;
-            sub_shapes.clear();
-            for (uint32_t k = cut[c]; k < cut[c + 1]; ++k) { WinShape sh = e->shapes[e->lpt[k]]; sh.nsym = 5; sub_shapes.push_back(sh); }
-            est += static_cast<uint64_t>(cut[c + 1] - cut[c]) * first_pass_caps(sub_shapes.begin(), sub_shapes.end(), fast).slot_bytes;
-        }
-        if (est <= scratch_budget(e) && (rc = e->d_scratch.reserve(est))) return rc;
+    {   // reserve the scratch for the usual alphabet (A, C, G, T and one more symbol) before anything runs; a piece that
+        // needs more grows the buffer below, behind a synchronisation.  (The symbol count of a window sizes its aligned
+        // rings and is only known once its bases have been read, which happens while its piece is packed.)
+        PassPlan est = pp;
+        std::vector<int32_t> keep(nw);
+        for (uint32_t w = 0; w < nw; ++w) { keep[w] = e->shapes[w].nsym; e->shapes[w].nsym = 5; }
+        uint32_t left = slots_total;
+        for (int c = 0; c < pp.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left); left -= std::min(left, est.L[c].slots); }
+        for (uint32_t w = 0; w < nw; ++w) e->shapes[w].nsym = keep[w];
+        if (est.scratch <= scratch_budget(e) && (rc = e->d_scratch.reserve(est.scratch))) return rc;
     }
     // the main stream zeroed the counters (begin_run): the sub-launches must not start before that
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
-        const uint32_t k0 = cut[c], k1 = cut[c + 1];
-        L[c].n_work = k1 - k0; L[c].work_base = k0; L[c].out_base = k0; L[c].ctr = c; L[c].stream = e->sub_stream[c];
+    uint32_t slots_left = slots_total;
+    for (int c = 0; c < pp.n; ++c) {
+        const uint32_t k0 = pp.cut[c], k1 = pp.cut[c + 1];
         if (k1 == k0) continue;
         const uint64_t b0 = win_base[k0], b1 = win_base[k1];
         // pack the piece into pinned staging and collect its symbol statistics in the same pass over the bases
         host_parallel(k1 - k0, threads, [&](size_t kk) {
-            const uint32_t k = k0 + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = b->win_seq_off[w], n = b->win_seq_off[w + 1] - s0;
-            const uint64_t src0 = b->seq_off[s0], len = b->seq_off[s0 + n] - src0;
-            scan_symbols(b->bases, src0, src0 + len, e->shapes[w].nsym, s_flags[k]);
-            std::memcpy(hs + o_bases + win_base[k], b->bases + src0, len);
-            std::memcpy(hs + o_quals + win_base[k], b->quals + src0, len);
+            const uint32_t k = k0 + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = v.win_seq_off[w], n = v.win_seq_off[w + 1] - s0;
+            uint8_t* db = hs + o_bases + win_base[k]; uint8_t* dq = hs + o_quals + win_base[k];
+            uint64_t present[4] = {0, 0, 0, 0};
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint64_t len = v.seq_off[s0 + i + 1] - v.seq_off[s0 + i];
+                if (!len) continue;
+                std::memcpy(db, v.seq[s0 + i], len);
+                symbols_add(present, db, len);
+                if (v.qual[s0 + i]) std::memcpy(dq, v.qual[s0 + i], len); else std::memset(dq, '!', len);
+                db += len; dq += len;
+            }
+            symbols_finish(present, e->shapes[w].nsym, s_flags[k]);
         });
-        sub_shapes.clear();
-        for (uint32_t k = k0; k < k1; ++k) sub_shapes.push_back(e->shapes[e->lpt[k]]);
-        L[c].c = first_pass_caps(sub_shapes.begin(), sub_shapes.end(), fast);
-        L[c].slots = L[c].n_work;                                  // one resident slot per window (nw <= max_slots)
-        L[c].scratch_off = scratch_total;
-        scratch_total += static_cast<uint64_t>(L[c].slots) * L[c].c.slot_bytes;
-        if (scratch_total > scratch_budget(e)) {
-            // does not fit next to each other: the plain path shares the slots (launches already made finish first)
+        plan_piece(e, pp, c, sp, fast, slots_left);
+        slots_left -= std::min(slots_left, pp.L[c].slots);
+        if (pp.L[c].slots == 0 || pp.scratch > scratch_budget(e)) {
+            // no slot left / does not fit next to each other: the plain path shares the slots (launches already made finish first)
             HIP_TRY(hipDeviceSynchronize());
-            const int rc2 = rcn_engine_upload(e, b);
-            return rc2 ? rc2 : rcn_engine_run(e);
+            return plain();
         }
         // growing the scratch buffer would move it under a running launch: the pieces before this one must be done
-        if (scratch_total > e->d_scratch.cap && c > 0) HIP_TRY(hipDeviceSynchronize());
-        if ((rc = e->d_scratch.reserve(scratch_total))) return rc;
+        if (pp.scratch > e->d_scratch.cap && c > 0) HIP_TRY(hipDeviceSynchronize());
+        if ((rc = e->d_scratch.reserve(pp.scratch))) return rc;
+        const Launch& L = pp.L[c];
         HIP_TRY(hipMemcpyAsync(e->d_win_flags.as<uint8_t>() + k0, s_flags + k0, k1 - k0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync(e->d_bases.as<uint8_t>() + b0, hs + o_bases + b0, b1 - b0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync(e->d_quals.as<uint8_t>() + b0, hs + o_quals + b0, b1 - b0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipEventRecord(e->sub_ev[c][0], cs));
-        HIP_TRY(hipStreamWaitEvent(L[c].stream, e->sub_ev[c][0], 0));
-        if (L[c].stream != e->stream) HIP_TRY(hipStreamWaitEvent(L[c].stream, e->ev0, 0));
-        HIP_TRY(hipEventRecord(e->sub_ev[c][1], L[c].stream));
-        if ((rc = launch_pass(e, L[c]))) return rc;
-        HIP_TRY(hipEventRecord(e->sub_ev[c][2], L[c].stream));
+        HIP_TRY(hipStreamWaitEvent(L.stream, e->sub_ev[c][0], 0));
+        if (L.stream != e->stream) HIP_TRY(hipStreamWaitEvent(L.stream, e->ev0, 0));
+        HIP_TRY(hipEventRecord(e->sub_ev[c][1], L.stream));
+        if ((rc = launch_pass(e, L))) return rc;
+        HIP_TRY(hipEventRecord(e->sub_ev[c][2], L.stream));
         if (dbg) fprintf(stderr, "[racon_hip] polish: piece %d enqueued at %.2f ms (host clock)\n", c, since());
     }
     HIP_TRY(hipEventRecord(t.b, cs));
-    float span0 = 0, span1 = 0;
-    bool have = false;
-    for (int c = 0; c < rcn_engine::kSubLaunches; ++c) {
-        if (cut[c + 1] == cut[c]) continue;
-        HIP_TRY(hipEventSynchronize(e->sub_ev[c][2]));
-        float a0 = 0, a1 = 0;       // begin / end of this launch relative to the first copy
-        HIP_TRY(hipEventElapsedTime(&a0, t.a, e->sub_ev[c][1]));
-        HIP_TRY(hipEventElapsedTime(&a1, t.a, e->sub_ev[c][2]));
-        if (!have) { span0 = a0; span1 = a1; have = true; } else { span0 = std::min(span0, a0); span1 = std::max(span1, a1); }
-        if (getenv("RCN_DEBUG")) {
-            float cp = 0; (void)hipEventElapsedTime(&cp, t.a, e->sub_ev[c][0]);
-            fprintf(stderr, "[racon_hip] streamed piece %d: windows [%u, %u) slots %u ncap %d lmax %d | copy done %.2f ms, kernel %.2f .. %.2f ms\n",
-                    c, cut[c], cut[c + 1], L[c].slots, L[c].c.ncap, L[c].c.lmax, cp, a0, a1);
-        }
-        e->stats.n_launches += 1;
-    }
-    e->stats.kernel_ms = span1 - span0;                              // the overlapping launches as one interval
+    if ((rc = finish_pieces(e, pp, t.a))) return rc;
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
     e->stats.h2d_ms = ms;
     e->stats.bytes_in = 2 * nb + 17ull * ns + 5ull * nw;
@@ -980,6 +1191,95 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     rc = collect(e);
     if (dbg) fprintf(stderr, "[racon_hip] polish: results collected at %.2f ms (host clock)\n", since());
     return rc;
+}
+
+__global__ void k_warm(unsigned* p) { if (p && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *p = 0; }
+
+}  // namespace
+
+extern "C" {
+
+int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
+    if (!e || !b || check_batch(b)) return RCN_E_ARG;
+    const uint32_t ns = b->n_seqs;
+    std::vector<const uint8_t*> sp(std::max<uint32_t>(1, ns)), qp(std::max<uint32_t>(1, ns));
+    for (uint32_t i = 0; i < ns; ++i) { sp[i] = b->bases + b->seq_off[i]; qp[i] = b->seq_has_qual[i] ? b->quals + b->seq_off[i] : nullptr; }
+    SrcView v;
+    v.nw = b->n_windows; v.ns = ns; v.win_seq_off = b->win_seq_off; v.win_type = b->win_type; v.seq_off = b->seq_off;
+    v.seq = sp.data(); v.qual = qp.data(); v.begin = b->seq_begin; v.end = b->seq_end;
+    if (v.nw == 0) { HIP_TRY(hipSetDevice(e->cfg.device)); const int rc = rcn_engine_upload(e, b); return rc ? rc : rcn_engine_run(e); }
+    return polish_view(e, v);
+}
+
+int rcn_engine_polish_refs(rcn_engine* e, const rcn_window_refs* w) {
+    if (!e || !w) return RCN_E_ARG;
+    if (w->n_windows && (!w->win_seq_off || !w->win_type || !w->seq || !w->qual || !w->seq_len || !w->seq_begin || !w->seq_end)) return RCN_E_ARG;
+    if (w->n_windows && w->win_seq_off[w->n_windows] != w->n_seqs) return RCN_E_ARG;
+    const uint32_t ns = w->n_seqs;
+    std::vector<uint64_t> so(static_cast<size_t>(ns) + 1, 0);
+    for (uint32_t i = 0; i < ns; ++i) {
+        if (w->seq_len[i] && !w->seq[i]) return RCN_E_ARG;
+        so[i + 1] = so[i] + w->seq_len[i];
+    }
+    static const uint8_t kNoByte = 0; static const uint32_t kNoWord = 0; static const uint8_t* const kNoPtr = nullptr;
+    SrcView v;
+    v.nw = w->n_windows; v.ns = ns; v.flags = w->flags; v.seq_off = so.data();
+    v.win_seq_off = w->n_windows ? w->win_seq_off : &kNoWord; v.win_type = w->n_windows ? w->win_type : &kNoByte;
+    v.seq = ns ? w->seq : &kNoPtr; v.qual = ns ? w->qual : &kNoPtr; v.begin = ns ? w->seq_begin : &kNoWord; v.end = ns ? w->seq_end : &kNoWord;
+    if (v.nw == 0) {
+        HIP_TRY(hipSetDevice(e->cfg.device));
+        HostBatch hb; materialize(v, hb);
+        const int rc = rcn_engine_upload(e, &hb.b);
+        return rc ? rc : rcn_engine_run(e);
+    }
+    return polish_view(e, v);
+}
+
+int rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* h) {
+    if (!e || !h) return RCN_E_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint64_t nw = h->n_windows, ns = std::max<uint64_t>(h->n_seqs, nw), nb = h->n_bases;
+    int rc;
+    if (!e->warmed) {
+        // first use of the code object (loaded lazily by the runtime), of every stream's queue and of the copy engines
+        (void)HostPool::get();
+        for (hipStream_t st : {e->stream, e->copy_stream, e->sub_stream[0], e->deep_stream, e->rest_stream}) {
+            if (!st) continue;
+            hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st, e->d_ctr.as<unsigned>());
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = e->h_out.reserve(4096))) return rc;
+        HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_ctr.p, 256, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_ctr.p, e->h_out.p, 256, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(hipDeviceSynchronize());
+        e->warmed = true;
+    }
+    if (nw == 0) return RCN_OK;
+    // inputs of a batch (polish_view's staging layout, rounded up)
+    if ((rc = e->d_win_seq_off.reserve(4 * (nw + 1))) || (rc = e->d_win_type.reserve(nw)) || (rc = e->d_win_flags.reserve(nw)) ||
+        (rc = e->d_seq_off.reserve(8 * (ns + 1))) || (rc = e->d_has_qual.reserve(ns)) || (rc = e->d_begin.reserve(4 * ns)) ||
+        (rc = e->d_end.reserve(4 * ns)) || (rc = e->d_order.reserve(4 * ns)) || (rc = e->d_full.reserve(ns)) ||
+        (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16)) || (rc = e->d_out_off.reserve(8 * (nw + 1))))
+        return rc;
+    if ((rc = e->h_stage.reserve(2 * nb + 29 * ns + 16 * nw + 4096))) return rc;
+    // results: first_pass_out_cap per window
+    const uint64_t L = std::max<uint32_t>(1, h->window_length);
+    const uint64_t out_bytes = nw * ((2 * L + 64 + 15) & ~uint64_t(15));
+    if ((rc = e->d_out_cons.reserve(out_bytes + 16)) || (rc = e->d_out_len.reserve(4 * nw)) || (rc = e->d_out_flags.reserve(nw))) return rc;
+    if ((rc = e->h_out.reserve(5 * nw + 64 + out_bytes + 16))) return rc;
+    // scratch arena: one slot per resident window at the capacities the hinted shape gets
+    WinShape sh;
+    sh.L = static_cast<int32_t>(L);
+    const uint64_t deepest = h->max_window_bases ? h->max_window_bases : nb / nw;
+    sh.sum_l = static_cast<int32_t>(std::min<uint64_t>(deepest > L ? deepest - L : 0, 1u << 30));
+    sh.lmax = static_cast<int32_t>(h->max_layer_length ? h->max_layer_length : L + (3 * L + 9) / 10);
+    sh.nsym = 5;
+    const Caps c = first_pass_caps(&sh, &sh + 1, !getenv("RCN_WIDE_ONLY"));
+    const uint64_t slots = std::min<uint64_t>(nw, e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint64_t>(e->n_cu) * 8u);
+    { size_t fr = 0, tot = 0; HIP_TRY(hipMemGetInfo(&fr, &tot)); e->free_mem = fr + e->d_scratch.cap; }
+    const uint64_t want = std::min<uint64_t>(slots * c.slot_bytes, scratch_budget(e));
+    if ((rc = e->d_scratch.reserve(want))) return rc;
+    return RCN_OK;
 }
 
 int rcn_engine_result(rcn_engine* e, rcn_result* out) {

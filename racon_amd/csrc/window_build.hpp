@@ -386,7 +386,7 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     if (O.n_overlaps && (!O.q_id || !O.t_id || !O.strand || !O.bp_off || (!C && !S && (!O.bp_t || !O.bp_q)))) return RCN_E_ARG;
     if (R.n_seqs > 0xfffffffeull || O.n_overlaps > 0xfffffffeull) return RCN_E_ARG;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    e->uploaded = false; e->ran = false;
+    e->uploaded = false; e->ran = false; e->queued = false;
     e->bstats = rcn_build_stats{};
     hipStream_t st = e->stream;
     hipEvent_t ev[4];
@@ -684,6 +684,7 @@ inline int build_windows_from_pairs(rcn_engine* e, const rcn_read_set& R, const 
     if (R.n_seqs == 0 || R.n_targets == 0 || R.n_targets > R.n_seqs || !R.seq_off || !R.bases || !R.quals || !R.seq_has_qual) return RCN_E_ARG;
     if ((rc = upload_reads(e, R, e->stream))) return rc;
     if ((rc = align_pairs(e, R, S, true))) return rc;
+    e->d_align[kAScratch].release();            // the aligner's per-wave scratch (sized for the longest read) is done with
     std::vector<uint64_t> bp_off(S.n_pairs + 1, 0);
     std::vector<uint32_t> q_start(S.n_pairs);
     for (uint64_t o = 0; o < S.n_pairs; ++o) {
@@ -700,6 +701,10 @@ inline int build_windows_from_pairs(rcn_engine* e, const rcn_read_set& R, const 
     const rcn_align_stats keep = e->astats;
     rc = build_windows(e, R, O, W, qthr, window_type, nullptr, &src, true);
     e->astats = keep;
+    // the paths have been walked into breaking points: their op bytes (one per row + column of every overlap) must not
+    // stay allocated through the consensus run (rcn_engine_alignment_cigars then reports RCN_E_STATE)
+    for (int k : {kAOps, kAOpsOff, kAQPos, kATPos, kAQLen, kATLen, kAQRc, kAOrder}) e->d_align[k].release();
+    e->a_n_pairs = 0; e->a_ops_off.clear();
     return rc;
 }
 

@@ -33,7 +33,8 @@ class RcnRunStats(C.Structure):
                 ("dp_pred_cells", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
                 ("dp_bytes", C.c_uint64), ("phase_clocks", C.c_uint64 * 8), ("n_sink_ties", C.c_uint64),
                 ("dp_cells_full", C.c_uint64), ("dp_bytes_full", C.c_uint64), ("n_banded", C.c_uint64), ("n_band_redone", C.c_uint64),
-                ("band_redo_why", C.c_uint64 * 8), ("wg_per_cu", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("band_redo_why", C.c_uint64 * 8), ("wg_per_cu", C.c_uint32), ("split_deep", C.c_uint32), ("split_cus", C.c_uint32),
+                ("split_deep_per_cu", C.c_uint32), ("launch_ms", C.c_double * 2)]
 
 
 class RcnWindowDesc(C.Structure):
@@ -42,11 +43,25 @@ class RcnWindowDesc(C.Structure):
                 ("begin", C.POINTER(C.c_uint32)), ("end", C.POINTER(C.c_uint32))]
 
 
+class RcnWindowRefs(C.Structure):
+    _fields_ = [("n_windows", C.c_uint32), ("n_seqs", C.c_uint32), ("win_seq_off", C.c_void_p), ("win_type", C.c_void_p),
+                ("seq", C.c_void_p), ("qual", C.c_void_p), ("seq_len", C.c_void_p), ("seq_begin", C.c_void_p), ("seq_end", C.c_void_p),
+                ("flags", C.c_uint32)]
+
+
+class RcnReserveHint(C.Structure):
+    _fields_ = [("n_windows", C.c_uint32), ("n_seqs", C.c_uint32), ("n_bases", C.c_uint64), ("window_length", C.c_uint32),
+                ("max_layer_length", C.c_uint32), ("max_window_bases", C.c_uint64)]
+
+
+REFS_QUEUED = 1
+
 EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_engine_run", "rcn_engine_result",
            "rcn_engine_stats", "rcn_engine_set_trim", "rcn_engine_add_window", "rcn_engine_has_windows", "rcn_engine_generate_consensus",
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
            "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory",
-           "rcn_engine_align_pairs", "rcn_engine_alignment_cigars", "rcn_engine_align_stats", "rcn_engine_build_windows_from_pairs"]
+           "rcn_engine_align_pairs", "rcn_engine_alignment_cigars", "rcn_engine_align_stats", "rcn_engine_build_windows_from_pairs",
+           "rcn_engine_polish_refs", "rcn_engine_reserve"]
 
 _lib = None
 
@@ -66,6 +81,8 @@ def load_library():
     lib.rcn_engine_upload.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
     lib.rcn_engine_run.argtypes = [C.c_void_p]
     lib.rcn_engine_polish.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
+    lib.rcn_engine_polish_refs.argtypes = [C.c_void_p, C.POINTER(RcnWindowRefs)]
+    lib.rcn_engine_reserve.argtypes = [C.c_void_p, C.POINTER(RcnReserveHint)]
     lib.rcn_device_free_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.rcn_engine_result.argtypes = [C.c_void_p, C.POINTER(RcnResult)]
     lib.rcn_engine_stats.argtypes = [C.c_void_p, C.POINTER(RcnRunStats)]
@@ -144,6 +161,7 @@ class HipEngine:
         d = {k: getattr(s, k) for k, _ in RcnRunStats._fields_}
         d["phase_clocks"] = list(s.phase_clocks)
         d["band_redo_why"] = list(s.band_redo_why)
+        d["launch_ms"] = list(s.launch_ms)
         return d
 
     def consensus(self, batch: WindowBatch) -> ConsensusResult:
@@ -152,6 +170,27 @@ class HipEngine:
         self._keep = (batch, cb)
         _check(self.lib.rcn_engine_polish(self.h, C.byref(cb)), "rcn_engine_polish")
         return self.result()
+
+    def consensus_refs(self, batch: WindowBatch, flags: int = 0) -> ConsensusResult:
+        """The same batch handed over as borrowed per-sequence pointers (rcn_engine_polish_refs: the form racon::Window holds
+        its sequences in); sequences without quality get a NULL quality pointer."""
+        batch.as_c()                                    # contiguous arrays of the ABI's dtypes
+        ns = batch.n_seqs
+        so = batch.seq_off.astype(np.uint64)
+        seq = (np.uint64(batch.bases.ctypes.data) + so[:-1]).astype(np.uint64)
+        qual = np.where(batch.seq_has_qual != 0, np.uint64(batch.quals.ctypes.data) + so[:-1], np.uint64(0)).astype(np.uint64)
+        ln = (so[1:] - so[:-1]).astype(np.uint32)
+        keep = (batch, seq, qual, ln)
+        r = RcnWindowRefs(batch.n_windows, ns, batch.win_seq_off.ctypes.data, batch.win_type.ctypes.data, seq.ctypes.data, qual.ctypes.data,
+                          ln.ctypes.data, batch.seq_begin.ctypes.data, batch.seq_end.ctypes.data, flags)
+        self._keep = keep
+        _check(self.lib.rcn_engine_polish_refs(self.h, C.byref(r)), "rcn_engine_polish_refs")
+        return self.result()
+
+    def reserve(self, n_windows: int, n_seqs: int, n_bases: int, window_length: int, max_layer_length: int = 0, max_window_bases: int = 0):
+        """Allocation ahead of the first batch (rcn_engine_reserve)."""
+        h = RcnReserveHint(n_windows, n_seqs, n_bases, window_length, max_layer_length, max_window_bases)
+        _check(self.lib.rcn_engine_reserve(self.h, C.byref(h)), "rcn_engine_reserve")
 
     # device-side window construction (reference src/polisher.cpp:388-461) --------
     def build_windows(self, reads: ReadSet, overlaps: OverlapSet, window_length: int, quality_threshold: float, window_type: int):

@@ -111,6 +111,9 @@ int rcnh_polisher_polish(rcnh_polisher* p, int drop, const char** fasta, uint64_
     });
 }
 
+double rcnh_polisher_polish_seconds(rcnh_polisher* p) { return p ? p->polisher->polish_seconds() : 0.0; }
+uint64_t rcnh_polisher_num_windows(rcnh_polisher* p) { return p ? p->polisher->num_windows() : 0; }
+
 void rcnh_polisher_destroy(rcnh_polisher* p) { delete p; }
 
 int rcnh_align_cigar(const char* q, uint32_t ql, const char* t, uint32_t tl, char** cigar) {

@@ -22,6 +22,8 @@ struct Abi {
     decltype(&rcn_engine_upload) upload = nullptr;
     decltype(&rcn_engine_run) run = nullptr;
     decltype(&rcn_engine_polish) polish = nullptr;
+    decltype(&rcn_engine_polish_refs) polish_refs = nullptr;
+    decltype(&rcn_engine_reserve) reserve = nullptr;
     decltype(&rcn_device_free_memory) free_memory = nullptr;
     decltype(&rcn_engine_result) result = nullptr;
     decltype(&rcn_engine_stats) stats = nullptr;
@@ -62,7 +64,7 @@ const Abi& abi() {
 #define RCN_BIND(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); \
         if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
-        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
+        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
         RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
         RCN_BIND(build_windows_from_pairs, "rcn_engine_build_windows_from_pairs")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
@@ -90,6 +92,31 @@ void PackedBatch::add(const Window& w) {
     }
     win_type.push_back(w.type_ == WindowType::kTGS ? 1 : 0);
     win_seq_off.push_back(static_cast<uint32_t>(seq_has_qual.size()));
+}
+
+void WindowRefs::clear() {
+    win_seq_off.assign(1, 0); win_type.clear(); seq.clear(); qual.clear(); seq_len.clear(); seq_begin.clear(); seq_end.clear(); bases = 0;
+}
+
+void WindowRefs::add(const Window& w) {
+    for (size_t i = 0; i < w.sequences_.size(); ++i) {
+        seq.push_back(reinterpret_cast<const uint8_t*>(w.sequences_[i].first));
+        qual.push_back(reinterpret_cast<const uint8_t*>(w.qualities_[i].first));
+        seq_len.push_back(w.sequences_[i].second);
+        seq_begin.push_back(w.positions_[i].first); seq_end.push_back(w.positions_[i].second);
+        bases += w.sequences_[i].second;
+    }
+    win_type.push_back(w.type_ == WindowType::kTGS ? 1 : 0);
+    win_seq_off.push_back(static_cast<uint32_t>(seq.size()));
+}
+
+rcn_window_refs WindowRefs::view(uint32_t flags) const {
+    rcn_window_refs r{};
+    r.n_windows = n_windows(); r.n_seqs = static_cast<uint32_t>(seq.size());
+    r.win_seq_off = win_seq_off.data(); r.win_type = win_type.data();
+    r.seq = seq.data(); r.qual = qual.data(); r.seq_len = seq_len.data(); r.seq_begin = seq_begin.data(); r.seq_end = seq_end.data();
+    r.flags = flags;
+    return r;
 }
 
 rcn_batch PackedBatch::view() const {
@@ -139,6 +166,24 @@ void HipEngine::consensus(const PackedBatch& batch, bool trim, std::vector<std::
     int rc = a.set_trim(handle_, trim ? 1 : 0);
     if (rc == RCN_OK) rc = a.polish(handle_, &b);              // upload hidden behind the kernel
     fetch(rc, consensus, polished, chimeric, /*run=*/false);
+}
+
+void HipEngine::consensus(const WindowRefs& refs, bool queued, bool trim, std::vector<std::string>* consensus,
+                          std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
+    const Abi& a = abi();
+    const rcn_window_refs r = refs.view(queued ? RCN_REFS_QUEUED : 0u);
+    int rc = a.set_trim(handle_, trim ? 1 : 0);
+    if (rc == RCN_OK) rc = a.polish_refs(handle_, &r);
+    fetch(rc, consensus, polished, chimeric, /*run=*/false);
+}
+
+void HipEngine::reserve(uint32_t n_windows, uint32_t n_seqs, uint64_t n_bases, uint32_t window_length, uint32_t max_layer_length,
+                        uint64_t max_window_bases) {
+    rcn_reserve_hint h{};
+    h.n_windows = n_windows; h.n_seqs = n_seqs; h.n_bases = n_bases; h.window_length = window_length; h.max_layer_length = max_layer_length;
+    h.max_window_bases = max_window_bases;
+    const int rc = abi().reserve(handle_, &h);
+    if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::reserve] error: ") + abi().strerror_(rc) + "!");
 }
 
 void HipEngine::consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,

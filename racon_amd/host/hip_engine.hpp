@@ -38,6 +38,21 @@ struct PackedBatch {
     rcn_batch view() const;           // pointers into this object
 };
 
+// The same information as BORROWED pointers (rcn_window_refs): what a Window already holds, one entry per sequence.
+// The engine packs straight from these into its pinned staging, so the host copies every base once, not twice.
+struct WindowRefs {
+    std::vector<uint32_t> win_seq_off{0};
+    std::vector<uint8_t> win_type;
+    std::vector<const uint8_t*> seq, qual;      // qual[i] == nullptr: no quality
+    std::vector<uint32_t> seq_len, seq_begin, seq_end;
+    uint64_t bases = 0;
+
+    void add(const Window& w);
+    void clear();
+    uint32_t n_windows() const { return static_cast<uint32_t>(win_type.size()); }
+    rcn_window_refs view(uint32_t flags) const;
+};
+
 class HipEngine {
 public:
     // Fatal (racon::fatal) when the library or the device is missing.
@@ -51,6 +66,13 @@ public:
     // Consensus of every window of `batch` (inputs are copied to HBM, results copied back).
     void consensus(const PackedBatch& batch, bool trim, std::vector<std::string>* consensus,
                    std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    // The same from borrowed pointers (rcn_engine_polish_refs); `queued`: the caller keeps further batches in flight.
+    void consensus(const WindowRefs& refs, bool queued, bool trim, std::vector<std::string>* consensus,
+                   std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    // Allocation ahead of the first batch (rcn_engine_reserve; the role of AlignmentEngine::Prealloc, reference
+    // src/polisher.cpp:180-182): arena, pinned staging, code object, copy engines.
+    void reserve(uint32_t n_windows, uint32_t n_seqs, uint64_t n_bases, uint32_t window_length, uint32_t max_layer_length,
+                 uint64_t max_window_bases = 0);
     // The same, with the windows built on the device from the flattened sequences / overlaps
     // (rcn_engine_build_windows: reference src/polisher.cpp:388-461 in HBM).
     void consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,

@@ -18,12 +18,19 @@
 namespace racon {
 
 // ---------------------------------------------------------------- fatal / logger
-namespace { bool g_fatal_throws = false; }
+namespace { bool g_fatal_throws = false; thread_local bool t_fatal_throws = false; }
 void set_fatal_throws(bool on) { g_fatal_throws = on; }
 void fatal(const std::string& message) {
-    if (g_fatal_throws) throw FatalError(message);
+    if (g_fatal_throws || t_fatal_throws) throw FatalError(message);
     fprintf(stderr, "%s\n", message.c_str());
     exit(1);
+}
+FatalThrowsScope::FatalThrowsScope() : previous(t_fatal_throws) { t_fatal_throws = true; }
+FatalThrowsScope::~FatalThrowsScope() { t_fatal_throws = previous; }
+void fatal_from(const std::exception_ptr& error) {
+    try { std::rethrow_exception(error); }
+    catch (const std::exception& e) { fatal(e.what()); }
+    catch (...) { fatal("[racon::] error: unknown exception in a worker thread!"); }
 }
 
 namespace {
@@ -44,6 +51,7 @@ void parallel_for(uint64_t n, uint32_t threads, F fn) {
     std::vector<std::thread> pool;
     for (uint32_t t = 0; t < threads; ++t)
         pool.emplace_back([&] {
+            FatalThrowsScope scope;
             try {
                 for (uint64_t i; (i = next.fetch_add(1)) < n;) fn(i);
             } catch (...) {
@@ -53,7 +61,7 @@ void parallel_for(uint64_t n, uint32_t threads, F fn) {
             }
         });
     for (auto& t : pool) t.join();
-    if (first_error) std::rethrow_exception(first_error);
+    if (first_error) fatal_from(first_error);
 }
 }  // namespace
 
@@ -121,6 +129,7 @@ void load_records(const std::string& path, uint32_t threads, std::vector<std::un
     std::mutex m;
     try {
         io::read_batches(path, format, threads, [&](io::Batch& b) {
+            FatalThrowsScope scope;             // (a parse worker: reported by the thread that called load_records)
             std::vector<std::unique_ptr<T>> local;
             local.reserve(b.recs.size());
             std::string data, qual;
@@ -129,7 +138,7 @@ void load_records(const std::string& path, uint32_t threads, std::vector<std::un
             if (parts.size() <= b.number) parts.resize(b.number + 1);
             parts[b.number] = std::move(local);
         });
-    } catch (const FatalError&) { throw; } catch (const std::runtime_error& e) { fatal(e.what()); }
+    } catch (const std::exception& e) { fatal(e.what()); }      // (a worker's FatalError included: print + exit or rethrow, per mode)
     size_t n = 0;
     for (const auto& p : parts) n += p.size();
     dst.reserve(dst.size() + n);
@@ -162,10 +171,10 @@ void Polisher::initialize() {
         return;
     }
     logger_->log();
-    if (!device_warmup_.joinable() && getenv("RACON_HIP_NO_WARMUP") == nullptr)
-        device_warmup_ = std::thread([] {
-            const int32_t n = HipEngine::DeviceCount();              // (0 without the library or a device: polish() reports that)
-            for (int32_t d = 0; d < n; ++d) HipEngine::FreeMemory(d);
+    if (!device_warmup_.joinable() && engines_.empty() && getenv("RACON_HIP_NO_WARMUP") == nullptr)
+        device_warmup_ = std::thread([this] {
+            FatalThrowsScope scope;
+            try { create_engines(); } catch (const std::exception& e) { engines_error_ = e.what(); engines_.clear(); }
         });
 
     // The three input files are read concurrently (one inflating thread each, num_threads_ parse workers shared out):
@@ -178,8 +187,8 @@ void Polisher::initialize() {
     std::exception_ptr reads_error, overlaps_error;
     std::thread reads_thread, overlaps_thread;
     if (!serial_ingest) {
-        reads_thread = std::thread([&] { try { load_sequences(sequences_path_, reads, parse_threads); } catch (...) { reads_error = std::current_exception(); } });
-        overlaps_thread = std::thread([&] { try { load_overlaps(overlaps_path_, overlaps, parse_threads); } catch (...) { overlaps_error = std::current_exception(); } });
+        reads_thread = std::thread([&] { FatalThrowsScope scope; try { load_sequences(sequences_path_, reads, parse_threads); } catch (...) { reads_error = std::current_exception(); } });
+        overlaps_thread = std::thread([&] { FatalThrowsScope scope; try { load_overlaps(overlaps_path_, overlaps, parse_threads); } catch (...) { overlaps_error = std::current_exception(); } });
     }
     struct Joiner { std::thread& a; std::thread& b; ~Joiner() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } joiner{reads_thread, overlaps_thread};
 
@@ -197,7 +206,7 @@ void Polisher::initialize() {
     uint64_t sequences_size = 0, total_sequences_length = 0;
     {
         if (serial_ingest) load_sequences(sequences_path_, reads, 1);
-        else { reads_thread.join(); if (reads_error) std::rethrow_exception(reads_error); }
+        else { reads_thread.join(); if (reads_error) fatal_from(reads_error); }
         for (auto& read : reads) {
             total_sequences_length += read->data().size();
             const auto it = name_to_id.find(read->name() + "t");
@@ -225,7 +234,7 @@ void Polisher::initialize() {
     // ---- overlaps: resolve ids, then filter each run of consecutive overlaps of one query
     //      (reference src/polisher.cpp:283-358)
     if (serial_ingest) load_overlaps(overlaps_path_, overlaps, 1);
-    else { overlaps_thread.join(); if (overlaps_error) std::rethrow_exception(overlaps_error); }
+    else { overlaps_thread.join(); if (overlaps_error) fatal_from(overlaps_error); }
     auto filter_group = [&](uint64_t begin, uint64_t end) {
         for (uint64_t i = begin; i < end; ++i) {
             if (!overlaps[i]) continue;
@@ -354,6 +363,56 @@ void Polisher::initialize() {
         o.reset();
     }
     logger_->log("[racon::Polisher::initialize] transformed data into windows");
+    reserve_for_windows();
+}
+
+// ---------------------------------------------------------------- engines
+// One engine = one device + its streams (a CUDABatchProcessor, reference src/cuda/cudabatch.hpp:27-122).  Two per batch
+// object and device: the kernel of one chunk fills the compute units that the tail of the other engine's chunk leaves
+// idle, while a host thread packs the next one.  Created with a first reservation for `-w` sized windows at ONT-like
+// depth; reserve_for_windows() corrects it once the windows exist.
+namespace { constexpr uint64_t kMaxChunkWindows = 8192, kMinChunkWindows = 2048, kMaxChunkBases = 512ull << 20; }
+
+void Polisher::create_engines() {
+    n_devices_ = HipEngine::DeviceCount();          // (0 without the library or a device: polish() reports that)
+    if (n_devices_ <= 0) return;
+    const uint32_t engines_per_device = 2 * hip_batches_;
+    std::vector<std::shared_ptr<HipEngine>> engines;
+    for (uint32_t k = 0; k < static_cast<uint32_t>(n_devices_) * engines_per_device; ++k) {
+        const int32_t device = static_cast<int32_t>(k % static_cast<uint32_t>(n_devices_));
+        // engines of one device split its free HBM (each would otherwise budget 80 % of it for its own scratch)
+        const uint64_t arena = static_cast<uint64_t>(HipEngine::FreeMemory(device) * 0.8 / engines_per_device);
+        engines.emplace_back(HipEngine::Create(device, match_, mismatch_, gap_, arena));
+    }
+    // a first guess at a chunk: 2048 windows of `-w` bases under 40 layers (the arena: ~3 MB per resident window at -w 500)
+    const uint64_t layers = 40, w = window_length_;
+    for (auto& e : engines)
+        e->reserve(static_cast<uint32_t>(kMinChunkWindows), static_cast<uint32_t>(kMinChunkWindows * (layers + 1)),
+                   std::min<uint64_t>(kMaxChunkBases, kMinChunkWindows * (layers + 1) * w), window_length_, 0);
+    engines_.swap(engines);
+}
+
+void Polisher::reserve_for_windows() {
+    if (device_warmup_.joinable()) device_warmup_.join();
+    if (engines_.empty() || windows_.empty() || device_windows_) return;
+    // the largest chunk polish() will hand to an engine (same rule as there)
+    const uint64_t nw = windows_.size();
+    uint64_t seqs = 0, bases = 0, lmax = 0, deepest = 0;
+    for (const auto& w : windows_) {
+        uint64_t b = 0;
+        for (size_t i = 0; i < w->sequences_.size(); ++i) { b += w->sequences_[i].second; if (i) lmax = std::max<uint64_t>(lmax, w->sequences_[i].second); }
+        seqs += w->sequences_.size(); bases += b; deepest = std::max(deepest, b);
+    }
+    const uint64_t chunk = std::min(nw, std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (nw + 2 * engines_.size() - 1) / (2 * engines_.size()))));
+    // chunks are cut from the windows in deepest-first order: the first one holds the deepest windows
+    const uint64_t chunk_bases = std::min(std::min(bases, deepest * chunk), kMaxChunkBases + deepest);
+    const uint64_t chunk_seqs = std::max<uint64_t>(chunk, static_cast<uint64_t>(static_cast<double>(seqs) / bases * chunk_bases) + chunk);
+    FatalThrowsScope scope;
+    try {
+        for (auto& e : engines_)
+            e->reserve(static_cast<uint32_t>(chunk), static_cast<uint32_t>(std::min<uint64_t>(chunk_seqs, 0xffffffffu)), chunk_bases, window_length_,
+                       static_cast<uint32_t>(lmax), deepest);
+    } catch (const std::exception& e) { engines_error_ = e.what(); engines_.clear(); }
 }
 
 void Polisher::find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>>& overlaps) {
@@ -394,29 +453,21 @@ void Polisher::assemble(const std::function<const std::string&(uint64_t)>& conse
 
 void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {
     logger_->log();
+    const auto polish_begin = std::chrono::steady_clock::now();
+    struct Stamp { const std::chrono::steady_clock::time_point& t0; double& out; ~Stamp() { out = seconds_since(t0); } } stamp{polish_begin, polish_seconds_};
     if (device_warmup_.joinable()) device_warmup_.join();
-    const int32_t n_devices = HipEngine::DeviceCount();
-    if (n_devices <= 0)
+    if (!engines_error_.empty()) fatal(engines_error_);
+    if (engines_.empty()) {                         // the warm-up was switched off, or initialize() was not called
+        std::exception_ptr error;
+        { FatalThrowsScope scope; try { create_engines(); } catch (...) { error = std::current_exception(); } }
+        if (error) fatal_from(error);
+    }
+    const int32_t n_devices = n_devices_ > 0 ? n_devices_ : HipEngine::DeviceCount();
+    if (n_devices <= 0 || engines_.empty())
         fatal("[racon::Polisher::polish] error: no MI355X device / libracon_hip.so available (the consensus stage has no CPU fallback)!");
 
-    // contiguous chunks of the window index space; engines pull them from a shared cursor
-    // (reference src/cuda/cudapolisher.cpp:254-276 hands out ranges the same way).  A chunk is at most what one engine
-    // keeps resident at once (2048 windows): the engine then hides the chunk's upload behind its kernel
-    // (rcn_engine_polish), and with TWO engines per batch object and device the kernel of one chunk fills the compute
-    // units that the tail of the other engine's chunk leaves idle, while a host thread packs the next one.
-    constexpr uint64_t kMaxChunkWindows = 2048, kMaxChunkBases = 512ull << 20;
     const uint64_t nw = windows_.size();
-    std::vector<std::pair<uint64_t, uint64_t>> chunks;
-    const uint32_t engines_per_device = 2 * hip_batches_;
-    const uint32_t n_engines = static_cast<uint32_t>(n_devices) * engines_per_device;
-    {
-        const uint64_t target = kMaxChunkWindows;
-        for (uint64_t a = 0; a < nw;) {
-            uint64_t b = a, bases = 0;
-            while (b < nw && b - a < target && bases < kMaxChunkBases) { bases += 600ull * windows_[b]->num_sequences(); ++b; }
-            chunks.emplace_back(a, b); a = b;
-        }
-    }
+    const uint32_t n_engines = static_cast<uint32_t>(engines_.size());
     std::vector<std::string> cons(nw);
     std::vector<uint8_t> pol(nw, 0), chim(nw, 0);
     if (device_windows_) {
@@ -495,9 +546,9 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
                     p_q_start = q_start.data(); p_t_begin = t_begin.data(); p_t_end = t_end.data(); p_q_begin = q_begin.data(); p_q_end = q_end.data();
                     p_cigar_off = cigar_off.data(); p_cigar = cigar.empty() ? &kNoByte : cigar.data();
                 }
+                // (the shards of one device run one after the other on its lane thread: they share the device's first engine)
                 const int32_t device = static_cast<int32_t>(sidx % static_cast<uint32_t>(n_devices));
-                const uint32_t sharing = (n_shards + n_devices - 1) / n_devices;
-                auto engine = HipEngine::Create(device, match_, mismatch_, gap_, sharing > 1 ? static_cast<uint64_t>(HipEngine::FreeMemory(device) * 0.8 / sharing) : 0);
+                auto engine = engines_[static_cast<size_t>(device)];
                 std::vector<std::string> c; std::vector<uint8_t> pl, ch;
                 if (device_align_) {
                     rcn_pair_set ps{};
@@ -520,7 +571,7 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
             // one thread per device; the shards of one device run one after the other on it
             std::vector<std::thread> pool;
             const uint32_t lanes = std::min<uint32_t>(n_shards, static_cast<uint32_t>(n_devices));
-            for (uint32_t l = 0; l < lanes; ++l) pool.emplace_back([&, l]() { for (uint32_t sidx = l; sidx < n_shards; sidx += lanes) run_shard(sidx); });
+            for (uint32_t l = 0; l < lanes; ++l) pool.emplace_back([&, l]() { FatalThrowsScope scope; for (uint32_t sidx = l; sidx < n_shards; sidx += lanes) run_shard(sidx); });
             for (auto& th : pool) th.join();
         }
         for (const auto& e : shard_errors) if (!e.empty()) fatal(e);
@@ -533,35 +584,61 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         logger_->log("[racon::Polisher::polish] generated consensus");
         return;
     }
+    // ---- host-built windows: chunks of the window index space in DEEPEST-FIRST order, pulled from a shared cursor ----
+    // (reference src/cuda/cudapolisher.cpp:254-276 hands out ranges under a mutex the same way.)  Results go back by
+    // window index, so the order windows are polished in is free -- and a queue of unequal jobs ends soonest when the long
+    // ones start first: the windows are ranked by the engine's own cost proxy (sequences x bases), chunk k is ranks
+    // [k C, (k+1) C).  The deepest windows are under way in the first launch, the last chunk holds the shallowest ones and
+    // its tail is short.  A job that fits one chunk (cfg2: 2000 windows) is one engine call with the windows resident
+    // all at once; larger jobs alternate between the engines of a device, each chunk flagged as part of a queue.
+    std::vector<uint32_t> rank(nw);
+    {
+        std::vector<uint64_t> cost(nw);
+        for (uint64_t i = 0; i < nw; ++i) {
+            uint64_t b = 0;
+            for (const auto& sq : windows_[i]->sequences_) b += sq.second;
+            cost[i] = windows_[i]->sequences_.size() < 3 ? 0 : b * windows_[i]->sequences_.size();
+            rank[i] = static_cast<uint32_t>(i);
+        }
+        std::stable_sort(rank.begin(), rank.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;          // [first, last) positions in `rank`
+    {
+        uint64_t target = std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (nw + 2 * n_engines - 1) / (2 * n_engines)));
+        if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) target = std::max(1, atoi(cw));       // tests: many small chunks
+        for (uint64_t a = 0; a < nw;) {
+            uint64_t b = a, bases = 0;
+            while (b < nw && b - a < target && bases < kMaxChunkBases) { for (const auto& sq : windows_[rank[b]]->sequences_) bases += sq.second; ++b; }
+            chunks.emplace_back(a, b); a = b;
+        }
+    }
+    const bool queued = chunks.size() > 1;
     std::atomic<size_t> cursor{0};
-    std::vector<std::string> errors(n_engines);
-    std::vector<uint64_t> arena(n_devices, 0);
-    for (int32_t d = 0; d < n_devices; ++d) arena[d] = static_cast<uint64_t>(HipEngine::FreeMemory(d) * 0.8);
+    std::vector<std::exception_ptr> errors(n_engines);
     auto worker = [&](uint32_t k) {
+        FatalThrowsScope scope;
         try {
-            const int32_t device = static_cast<int32_t>(k % n_devices);
-            // engines of one device split its free HBM (each would otherwise budget 80 % of it for its own scratch)
-            const uint32_t sharing = std::min<uint32_t>(engines_per_device, std::max<uint32_t>(1, (static_cast<uint32_t>(chunks.size()) + n_devices - 1) / n_devices));
-            auto engine = HipEngine::Create(device, match_, mismatch_, gap_, arena[device] / sharing);
-            PackedBatch batch;
+            auto& engine = engines_[k];
+            WindowRefs refs;
             std::vector<std::string> c; std::vector<uint8_t> p, h;
             for (size_t ci; (ci = cursor.fetch_add(1)) < chunks.size();) {
-                batch.clear();
-                for (uint64_t i = chunks[ci].first; i < chunks[ci].second; ++i) batch.add(*windows_[i]);
-                engine->consensus(batch, trim_, &c, &p, &h);
-                for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { cons[i].swap(c[j]); pol[i] = p[j]; chim[i] = h[j]; }
+                refs.clear();
+                for (uint64_t i = chunks[ci].first; i < chunks[ci].second; ++i) refs.add(*windows_[rank[i]]);
+                engine->consensus(refs, queued, trim_, &c, &p, &h);
+                for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { const uint32_t w = rank[i]; cons[w].swap(c[j]); pol[w] = p[j]; chim[w] = h[j]; }
             }
-        } catch (const std::exception& e) { errors[k] = e.what(); }
+        } catch (...) { errors[k] = std::current_exception(); cursor.store(chunks.size()); }
     };
-    const bool throws = g_fatal_throws;
-    set_fatal_throws(true);                     // engine threads report through `errors`
     {
-        std::vector<std::thread> pool;
-        for (uint32_t k = 0; k < std::min<uint32_t>(n_engines, std::max<size_t>(1, chunks.size())); ++k) pool.emplace_back(worker, k);
-        for (auto& t : pool) t.join();
+        const uint32_t n_workers = static_cast<uint32_t>(std::min<size_t>(n_engines, std::max<size_t>(1, chunks.size())));
+        if (n_workers <= 1) worker(0);
+        else {
+            std::vector<std::thread> pool;
+            for (uint32_t k = 0; k < n_workers; ++k) pool.emplace_back(worker, k);
+            for (auto& t : pool) t.join();
+        }
     }
-    set_fatal_throws(throws);
-    for (const auto& e : errors) if (!e.empty()) fatal(e);
+    for (const auto& e : errors) if (e) fatal_from(e);
 
     for (uint64_t i = 0; i < nw; ++i)
         if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",

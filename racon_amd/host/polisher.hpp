@@ -23,6 +23,7 @@ namespace racon {
 
 class Sequence;
 class Overlap;
+class HipEngine;
 struct PackedBatch;
 
 enum class PolisherType { kC, kF };   // contig polishing / fragment error correction
@@ -134,6 +135,18 @@ protected:
     // Started by initialize(): loads libracon_hip.so and brings up the HIP runtime and the devices' contexts while the input
     // files are parsed (0.2 s that polish() would otherwise spend before its first launch); joined by polish() / the destructor.
     std::thread device_warmup_;
+    // The engines polish() drives: `2 * hip_batches_` per device, created ONCE by the warm-up thread together with their
+    // arenas, pinned staging and the first use of the code object (HipEngine::reserve; the reference creates its
+    // alignment engines in the constructor and Preallocs them, src/polisher.cpp:176-183), so that the interval the
+    // Logger brackets around polish() (reference src/polisher.cpp:493 -> :539-543) holds consensus work only.
+    std::vector<std::shared_ptr<HipEngine>> engines_;
+    std::string engines_error_;     // what went wrong in the warm-up thread (reported by polish())
+    int32_t n_devices_ = -1;
+    double polish_seconds_ = 0;     // the Logger-bracketed interval of the last polish()
+    void create_engines();          // (warm-up thread, or polish() when the warm-up was switched off)
+    void reserve_for_windows();     // end of initialize(): the arenas sized for the windows that were built
+public:
+    double polish_seconds() const { return polish_seconds_; }
 };
 
 }  // namespace racon

@@ -17,6 +17,7 @@ enum class WindowType { kNGS, kTGS };      // reference src/window.hpp:21-24
 class HipEngine;
 class Window;
 struct PackedBatch;
+struct WindowRefs;
 
 std::shared_ptr<Window> createWindow(uint64_t id, uint32_t rank, WindowType type, const char* backbone,
                                      uint32_t backbone_length, const char* quality, uint32_t quality_length);
@@ -38,6 +39,7 @@ public:
 
     friend std::shared_ptr<Window> createWindow(uint64_t, uint32_t, WindowType, const char*, uint32_t, const char*, uint32_t);
     friend struct PackedBatch;      // reads the borrowed pointers (as CUDABatchProcessor does, window.hpp:58-60)
+    friend struct WindowRefs;       // ... and hands them to the engine as they are
     friend class Polisher;          // writes consensus_ back (as cudabatch.cpp:221,230,253 does)
 
 private:

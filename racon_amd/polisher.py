@@ -29,7 +29,7 @@ class RcnhParams(C.Structure):
 
 EXPORTS = ["rcnh_polisher_create", "rcnh_polisher_initialize", "rcnh_polisher_windows", "rcnh_polisher_assemble",
            "rcnh_polisher_polish", "rcnh_polisher_destroy", "rcnh_align_cigar", "rcnh_edit_distance", "rcnh_free",
-           "rcnh_last_error"]
+           "rcnh_last_error", "rcnh_polisher_polish_seconds", "rcnh_polisher_num_windows"]
 
 _lib = None
 
@@ -54,6 +54,10 @@ def load_library():
     lib.rcnh_polisher_alignments.argtypes = [C.c_void_p, C.POINTER(RcnCigarSet)]
     lib.rcnh_polisher_assemble.argtypes = [C.c_void_p, C.POINTER(RcnResult), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_polish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    lib.rcnh_polisher_polish_seconds.argtypes = [C.c_void_p]
+    lib.rcnh_polisher_polish_seconds.restype = C.c_double
+    lib.rcnh_polisher_num_windows.argtypes = [C.c_void_p]
+    lib.rcnh_polisher_num_windows.restype = C.c_uint64
     lib.rcnh_polisher_destroy.argtypes = [C.c_void_p]
     lib.rcnh_polisher_destroy.restype = None
     lib.rcnh_align_cigar.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -171,6 +175,14 @@ class Polisher:
         n = C.c_uint64()
         _check(self.lib.rcnh_polisher_polish(self.h, int(drop_unpolished_sequences), C.byref(out), C.byref(n)))
         return C.string_at(out, n.value)
+
+
+    def polish_seconds(self) -> float:
+        """The Logger-bracketed interval of the last polish() (reference src/polisher.cpp:493 -> :539-543)."""
+        return float(self.lib.rcnh_polisher_polish_seconds(self.h))
+
+    def num_windows(self) -> int:
+        return int(self.lib.rcnh_polisher_num_windows(self.h))
 
 
 def align_cigar(query: bytes, target: bytes) -> str:

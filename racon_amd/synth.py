@@ -14,6 +14,36 @@ from .batch import WindowBatch
 _ACGT = np.frombuffer(b"ACGT", np.uint8)
 
 
+def _sim_read(rng, contig: np.ndarray, read_len: int, sub: float, ins: float, dele: float, with_quality: bool,
+              phred_mean: float, phred_sd: float, phred_lo: int, phred_hi: int):
+    """One error-bearing read over `contig` (the order of the rng calls is part of the seeded workloads' definition).
+    Returns (ts, te, read, quality | None, deleted, has_ins, match columns, qpos: query index of every column's base)."""
+    contig_len = len(contig)
+    ts = int(rng.integers(0, max(1, contig_len - read_len // 4)))
+    te = min(contig_len, ts + read_len)
+    n = te - ts
+    tgt = contig[ts:te]
+    deleted = rng.random(n) < dele
+    deleted[0] = deleted[-1] = False
+    subst = rng.random(n) < sub
+    base = tgt.copy()
+    base[subst] = _ACGT[(np.searchsorted(_ACGT, tgt[subst]) + rng.integers(1, 4, int(subst.sum()))) % 4]
+    has_ins = rng.random(n) < ins
+    has_ins[-1] = False
+    emit = (~deleted).astype(np.int64) + has_ins.astype(np.int64)      # bases emitted per target column
+    qpos = np.concatenate([[0], np.cumsum(emit)])                        # query index of column's M base
+    qlen = int(qpos[-1])
+    read = np.empty(qlen, np.uint8)
+    mcols = np.nonzero(~deleted)[0]
+    read[qpos[mcols]] = base[mcols]
+    icols = np.nonzero(has_ins)[0]
+    read[qpos[icols] + (~deleted[icols]).astype(np.int64)] = _ACGT[rng.integers(0, 4, icols.size)]
+    q = None
+    if with_quality:
+        q = np.clip(np.rint(rng.normal(phred_mean, phred_sd, qlen)), phred_lo, phred_hi).astype(np.uint8) + 33
+    return ts, te, read, q, deleted, has_ins, mcols, qpos
+
+
 def simulate_windows(contig_len: int, window_len: int = 500, coverage: float = 30.0, read_len: int = 10000,
                      sub: float = 0.03, ins: float = 0.03, dele: float = 0.04, seed: int = 20260921,
                      phred_mean: float = 15.0, phred_sd: float = 4.0, phred_lo: int = 5, phred_hi: int = 30,
@@ -32,28 +62,9 @@ def simulate_windows(contig_len: int, window_len: int = 500, coverage: float = 3
     n_reads = int(round(coverage * contig_len / read_len))
     total_read_len = 0
     for _ in range(n_reads):
-        ts = int(rng.integers(0, max(1, contig_len - read_len // 4)))
-        te = min(contig_len, ts + read_len)
-        n = te - ts
-        tgt = contig[ts:te]
-        deleted = rng.random(n) < dele
-        deleted[0] = deleted[-1] = False
-        subst = rng.random(n) < sub
-        base = tgt.copy()
-        base[subst] = _ACGT[(np.searchsorted(_ACGT, tgt[subst]) + rng.integers(1, 4, int(subst.sum()))) % 4]
-        has_ins = rng.random(n) < ins
-        has_ins[-1] = False
-        emit = (~deleted).astype(np.int64) + has_ins.astype(np.int64)      # bases emitted per target column
-        qpos = np.concatenate([[0], np.cumsum(emit)])                        # query index of column's M base
-        qlen = int(qpos[-1])
-        total_read_len += qlen
-        read = np.empty(qlen, np.uint8)
-        mcols = np.nonzero(~deleted)[0]
-        read[qpos[mcols]] = base[mcols]
-        icols = np.nonzero(has_ins)[0]
-        read[qpos[icols] + (~deleted[icols]).astype(np.int64)] = _ACGT[rng.integers(0, 4, icols.size)]
-        if with_quality:
-            q = np.clip(np.rint(rng.normal(phred_mean, phred_sd, qlen)), phred_lo, phred_hi).astype(np.uint8) + 33
+        ts, te, read, q, deleted, has_ins, mcols, qpos = _sim_read(rng, contig, read_len, sub, ins, dele, with_quality,
+                                                                   phred_mean, phred_sd, phred_lo, phred_hi)
+        total_read_len += len(read)
         # cut at window boundaries: first / last MATCH column inside each window
         w0, w1 = ts // window_len, (te - 1) // window_len
         for w in range(w0, w1 + 1):
@@ -81,6 +92,81 @@ def simulate_windows(contig_len: int, window_len: int = 500, coverage: float = 3
         bb = backbone[w * window_len:min(contig_len, (w + 1) * window_len)].tobytes()
         windows.append({"type": 1 if tgs else 0, "seqs": [(bb, b"!" * len(bb), 0, 0)] + layers[w]})
     return WindowBatch.from_windows(windows)
+
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _cigar_of(n: int, deleted: np.ndarray, has_ins: np.ndarray) -> bytes:
+    """The true alignment of a simulated read as CIGAR text: per target column D or M, an I behind a column with an insertion."""
+    pos = np.arange(n) + np.cumsum(has_ins) - has_ins
+    ops = np.full(n + int(has_ins.sum()), ord("I"), np.uint8)
+    ops[pos] = np.where(deleted, ord("D"), ord("M"))
+    cut = np.nonzero(np.diff(ops))[0] + 1
+    starts = np.concatenate([[0], cut]); lens = np.diff(np.concatenate([starts, [ops.size]]))
+    return b"".join(b"%d%c" % (int(l), int(ops[a])) for a, l in zip(starts.tolist(), lens.tolist()))
+
+
+def _sim_piece_files(args):
+    """One stretch of simulate_window_files as text: (target FASTA, reads FASTQ, SAM, PAF) of contig `index`."""
+    contig_len, coverage, read_len, seed, index, sub, ins, dele, phred = args
+    rng = np.random.default_rng(seed)                      # the stream of simulate_windows(contig_len, ..., seed)
+    srng = np.random.default_rng([seed, 0x5bd1e995])       # strands: a stream of their own
+    contig = _ACGT[rng.integers(0, 4, contig_len)]
+    tname = b"ctg%d" % index
+    fa = b">" + tname + b"\n" + contig.tobytes() + b"\n"
+    fq, sam, paf = [], [b"@SQ\tSN:" + tname + b"\tLN:%d\n" % contig_len], []
+    for i in range(int(round(coverage * contig_len / read_len))):
+        ts, te, read, q, deleted, has_ins, mcols, qpos = _sim_read(rng, contig, read_len, sub, ins, dele, True, *phred)
+        seq, qual = read.tobytes(), q.tobytes()
+        strand = int(srng.integers(0, 2))
+        name = b"r%d_%d" % (index, i)
+        if strand:        # the read file holds the reverse complement; SAM lists SEQ on the target's strand
+            fq.append(b"@" + name + b"\n" + seq.translate(_COMP)[::-1] + b"\n+\n" + qual[::-1] + b"\n")
+        else:
+            fq.append(b"@" + name + b"\n" + seq + b"\n+\n" + qual + b"\n")
+        sam.append(name + b"\t%d\t" % (16 if strand else 0) + tname + b"\t%d\t60\t" % (ts + 1) + _cigar_of(te - ts, deleted, has_ins) +
+                   b"\t*\t0\t0\t" + seq + b"\t" + qual + b"\n")
+        paf.append(name + b"\t%d\t0\t%d\t" % (len(seq), len(seq)) + (b"-" if strand else b"+") + b"\t" + tname +
+                   b"\t%d\t%d\t%d\t%d\t%d\t60\n" % (contig_len, ts, te, te - ts, te - ts))
+    return fa, b"".join(fq), b"".join(sam), b"".join(paf)
+
+
+def simulate_window_files(out_dir: str, contig_len: int, coverage: float = 30.0, read_len: int = 10000, seed: int = 20260921,
+                          piece: int = 1_000_000, workers: int = 16, sub: float = 0.03, ins: float = 0.03, dele: float = 0.04,
+                          phred=(15.0, 4.0, 5, 30)) -> dict:
+    """The workload of simulate_windows_parallel(contig_len, ..., seed) as racon INPUT FILES (what `racon reads overlaps
+    targets` takes, reference src/main.cpp:139-157): one target per `piece`-bp stretch (FASTA, the true contig: a backbone
+    without quality, like simulate_windows'), the reads on both strands (FASTQ), and the read-to-target overlaps as SAM
+    with the simulator's true CIGAR (reference src/overlap.cpp:192: no pre-alignment) and as PAF.  The windows the
+    reference's initialize() cuts from these files (src/polisher.cpp:388-461) are, byte for byte and in the same order,
+    the WindowBatch simulate_windows_parallel returns for the same arguments (tests/test_synth_files.py) -- so the product
+    path (files -> initialize -> polish) and the kernel path (packed batch) can be timed and checked on ONE workload.
+    Plain text, not gzip (the reference's parsers read both): these files only ever live in a scratch directory."""
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    sizes = [piece] * (contig_len // piece) + ([contig_len % piece] if contig_len % piece else [])
+    seeds = [seed] if len(sizes) == 1 else [seed * 1000 + k for k in range(len(sizes))]
+    jobs = [(n, coverage, read_len, sd, k, sub, ins, dele, tuple(phred)) for k, (n, sd) in enumerate(zip(sizes, seeds))]
+    if len(jobs) > 1 and workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(max(1, min(workers, len(jobs)))) as pool:
+            parts = pool.map(_sim_piece_files, jobs)
+    else:
+        parts = [_sim_piece_files(j) for j in jobs]
+    paths = {k: os.path.join(out_dir, n) for k, n in (("targets", "targets.fasta"), ("reads", "reads.fastq"),
+                                                       ("sam", "overlaps.sam"), ("paf", "overlaps.paf"))}
+    for col, key in enumerate(("targets", "reads", "sam", "paf")):
+        with open(paths[key], "wb") as f:
+            if key == "sam":        # header lines first, then the records
+                heads = [p[col][:p[col].index(b"\n") + 1] for p in parts]
+                f.write(b"".join(heads))
+                for p, h in zip(parts, heads):
+                    f.write(p[col][len(h):])
+            else:
+                for p in parts:
+                    f.write(p[col])
+    return paths
 
 
 def simulate_fragment_windows(genome_len: int, n_reads: int, read_len: int = 10000, window_len: int = 500,

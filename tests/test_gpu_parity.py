@@ -111,6 +111,7 @@ def test_work_groups_per_cu_do_not_change_results(Engine, oracle, monkeypatch):
     """The engine runs a batch that is resident all at once with six work-groups per CU instead of eight
     (engine.hip: wg_per_cu); the choice, and any forced value, must not show in the output."""
     b = simulate_windows(300_000, 500, 30.0, 10000, seed=77)             # 600 windows: all resident, the deepest one bounds the launch
+    monkeypatch.setenv("RCN_SPLIT", "0")                                 # (the split launch has its own tests: test_gpu_product_path.py)
     eng = Engine(3, -5, -4, True)
     base = eng.consensus(b)
     assert eng.stats()["wg_per_cu"] == 6

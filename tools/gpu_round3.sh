@@ -1,0 +1,72 @@
+#!/bin/bash
+# Round-3 GPU visit (see tools/gpu_round.sh for the profile passes): parity tests, the bench line with the product legs
+# and the CPU sweep, the split-launch A/B, the host-core probe.
+# Usage: bash tools/gpu_round3.sh <tag> [what...]   what: tests bench split probe debug prof pmc big
+set -u
+TAG=${1:-r03a}; shift || true
+WHAT=${*:-tests bench split probe debug}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+(nproc; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocm-smi --showproductname 2>/dev/null | head -20) > "$OUT/box.txt" 2>&1
+
+if has tests; then
+  timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
+  tail -30 "$OUT/pytest_gpu.log"
+fi
+if has bench; then
+  timeout 1200 python bench.py --steps 5 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "bench exit $?"; cat "$OUT/bench.json"; tail -5 "$OUT/bench.err"
+fi
+if has split; then
+  B="python bench.py --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg"
+  run() { echo "== $1"; shift; env "$@" $B 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print('%.0f windows/s  step %.2f ms  launches %s  frac %.3f  split %s' % (j['value'], r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], r['frac'], r['split_launch']))"; }
+  { run "no split" RCN_SPLIT=0
+    run "default (96 CUs, 1 per CU)" RCN_X=0
+    run "64 CUs x1" RCN_SPLIT_CUS=64
+    run "128 CUs x1" RCN_SPLIT_CUS=128
+    run "64 CUs x2" RCN_SPLIT_CUS=64 RCN_SPLIT_DEEP_PER_CU=2
+    run "96 CUs x2" RCN_SPLIT_CUS=96 RCN_SPLIT_DEEP_PER_CU=2
+    run "128 CUs x2" RCN_SPLIT_CUS=128 RCN_SPLIT_DEEP_PER_CU=2
+    run "96 CUs x1, rest 6 per CU" RCN_SPLIT_REST_PER_CU=6
+    run "no split again" RCN_SPLIT=0
+    run "default again" RCN_X=0
+  } > "$OUT/split_ab.txt" 2>&1
+  cat "$OUT/split_ab.txt"
+fi
+if has probe; then
+  timeout 300 python tools/cpu_probe.py > "$OUT/cpu_probe.json" 2>&1; cat "$OUT/cpu_probe.json"
+fi
+if has debug; then
+  # host timeline of one product polish() (RCN_DEBUG prints the engine's own clock)
+  F=/tmp/racon_amd_cache/files_1000000_30_20260921
+  if [ -d "$F" ]; then
+    for k in 1 2; do RCN_DEBUG=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/debug_polish_$k.err" | md5sum; done
+    grep -E "racon::|polish:|piece" "$OUT/debug_polish_2.err" | head -40
+    RACON_HIP_NO_WARMUP=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/debug_polish_nowarm.err" | md5sum
+    grep -E "racon::" "$OUT/debug_polish_nowarm.err"
+  fi
+fi
+if has big; then
+  # cfg3 at full size on one GPU (100 000 windows through the engine's queue) with every window checked against the oracle,
+  # and one GPU's share of cfg5 (scale 0.125 = 250 k windows)
+  timeout 2400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu --no-product --verify > "$OUT/bench_cfg3_1gpu.json" 2> "$OUT/bench_cfg3_1gpu.err"
+  echo "cfg3 exit $?"; cut -c1-1500 "$OUT/bench_cfg3_1gpu.json"; tail -3 "$OUT/bench_cfg3_1gpu.err"
+fi
+BENCH_PROF="python bench.py --steps 3 --warmup 1 --no-cpu --no-upload-leg --no-product"
+if has prof; then
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- $BENCH_PROF > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+  echo "prof exit $?"; cat "$OUT/prof_bench.json"
+  find "$OUT/prof" -name "*kernel_stats.csv" -exec head -5 {} \;
+fi
+if has pmc; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- $BENCH_PROF > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
+    echo "pmc $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; cat "$OUT/pmc_summary.txt"
+fi
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+du -sh "$OUT"
