@@ -122,6 +122,20 @@ def product_polish(paths, window, scores, threads, expect=None, reps=2):
                     % (paths["contig"], threads, reps)}
 
 
+def pick_workload(config: str, contig: int, rank: int, world: int):
+    """(contig bp on this rank, seed, scaling, name) of the seeded ONT-like workloads:
+    N = 1: cfg2 (1 Mbp, seed 20260921).  N > 1: cfg3, the 50 Mbp / 100 000-window job cut into N equal stretches, rank r
+    generating its own (seed 20260922 + r): total work is fixed -> "strong".  --contig: that many bp on EVERY rank -> "weak".
+    --config cfg3: the whole 50 Mbp job on this rank's one GPU."""
+    if config == "cfg3":
+        return 50_000_000, 20260922, "weak", "cfg3 (whole job on one GPU)"
+    if contig:
+        return contig, 20260921 + rank, "weak", "cfg2-shaped"
+    if world == 1:
+        return 1_000_000, 20260921, "weak", "cfg2"
+    return 50_000_000 // world, 20260922 + rank, "strong", "cfg3 (50 Mbp / %d ranks)" % world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,14 +182,7 @@ def main():
                     "w1000": "w1000: synthetic 1 Mbp contig, 30x ONT-error reads, -w 1000"}.get(a.config, a.config)
         contig = 0
     else:
-        if a.config == "cfg3":          # the whole 100 000-window job on this rank's GPU (fits one MI355X: 3.1 GB packed)
-            contig, seed, scaling, cfg_name = 50_000_000, 20260922, "weak", "cfg3 (whole job on one GPU)"
-        elif a.contig:
-            contig, seed, scaling, cfg_name = a.contig, 20260921 + rank, "weak", "cfg2-shaped"
-        elif world == 1:
-            contig, seed, scaling, cfg_name = 1_000_000, 20260921, "weak", "cfg2"
-        else:
-            contig, seed, scaling, cfg_name = 50_000_000 // world, 20260922 + rank, "strong", "cfg3 (50 Mbp / %d ranks)" % world
+        contig, seed, scaling, cfg_name = pick_workload(a.config, a.contig, rank, world)
         batch = cached_windows(contig, a.window, a.coverage, 10000, seed, workers)
         what = "%s: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d" % (cfg_name, contig, a.coverage, a.window)
     a.contig = contig

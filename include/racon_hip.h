@@ -156,6 +156,9 @@ typedef struct rcn_reserve_hint {
                                         scratch slot); 0 = n_bases / n_windows                        */
 } rcn_reserve_hint;
 int  rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* hint);
+/* The same for ONE known batch: exactly what rcn_engine_polish_refs(w) will allocate (inputs, pinned staging, results,
+ * the scratch of its launches as it will plan them), without packing, copying or running anything.                */
+int  rcn_engine_reserve_refs(rcn_engine* e, const rcn_window_refs* w);
 
 int  rcn_engine_result(rcn_engine* e, rcn_result* out);
 int  rcn_engine_stats(rcn_engine* e, rcn_run_stats* out);

@@ -324,7 +324,11 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.heavy_ns = e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.force_tie = getenv("RCN_FORCE_TIE") ? atoi(getenv("RCN_FORCE_TIE")) : 0;
     P.force_slow_tb = getenv("RCN_FORCE_SLOW_TB") ? 1 : 0;
-    P.band = getenv("RCN_NO_BAND") ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : (getenv("RCN_BAND_SCORES") ? 3 : 1));
+    // the band's exactness certificate (poa_band.hpp: a cell is alive when H' + m (len - j) >= T) assumes that a remaining
+    // base adds at most m: any -m/-x/-g is legal on the command line (reference src/main.cpp:51-53,91-99), so score sets
+    // with x > m or g > m take full rows
+    const bool band_sound = e->cfg.match >= e->cfg.mismatch && e->cfg.match >= e->cfg.gap;
+    P.band = (!band_sound || getenv("RCN_NO_BAND")) ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : (getenv("RCN_BAND_SCORES") ? 3 : 1));
     P.scratch = e->d_scratch.as<uint8_t>() + L.scratch_off; P.slot_bytes = L.c.slot_bytes;
     P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride;
     P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_off = e->d_out_off.as<uint64_t>(); P.out_base = L.out_base;
@@ -511,7 +515,9 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     for (auto& evs : e->sub_ev) for (auto& ev : evs) HIP_TRY(hipEventCreate(&ev));
     {
         // the CU-masked stream pair of the split launch (split_plan); a runtime that refuses masks leaves them null
-        int cus = 96;
+        // 64 of the 256 CUs for the deep launch: A/B on cfg2 (profiles/r03/a_split_ab.txt) 20.81 ms per step against 21.22
+        // with 96, 23.3 with 128 (the other launch then lacks CUs) and 21.62 without the split
+        int cus = 64;
         if (const char* v = getenv("RCN_SPLIT_CUS")) cus = atoi(v);
         cus = (cus / 8) * 8;                                   // an even slice of the eight XCDs
         const char* sw = getenv("RCN_SPLIT");
@@ -734,6 +740,9 @@ int rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_t
 // per-window results in caller order.
 static int collect(rcn_engine* e) {
     const uint32_t nw = e->n_windows;
+    const bool dbg = getenv("RCN_DEBUG") != nullptr;
+    const auto c0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count(); };
     const uint64_t cons_bytes = e->out_off[nw];
     // pinned layout: [lengths 4 nw][flags nw, padded][consensus bytes]
     const uint64_t off_flags = 4ull * nw, off_cons = (off_flags + nw + 15) & ~uint64_t(15);
@@ -749,6 +758,7 @@ static int collect(rcn_engine* e) {
     HIP_TRY(hipEventRecord(t.b, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); e->stats.d2h_ms += ms;
+    if (dbg) fprintf(stderr, "[racon_hip] collect: results on the host (%.1f MB) after %.2f ms\n", (off_cons + cons_bytes) / 1e6, since());
     const uint32_t* len_item = reinterpret_cast<const uint32_t*>(hb);
     const uint8_t* flag_item = hb + off_flags;
     const uint8_t* raw = hb + off_cons;
@@ -795,14 +805,19 @@ static int collect(rcn_engine* e) {
             const uint32_t w = retry[k];
             if (fl2[k] & (rcn::kFlagOverflow | rcn::kFlagError)) return RCN_E_CAPACITY;
             retry_cons[k].resize(len2[k]);
-            if (len2[k]) HIP_TRY(hipMemcpy(&retry_cons[k][0], e->d_out_cons.as<uint8_t>() + off2[k], len2[k], hipMemcpyDeviceToHost));
+            if (len2[k]) HIP_TRY(hipMemcpyAsync(&retry_cons[k][0], e->d_out_cons.as<uint8_t>() + off2[k], len2[k], hipMemcpyDeviceToHost, e->stream));
             out_len[w] = len2[k]; flags[w] = fl2[k];
         }
+        HIP_TRY(hipStreamSynchronize(e->stream));
         e->stats.n_retried = static_cast<uint32_t>(retry.size());
     }
 
     unsigned long long st[24] = {0};
-    HIP_TRY(hipMemcpy(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost));
+    // (on the engine's own non-blocking stream: a plain hipMemcpy runs on the null stream and waits for every blocking stream
+    //  of the process -- the CU-masked launch streams of the device's OTHER engine among them)
+    HIP_TRY(hipMemcpyAsync(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (dbg) fprintf(stderr, "[racon_hip] collect: counters read after %.2f ms\n", since());
     e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
     for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
     e->stats.n_sink_ties = st[11];
@@ -862,6 +877,7 @@ static int collect(rcn_engine* e) {
     }
     e->stats.bytes_out = e->cons_off[nw] + 5ull * nw;
     e->ran = true;
+    if (dbg) fprintf(stderr, "[racon_hip] collect: results in window order after %.2f ms\n", since());
     return RCN_OK;
 }
 
@@ -1036,7 +1052,9 @@ inline void symbols_finish(const uint64_t present[4], int32_t& nsym, uint8_t& ac
 // the first, small piece.  With the split plan the first piece is the deep launch on its own CUs.  A batch with more
 // windows than resident slots runs the same way, its launches persistent over their queues.  Same results as
 // upload + run.
-int polish_view(rcn_engine* e, const SrcView& v) {
+// `dry`: everything polish_view(v) would allocate -- device inputs, pinned staging, result buffers, the scratch of its
+// launches (their slots and capacities planned from v's own shapes) -- and nothing else: rcn_engine_reserve_refs.
+int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     const uint32_t nw = v.nw, ns = v.ns;
     HIP_TRY(hipSetDevice(e->cfg.device));
     e->queued = (v.flags & RCN_REFS_QUEUED) != 0;
@@ -1047,7 +1065,7 @@ int polish_view(rcn_engine* e, const SrcView& v) {
         return rc ? rc : rcn_engine_run(e);
     };
     const bool fast = !getenv("RCN_WIDE_ONLY");
-    if (nw < 64 || getenv("RCN_NO_STREAM")) return plain();
+    if (nw < 64 || getenv("RCN_NO_STREAM")) return dry ? RCN_OK : plain();
     e->uploaded = false; e->ran = false;
     e->n_windows = nw; e->n_seqs = ns; e->n_bases = v.seq_off[ns];
     const bool dbg = getenv("RCN_DEBUG") != nullptr;
@@ -1072,6 +1090,37 @@ int polish_view(rcn_engine* e, const SrcView& v) {
                    o_full = o_ord + 4ull * ns, o_bases = (o_full + ns + 255) & ~uint64_t(255), o_quals = (o_bases + nb + 255) & ~uint64_t(255),
                    total = o_quals + nb + 256;
     if ((rc = e->h_stage.reserve(total))) return rc;
+    if (dbg) fprintf(stderr, "[racon_hip] polish: pinned staging (%.1f MB) at %.2f ms\n", total / 1e6, since());
+    if ((rc = e->d_win_seq_off.reserve(4ull * (nw + 1))) || (rc = e->d_win_type.reserve(nw)) || (rc = e->d_win_flags.reserve(nw)) ||
+        (rc = e->d_seq_off.reserve(8ull * (ns + 1))) || (rc = e->d_has_qual.reserve(ns)) || (rc = e->d_begin.reserve(4ull * ns)) ||
+        (rc = e->d_end.reserve(4ull * ns)) || (rc = e->d_order.reserve(4ull * ns)) || (rc = e->d_full.reserve(ns)) ||
+        (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16)) || (rc = e->d_out_off.reserve(8ull * (nw + 1))))
+        return rc;
+    if (dbg) fprintf(stderr, "[racon_hip] polish: device inputs reserved at %.2f ms\n", since());
+    const SplitPlan sp = split_plan(e, nw, fast);
+    const uint32_t slots_total = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e);
+    if (dry) {
+        // the launches' scratch as polish_view will lay it out (usual alphabet: A, C, G, T and one more symbol), and the pinned
+        // result buffer of collect()
+        if (slots_total < 2) return RCN_OK;
+        PassPlan est; est.n = rcn_engine::kSubLaunches; est.split = sp.on;
+        est.cut[0] = 0; est.cut[2] = nw;
+        if (sp.on) est.cut[1] = sp.n_deep;
+        else {
+            uint64_t acc = 0; uint32_t k = 0;
+            while (k < nw && acc < nb / 24) { const uint32_t w = e->lpt[k], s0 = v.win_seq_off[w]; acc += v.seq_off[v.win_seq_off[w + 1]] - v.seq_off[s0]; ++k; }
+            est.cut[1] = std::min(std::min(std::max(k, 1u), nw), std::max(1u, slots_total / 2));
+        }
+        for (uint32_t w = 0; w < nw; ++w) e->shapes[w].nsym = 5;
+        uint32_t left = slots_total;
+        for (int c = 0; c < est.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left); left -= std::min(left, est.L[c].slots); }
+        if (est.scratch <= scratch_budget(e) && (rc = e->d_scratch.reserve(est.scratch))) return rc;
+        if (dbg) fprintf(stderr, "[racon_hip] reserve: scratch arena (%.2f GB, %u + %u slots) at %.2f ms\n", est.scratch / 1e9, est.L[0].slots, est.L[1].slots, since());
+        const uint64_t off_cons = (5ull * nw + 15) & ~uint64_t(15);
+        if ((rc = e->h_out.reserve(off_cons + e->out_off[nw] + 16))) return rc;
+        if (dbg) fprintf(stderr, "[racon_hip] reserve: done at %.2f ms\n", since());
+        return RCN_OK;
+    }
     uint8_t* hs = e->h_stage.as<uint8_t>();
     uint32_t* s_wso = reinterpret_cast<uint32_t*>(hs + o_wso); uint8_t* s_type = hs + o_type; uint8_t* s_flags = hs + o_flags;
     uint64_t* s_so = reinterpret_cast<uint64_t*>(hs + o_so); uint8_t* s_hq = hs + o_hq;
@@ -1095,11 +1144,7 @@ int polish_view(rcn_engine* e, const SrcView& v) {
             s_ord[d0 + i] = hp.order[s0 + i]; s_full[d0 + i] = hp.full[s0 + i];
         }
     });
-    if ((rc = e->d_win_seq_off.reserve(4ull * (nw + 1))) || (rc = e->d_win_type.reserve(nw)) || (rc = e->d_win_flags.reserve(nw)) ||
-        (rc = e->d_seq_off.reserve(8ull * (ns + 1))) || (rc = e->d_has_qual.reserve(ns)) || (rc = e->d_begin.reserve(4ull * ns)) ||
-        (rc = e->d_end.reserve(4ull * ns)) || (rc = e->d_order.reserve(4ull * ns)) || (rc = e->d_full.reserve(ns)) ||
-        (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16)) || (rc = e->d_out_off.reserve(8ull * (nw + 1))))
-        return rc;
+    if (dbg) fprintf(stderr, "[racon_hip] polish: metadata staged at %.2f ms\n", since());
     hipStream_t cs = e->copy_stream;
     HIP_TRY(hipMemcpyAsync(e->d_win_seq_off.p, s_wso, 4ull * (nw + 1), hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_win_type.p, s_type, nw, hipMemcpyHostToDevice, cs));
@@ -1115,8 +1160,6 @@ int polish_view(rcn_engine* e, const SrcView& v) {
     // split plan: the deep launch's windows, then the rest.  Otherwise: the deepest windows that hold 1/24 of the bases
     // (they decide when the batch ends and must start first; the fewer there are, the sooner the first launch is under
     // way), then the rest.
-    const SplitPlan sp = split_plan(e, nw, fast);
-    const uint32_t slots_total = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e);
     if (slots_total < 2) { HIP_TRY(hipStreamSynchronize(cs)); return plain(); }
     PassPlan pp; pp.n = rcn_engine::kSubLaunches; pp.split = sp.on; pp.copied = true;
     pp.cut[0] = 0; pp.cut[2] = nw;
@@ -1137,6 +1180,7 @@ int polish_view(rcn_engine* e, const SrcView& v) {
         for (int c = 0; c < pp.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left); left -= std::min(left, est.L[c].slots); }
         for (uint32_t w = 0; w < nw; ++w) e->shapes[w].nsym = keep[w];
         if (est.scratch <= scratch_budget(e) && (rc = e->d_scratch.reserve(est.scratch))) return rc;
+        if (dbg) fprintf(stderr, "[racon_hip] polish: scratch arena (%.2f GB) at %.2f ms\n", est.scratch / 1e9, since());
     }
     // the main stream zeroed the counters (begin_run): the sub-launches must not start before that
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
@@ -1184,6 +1228,7 @@ int polish_view(rcn_engine* e, const SrcView& v) {
     }
     HIP_TRY(hipEventRecord(t.b, cs));
     if ((rc = finish_pieces(e, pp, t.a))) return rc;
+    if (dbg) fprintf(stderr, "[racon_hip] polish: launches done at %.2f ms (host clock)\n", since());
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
     e->stats.h2d_ms = ms;
     e->stats.bytes_in = 2 * nb + 17ull * ns + 5ull * nw;
@@ -1191,6 +1236,22 @@ int polish_view(rcn_engine* e, const SrcView& v) {
     rc = collect(e);
     if (dbg) fprintf(stderr, "[racon_hip] polish: results collected at %.2f ms (host clock)\n", since());
     return rc;
+}
+
+int refs_view(const rcn_window_refs* w, std::vector<uint64_t>& so, SrcView& v) {
+    if (w->n_windows && (!w->win_seq_off || !w->win_type || !w->seq || !w->qual || !w->seq_len || !w->seq_begin || !w->seq_end)) return RCN_E_ARG;
+    if (w->n_windows && w->win_seq_off[w->n_windows] != w->n_seqs) return RCN_E_ARG;
+    const uint32_t ns = w->n_seqs;
+    so.assign(static_cast<size_t>(ns) + 1, 0);
+    for (uint32_t i = 0; i < ns; ++i) {
+        if (w->seq_len[i] && !w->seq[i]) return RCN_E_ARG;
+        so[i + 1] = so[i] + w->seq_len[i];
+    }
+    static const uint8_t kNoByte = 0; static const uint32_t kNoWord = 0; static const uint8_t* const kNoPtr = nullptr;
+    v.nw = w->n_windows; v.ns = ns; v.flags = w->flags; v.seq_off = so.data();
+    v.win_seq_off = w->n_windows ? w->win_seq_off : &kNoWord; v.win_type = w->n_windows ? w->win_type : &kNoByte;
+    v.seq = ns ? w->seq : &kNoPtr; v.qual = ns ? w->qual : &kNoPtr; v.begin = ns ? w->seq_begin : &kNoWord; v.end = ns ? w->seq_end : &kNoWord;
+    return RCN_OK;
 }
 
 __global__ void k_warm(unsigned* p) { if (p && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *p = 0; }
@@ -1213,19 +1274,9 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
 
 int rcn_engine_polish_refs(rcn_engine* e, const rcn_window_refs* w) {
     if (!e || !w) return RCN_E_ARG;
-    if (w->n_windows && (!w->win_seq_off || !w->win_type || !w->seq || !w->qual || !w->seq_len || !w->seq_begin || !w->seq_end)) return RCN_E_ARG;
-    if (w->n_windows && w->win_seq_off[w->n_windows] != w->n_seqs) return RCN_E_ARG;
-    const uint32_t ns = w->n_seqs;
-    std::vector<uint64_t> so(static_cast<size_t>(ns) + 1, 0);
-    for (uint32_t i = 0; i < ns; ++i) {
-        if (w->seq_len[i] && !w->seq[i]) return RCN_E_ARG;
-        so[i + 1] = so[i] + w->seq_len[i];
-    }
-    static const uint8_t kNoByte = 0; static const uint32_t kNoWord = 0; static const uint8_t* const kNoPtr = nullptr;
-    SrcView v;
-    v.nw = w->n_windows; v.ns = ns; v.flags = w->flags; v.seq_off = so.data();
-    v.win_seq_off = w->n_windows ? w->win_seq_off : &kNoWord; v.win_type = w->n_windows ? w->win_type : &kNoByte;
-    v.seq = ns ? w->seq : &kNoPtr; v.qual = ns ? w->qual : &kNoPtr; v.begin = ns ? w->seq_begin : &kNoWord; v.end = ns ? w->seq_end : &kNoWord;
+    std::vector<uint64_t> so; SrcView v;
+    const int rc0 = refs_view(w, so, v);
+    if (rc0) return rc0;
     if (v.nw == 0) {
         HIP_TRY(hipSetDevice(e->cfg.device));
         HostBatch hb; materialize(v, hb);
@@ -1233,6 +1284,17 @@ int rcn_engine_polish_refs(rcn_engine* e, const rcn_window_refs* w) {
         return rc ? rc : rcn_engine_run(e);
     }
     return polish_view(e, v);
+}
+
+int rcn_engine_reserve_refs(rcn_engine* e, const rcn_window_refs* w) {
+    if (!e || !w) return RCN_E_ARG;
+    std::vector<uint64_t> so; SrcView v;
+    int rc = refs_view(w, so, v);
+    if (rc) return rc;
+    rcn_reserve_hint warm{};
+    if ((rc = rcn_engine_reserve(e, &warm))) return rc;                 // first use of the code object / copy engines
+    if (v.nw == 0) return RCN_OK;
+    return polish_view(e, v, /*dry=*/true);
 }
 
 int rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* h) {

@@ -61,7 +61,7 @@ EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
            "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory",
            "rcn_engine_align_pairs", "rcn_engine_alignment_cigars", "rcn_engine_align_stats", "rcn_engine_build_windows_from_pairs",
-           "rcn_engine_polish_refs", "rcn_engine_reserve"]
+           "rcn_engine_polish_refs", "rcn_engine_reserve", "rcn_engine_reserve_refs"]
 
 _lib = None
 
@@ -83,6 +83,7 @@ def load_library():
     lib.rcn_engine_polish.argtypes = [C.c_void_p, C.POINTER(RcnBatch)]
     lib.rcn_engine_polish_refs.argtypes = [C.c_void_p, C.POINTER(RcnWindowRefs)]
     lib.rcn_engine_reserve.argtypes = [C.c_void_p, C.POINTER(RcnReserveHint)]
+    lib.rcn_engine_reserve_refs.argtypes = [C.c_void_p, C.POINTER(RcnWindowRefs)]
     lib.rcn_device_free_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.rcn_engine_result.argtypes = [C.c_void_p, C.POINTER(RcnResult)]
     lib.rcn_engine_stats.argtypes = [C.c_void_p, C.POINTER(RcnRunStats)]
@@ -171,21 +172,29 @@ class HipEngine:
         _check(self.lib.rcn_engine_polish(self.h, C.byref(cb)), "rcn_engine_polish")
         return self.result()
 
-    def consensus_refs(self, batch: WindowBatch, flags: int = 0) -> ConsensusResult:
-        """The same batch handed over as borrowed per-sequence pointers (rcn_engine_polish_refs: the form racon::Window holds
-        its sequences in); sequences without quality get a NULL quality pointer."""
+    def _refs(self, batch: WindowBatch, flags: int):
         batch.as_c()                                    # contiguous arrays of the ABI's dtypes
         ns = batch.n_seqs
         so = batch.seq_off.astype(np.uint64)
         seq = (np.uint64(batch.bases.ctypes.data) + so[:-1]).astype(np.uint64)
         qual = np.where(batch.seq_has_qual != 0, np.uint64(batch.quals.ctypes.data) + so[:-1], np.uint64(0)).astype(np.uint64)
         ln = (so[1:] - so[:-1]).astype(np.uint32)
-        keep = (batch, seq, qual, ln)
         r = RcnWindowRefs(batch.n_windows, ns, batch.win_seq_off.ctypes.data, batch.win_type.ctypes.data, seq.ctypes.data, qual.ctypes.data,
                           ln.ctypes.data, batch.seq_begin.ctypes.data, batch.seq_end.ctypes.data, flags)
-        self._keep = keep
+        self._keep = (batch, seq, qual, ln)
+        return r
+
+    def consensus_refs(self, batch: WindowBatch, flags: int = 0) -> ConsensusResult:
+        """The same batch handed over as borrowed per-sequence pointers (rcn_engine_polish_refs: the form racon::Window holds
+        its sequences in); sequences without quality get a NULL quality pointer."""
+        r = self._refs(batch, flags)
         _check(self.lib.rcn_engine_polish_refs(self.h, C.byref(r)), "rcn_engine_polish_refs")
         return self.result()
+
+    def reserve_refs(self, batch: WindowBatch, flags: int = 0):
+        """Everything consensus_refs(batch) will allocate, ahead of time (rcn_engine_reserve_refs)."""
+        r = self._refs(batch, flags)
+        _check(self.lib.rcn_engine_reserve_refs(self.h, C.byref(r)), "rcn_engine_reserve_refs")
 
     def reserve(self, n_windows: int, n_seqs: int, n_bases: int, window_length: int, max_layer_length: int = 0, max_window_bases: int = 0):
         """Allocation ahead of the first batch (rcn_engine_reserve)."""

@@ -24,6 +24,7 @@ struct Abi {
     decltype(&rcn_engine_polish) polish = nullptr;
     decltype(&rcn_engine_polish_refs) polish_refs = nullptr;
     decltype(&rcn_engine_reserve) reserve = nullptr;
+    decltype(&rcn_engine_reserve_refs) reserve_refs = nullptr;
     decltype(&rcn_device_free_memory) free_memory = nullptr;
     decltype(&rcn_engine_result) result = nullptr;
     decltype(&rcn_engine_stats) stats = nullptr;
@@ -64,7 +65,7 @@ const Abi& abi() {
 #define RCN_BIND(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); \
         if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
-        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
+        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(reserve_refs, "rcn_engine_reserve_refs") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
         RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
         RCN_BIND(build_windows_from_pairs, "rcn_engine_build_windows_from_pairs")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
@@ -186,6 +187,12 @@ void HipEngine::reserve(uint32_t n_windows, uint32_t n_seqs, uint64_t n_bases, u
     if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::reserve] error: ") + abi().strerror_(rc) + "!");
 }
 
+void HipEngine::reserve(const WindowRefs& refs, bool queued) {
+    const rcn_window_refs r = refs.view(queued ? RCN_REFS_QUEUED : 0u);
+    const int rc = abi().reserve_refs(handle_, &r);
+    if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::reserve] error: ") + abi().strerror_(rc) + "!");
+}
+
 void HipEngine::consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,
                           uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                           std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
@@ -226,7 +233,9 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
     if (a.stats(handle_, &st) == RCN_OK) last_kernel_ms_ = st.kernel_ms;
     consensus->resize(r.n_windows); polished->resize(r.n_windows); chimeric->resize(r.n_windows);
     for (uint32_t w = 0; w < r.n_windows; ++w) {
-        (*consensus)[w].assign(reinterpret_cast<const char*>(r.cons + r.cons_off[w]), r.cons_off[w + 1] - r.cons_off[w]);
+        if (w >= fetch_first_ && w < fetch_last_)
+            (*consensus)[w].assign(reinterpret_cast<const char*>(r.cons + r.cons_off[w]), r.cons_off[w + 1] - r.cons_off[w]);
+        else (*consensus)[w].clear();
         (*polished)[w] = r.polished[w]; (*chimeric)[w] = r.chimeric[w];
     }
 }

@@ -73,6 +73,8 @@ public:
     // src/polisher.cpp:180-182): arena, pinned staging, code object, copy engines.
     void reserve(uint32_t n_windows, uint32_t n_seqs, uint64_t n_bases, uint32_t window_length, uint32_t max_layer_length,
                  uint64_t max_window_bases = 0);
+    // ... for one known batch: exactly what consensus(refs, queued, ...) will allocate (rcn_engine_reserve_refs)
+    void reserve(const WindowRefs& refs, bool queued);
     // The same, with the windows built on the device from the flattened sequences / overlaps
     // (rcn_engine_build_windows: reference src/polisher.cpp:388-461 in HBM).
     void consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,
@@ -88,6 +90,9 @@ public:
                    uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                    std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
     double last_kernel_ms() const { return last_kernel_ms_; }
+    // Only windows [first, last) of the next consensus() calls are copied into strings (the others come back empty):
+    // a shard of a device-built job owns a range of the windows its engine returns.  (0, ~0) = all.
+    void set_fetch_range(uint64_t first, uint64_t last) { fetch_first_ = first; fetch_last_ = last; }
 
 private:
     HipEngine() = default;
@@ -95,6 +100,7 @@ private:
     void fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run = true);
     rcn_engine* handle_ = nullptr;
     double last_kernel_ms_ = 0;
+    uint64_t fetch_first_ = 0, fetch_last_ = ~uint64_t(0);
 };
 
 }  // namespace racon

@@ -207,10 +207,14 @@ void read_batches(const std::string& path, Format format, uint32_t threads, cons
             Batch b;
             b.text.swap(carry);
             const size_t had = b.text.size();
-            b.text.resize(had + kBlock);
+            // A record longer than a block (a chromosome-scale FASTA entry) is carried over and framed again from its start
+            // with every block: reading as much as is already carried doubles the block each time, so a record of N bytes
+            // is scanned and copied O(N) in total, not O(N^2 / block).
+            const size_t want = std::min<size_t>(std::max(kBlock, had), size_t(1) << 30);
+            b.text.resize(had + want);
             size_t got = 0;
-            while (got < kBlock) {
-                const int n = gzread(f, &b.text[had + got], static_cast<unsigned>(kBlock - got));
+            while (got < want) {
+                const int n = gzread(f, &b.text[had + got], static_cast<unsigned>(want - got));
                 if (n < 0) throw std::runtime_error("[racon::io] error: corrupted compressed stream!");
                 if (n == 0) { eof = true; break; }
                 got += static_cast<size_t>(n);

@@ -374,45 +374,70 @@ void Polisher::initialize() {
 namespace { constexpr uint64_t kMaxChunkWindows = 8192, kMinChunkWindows = 2048, kMaxChunkBases = 512ull << 20; }
 
 void Polisher::create_engines() {
-    n_devices_ = HipEngine::DeviceCount();          // (0 without the library or a device: polish() reports that)
-    if (n_devices_ <= 0) return;
+    const int32_t real_devices = HipEngine::DeviceCount();      // (0 without the library or a device: polish() reports that)
+    n_devices_ = real_devices;
+    if (real_devices <= 0) return;
+    // RACON_HIP_FAKE_DEVICES=n: drive n logical devices (engine k belongs to logical device k mod n, which is physical device
+    // (k mod n) mod the real count): the multi-device code paths on a one-GPU box (tests)
+    if (const char* fd = getenv("RACON_HIP_FAKE_DEVICES")) n_devices_ = std::max(1, atoi(fd));
     const uint32_t engines_per_device = 2 * hip_batches_;
+    const uint32_t sharing = engines_per_device * static_cast<uint32_t>((n_devices_ + real_devices - 1) / real_devices);
     std::vector<std::shared_ptr<HipEngine>> engines;
     for (uint32_t k = 0; k < static_cast<uint32_t>(n_devices_) * engines_per_device; ++k) {
-        const int32_t device = static_cast<int32_t>(k % static_cast<uint32_t>(n_devices_));
+        const int32_t device = static_cast<int32_t>(k % static_cast<uint32_t>(n_devices_)) % real_devices;
         // engines of one device split its free HBM (each would otherwise budget 80 % of it for its own scratch)
-        const uint64_t arena = static_cast<uint64_t>(HipEngine::FreeMemory(device) * 0.8 / engines_per_device);
+        const uint64_t arena = static_cast<uint64_t>(HipEngine::FreeMemory(device) * 0.8 / sharing);
         engines.emplace_back(HipEngine::Create(device, match_, mismatch_, gap_, arena));
     }
-    // a first guess at a chunk: 2048 windows of `-w` bases under 40 layers (the arena: ~3 MB per resident window at -w 500)
-    const uint64_t layers = 40, w = window_length_;
-    for (auto& e : engines)
-        e->reserve(static_cast<uint32_t>(kMinChunkWindows), static_cast<uint32_t>(kMinChunkWindows * (layers + 1)),
-                   std::min<uint64_t>(kMaxChunkBases, kMinChunkWindows * (layers + 1) * w), window_length_, 0);
+    // first use of the code object, the streams' queues and the copy engines; the arenas and the pinned staging are sized
+    // once the windows exist (reserve_for_windows): device memory that is allocated, freed and allocated again is what
+    // costs (the driver clears it), so nothing is allocated on a guess
+    for (auto& e : engines) e->reserve(0, 0, 0, window_length_, 0);
     engines_.swap(engines);
+}
+
+// The work list of polish(): chunks of the window index space in DEEPEST-FIRST order (see polish()).
+void Polisher::plan_chunks() {
+    const uint64_t nw = windows_.size();
+    const uint64_t n_engines = std::max<size_t>(1, engines_.size());
+    rank_.resize(nw);
+    chunks_.clear();
+    std::vector<uint64_t> cost(nw), bases(nw);
+    for (uint64_t i = 0; i < nw; ++i) {
+        uint64_t b = 0;
+        for (const auto& sq : windows_[i]->sequences_) b += sq.second;
+        bases[i] = b;
+        cost[i] = windows_[i]->sequences_.size() < 3 ? 0 : b * windows_[i]->sequences_.size();
+        rank_[i] = static_cast<uint32_t>(i);
+    }
+    std::stable_sort(rank_.begin(), rank_.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    uint64_t target = std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (nw + 2 * n_engines - 1) / (2 * n_engines)));
+    if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) target = std::max(1, atoi(cw));       // tests: many small chunks
+    for (uint64_t a = 0; a < nw;) {
+        uint64_t b = a, sum = 0;
+        while (b < nw && b - a < target && sum < kMaxChunkBases) sum += bases[rank_[b++]];
+        chunks_.emplace_back(a, b); a = b;
+    }
 }
 
 void Polisher::reserve_for_windows() {
     if (device_warmup_.joinable()) device_warmup_.join();
     if (engines_.empty() || windows_.empty() || device_windows_) return;
-    // the largest chunk polish() will hand to an engine (same rule as there)
-    const uint64_t nw = windows_.size();
-    uint64_t seqs = 0, bases = 0, lmax = 0, deepest = 0;
-    for (const auto& w : windows_) {
-        uint64_t b = 0;
-        for (size_t i = 0; i < w->sequences_.size(); ++i) { b += w->sequences_[i].second; if (i) lmax = std::max<uint64_t>(lmax, w->sequences_[i].second); }
-        seqs += w->sequences_.size(); bases += b; deepest = std::max(deepest, b);
-    }
-    const uint64_t chunk = std::min(nw, std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (nw + 2 * engines_.size() - 1) / (2 * engines_.size()))));
-    // chunks are cut from the windows in deepest-first order: the first one holds the deepest windows
-    const uint64_t chunk_bases = std::min(std::min(bases, deepest * chunk), kMaxChunkBases + deepest);
-    const uint64_t chunk_seqs = std::max<uint64_t>(chunk, static_cast<uint64_t>(static_cast<double>(seqs) / bases * chunk_bases) + chunk);
+    const bool timing = getenv("RACON_HIP_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    plan_chunks();
+    // engine k takes chunk k first (the shared cursor of polish() hands them out in this order): each gets exactly what that
+    // chunk needs -- later chunks are shallower and fit in the same buffers -- and an engine without a chunk gets nothing
     FatalThrowsScope scope;
     try {
-        for (auto& e : engines_)
-            e->reserve(static_cast<uint32_t>(chunk), static_cast<uint32_t>(std::min<uint64_t>(chunk_seqs, 0xffffffffu)), chunk_bases, window_length_,
-                       static_cast<uint32_t>(lmax), deepest);
+        WindowRefs refs;
+        for (size_t k = 0; k < engines_.size() && k < chunks_.size(); ++k) {
+            refs.clear();
+            for (uint64_t i = chunks_[k].first; i < chunks_[k].second; ++i) refs.add(*windows_[rank_[i]]);
+            engines_[k]->reserve(refs, chunks_.size() > 1);
+        }
     } catch (const std::exception& e) { engines_error_ = e.what(); engines_.clear(); }
+    if (timing) fprintf(stderr, "[racon::Polisher::initialize] timing: %zu chunk(s) planned, engines reserved in %.1f ms\n", chunks_.size(), 1e3 * seconds_since(t0));
 }
 
 void Polisher::find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>>& overlaps) {
@@ -546,23 +571,52 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
                     p_q_start = q_start.data(); p_t_begin = t_begin.data(); p_t_end = t_end.data(); p_q_begin = q_begin.data(); p_q_end = q_end.data();
                     p_cigar_off = cigar_off.data(); p_cigar = cigar.empty() ? &kNoByte : cigar.data();
                 }
+                // The reads this shard's overlaps point into, and nothing else: every shard needs every target (their
+                // windows outside the range come out as bare backbones), but of the reads only its own -- one eighth of
+                // cfg3's 1.5 G bases per device instead of all of them on each (the reference's multi-device path keeps the
+                // reads on the host and packs per batch, src/cuda/cudapolisher.cpp:254-276).
+                rcn_read_set sr = r;
+                std::vector<uint64_t> r_seq_off; std::vector<uint8_t> r_bases, r_quals, r_hq;
+                if (!all && r.n_seqs > r.n_targets) {
+                    constexpr uint32_t kUnused = 0xffffffffu;
+                    std::vector<uint32_t> remap(r.n_seqs, kUnused), old_of;
+                    for (uint64_t t = 0; t < r.n_targets; ++t) { remap[t] = static_cast<uint32_t>(t); old_of.push_back(static_cast<uint32_t>(t)); }
+                    for (uint32_t& q : q_id) {
+                        if (remap[q] == kUnused) { remap[q] = static_cast<uint32_t>(old_of.size()); old_of.push_back(q); }
+                        q = remap[q];
+                    }
+                    uint64_t total = 0;
+                    for (uint32_t old : old_of) total += r.seq_off[old + 1] - r.seq_off[old];
+                    r_seq_off.assign(1, 0); r_seq_off.reserve(old_of.size() + 1);
+                    r_bases.resize(total + 1); r_quals.resize(total + 1); r_hq.reserve(old_of.size());
+                    for (uint32_t old : old_of) {
+                        const uint64_t a = r.seq_off[old], len = r.seq_off[old + 1] - a, d = r_seq_off.back();
+                        std::copy(r.bases + a, r.bases + a + len, r_bases.begin() + d);
+                        std::copy(r.quals + a, r.quals + a + len, r_quals.begin() + d);
+                        r_hq.push_back(r.seq_has_qual[old]);
+                        r_seq_off.push_back(d + len);
+                    }
+                    sr.n_seqs = old_of.size(); sr.seq_off = r_seq_off.data(); sr.bases = r_bases.data(); sr.quals = r_quals.data(); sr.seq_has_qual = r_hq.data();
+                }
                 // (the shards of one device run one after the other on its lane thread: they share the device's first engine)
                 const int32_t device = static_cast<int32_t>(sidx % static_cast<uint32_t>(n_devices));
                 auto engine = engines_[static_cast<size_t>(device)];
+                engine->set_fetch_range(wa, wb);                       // the strings of its own windows only
                 std::vector<std::string> c; std::vector<uint8_t> pl, ch;
                 if (device_align_) {
                     rcn_pair_set ps{};
                     ps.n_pairs = so.n_overlaps; ps.q_id = so.q_id; ps.t_id = so.t_id; ps.strand = so.strand;
                     ps.q_begin = p_q_begin; ps.q_end = p_q_end; ps.t_begin = p_t_begin; ps.t_end = p_t_end;
-                    engine->consensus(r, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                    engine->consensus(sr, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
                 } else if (device_cigars_) {
                     rcn_cigar_set a{};
                     a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
                     a.q_start = p_q_start; a.t_begin = p_t_begin; a.t_end = p_t_end; a.cigar_off = p_cigar_off; a.cigar = p_cigar;
-                    engine->consensus(r, a, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                    engine->consensus(sr, a, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
                 } else {
-                    engine->consensus(r, so, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                    engine->consensus(sr, so, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
                 }
+                engine->set_fetch_range(0, ~uint64_t(0));
                 if (c.size() != nw) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
                 for (uint64_t w = wa; w < wb; ++w) { cons[w].swap(c[w]); pol[w] = pl[w]; chim[w] = ch[w]; }
             } catch (const std::exception& ex) { shard_errors[sidx] = ex.what(); }
@@ -591,29 +645,13 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
     // [k C, (k+1) C).  The deepest windows are under way in the first launch, the last chunk holds the shallowest ones and
     // its tail is short.  A job that fits one chunk (cfg2: 2000 windows) is one engine call with the windows resident
     // all at once; larger jobs alternate between the engines of a device, each chunk flagged as part of a queue.
-    std::vector<uint32_t> rank(nw);
-    {
-        std::vector<uint64_t> cost(nw);
-        for (uint64_t i = 0; i < nw; ++i) {
-            uint64_t b = 0;
-            for (const auto& sq : windows_[i]->sequences_) b += sq.second;
-            cost[i] = windows_[i]->sequences_.size() < 3 ? 0 : b * windows_[i]->sequences_.size();
-            rank[i] = static_cast<uint32_t>(i);
-        }
-        std::stable_sort(rank.begin(), rank.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-    }
-    std::vector<std::pair<uint64_t, uint64_t>> chunks;          // [first, last) positions in `rank`
-    {
-        uint64_t target = std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (nw + 2 * n_engines - 1) / (2 * n_engines)));
-        if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) target = std::max(1, atoi(cw));       // tests: many small chunks
-        for (uint64_t a = 0; a < nw;) {
-            uint64_t b = a, bases = 0;
-            while (b < nw && b - a < target && bases < kMaxChunkBases) { for (const auto& sq : windows_[rank[b]]->sequences_) bases += sq.second; ++b; }
-            chunks.emplace_back(a, b); a = b;
-        }
-    }
+    if (chunks_.empty() || rank_.size() != nw) plan_chunks();
+    const std::vector<uint32_t>& rank = rank_;
+    const std::vector<std::pair<uint64_t, uint64_t>>& chunks = chunks_;
+    const bool timing = getenv("RACON_HIP_TIMING") != nullptr;
     const bool queued = chunks.size() > 1;
-    std::atomic<size_t> cursor{0};
+    const uint32_t n_workers = static_cast<uint32_t>(std::min<size_t>(n_engines, std::max<size_t>(1, chunks.size())));
+    std::atomic<size_t> cursor{n_workers};          // engine k starts with chunk k (what reserve_for_windows sized it for)
     std::vector<std::exception_ptr> errors(n_engines);
     auto worker = [&](uint32_t k) {
         FatalThrowsScope scope;
@@ -621,16 +659,20 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
             auto& engine = engines_[k];
             WindowRefs refs;
             std::vector<std::string> c; std::vector<uint8_t> p, h;
-            for (size_t ci; (ci = cursor.fetch_add(1)) < chunks.size();) {
+            for (size_t ci = k; ci < chunks.size(); ci = cursor.fetch_add(1)) {
+                const double t_a = seconds_since(polish_begin);
                 refs.clear();
                 for (uint64_t i = chunks[ci].first; i < chunks[ci].second; ++i) refs.add(*windows_[rank[i]]);
+                const double t_b = seconds_since(polish_begin);
                 engine->consensus(refs, queued, trim_, &c, &p, &h);
+                const double t_c = seconds_since(polish_begin);
                 for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { const uint32_t w = rank[i]; cons[w].swap(c[j]); pol[w] = p[j]; chim[w] = h[j]; }
+                if (timing) fprintf(stderr, "[racon::Polisher::polish] timing: engine %u chunk %zu (%lu windows): start %.1f ms, refs %.1f, engine done %.1f (kernel %.1f), stored %.1f\n",
+                                    k, ci, static_cast<unsigned long>(chunks[ci].second - chunks[ci].first), 1e3 * t_a, 1e3 * t_b, 1e3 * t_c, engine->last_kernel_ms(), 1e3 * seconds_since(polish_begin));
             }
         } catch (...) { errors[k] = std::current_exception(); cursor.store(chunks.size()); }
     };
     {
-        const uint32_t n_workers = static_cast<uint32_t>(std::min<size_t>(n_engines, std::max<size_t>(1, chunks.size())));
         if (n_workers <= 1) worker(0);
         else {
             std::vector<std::thread> pool;

@@ -145,6 +145,10 @@ protected:
     double polish_seconds_ = 0;     // the Logger-bracketed interval of the last polish()
     void create_engines();          // (warm-up thread, or polish() when the warm-up was switched off)
     void reserve_for_windows();     // end of initialize(): the arenas sized for the windows that were built
+    // polish()'s work list: windows ranked deepest first, cut into chunks (planned once, by reserve_for_windows or polish)
+    std::vector<uint32_t> rank_;
+    std::vector<std::pair<uint64_t, uint64_t>> chunks_;     // [first, last) positions in rank_
+    void plan_chunks();
 public:
     double polish_seconds() const { return polish_seconds_; }
 };

@@ -251,6 +251,79 @@ def simulate_fragment_windows(genome_len: int, n_reads: int, read_len: int = 100
     return WindowBatch.from_windows(windows)
 
 
+def simulate_fragment_files(out_dir: str, genome_len: int, n_reads: int, read_len: int = 10000, sub: float = 0.03, ins: float = 0.03,
+                            dele: float = 0.04, seed: int = 20260924, min_overlap: int = 2000,
+                            phred=(15.0, 4.0, 5, 30)) -> dict:
+    """The fragment-correction workload (BASELINE.json configs[4], `racon -f reads overlaps reads`) as INPUT FILES: the reads
+    of simulate_fragment_windows(genome_len, n_reads, ..., seed) -- same rng stream, so the same reads -- on random strands
+    (FASTQ), and the all-vs-all overlaps from the true coordinates as PAF, BOTH directions per pair (dual overlaps, grouped
+    by query; reference src/polisher.cpp:295 keeps every overlap per query in kF mode).  PAF carries no alignment: the
+    pre-alignment (reference src/overlap.cpp:205-224) is part of the job, on the host or on the device."""
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    srng = np.random.default_rng([seed, 0x5bd1e995])
+    genome = _ACGT[rng.integers(0, 4, genome_len)]
+    starts = np.sort(rng.integers(0, max(1, genome_len - read_len // 2), n_reads))
+    reads = []          # (ts, te, read length, qstart[col] = read index of the first base emitted at or after the column, strand)
+    paths = {"reads": os.path.join(out_dir, "reads.fastq"), "paf": os.path.join(out_dir, "overlaps.paf")}
+    with open(paths["reads"], "wb") as fr:
+        for i, ts in enumerate(starts.tolist()):
+            te = min(genome_len, ts + read_len)
+            n = te - ts
+            tgt = genome[ts:te]
+            deleted = rng.random(n) < dele
+            deleted[0] = deleted[-1] = False
+            subst = rng.random(n) < sub
+            base = tgt.copy()
+            base[subst] = _ACGT[(np.searchsorted(_ACGT, tgt[subst]) + rng.integers(1, 4, int(subst.sum()))) % 4]
+            has_ins = rng.random(n) < ins
+            has_ins[-1] = False
+            emit = (~deleted).astype(np.int64) + has_ins.astype(np.int64)
+            qstart = np.concatenate([[0], np.cumsum(emit)])
+            qlen = int(qstart[-1])
+            read = np.empty(qlen, np.uint8)
+            mcols = np.nonzero(~deleted)[0]
+            read[qstart[mcols]] = base[mcols]
+            icols = np.nonzero(has_ins)[0]
+            read[qstart[icols] + (~deleted[icols]).astype(np.int64)] = _ACGT[rng.integers(0, 4, icols.size)]
+            q = np.clip(np.rint(rng.normal(phred[0], phred[1], qlen)), phred[2], phred[3]).astype(np.uint8) + 33
+            strand = int(srng.integers(0, 2))
+            seq, qual = read.tobytes(), q.tobytes()
+            if strand:
+                seq, qual = seq.translate(_COMP)[::-1], qual[::-1]
+            fr.write(b"@f%d\n" % i + seq + b"\n+\n" + qual + b"\n")
+            reads.append((ts, te, qlen, qstart, strand))
+    n_ovl = 0
+    with open(paths["paf"], "wb") as fp:
+        lo = 0
+        for a, (ats, ate, alen, aq, astr) in enumerate(reads):          # a = query
+            while lo < n_reads and reads[lo][1] <= ats:
+                lo += 1
+            for b in range(lo, n_reads):
+                bts, bte, blen, bq, bstr = reads[b]
+                if bts >= ate:
+                    break
+                if b == a:
+                    continue
+                g0, g1 = max(ats, bts), min(ate, bte)
+                if g1 - g0 < min_overlap:
+                    continue
+                qb, qe = int(aq[g0 - ats]), int(aq[g1 - ats])
+                tb, te_ = int(bq[g0 - bts]), int(bq[g1 - bts])
+                if qe - qb < 1 or te_ - tb < 1:
+                    continue
+                if astr:            # PAF query coordinates are on the query's own (file) strand
+                    qb, qe = alen - qe, alen - qb
+                if bstr:
+                    tb, te_ = blen - te_, blen - tb
+                fp.write(b"f%d\t%d\t%d\t%d\t%c\tf%d\t%d\t%d\t%d\t%d\t%d\t60\n" % (a, alen, qb, qe, b"-"[0] if astr != bstr else b"+"[0], b, blen, tb, te_,
+                                                                                          min(qe - qb, te_ - tb), max(qe - qb, te_ - tb)))
+                n_ovl += 1
+    paths["n_overlaps"] = n_ovl
+    return paths
+
+
 def config_windows(name: str, scale: float = 1.0) -> WindowBatch:
     """The named synthetic configurations of SURVEY.md §8(d).  `scale` shrinks the
     contig (tests use small scales; bench.py uses 1.0)."""

@@ -105,3 +105,20 @@ def test_cli_device_windows_sharded(P, oracle, data, ovl, mode):
     out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
     assert out == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ovl,mode", [("sam", "0"), ("paf", "0"), ("sam", "2"), ("paf", "3")])
+def test_cli_on_three_logical_devices(P, oracle, data, ovl, mode):
+    """RACON_HIP_FAKE_DEVICES=3: the host layer drives three logical devices (all mapped onto the one GPU of the box) --
+    six engines pulling small chunks from the shared cursor (mode 0, reference src/cuda/cudapolisher.cpp:254-276,336-350),
+    or one window range per device with only that range's reads uploaded (device-built windows) -- same FASTA."""
+    paths, _ = data
+    ref, _ = _oracle_fasta(P, oracle, paths, ovl)
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    env = dict(os.environ, RACON_HIP_FAKE_DEVICES="3", RACON_HIP_CHUNK_WINDOWS="7")
+    if mode != "0":
+        env["RACON_HIP_DEVICE_WINDOWS"] = mode
+    out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
+    assert out == ref

@@ -174,3 +174,17 @@ def test_band_rows_with_seven_and_eight_in_edges(oracle, n_variants, scores):
         assert st["band_redo_why"][3] == 0, st["band_redo_why"]
     else:
         assert st["band_redo_why"][3] > 0, st["band_redo_why"]
+
+
+@pytest.mark.parametrize("scores", [(1, 2, -1), (-2, -3, -1), (0, -1, -1), (2, 2, -2), (4, -6, 0), (3, -5, 2)])
+def test_score_sets_the_band_certificate_does_not_cover(oracle, scores):
+    """Any -m / -x / -g is legal (reference src/main.cpp:51-53,91-99).  The certificate bounds what a remaining base can
+    add by m: sets with x > m or g > m must take full rows, g >= 0 the int32 kernel -- same bytes as the oracle either way."""
+    from racon_amd.engine import HipEngine
+    rng = np.random.default_rng(77)
+    b = WindowBatch.from_windows([long_window(rng, s) for s in range(8)]).concat(simulate_windows(6000, 500, 12.0, 3000, seed=7009))
+    eng = HipEngine(*scores, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, *scores, True, 0), f"scores {scores}")
+    m, x, g = scores
+    if x > m or g > m:
+        assert eng.stats()["n_banded"] == 0

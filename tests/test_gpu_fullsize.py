@@ -156,3 +156,47 @@ def test_two_ranks_two_gpus_rccl_gather():
     b = simulate_windows(300_000, 500, 30.0, 10000, seed=20260922)
     one = HipEngine(3, -5, -4, True).consensus(b)
     assert n == b.n_windows and digest == _digest(one.consensus)
+
+
+def _gloo_hip_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from racon_amd import distributed as rd
+    from racon_amd.engine import HipEngine, load_library
+    from racon_amd.synth import simulate_windows
+    import ctypes as C
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = simulate_windows(400_000, 500, 30.0, 10000, seed=20260922)
+    fr, tot = C.c_uint64(), C.c_uint64()
+    load_library().rcn_device_free_memory(0, C.byref(fr), C.byref(tot))
+    eng = HipEngine(3, -5, -4, True, device=0, arena_bytes=int(fr.value * 0.8 / world))      # the ranks share the one device
+    out = rd.polish_sharded(b, eng.consensus, rank, world)
+    if rank == 0:
+        q.put((len(out.consensus), _digest(out.consensus), int(out.polished.sum())))
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+def test_four_ranks_on_one_gpu_gather_to_rank_zero():
+    """The rank-per-GPU path (racon_amd.distributed.polish_sharded: cost-balanced contiguous shards, no data-path
+    collective, one gather to rank 0) with the HIP engine under every rank: four processes, four engines with a quarter of
+    the arena each, on the ONE device of the box, gloo for the gather -- the bytes of one engine polishing everything."""
+    import socket
+    import torch.multiprocessing as mp
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_hip_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    n, digest, npol = q.get(timeout=600)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    b = simulate_windows(400_000, 500, 30.0, 10000, seed=20260922)
+    one = HipEngine(3, -5, -4, True).consensus(b)
+    assert n == b.n_windows == 800 and digest == _digest(one.consensus) and npol == int(one.polished.sum())

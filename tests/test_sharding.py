@@ -92,3 +92,21 @@ def test_parallel_generator_is_the_concatenation_of_its_pieces():
     one = simulate_windows_parallel(40_000, 500, 12.0, 4000, seed=5, piece=50_000)
     same = simulate_windows(40_000, 500, 12.0, 4000, seed=5)
     assert np.array_equal(one.bases, same.bases) and np.array_equal(one.seq_off, same.seq_off)
+
+
+def test_bench_workload_slicing():
+    """What `bench.py --gpus N` runs on each rank (the driver launches it at N = 1, 2, 4, 8): cfg2 alone, else cfg3 cut into
+    N equal stretches with per-rank seeds and the total fixed ("strong"); --contig gives every rank the same size ("weak")."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.pick_workload("", 0, 0, 1) == (1_000_000, 20260921, "weak", "cfg2")
+    for world in (2, 4, 8):
+        parts = [bench.pick_workload("", 0, r, world) for r in range(world)]
+        assert sum(p[0] for p in parts) == 50_000_000 and {p[2] for p in parts} == {"strong"}
+        assert [p[1] for p in parts] == [20260922 + r for r in range(world)]                 # independent stretches
+        assert sum((p[0] + 499) // 500 for p in parts) == 100_000                               # cfg3's window count
+    assert [bench.pick_workload("", 300_000, r, 4)[:3] for r in range(2)] == [(300_000, 20260921, "weak"), (300_000, 20260922, "weak")]
+    assert bench.pick_workload("cfg3", 0, 0, 1)[:2] == (50_000_000, 20260922)

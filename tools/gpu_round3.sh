@@ -39,6 +39,27 @@ fi
 if has probe; then
   timeout 300 python tools/cpu_probe.py > "$OUT/cpu_probe.json" 2>&1; cat "$OUT/cpu_probe.json"
 fi
+if has tests2; then
+  timeout 2400 python -m pytest tests/test_gpu_product_path.py tests/test_gpu_unbounded_shapes.py tests/test_gpu_window_build.py tests/test_gpu_band.py tests/test_cli_e2e.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q --durations=12 > "$OUT/pytest_gpu2.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_gpu2.log"
+  tail -40 "$OUT/pytest_gpu2.log"
+fi
+if has timeline; then
+  # host timelines of the product's polish(): cfg2 (one chunk) and one GPU's share of cfg3 (12 500 windows, four chunks)
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+for c, s in ((1_000_000, 20260921), (6_250_000, 20260922)):
+    print(bench.product_files(c, 30.0, s, 32))
+PY
+  for F in /tmp/racon_amd_cache/files_1000000_30_20260921 /tmp/racon_amd_cache/files_6250000_30_20260922; do
+    for k in 1 2 3; do
+      RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/timeline_$(basename $F)_$k.err" | md5sum
+    done
+    grep -E "racon::|polish:|piece|collect|reserve" "$OUT/timeline_$(basename $F)_3.err" | head -80
+  done
+fi
 if has debug; then
   # host timeline of one product polish() (RCN_DEBUG prints the engine's own clock)
   F=/tmp/racon_amd_cache/files_1000000_30_20260921
