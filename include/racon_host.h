@@ -53,6 +53,9 @@ int  rcnh_polisher_layout(rcnh_polisher* p, rcn_read_set* reads, rcn_overlap_set
 /* ... and the alignments those breaking points were derived from (the CIGAR of the overlap file or of the host's
  * pairwise alignment), for rcn_engine_build_windows_from_cigars. */
 int  rcnh_polisher_alignments(rcnh_polisher* p, rcn_cigar_set* alignments);
+/* ... and, for overlaps that came without an alignment (PAF / MHAP), the segment pairs the pre-alignment works on
+ * (reference src/overlap.cpp:176-224): the input of rcn_engine_align_pairs / rcn_engine_build_windows_from_pairs. */
+int  rcnh_polisher_pairs(rcnh_polisher* p, rcn_pair_set* pairs);
 /* Stitch per-window results (same order as the batch) into FASTA text
  * ">name tags\nsequence\n..." exactly as reference src/main.cpp:159-161 prints it. */
 int  rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* results, int drop_unpolished_sequences,

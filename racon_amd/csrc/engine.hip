@@ -148,6 +148,7 @@ struct rcn_engine {
     hipStream_t deep_stream = nullptr, rest_stream = nullptr;
     int split_cus = 0;
     bool warmed = false;                            // rcn_engine_reserve ran its warm-up launch
+    bool stats_pending = false;                     // the last run's device counters have not been read yet (rcn_engine_stats)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
     int n_cu = 256;
@@ -201,16 +202,18 @@ int upload_vec(DevBuf& d, const void* src, size_t bytes, hipStream_t s) {
     return RCN_OK;
 }
 
-struct Caps { int32_t ncap, ecap, ring, lmax, hstride; uint64_t slot_bytes; bool fast; };
+struct Caps { int32_t ncap, ecap, ring, lmax, hstride, hrows; uint64_t slot_bytes; bool fast; };
 
 // fast = poa_window_kernel2 (4 waves per window, int16 Z matrix); else poa_window_kernel (1 wave, int32 H)
-Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast) {
+// hrows: rows of the DP matrix (0 = ncap + 1, one per node the graph arrays can hold)
+Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast, int32_t hrows = 0) {
     Caps c; c.ncap = ncap; c.ecap = ecap; c.ring = ring; c.lmax = lmax; c.fast = fast;
+    c.hrows = (hrows > 0 && hrows < ncap + 1) ? hrows : ncap + 1;
     // fast: row stride in int16 cells, a multiple of 512: every DP shape (64 or 256 lanes x 2..8 cells) then
     // covers whole rows only, so the row store needs no lane mask
     c.hstride = fast ? ((lmax + 1 + 511) / 512) * 512 : (lmax + 1 + 128 + 3) & ~3;
     rcn::Win tmp;
-    c.slot_bytes = rcn::win_bind(tmp, nullptr, ncap, ecap, ring, lmax, c.hstride, fast ? 2 : 4);
+    c.slot_bytes = rcn::win_bind(tmp, nullptr, ncap, ecap, ring, lmax, c.hstride, fast ? 2 : 4, c.hrows);
     c.slot_bytes = (c.slot_bytes + 255) & ~uint64_t(255);
     return c;
 }
@@ -219,15 +222,22 @@ Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast
 // pass with worst-case capacities)
 template <class It>
 Caps first_pass_caps(It first, It last, bool fast) {
-    int32_t ncap = 0, lmax = 1, nsym = 2;
+    // The graph arrays (~230 B per node) for a node per four layer bases; the DP matrix -- one row of 1 or 2 KB per node,
+    // nine tenths of a slot -- for one per six: cfg2's windows end with a node per ~12 layer bases (10 % read error, most
+    // errors shared by no other read), so both leave room, and the arena (slots x slot bytes, tens of GB that the driver
+    // has to find and clear) shrinks by a third.  RCN_HROWS_DIV overrides the divisor (tests: a small matrix forces retries).
+    const char* hd = getenv("RCN_HROWS_DIV");
+    const int hdiv = hd ? std::max(1, atoi(hd)) : 6;
+    int32_t ncap = 0, hrows = 0, lmax = 1, nsym = 2;
     for (It it = first; it != last; ++it) {
         const WinShape& s = *it;
         const int64_t worst = static_cast<int64_t>(s.L) + s.sum_l + 8;
         const int64_t est = static_cast<int64_t>(s.L) + s.sum_l / 4 + 256;
         ncap = std::max<int32_t>(ncap, static_cast<int32_t>(std::min(worst, est)));
+        hrows = std::max<int32_t>(hrows, static_cast<int32_t>(std::min(worst + 1, static_cast<int64_t>(s.L) + s.sum_l / hdiv + 129)));
         lmax = std::max(lmax, s.lmax); nsym = std::max(nsym, s.nsym);
     }
-    return make_caps(ncap, 2 * ncap, std::max(1, nsym - 1), lmax, fast);
+    return make_caps(ncap, 2 * ncap, std::max(1, nsym - 1), lmax, fast, fast ? hrows : 0);
 }
 
 // Consensus bytes reserved for a window in the first pass.  The consensus is a path of the graph: it can be as long as
@@ -298,11 +308,15 @@ SplitPlan split_plan(const rcn_engine* e, uint32_t nw, bool fast) {
     return sp;
 }
 
+struct ResultLayout { uint64_t off_flags, off_cons; };
+inline ResultLayout result_layout(uint32_t nw) { ResultLayout r; r.off_flags = 4ull * nw; r.off_cons = (r.off_flags + nw + 15) & ~uint64_t(15); return r; }
+
 struct Launch {
     Caps c;
     const uint32_t* d_ids = nullptr;    // work item -> device window, or nullptr: work_base + work item
     uint32_t n_work = 0, work_base = 0, out_base = 0, slots = 0;
     uint32_t per_cu = 0;                // work-groups per CU of the fast kernel (0: wg_per_cu)
+    bool host_out = true;               // results go straight into the pinned result block (first pass); false: d_out_* (retry pass)
     uint64_t scratch_off = 0;
     int ctr = 0;                        // which work-queue counter of d_ctr
     hipStream_t stream = nullptr;
@@ -330,9 +344,19 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     const bool band_sound = e->cfg.match >= e->cfg.mismatch && e->cfg.match >= e->cfg.gap;
     P.band = (!band_sound || getenv("RCN_NO_BAND")) ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : (getenv("RCN_BAND_SCORES") ? 3 : 1));
     P.scratch = e->d_scratch.as<uint8_t>() + L.scratch_off; P.slot_bytes = L.c.slot_bytes;
-    P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride;
-    P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_off = e->d_out_off.as<uint64_t>(); P.out_base = L.out_base;
-    P.out_len = e->d_out_len.as<uint32_t>(); P.out_flags = e->d_out_flags.as<uint8_t>();
+    P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride; P.hrows = L.c.hrows;
+    P.out_off = e->d_out_off.as<uint64_t>(); P.out_base = L.out_base;
+    if (L.host_out) {
+        // The first pass writes lengths, flags and consensus bytes straight into pinned host memory (hipHostMalloc memory is
+        // device-visible): ~1 KB per window over PCIe from the kernel's own stores, and no device-to-host copy afterwards -- a
+        // copy that, queued behind another engine's persistent launch or simply first of its kind on a stream, was observed
+        // to take 8-9 ms for 2-3 MB (profiles/r03/b_timeline_*).  Layout: [lengths 4 nw][flags nw, padded][bytes].
+        const ResultLayout rl = result_layout(e->n_windows);
+        uint8_t* hb = e->h_out.as<uint8_t>();
+        P.out_len = reinterpret_cast<uint32_t*>(hb); P.out_flags = hb + rl.off_flags; P.out_cons = hb + rl.off_cons;
+    } else {
+        P.out_cons = e->d_out_cons.as<uint8_t>(); P.out_len = e->d_out_len.as<uint32_t>(); P.out_flags = e->d_out_flags.as<uint8_t>();
+    }
     P.next = e->d_ctr.as<unsigned int>() + L.ctr;
     P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + kStatsOff);
     const uint32_t per_cu = L.per_cu ? L.per_cu : wg_per_cu(e);
@@ -353,9 +377,9 @@ uint32_t slots_for(const rcn_engine* e, const Caps& c, uint32_t n_work, uint64_t
 }
 
 // one synchronous kernel pass on the main stream (resident batch / retry pass), timed with HIP events
-int run_pass(rcn_engine* e, const Caps& c, const uint32_t* d_ids, uint32_t n_work) {
+int run_pass(rcn_engine* e, const Caps& c, const uint32_t* d_ids, uint32_t n_work, bool host_out = true) {
     if (n_work == 0) return RCN_OK;
-    Launch L; L.c = c; L.d_ids = d_ids; L.n_work = n_work; L.stream = e->stream;
+    Launch L; L.c = c; L.d_ids = d_ids; L.n_work = n_work; L.stream = e->stream; L.host_out = host_out;
     L.slots = slots_for(e, c, n_work, scratch_budget(e));
     if (L.slots == 0) return RCN_E_CAPACITY;
     int rc = e->d_scratch.reserve(static_cast<uint64_t>(L.slots) * c.slot_bytes);
@@ -744,20 +768,13 @@ static int collect(rcn_engine* e) {
     const auto c0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count(); };
     const uint64_t cons_bytes = e->out_off[nw];
-    // pinned layout: [lengths 4 nw][flags nw, padded][consensus bytes]
-    const uint64_t off_flags = 4ull * nw, off_cons = (off_flags + nw + 15) & ~uint64_t(15);
+    // the kernel wrote its results into the pinned block (launch_pass): [lengths 4 nw][flags nw, padded][consensus bytes];
+    // every launch of the pass has been waited for (events), so the bytes are here
+    const ResultLayout rl = result_layout(nw);
+    const uint64_t off_flags = rl.off_flags, off_cons = rl.off_cons;
     int rc;
-    if ((rc = e->h_out.reserve(off_cons + cons_bytes + 16))) return rc;
+    if (e->h_out.cap < off_cons + cons_bytes + 16) return RCN_E_STATE;
     uint8_t* hb = e->h_out.as<uint8_t>();
-    EventPair t;
-    if (t.create()) return RCN_E_HIP;
-    HIP_TRY(hipEventRecord(t.a, e->stream));
-    HIP_TRY(hipMemcpyAsync(hb, e->d_out_len.p, 4ull * nw, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(hb + off_flags, e->d_out_flags.p, nw, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(hb + off_cons, e->d_out_cons.p, cons_bytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipEventRecord(t.b, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); e->stats.d2h_ms += ms;
     if (dbg) fprintf(stderr, "[racon_hip] collect: results on the host (%.1f MB) after %.2f ms\n", (off_cons + cons_bytes) / 1e6, since());
     const uint32_t* len_item = reinterpret_cast<const uint32_t*>(hb);
     const uint8_t* flag_item = hb + off_flags;
@@ -788,10 +805,10 @@ static int collect(rcn_engine* e) {
         Caps c2 = make_caps(n2, n2 + 8, std::max(1, nsym - 1), l2, false);     // int32 kernel, worst-case capacities
         const uint32_t nr = static_cast<uint32_t>(retry.size());
         // first-pass bytes are already on the host; the retry pass indexes its outputs by its own work items
-        if ((rc = e->d_out_cons.reserve(off2[nr] + 16))) return rc;
+        if ((rc = e->d_out_cons.reserve(off2[nr] + 16)) || (rc = e->d_out_len.reserve(4ull * nr)) || (rc = e->d_out_flags.reserve(nr))) return rc;
         if ((rc = upload_vec(e->d_out_off, off2.data(), 8ull * (nr + 1), e->stream))) return rc;
         if ((rc = upload_vec(e->d_win_ids, ids.data(), 4ull * nr, e->stream))) return rc;
-        rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr);
+        rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr, /*host_out=*/false);
         // the resident batch keeps its first-pass offsets for the next rcn_engine_run
         int rc2 = upload_vec(e->d_out_off, e->out_off.data(), 8ull * (nw + 1), e->stream);
         if (rc) return rc;
@@ -812,17 +829,7 @@ static int collect(rcn_engine* e) {
         e->stats.n_retried = static_cast<uint32_t>(retry.size());
     }
 
-    unsigned long long st[24] = {0};
-    // (on the engine's own non-blocking stream: a plain hipMemcpy runs on the null stream and waits for every blocking stream
-    //  of the process -- the CU-masked launch streams of the device's OTHER engine among them)
-    HIP_TRY(hipMemcpyAsync(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (dbg) fprintf(stderr, "[racon_hip] collect: counters read after %.2f ms\n", since());
-    e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
-    for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
-    e->stats.n_sink_ties = st[11];
-    e->stats.dp_cells_full = st[12]; e->stats.dp_bytes_full = st[13]; e->stats.n_banded = st[14]; e->stats.n_band_redone = st[15];
-    for (int k = 0; k < 8; ++k) e->stats.band_redo_why[k] = st[16 + k];
+    e->stats_pending = true;                      // the device counters of this run: fetched by rcn_engine_stats on demand
 #ifdef RCN_PROF_ROWS
     { static unsigned long long rp[256][16]; HIP_TRY(hipMemcpyFromSymbol(rp, HIP_SYMBOL(rcn::g_rowprof), sizeof(rp)));
       unsigned long long clk[8] = {0}, cnt[8] = {0}, allc = 0, alln = 0;
@@ -887,9 +894,8 @@ static int begin_run(rcn_engine* e) {
     e->stats = rcn_run_stats{}; e->stats.h2d_ms = h2d; e->stats.bytes_in = bin;
     { size_t fr = 0, tot = 0; HIP_TRY(hipMemGetInfo(&fr, &tot)); e->free_mem = fr + e->d_scratch.cap; }
     int rc;
-    if ((rc = e->d_out_cons.reserve(e->out_off[nw] + 16))) return rc;
-    if ((rc = e->d_out_len.reserve(4ull * nw))) return rc;
-    if ((rc = e->d_out_flags.reserve(nw))) return rc;
+    if ((rc = e->h_out.reserve(result_layout(nw).off_cons + e->out_off[nw] + 16))) return rc;
+    e->stats_pending = false;
     HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, kCtrBytes, e->stream));
     {
         // windows in the top tail of the depth distribution can be given the 4-wave DP (RCN_HEAVY_PCT; off by default:
@@ -1087,8 +1093,8 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     // staging: metadata block first, then bases, then qualities (each in deepest-first order)
     const uint64_t o_wso = 0, o_type = o_wso + 4ull * (nw + 1), o_flags = o_type + nw, o_so = (o_flags + nw + 15) & ~uint64_t(15),
                    o_hq = o_so + 8ull * (ns + 1), o_bg = (o_hq + ns + 15) & ~uint64_t(15), o_en = o_bg + 4ull * ns, o_ord = o_en + 4ull * ns,
-                   o_full = o_ord + 4ull * ns, o_bases = (o_full + ns + 255) & ~uint64_t(255), o_quals = (o_bases + nb + 255) & ~uint64_t(255),
-                   total = o_quals + nb + 256;
+                   o_full = o_ord + 4ull * ns, o_ooff = (o_full + ns + 15) & ~uint64_t(15), o_bases = (o_ooff + 8ull * (nw + 1) + 255) & ~uint64_t(255),
+                   o_quals = (o_bases + nb + 255) & ~uint64_t(255), total = o_quals + nb + 256;
     if ((rc = e->h_stage.reserve(total))) return rc;
     if (dbg) fprintf(stderr, "[racon_hip] polish: pinned staging (%.1f MB) at %.2f ms\n", total / 1e6, since());
     if ((rc = e->d_win_seq_off.reserve(4ull * (nw + 1))) || (rc = e->d_win_type.reserve(nw)) || (rc = e->d_win_flags.reserve(nw)) ||
@@ -1116,8 +1122,7 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         for (int c = 0; c < est.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left); left -= std::min(left, est.L[c].slots); }
         if (est.scratch <= scratch_budget(e) && (rc = e->d_scratch.reserve(est.scratch))) return rc;
         if (dbg) fprintf(stderr, "[racon_hip] reserve: scratch arena (%.2f GB, %u + %u slots) at %.2f ms\n", est.scratch / 1e9, est.L[0].slots, est.L[1].slots, since());
-        const uint64_t off_cons = (5ull * nw + 15) & ~uint64_t(15);
-        if ((rc = e->h_out.reserve(off_cons + e->out_off[nw] + 16))) return rc;
+        if ((rc = e->h_out.reserve(result_layout(nw).off_cons + e->out_off[nw] + 16))) return rc;
         if (dbg) fprintf(stderr, "[racon_hip] reserve: done at %.2f ms\n", since());
         return RCN_OK;
     }
@@ -1154,7 +1159,10 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     HIP_TRY(hipMemcpyAsync(e->d_end.p, s_en, 4ull * ns, hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_order.p, s_ord, 4ull * ns, hipMemcpyHostToDevice, cs));
     HIP_TRY(hipMemcpyAsync(e->d_full.p, s_full, ns, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_out_off.p, e->out_off.data(), 8ull * (nw + 1), hipMemcpyHostToDevice, cs));   // (pageable: small)
+    // (from the pinned block like everything else: the first asynchronous copy out of PAGEABLE memory makes the runtime set
+    //  up its own staging -- 9 ms on the first batch of an engine, profiles/r03/b_timeline_*)
+    std::memcpy(hs + o_ooff, e->out_off.data(), 8ull * (nw + 1));
+    HIP_TRY(hipMemcpyAsync(e->d_out_off.p, hs + o_ooff, 8ull * (nw + 1), hipMemcpyHostToDevice, cs));
 
     // ---- pieces ----
     // split plan: the deep launch's windows, then the rest.  Otherwise: the deepest windows that hold 1/24 of the bases
@@ -1188,22 +1196,35 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     for (int c = 0; c < pp.n; ++c) {
         const uint32_t k0 = pp.cut[c], k1 = pp.cut[c + 1];
         if (k1 == k0) continue;
-        const uint64_t b0 = win_base[k0], b1 = win_base[k1];
-        // pack the piece into pinned staging and collect its symbol statistics in the same pass over the bases
-        host_parallel(k1 - k0, threads, [&](size_t kk) {
-            const uint32_t k = k0 + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = v.win_seq_off[w], n = v.win_seq_off[w + 1] - s0;
-            uint8_t* db = hs + o_bases + win_base[k]; uint8_t* dq = hs + o_quals + win_base[k];
-            uint64_t present[4] = {0, 0, 0, 0};
-            for (uint32_t i = 0; i < n; ++i) {
-                const uint64_t len = v.seq_off[s0 + i + 1] - v.seq_off[s0 + i];
-                if (!len) continue;
-                std::memcpy(db, v.seq[s0 + i], len);
-                symbols_add(present, db, len);
-                if (v.qual[s0 + i]) std::memcpy(dq, v.qual[s0 + i], len); else std::memset(dq, '!', len);
-                db += len; dq += len;
+        // pack the piece into pinned staging and collect its symbol statistics in the same pass over the bases -- a few MB
+        // at a time, each part's copy queued as soon as it is packed, so that the copy engine works while the host packs
+        // the next part (a piece is up to 60 MB at cfg2: ~2.5 ms of packing and ~1.5 ms of PCIe that used to run one after
+        // the other before the piece's launch could start)
+        constexpr uint64_t kPart = 6ull << 20;
+        for (uint32_t ka = k0; ka < k1;) {
+            uint32_t kb = ka + 1;
+            while (kb < k1 && win_base[kb] - win_base[ka] < kPart) ++kb;
+            host_parallel(kb - ka, threads, [&](size_t kk) {
+                const uint32_t k = ka + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = v.win_seq_off[w], n = v.win_seq_off[w + 1] - s0;
+                uint8_t* db = hs + o_bases + win_base[k]; uint8_t* dq = hs + o_quals + win_base[k];
+                uint64_t present[4] = {0, 0, 0, 0};
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint64_t len = v.seq_off[s0 + i + 1] - v.seq_off[s0 + i];
+                    if (!len) continue;
+                    std::memcpy(db, v.seq[s0 + i], len);
+                    symbols_add(present, db, len);
+                    if (v.qual[s0 + i]) std::memcpy(dq, v.qual[s0 + i], len); else std::memset(dq, '!', len);
+                    db += len; dq += len;
+                }
+                symbols_finish(present, e->shapes[w].nsym, s_flags[k]);
+            });
+            const uint64_t pa = win_base[ka], pz = win_base[kb];
+            if (pz > pa) {
+                HIP_TRY(hipMemcpyAsync(e->d_bases.as<uint8_t>() + pa, hs + o_bases + pa, pz - pa, hipMemcpyHostToDevice, cs));
+                HIP_TRY(hipMemcpyAsync(e->d_quals.as<uint8_t>() + pa, hs + o_quals + pa, pz - pa, hipMemcpyHostToDevice, cs));
             }
-            symbols_finish(present, e->shapes[w].nsym, s_flags[k]);
-        });
+            ka = kb;
+        }
         plan_piece(e, pp, c, sp, fast, slots_left);
         slots_left -= std::min(slots_left, pp.L[c].slots);
         if (pp.L[c].slots == 0 || pp.scratch > scratch_budget(e)) {
@@ -1216,8 +1237,6 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         if ((rc = e->d_scratch.reserve(pp.scratch))) return rc;
         const Launch& L = pp.L[c];
         HIP_TRY(hipMemcpyAsync(e->d_win_flags.as<uint8_t>() + k0, s_flags + k0, k1 - k0, hipMemcpyHostToDevice, cs));
-        HIP_TRY(hipMemcpyAsync(e->d_bases.as<uint8_t>() + b0, hs + o_bases + b0, b1 - b0, hipMemcpyHostToDevice, cs));
-        HIP_TRY(hipMemcpyAsync(e->d_quals.as<uint8_t>() + b0, hs + o_quals + b0, b1 - b0, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipEventRecord(e->sub_ev[c][0], cs));
         HIP_TRY(hipStreamWaitEvent(L.stream, e->sub_ev[c][0], 0));
         if (L.stream != e->stream) HIP_TRY(hipStreamWaitEvent(L.stream, e->ev0, 0));
@@ -1327,7 +1346,6 @@ int rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* h) {
     // results: first_pass_out_cap per window
     const uint64_t L = std::max<uint32_t>(1, h->window_length);
     const uint64_t out_bytes = nw * ((2 * L + 64 + 15) & ~uint64_t(15));
-    if ((rc = e->d_out_cons.reserve(out_bytes + 16)) || (rc = e->d_out_len.reserve(4 * nw)) || (rc = e->d_out_flags.reserve(nw))) return rc;
     if ((rc = e->h_out.reserve(5 * nw + 64 + out_bytes + 16))) return rc;
     // scratch arena: one slot per resident window at the capacities the hinted shape gets
     WinShape sh;
@@ -1355,6 +1373,21 @@ int rcn_engine_result(rcn_engine* e, rcn_result* out) {
 
 int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
     if (!e || !out) return RCN_E_ARG;
+    if (e->stats_pending) {
+        // the work counters live on the device (every work-group adds its share when it retires): read on demand, on the
+        // engine's own non-blocking stream (a plain hipMemcpy runs on the null stream and waits for every blocking stream of
+        // the process -- the CU-masked launch streams of the device's other engine among them)
+        HIP_TRY(hipSetDevice(e->cfg.device));
+        unsigned long long st[24] = {0};
+        HIP_TRY(hipMemcpyAsync(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
+        for (int k = 0; k < 8; ++k) e->stats.phase_clocks[k] = st[3 + k];
+        e->stats.n_sink_ties = st[11];
+        e->stats.dp_cells_full = st[12]; e->stats.dp_bytes_full = st[13]; e->stats.n_banded = st[14]; e->stats.n_band_redone = st[15];
+        for (int k = 0; k < 8; ++k) e->stats.band_redo_why[k] = st[16 + k];
+        e->stats_pending = false;
+    }
     *out = e->stats;
     return RCN_OK;
 }

@@ -502,7 +502,11 @@ RCN_HD uint32_t consensus_coverage(const Win& g, int32_t v) {
 
 // Carve a Win out of one slot's scratch block.  Returns bytes used.
 // `hcell` = bytes per score cell: 4 (int32 H, poa_window_kernel) or 2 (int16 Z, poa_window_kernel2).
-RCN_HD uint64_t win_bind(Win& g, RCN_G uint8_t* base, int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, int32_t hstride, int32_t hcell = 4) {
+// `hrows`: rows of the DP matrix H (the last and by far the largest array of a slot) when that is fewer than ncap + 1 -- the
+// first pass sizes the graph arrays generously and the matrix by what a window of its depth is expected to reach; an
+// alignment with more rows flags the window for the retry pass (poa_window_kernel2).  -1: ncap + 1.
+RCN_HD uint64_t win_bind(Win& g, RCN_G uint8_t* base, int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, int32_t hstride, int32_t hcell = 4,
+                         int32_t hrows = -1) {
     uint64_t off = 0;
     g.ncap = ncap; g.ecap = ecap; g.ring = ring; g.hstride = hstride;
     g.n_nodes = 0; g.n_edges = 0; g.overflow = 0;
@@ -524,7 +528,7 @@ RCN_HD uint64_t win_bind(Win& g, RCN_G uint8_t* base, int32_t ncap, int32_t ecap
     RCN_TAKE(path_node, 4 * (n + lmax + 2)); RCN_TAKE(path_pos, 4 * (n + lmax + 2));
     RCN_TAKE(desc, sizeof(RowDesc) * n);
     RCN_TAKE(stack, 4 * (e + n * (ring + 1) + 64));
-    const uint64_t hints = (n + 1) * static_cast<uint64_t>(hstride);
+    const uint64_t hints = (hrows > 0 ? static_cast<uint64_t>(hrows) : n + 1) * static_cast<uint64_t>(hstride);
     g.hcap = static_cast<int64_t>(hints);
     RCN_TAKE(H, static_cast<uint64_t>(hcell) * hints + 1024);   // last array; +1 KiB: traceback tiles may read past the final row
 #undef RCN_TAKE

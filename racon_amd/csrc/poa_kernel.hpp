@@ -48,6 +48,7 @@ struct KParams {
     int32_t m, x, g, trim;
     // per-slot scratch
     uint8_t* scratch; uint64_t slot_bytes; int32_t ncap, ecap, ring, lmax, hstride;
+    int32_t hrows;                // rows of a slot's DP matrix (win_bind); poa_window_kernel2 flags a window whose alignment needs more
     // outputs
     // outputs, indexed by out_base + work item: consensus bytes at out_cons + out_off[k], capacity out_off[k + 1] - out_off[k]
     // (a consensus that does not fit is flagged kFlagOverflow and redone by the retry pass)
@@ -414,6 +415,7 @@ struct Ctx {
     unsigned long long cells_full, bytes_full;     // the full-matrix figures next to the evaluated ones (cells / bytes)
     unsigned int n_banded, n_band_fail;
     unsigned int band_why, band_whyn[8];            // reasons of the redos (bit k of dp2_rows_band's `why`), counted
+    int32_t hrows;                                  // KParams::hrows
 };
 static_assert(sizeof(Ctx) % 4 == 0 && sizeof(Ctx) <= 512, "Ctx must fit its LDS slot");
 constexpr int kCtxBytes = 512;
@@ -445,7 +447,7 @@ __device__ __forceinline__ Ctx ctx_load() {
 }
 __device__ __forceinline__ Win ctx_win(const Ctx& c) {
     Win g;
-    win_bind(g, gcast(c.scratch), c.ncap, c.ecap, c.ring, c.lmax, c.hstride);
+    win_bind(g, gcast(c.scratch), c.ncap, c.ecap, c.ring, c.lmax, c.hstride, 4, c.hrows);
     g.n_nodes = c.n_nodes; g.n_edges = c.n_edges; g.overflow = c.overflow;
     if (c.swapped) { const Arr<int32_t> t = g.rank_full; g.rank_full = g.rank_tmp; g.rank_tmp = t; }
     return g;
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
     Ctx* ctx = ctx_lds();
     if (lane == 0) {
         ctx->scratch = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
-        ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride;
+        ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride; ctx->hrows = P.hrows;
         ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
         ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0; ctx->cells_full = 0; ctx->bytes_full = 0;
     }
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
         // ---- backbone -> graph (window.cpp:73-77) ----
         {
             Win g;
-            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
+            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride, 4, P.hrows);
             RCN_G const uint8_t* q0 = P.seq_has_qual[s0] ? gcast(P.quals + P.seq_off[s0]) : nullptr;
             for (int i = lane; i < L; i += 64) {
                 g.code[i] = bb[i]; g.al_cnt[i] = 0;

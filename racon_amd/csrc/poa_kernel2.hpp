@@ -2068,7 +2068,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
     Ctx* ctx = ctx_lds2();
     if (t == 0) {
         ctx->scratch = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
-        ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride;
+        ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride; ctx->hrows = P.hrows;
         ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
         ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
         ctx->cells_full = 0; ctx->bytes_full = 0; ctx->n_banded = 0; ctx->n_band_fail = 0; ctx->band = 0; ctx->band_fail = 0;
@@ -2104,7 +2104,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         // ---- backbone -> graph (window.cpp:73-77) ----
         {
             Win g;
-            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
+            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride, 4, P.hrows);
             RCN_G const uint8_t* q0 = P.seq_has_qual[s0] ? gcast(P.quals + P.seq_off[s0]) : nullptr;
             for (int i = t; i < L; i += kThreads2) {
                 g.code[i] = bb[i]; g.al_cnt[i] = 0;
@@ -2147,6 +2147,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             // int16 (Z domain) validity of this alignment; otherwise the window goes to the int32 kernel
             const int V = bcast0(ctx->V);
             const int cfg = dp2_cfg(len, heavy), np_regs = cfg & 255, nwv = cfg >> 8;
+            if (V + 1 > P.hrows) { overflow = 1; break; }          // more rows than this slot's matrix holds: the retry pass takes the window
             {
                 const int ag = P.g < 0 ? -P.g : P.g, smax = max(max(P.m, P.x), 0);
                 if (P.g >= 0 || cfg == 0 || static_cast<long long>(ag) * (V + 2) > kZLimit ||
@@ -2237,7 +2238,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                             phase_desc2();
                         } else {
                             Win g;
-                            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride);
+                            win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride, 4, P.hrows);
                             const int nn_ = bcast0(ctx->n_nodes);
                             for (int v = t; v < nn_; v += kThreads2) g.mark[v] = 0;
                             Block4::sync();

@@ -86,6 +86,15 @@ int rcnh_polisher_alignments(rcnh_polisher* p, rcn_cigar_set* a) {
     return 0;
 }
 
+int rcnh_polisher_pairs(rcnh_polisher* p, rcn_pair_set* a) {
+    if (!p || !a) { g_error = "invalid argument"; return -1; }
+    const racon::Polisher::Layout& l = p->polisher->layout();
+    if (l.seq_off.size() < 2) { g_error = "no layout recorded (rcnh_polisher_keep_layout before initialize)"; return -1; }
+    a->n_pairs = l.q_id.size(); a->q_id = l.q_id.data(); a->t_id = l.t_id.data(); a->strand = l.strand.data();
+    a->q_begin = l.q_begin.data(); a->q_end = l.q_end.data(); a->t_begin = l.t_begin.data(); a->t_end = l.t_end.data();
+    return 0;
+}
+
 int rcnh_polisher_assemble(rcnh_polisher* p, const rcn_result* r, int drop, const char** fasta, uint64_t* len) {
     if (!p || !r || !fasta || !len) { g_error = "invalid argument"; return -1; }
     return guarded([&] {

@@ -114,6 +114,7 @@ Polisher::Polisher(const std::string& sequences_path, const std::string& overlap
 
 Polisher::~Polisher() {
     if (device_warmup_.joinable()) device_warmup_.join();
+    if (cleanup_.joinable()) cleanup_.join();
     logger_->total("[racon::Polisher::] total =");
 }
 
@@ -470,10 +471,16 @@ void Polisher::assemble(const std::function<const std::string&(uint64_t)>& conse
             num_polished_windows = 0;
             polished_data.clear();
         }
-        windows_[i].reset();
     }
-    std::vector<std::shared_ptr<Window>>().swap(windows_);
-    std::vector<std::unique_ptr<Sequence>>().swap(sequences_);
+    // The reference frees every window and every sequence here, inside the interval its Logger brackets
+    // (src/polisher.cpp:532,545-546).  For one GPU's share of cfg3 that is ~400 MB in ~40 000 heap blocks -- 30 ms of
+    // free() in a 110 ms polish() -- and nobody waits for it: a helper thread does it while the caller goes on with the
+    // polished sequences (joined by the destructor / the next call).
+    if (cleanup_.joinable()) cleanup_.join();
+    auto* old_windows = new std::vector<std::shared_ptr<Window>>(std::move(windows_));
+    auto* old_sequences = new std::vector<std::unique_ptr<Sequence>>(std::move(sequences_));
+    windows_.clear(); sequences_.clear();
+    cleanup_ = std::thread([old_windows, old_sequences] { delete old_windows; delete old_sequences; });
 }
 
 void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {

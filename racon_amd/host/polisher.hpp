@@ -135,6 +135,7 @@ protected:
     // Started by initialize(): loads libracon_hip.so and brings up the HIP runtime and the devices' contexts while the input
     // files are parsed (0.2 s that polish() would otherwise spend before its first launch); joined by polish() / the destructor.
     std::thread device_warmup_;
+    std::thread cleanup_;           // frees the windows and sequences polish() is done with (see assemble())
     // The engines polish() drives: `2 * hip_batches_` per device, created ONCE by the warm-up thread together with their
     // arenas, pinned staging and the first use of the code object (HipEngine::reserve; the reference creates its
     // alignment engines in the constructor and Preallocs them, src/polisher.cpp:176-183), so that the interval the

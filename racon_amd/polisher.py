@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 from .batch import ConsensusResult, RcnBatch, RcnResult, WindowBatch
-from .layout import CigarSet, OverlapSet, RcnCigarSet, RcnOverlapSet, RcnReadSet, ReadSet
+from .layout import CigarSet, OverlapSet, PairSet, RcnCigarSet, RcnOverlapSet, RcnPairSet, RcnReadSet, ReadSet
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_DIR = os.path.join(_HERE, "host")
@@ -29,7 +29,7 @@ class RcnhParams(C.Structure):
 
 EXPORTS = ["rcnh_polisher_create", "rcnh_polisher_initialize", "rcnh_polisher_windows", "rcnh_polisher_assemble",
            "rcnh_polisher_polish", "rcnh_polisher_destroy", "rcnh_align_cigar", "rcnh_edit_distance", "rcnh_free",
-           "rcnh_last_error", "rcnh_polisher_polish_seconds", "rcnh_polisher_num_windows"]
+           "rcnh_last_error", "rcnh_polisher_polish_seconds", "rcnh_polisher_num_windows", "rcnh_polisher_pairs"]
 
 _lib = None
 
@@ -52,6 +52,7 @@ def load_library():
     lib.rcnh_polisher_keep_layout.argtypes = [C.c_void_p, C.c_int]
     lib.rcnh_polisher_layout.argtypes = [C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnOverlapSet), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     lib.rcnh_polisher_alignments.argtypes = [C.c_void_p, C.POINTER(RcnCigarSet)]
+    lib.rcnh_polisher_pairs.argtypes = [C.c_void_p, C.POINTER(RcnPairSet)]
     lib.rcnh_polisher_assemble.argtypes = [C.c_void_p, C.POINTER(RcnResult), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_polish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_polish_seconds.argtypes = [C.c_void_p]
@@ -155,6 +156,17 @@ class Polisher:
         a = RcnCigarSet()
         _check(self.lib.rcnh_polisher_alignments(self.h, C.byref(a)))
         return CigarSet.from_c(a)
+
+    def pairs(self) -> PairSet:
+        """The segment pairs of the overlaps (what the pre-alignment of reference src/overlap.cpp:205-224 works on)."""
+        a = RcnPairSet()
+        _check(self.lib.rcnh_polisher_pairs(self.h, C.byref(a)))
+        n = int(a.n_pairs)
+
+        def arr(ptr, dt):
+            return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True)
+        return PairSet(arr(a.q_id, np.uint32), arr(a.t_id, np.uint32), arr(a.strand, np.uint8), arr(a.q_begin, np.uint32),
+                       arr(a.q_end, np.uint32), arr(a.t_begin, np.uint32), arr(a.t_end, np.uint32))
 
     def windows(self) -> WindowBatch:
         cb = RcnBatch()

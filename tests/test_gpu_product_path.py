@@ -160,3 +160,15 @@ def test_polish_interval_chunks_and_warmup(files, oracle, monkeypatch):
     assert p.polish(True) == ref
     assert p.polish_seconds() > 0.0
     p.close()
+
+
+def test_matrix_rows_smaller_than_the_graph(Engine, mid, mid_ref, monkeypatch):
+    """A slot's DP matrix is sized for fewer rows than its graph arrays hold nodes (engine.hip: first_pass_caps); an
+    alignment that needs more flags the window and the retry pass (worst-case capacities) takes it.  RCN_HROWS_DIV=400
+    leaves room for the backbone and ~160 more rows: most ONT-like windows outgrow that after a few layers."""
+    monkeypatch.setenv("RCN_HROWS_DIV", "400")
+    eng = Engine(3, -5, -4, True)
+    sub = mid.select(range(96))
+    got = eng.consensus(sub)
+    assert eng.stats()["n_retried"] > 48
+    assert got.consensus == mid_ref.consensus[:96] and list(got.polished) == list(mid_ref.polished[:96])

@@ -40,7 +40,7 @@ if has probe; then
   timeout 300 python tools/cpu_probe.py > "$OUT/cpu_probe.json" 2>&1; cat "$OUT/cpu_probe.json"
 fi
 if has tests2; then
-  timeout 2400 python -m pytest tests/test_gpu_product_path.py tests/test_gpu_unbounded_shapes.py tests/test_gpu_window_build.py tests/test_gpu_band.py tests/test_cli_e2e.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q --durations=12 > "$OUT/pytest_gpu2.log" 2>&1
+  timeout 2400 python -m pytest tests/test_gpu_product_path.py tests/test_gpu_unbounded_shapes.py tests/test_gpu_band.py tests/test_cli_e2e.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_bench_contract.py -m gpu -q -x --durations=8 > "$OUT/pytest_gpu2.log" 2>&1
   echo "pytest exit $?" >> "$OUT/pytest_gpu2.log"
   tail -40 "$OUT/pytest_gpu2.log"
 fi
@@ -59,6 +59,10 @@ PY
     done
     grep -E "racon::|polish:|piece|collect|reserve" "$OUT/timeline_$(basename $F)_3.err" | head -80
   done
+fi
+if has malloc; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/malloc_time tools/probe/malloc_time.hip && /tmp/malloc_time > "$OUT/malloc_time.txt" 2>&1; cat "$OUT/malloc_time.txt"
+  /tmp/malloc_time > "$OUT/malloc_time_second_process.txt" 2>&1; head -3 "$OUT/malloc_time_second_process.txt"
 fi
 if has debug; then
   # host timeline of one product polish() (RCN_DEBUG prints the engine's own clock)
