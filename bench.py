@@ -97,13 +97,13 @@ def product_files(contig, coverage, seed, workers):
             "contig": contig, "files_s": round(time.perf_counter() - t0, 1)}
 
 
-def product_polish(paths, window, scores, threads, expect=None, reps=2):
+def product_polish(paths, window, scores, threads, expect=None, reps=2, batches=1):
     """files -> racon_amd.host Polisher -> initialize() -> polish(); returns the Logger-bracketed polish() interval."""
     from racon_amd.polisher import Polisher
     m, x, g = scores
     best, runs, nw, same = None, [], 0, None
     for _ in range(reps):
-        p = Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", window, 10.0, 0.3, True, m, x, g, threads, 1)
+        p = Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", window, 10.0, 0.3, True, m, x, g, threads, batches)
         t1 = time.perf_counter()
         p.initialize()
         t_init = time.perf_counter() - t1
@@ -155,6 +155,7 @@ def main():
                                                                  "use it so that every traced launch of the kernel is one of the timed whole-batch launches")
     ap.add_argument("--no-product", action="store_true", help="skip the product leg (files -> Polisher::polish)")
     ap.add_argument("--product-contig", type=int, default=6_250_000, help="second product job: contig bp (one GPU's share of cfg3)")
+    ap.add_argument("--product-batches", type=int, default=1, help="-c of the product legs: batch objects (pairs of engines) per device")
     ap.add_argument("--verify", action="store_true", help="also check every window against the oracle (untimed)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (code-path test with several ranks on ONE GPU)")
     a = ap.parse_args()
@@ -187,9 +188,11 @@ def main():
         what = "%s: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d" % (cfg_name, contig, a.coverage, a.window)
     a.contig = contig
     # the product leg's input files (same seeds -> the same windows as the packed batches; generated in forked workers too)
-    do_product = not a.no_product and world == 1 and not a.config and contig == 1_000_000 and a.window == 500
+    do_product = not a.no_product and world == 1 and a.window == 500 and ((not a.config and contig == 1_000_000) or a.config == "cfg3")
     pfiles = []
-    if do_product:
+    if do_product and a.config == "cfg3":
+        pfiles.append(("cfg3", product_files(50_000_000, a.coverage, 20260922, workers)))       # the whole 100 000-window job as files
+    elif do_product:
         pfiles.append(("cfg2", product_files(1_000_000, a.coverage, 20260921, workers)))
         if a.product_contig > 1_000_000:
             pfiles.append(("cfg3_share", product_files(a.product_contig, a.coverage, 20260922, workers)))
@@ -315,8 +318,10 @@ def main():
                 th = max(1, min(32, len(os.sched_getaffinity(0))))
                 out["product_polish"] = {}
                 for name, paths in pfiles:
-                    out["product_polish"][name] = product_polish(paths, a.window, (m, x, g), th, expect=b"".join(res.consensus) if name == "cfg2" else None)
-                out["value_product_polish"] = out["product_polish"]["cfg2"]["windows_per_s"]
+                    same_windows = name in ("cfg2", "cfg3")             # (the packed batch of this run holds the same windows)
+                    out["product_polish"][name] = product_polish(paths, a.window, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
+                                                                 reps=1 if name == "cfg3" else 2, batches=a.product_batches)
+                out["value_product_polish"] = out["product_polish"][pfiles[0][0]]["windows_per_s"]
                 if "cfg3_share" in out["product_polish"]:
                     out["value_product_polish_12k"] = out["product_polish"]["cfg3_share"]["windows_per_s"]
             except Exception as e:                       # the headline line must not die with the product leg

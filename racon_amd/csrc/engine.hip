@@ -1040,6 +1040,8 @@ int rcn_engine_run(rcn_engine* e) {
 
 namespace {
 
+__global__ void k_warm_out(uint32_t* p) { p[threadIdx.x] = 0u; }
+
 inline void symbols_add(uint64_t present[4], const uint8_t* p, uint64_t n) {
     for (uint64_t k = 0; k < n; ++k) present[p[k] >> 6] |= 1ull << (p[k] & 63);
 }
@@ -1123,6 +1125,24 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         if (est.scratch <= scratch_budget(e) && (rc = e->d_scratch.reserve(est.scratch))) return rc;
         if (dbg) fprintf(stderr, "[racon_hip] reserve: scratch arena (%.2f GB, %u + %u slots) at %.2f ms\n", est.scratch / 1e9, est.L[0].slots, est.L[1].slots, since());
         if ((rc = e->h_out.reserve(result_layout(nw).off_cons + e->out_off[nw] + 16))) return rc;
+        {
+            // The first copies out of a new pinned block into new device buffers cost 8-30 ms on their stream (measured:
+            // profiles/r03/c_timeline_*, the same copies take 0.05 ms on the second batch): make them here, with whatever
+            // the staging block holds -- the real call overwrites every byte.
+            uint8_t* hs = e->h_stage.as<uint8_t>();
+            hipStream_t cs = e->copy_stream;
+            const uint64_t part = std::min<uint64_t>(nb, 4ull << 20);
+            for (DevBuf* d : {&e->d_win_seq_off, &e->d_win_type, &e->d_seq_off, &e->d_has_qual, &e->d_begin, &e->d_end, &e->d_order, &e->d_full,
+                              &e->d_out_off, &e->d_win_flags})
+                HIP_TRY(hipMemcpyAsync(d->p, hs, std::min<uint64_t>(d->cap, 4096), hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync(e->d_bases.p, hs + o_bases, part, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync(e->d_quals.p, hs + o_quals, part, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipStreamSynchronize(cs));
+            // ... and the kernel's first stores into the pinned result block
+            hipLaunchKernelGGL(k_warm_out, dim3(1), dim3(64), 0, e->stream, e->h_out.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(e->stream));
+        }
         if (dbg) fprintf(stderr, "[racon_hip] reserve: done at %.2f ms\n", since());
         return RCN_OK;
     }

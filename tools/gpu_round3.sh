@@ -77,8 +77,13 @@ fi
 if has big; then
   # cfg3 at full size on one GPU (100 000 windows through the engine's queue) with every window checked against the oracle,
   # and one GPU's share of cfg5 (scale 0.125 = 250 k windows)
-  timeout 2400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu --no-product --verify > "$OUT/bench_cfg3_1gpu.json" 2> "$OUT/bench_cfg3_1gpu.err"
-  echo "cfg3 exit $?"; cut -c1-1500 "$OUT/bench_cfg3_1gpu.json"; tail -3 "$OUT/bench_cfg3_1gpu.err"
+  cat /sys/fs/cgroup/memory.max /proc/meminfo 2>/dev/null | head -4; df -h /tmp | tail -1
+  timeout 2400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu --verify > "$OUT/bench_cfg3_1gpu.json" 2> "$OUT/bench_cfg3_1gpu.err"
+  echo "cfg3 exit $?"; cut -c1-3000 "$OUT/bench_cfg3_1gpu.json"; tail -3 "$OUT/bench_cfg3_1gpu.err"
+fi
+if has cfg5; then
+  timeout 2400 python tools/cfg5_at_size.py --scale ${CFG5_SCALE:-0.125} > "$OUT/cfg5_at_size.json" 2> "$OUT/cfg5_at_size.err"
+  echo "cfg5 exit $?"; cat "$OUT/cfg5_at_size.json"; tail -5 "$OUT/cfg5_at_size.err"
 fi
 BENCH_PROF="python bench.py --steps 3 --warmup 1 --no-cpu --no-upload-leg --no-product"
 if has prof; then
