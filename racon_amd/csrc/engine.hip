@@ -63,6 +63,21 @@ struct HostBuf {                       // pinned host staging (D2H of the consen
 
 struct WinShape { int32_t L, sum_l, lmax, nsym; };
 
+// The metadata of a streamed batch (polish_view) as ONE block, laid out alike in pinned staging and in HBM: byte offsets of
+// win_seq_off, win_type, the per-window flags, seq_off, has_qual, begin, end, layer order, full-span flags, output offsets.
+// One block because of how the runtime copies: a copy below its blit threshold (tens of KB) is a shader kernel, and a
+// shader kernel waits for a compute unit -- behind the persistent consensus launch of the device's OTHER engine that was
+// 15-36 ms (profiles/r03/c_timeline_cfg3_share.txt, d_...), for 3 KB of flags.  Large copies go to the DMA engines.
+struct MetaLayout { uint64_t wso, type, flags, so, hq, bg, en, ord, full, ooff, end; };
+inline MetaLayout meta_layout(uint64_t nw, uint64_t ns) {
+    MetaLayout m;
+    m.wso = 0; m.type = m.wso + 4 * (nw + 1); m.flags = m.type + nw; m.so = (m.flags + nw + 15) & ~uint64_t(15);
+    m.hq = m.so + 8 * (ns + 1); m.bg = (m.hq + ns + 15) & ~uint64_t(15); m.en = m.bg + 4 * ns; m.ord = m.en + 4 * ns;
+    m.full = m.ord + 4 * ns; m.ooff = (m.full + ns + 15) & ~uint64_t(15); m.end = (m.ooff + 8 * (nw + 1) + 255) & ~uint64_t(255);
+    return m;
+}
+constexpr uint64_t kDmaCopyBytes = 64 << 10;    // copies are padded up to this (with bytes the destination already holds)
+
 // two HIP events for a timed interval, destroyed on every exit path
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
@@ -164,6 +179,8 @@ struct rcn_engine {
     bool lpt_layout = false;
     DevBuf d_win_seq_off, d_win_type, d_seq_off, d_has_qual, d_begin, d_end, d_bases, d_quals, d_order, d_full;
     DevBuf d_lpt_ids, d_win_ids, d_win_flags, d_scratch, d_out_cons, d_out_len, d_out_flags, d_out_off, d_ctr;
+    DevBuf d_meta, d_retry_off;         // streamed batches (lpt_layout): the metadata block (MetaLayout ml); output offsets of a retry pass
+    MetaLayout ml{};
     HostBuf h_out, h_stage;                         // pinned: outputs of a pass; inputs of a streamed batch
     std::vector<WinShape> shapes;                   // by window (caller order)
     int32_t heavy_ns = 0;
@@ -327,13 +344,28 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     if (L.n_work == 0) return RCN_OK;
     HIP_TRY(hipMemsetAsync(e->d_ctr.as<uint8_t>() + 4 * L.ctr, 0, 4, L.stream));
     rcn::KParams P{};
-    P.win_seq_off = e->d_win_seq_off.as<uint32_t>(); P.win_type = e->d_win_type.as<uint8_t>();
-    P.seq_off = e->d_seq_off.as<uint64_t>(); P.seq_has_qual = e->d_has_qual.as<uint8_t>();
-    P.seq_begin = e->d_begin.as<uint32_t>(); P.seq_end = e->d_end.as<uint32_t>();
+    const uint8_t* win_flags;
+    if (e->lpt_layout) {                // a streamed batch: everything but the bases sits in the metadata block
+        const uint8_t* mb = e->d_meta.as<uint8_t>();
+        const MetaLayout& m = e->ml;
+        P.win_seq_off = reinterpret_cast<const uint32_t*>(mb + m.wso); P.win_type = mb + m.type;
+        P.seq_off = reinterpret_cast<const uint64_t*>(mb + m.so); P.seq_has_qual = mb + m.hq;
+        P.seq_begin = reinterpret_cast<const uint32_t*>(mb + m.bg); P.seq_end = reinterpret_cast<const uint32_t*>(mb + m.en);
+        P.order = reinterpret_cast<const uint32_t*>(mb + m.ord); P.seq_full = mb + m.full;
+        P.out_off = reinterpret_cast<const uint64_t*>(mb + m.ooff);
+        win_flags = mb + m.flags;
+    } else {
+        P.win_seq_off = e->d_win_seq_off.as<uint32_t>(); P.win_type = e->d_win_type.as<uint8_t>();
+        P.seq_off = e->d_seq_off.as<uint64_t>(); P.seq_has_qual = e->d_has_qual.as<uint8_t>();
+        P.seq_begin = e->d_begin.as<uint32_t>(); P.seq_end = e->d_end.as<uint32_t>();
+        P.order = e->d_order.as<uint32_t>(); P.seq_full = e->d_full.as<uint8_t>();
+        P.out_off = e->d_out_off.as<uint64_t>();
+        win_flags = e->d_win_flags.as<uint8_t>();
+    }
+    if (!L.host_out) P.out_off = e->d_retry_off.as<uint64_t>();         // a retry pass numbers its outputs by its own work items
     P.bases = e->d_bases.as<uint8_t>(); P.quals = e->d_quals.as<uint8_t>();
-    P.order = e->d_order.as<uint32_t>(); P.seq_full = e->d_full.as<uint8_t>();
     P.win_ids = L.d_ids; P.n_work = L.n_work; P.work_base = L.work_base;
-    P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : e->d_win_flags.as<uint8_t>();
+    P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : win_flags;
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
     P.heavy_ns = e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.force_tie = getenv("RCN_FORCE_TIE") ? atoi(getenv("RCN_FORCE_TIE")) : 0;
@@ -345,7 +377,7 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.band = (!band_sound || getenv("RCN_NO_BAND")) ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : (getenv("RCN_BAND_SCORES") ? 3 : 1));
     P.scratch = e->d_scratch.as<uint8_t>() + L.scratch_off; P.slot_bytes = L.c.slot_bytes;
     P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride; P.hrows = L.c.hrows;
-    P.out_off = e->d_out_off.as<uint64_t>(); P.out_base = L.out_base;
+    P.out_base = L.out_base;
     if (L.host_out) {
         // The first pass writes lengths, flags and consensus bytes straight into pinned host memory (hipHostMalloc memory is
         // device-visible): ~1 KB per window over PCIe from the kernel's own stores, and no device-to-host copy afterwards -- a
@@ -571,7 +603,7 @@ void rcn_engine_destroy(rcn_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     for (DevBuf* d : {&e->d_win_seq_off, &e->d_win_type, &e->d_seq_off, &e->d_has_qual, &e->d_begin, &e->d_end,
                       &e->d_bases, &e->d_quals, &e->d_order, &e->d_full, &e->d_lpt_ids, &e->d_win_ids, &e->d_win_flags, &e->d_scratch,
-                      &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_out_off, &e->d_ctr})
+                      &e->d_out_cons, &e->d_out_len, &e->d_out_flags, &e->d_out_off, &e->d_ctr, &e->d_meta, &e->d_retry_off})
         d->release();
     for (DevBuf& d : e->d_build) d.release();
     for (DevBuf& d : e->d_align) d.release();
@@ -731,11 +763,14 @@ int rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_t
     std::vector<uint32_t> d_wso(nw + 1), d_bg(ns), d_en(ns);
     std::vector<uint64_t> d_so(ns + 1);
     std::vector<uint8_t> d_type(nw), d_hq(ns), d_b(bases ? e->n_bases : 0), d_q(quals ? e->n_bases : 0);
-    if ((rc = get(d_wso.data(), e->d_win_seq_off, 4 * (nw + 1))) || (rc = get(d_type.data(), e->d_win_type, nw)) ||
-        (rc = get(d_so.data(), e->d_seq_off, 8 * (ns + 1))) || (rc = get(d_hq.data(), e->d_has_qual, ns)) ||
-        (rc = get(d_bg.data(), e->d_begin, 4 * ns)) || (rc = get(d_en.data(), e->d_end, 4 * ns)) ||
-        (rc = get(d_b.data(), e->d_bases, d_b.size())) || (rc = get(d_q.data(), e->d_quals, d_q.size())))
-        return rc;
+    {
+        std::vector<uint8_t> meta(e->ml.end);
+        if ((rc = get(meta.data(), e->d_meta, e->ml.end))) return rc;
+        std::memcpy(d_wso.data(), meta.data() + e->ml.wso, 4 * (nw + 1)); std::memcpy(d_type.data(), meta.data() + e->ml.type, nw);
+        std::memcpy(d_so.data(), meta.data() + e->ml.so, 8 * (ns + 1)); std::memcpy(d_hq.data(), meta.data() + e->ml.hq, ns);
+        std::memcpy(d_bg.data(), meta.data() + e->ml.bg, 4 * ns); std::memcpy(d_en.data(), meta.data() + e->ml.en, 4 * ns);
+    }
+    if ((rc = get(d_b.data(), e->d_bases, d_b.size())) || (rc = get(d_q.data(), e->d_quals, d_q.size()))) return rc;
     std::vector<uint32_t> item_of(nw);
     for (uint32_t k = 0; k < nw; ++k) item_of[e->lpt[k]] = k;
     uint32_t so = 0; uint64_t bo = 0;
@@ -806,13 +841,9 @@ static int collect(rcn_engine* e) {
         const uint32_t nr = static_cast<uint32_t>(retry.size());
         // first-pass bytes are already on the host; the retry pass indexes its outputs by its own work items
         if ((rc = e->d_out_cons.reserve(off2[nr] + 16)) || (rc = e->d_out_len.reserve(4ull * nr)) || (rc = e->d_out_flags.reserve(nr))) return rc;
-        if ((rc = upload_vec(e->d_out_off, off2.data(), 8ull * (nr + 1), e->stream))) return rc;
+        if ((rc = upload_vec(e->d_retry_off, off2.data(), 8ull * (nr + 1), e->stream))) return rc;
         if ((rc = upload_vec(e->d_win_ids, ids.data(), 4ull * nr, e->stream))) return rc;
-        rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr, /*host_out=*/false);
-        // the resident batch keeps its first-pass offsets for the next rcn_engine_run
-        int rc2 = upload_vec(e->d_out_off, e->out_off.data(), 8ull * (nw + 1), e->stream);
-        if (rc) return rc;
-        if (rc2) return rc2;
+        if ((rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr, /*host_out=*/false))) return rc;
         std::vector<uint32_t> len2(nr);
         std::vector<uint8_t> fl2(nr);
         HIP_TRY(hipMemcpyAsync(len2.data(), e->d_out_len.p, 4ull * nr, hipMemcpyDeviceToHost, e->stream));
@@ -1093,17 +1124,13 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     // ---- device layout: window k of the device arrays = work item k = caller window lpt[k] ----
     const uint64_t nb = e->n_bases;
     // staging: metadata block first, then bases, then qualities (each in deepest-first order)
-    const uint64_t o_wso = 0, o_type = o_wso + 4ull * (nw + 1), o_flags = o_type + nw, o_so = (o_flags + nw + 15) & ~uint64_t(15),
-                   o_hq = o_so + 8ull * (ns + 1), o_bg = (o_hq + ns + 15) & ~uint64_t(15), o_en = o_bg + 4ull * ns, o_ord = o_en + 4ull * ns,
-                   o_full = o_ord + 4ull * ns, o_ooff = (o_full + ns + 15) & ~uint64_t(15), o_bases = (o_ooff + 8ull * (nw + 1) + 255) & ~uint64_t(255),
-                   o_quals = (o_bases + nb + 255) & ~uint64_t(255), total = o_quals + nb + 256;
+    const MetaLayout ml = meta_layout(nw, ns);
+    const uint64_t o_wso = ml.wso, o_type = ml.type, o_flags = ml.flags, o_so = ml.so, o_hq = ml.hq, o_bg = ml.bg, o_en = ml.en, o_ord = ml.ord,
+                   o_full = ml.full, o_ooff = ml.ooff, o_bases = ml.end, o_quals = (o_bases + nb + 255) & ~uint64_t(255), total = o_quals + nb + 256;
+    e->ml = ml;
     if ((rc = e->h_stage.reserve(total))) return rc;
     if (dbg) fprintf(stderr, "[racon_hip] polish: pinned staging (%.1f MB) at %.2f ms\n", total / 1e6, since());
-    if ((rc = e->d_win_seq_off.reserve(4ull * (nw + 1))) || (rc = e->d_win_type.reserve(nw)) || (rc = e->d_win_flags.reserve(nw)) ||
-        (rc = e->d_seq_off.reserve(8ull * (ns + 1))) || (rc = e->d_has_qual.reserve(ns)) || (rc = e->d_begin.reserve(4ull * ns)) ||
-        (rc = e->d_end.reserve(4ull * ns)) || (rc = e->d_order.reserve(4ull * ns)) || (rc = e->d_full.reserve(ns)) ||
-        (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16)) || (rc = e->d_out_off.reserve(8ull * (nw + 1))))
-        return rc;
+    if ((rc = e->d_meta.reserve(ml.end + kDmaCopyBytes)) || (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16))) return rc;
     if (dbg) fprintf(stderr, "[racon_hip] polish: device inputs reserved at %.2f ms\n", since());
     const SplitPlan sp = split_plan(e, nw, fast);
     const uint32_t slots_total = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e);
@@ -1132,9 +1159,7 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
             uint8_t* hs = e->h_stage.as<uint8_t>();
             hipStream_t cs = e->copy_stream;
             const uint64_t part = std::min<uint64_t>(nb, 4ull << 20);
-            for (DevBuf* d : {&e->d_win_seq_off, &e->d_win_type, &e->d_seq_off, &e->d_has_qual, &e->d_begin, &e->d_end, &e->d_order, &e->d_full,
-                              &e->d_out_off, &e->d_win_flags})
-                HIP_TRY(hipMemcpyAsync(d->p, hs, std::min<uint64_t>(d->cap, 4096), hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync(e->d_meta.p, hs, ml.end, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipMemcpyAsync(e->d_bases.p, hs + o_bases, part, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipMemcpyAsync(e->d_quals.p, hs + o_quals, part, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipStreamSynchronize(cs));
@@ -1171,18 +1196,10 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     });
     if (dbg) fprintf(stderr, "[racon_hip] polish: metadata staged at %.2f ms\n", since());
     hipStream_t cs = e->copy_stream;
-    HIP_TRY(hipMemcpyAsync(e->d_win_seq_off.p, s_wso, 4ull * (nw + 1), hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_win_type.p, s_type, nw, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_seq_off.p, s_so, 8ull * (ns + 1), hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_has_qual.p, s_hq, ns, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_begin.p, s_bg, 4ull * ns, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_end.p, s_en, 4ull * ns, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_order.p, s_ord, 4ull * ns, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(e->d_full.p, s_full, ns, hipMemcpyHostToDevice, cs));
-    // (from the pinned block like everything else: the first asynchronous copy out of PAGEABLE memory makes the runtime set
-    //  up its own staging -- 9 ms on the first batch of an engine, profiles/r03/b_timeline_*)
+    // (the output offsets travel in the block like everything else: the first asynchronous copy out of PAGEABLE memory makes
+    //  the runtime set up its own staging)
     std::memcpy(hs + o_ooff, e->out_off.data(), 8ull * (nw + 1));
-    HIP_TRY(hipMemcpyAsync(e->d_out_off.p, hs + o_ooff, 8ull * (nw + 1), hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(e->d_meta.p, hs, ml.end, hipMemcpyHostToDevice, cs));        // (the flags follow piece by piece)
 
     // ---- pieces ----
     // split plan: the deep launch's windows, then the rest.  Otherwise: the deepest windows that hold 1/24 of the bases
@@ -1256,7 +1273,12 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         if (pp.scratch > e->d_scratch.cap && c > 0) HIP_TRY(hipDeviceSynchronize());
         if ((rc = e->d_scratch.reserve(pp.scratch))) return rc;
         const Launch& L = pp.L[c];
-        HIP_TRY(hipMemcpyAsync(e->d_win_flags.as<uint8_t>() + k0, s_flags + k0, k1 - k0, hipMemcpyHostToDevice, cs));
+        {   // the piece's window flags, padded up to a DMA-sized copy with the bytes behind them (metadata the device block
+            // already holds: the same bytes again)
+            const uint64_t a = (o_flags + k0) & ~uint64_t(15);
+            const uint64_t z = std::min<uint64_t>(ml.end, std::max<uint64_t>(o_flags + k1, a + kDmaCopyBytes));
+            HIP_TRY(hipMemcpyAsync(e->d_meta.as<uint8_t>() + a, hs + a, z - a, hipMemcpyHostToDevice, cs));
+        }
         HIP_TRY(hipEventRecord(e->sub_ev[c][0], cs));
         HIP_TRY(hipStreamWaitEvent(L.stream, e->sub_ev[c][0], 0));
         if (L.stream != e->stream) HIP_TRY(hipStreamWaitEvent(L.stream, e->ev0, 0));
@@ -1268,6 +1290,7 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     HIP_TRY(hipEventRecord(t.b, cs));
     if ((rc = finish_pieces(e, pp, t.a))) return rc;
     if (dbg) fprintf(stderr, "[racon_hip] polish: launches done at %.2f ms (host clock)\n", since());
+    HIP_TRY(hipEventSynchronize(t.b));          // (the last command of the copy stream: not necessarily flushed yet)
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
     e->stats.h2d_ms = ms;
     e->stats.bytes_in = 2 * nb + 17ull * ns + 5ull * nw;
@@ -1356,13 +1379,9 @@ int rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* h) {
         e->warmed = true;
     }
     if (nw == 0) return RCN_OK;
-    // inputs of a batch (polish_view's staging layout, rounded up)
-    if ((rc = e->d_win_seq_off.reserve(4 * (nw + 1))) || (rc = e->d_win_type.reserve(nw)) || (rc = e->d_win_flags.reserve(nw)) ||
-        (rc = e->d_seq_off.reserve(8 * (ns + 1))) || (rc = e->d_has_qual.reserve(ns)) || (rc = e->d_begin.reserve(4 * ns)) ||
-        (rc = e->d_end.reserve(4 * ns)) || (rc = e->d_order.reserve(4 * ns)) || (rc = e->d_full.reserve(ns)) ||
-        (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16)) || (rc = e->d_out_off.reserve(8 * (nw + 1))))
-        return rc;
-    if ((rc = e->h_stage.reserve(2 * nb + 29 * ns + 16 * nw + 4096))) return rc;
+    // inputs of a batch (polish_view's layout)
+    if ((rc = e->d_meta.reserve(meta_layout(nw, ns).end + kDmaCopyBytes)) || (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16))) return rc;
+    if ((rc = e->h_stage.reserve(meta_layout(nw, ns).end + 2 * nb + 1024))) return rc;
     // results: first_pass_out_cap per window
     const uint64_t L = std::max<uint32_t>(1, h->window_length);
     const uint64_t out_bytes = nw * ((2 * L + 64 + 15) & ~uint64_t(15));

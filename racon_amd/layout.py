@@ -113,8 +113,9 @@ class OverlapSet:
         n = int(o.n_overlaps)
         off = np.ctypeslib.as_array(o.bp_off, shape=(n + 1,)).copy()
         npt = int(off[-1])
-        g = lambda p, k: np.ctypeslib.as_array(p, shape=(max(k, 1),))[:k].copy()
-        return OverlapSet(g(o.q_id, n), g(o.t_id, n), g(o.strand, n), off, g(o.bp_t, npt), g(o.bp_q, npt))
+        # (an empty std::vector hands over a null pointer: no breaking points when they are left to the device)
+        g = lambda p, k: np.ctypeslib.as_array(p, shape=(k,)).copy() if k and p else np.zeros(0, np.uint32)
+        return OverlapSet(g(o.q_id, n), g(o.t_id, n), g(o.strand, n).astype(np.uint8), off, g(o.bp_t, npt), g(o.bp_q, npt))
 
     @staticmethod
     def from_lists(overlaps) -> "OverlapSet":

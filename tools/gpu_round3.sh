@@ -60,6 +60,15 @@ PY
     grep -E "racon::|polish:|piece|collect|reserve" "$OUT/timeline_$(basename $F)_3.err" | head -80
   done
 fi
+if has batches; then
+  # the product legs with one and with two batch objects per device (-c 1 / -c 2: two / four engines)
+  for c in 1 2; do
+    timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu --no-upload-leg --product-batches $c 2> "$OUT/bench_c$c.err" | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=j.get('product_polish',{})
+print('-c $c:', {k:(round(v['polish_s']*1e3,1), round(v['windows_per_s'])) if isinstance(v,dict) and 'polish_s' in v else v for k,v in p.items()}, 'value', round(j['value']))"
+  done 2>&1 | tee "$OUT/product_batches.txt"
+fi
 if has malloc; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/malloc_time tools/probe/malloc_time.hip && /tmp/malloc_time > "$OUT/malloc_time.txt" 2>&1; cat "$OUT/malloc_time.txt"
   /tmp/malloc_time > "$OUT/malloc_time_second_process.txt" 2>&1; head -3 "$OUT/malloc_time_second_process.txt"
