@@ -33,21 +33,6 @@
 namespace rcn {
 
 constexpr int kBandG = 32;            // window offsets are multiples of this many columns
-// How the rows of the matrix go to HBM (-DRCN_STORE_MODE, experiments): 0 one store per row as it is finished, 1 the same
-// non-temporal, 2 the eight rows of the register window at once every eighth row (a 4-8 KB burst per wave), 3 = 2 non-temporal
-#ifndef RCN_STORE_MODE
-#define RCN_STORE_MODE 0
-#endif
-#ifndef RCN_CODE_STORE
-#define RCN_CODE_STORE 0          // how the move codes of a row go to HBM (experiments, see dp2_rows_band)
-#endif
-template <bool NT>
-__device__ __forceinline__ void row_store2(RCN_G uint32_t* dst, uint32_t a, uint32_t b) {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 v = {a, b};
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<RCN_G u32x2*>(dst));
-    else *reinterpret_cast<RCN_G u32x2*>(dst) = v;
-}
 constexpr int kBandSeq = 1536;        // LDS copy of the layer's bases (window shifts re-read their columns from it)
 
 // NP of the banded DP for a layer of `len` bases (0 = not banded).  The alive zone is about len / 3 wide
@@ -118,20 +103,15 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 __device__ unsigned long long g_rowprof[256][16];
 #endif
 // ---- the banded one-wave DP (wave 0 of the work-group) ----
-// ABL (profiling builds only, -DRCN_ABLATE=k): the pass is run an extra time before the real one with one piece compiled
-// out; the difference of the DP phase clocks against ABL = 0 (a plain second pass) is what that piece costs in situ.
-//   1 the six DPP steps of the prefix max, 2 the row store to HBM, 3 the LDS ring write, 4 the register-window update,
-//   5 the profile (LDS read / computation), 6 the row-class dispatch (every row treated as a chain row), 7 the sink branch,
-//   8 the row store goes to 16 L2-resident rows instead of the matrix, 9 only every other row is stored
 // CODE: instead of the row of scores the wave stores, per cell, what the traceback would find out from the scores (one
 // byte: bit 0 clear = a diagonal move reproduces the cell, bit 1 clear = a vertical one does, bits 2-4 / 5-7 = the first
 // predecessor in in-edge order that attains the predecessor maximum at the previous / at this column) -- see
 // phase_traceback_code.  A quarter of the bytes of the full int16 row, and the traceback neither re-reads scores nor
 // compares them.  Rows with more than EIGHT in-edges (three bits name a predecessor) are left to the score-matrix path
 // (band_fail); the seventh and eighth are not in the row descriptor, the traceback finds them on the in-edge list.
-template <int NP, bool TAB, int ABL = 0, bool CODE = false>
+template <int NP, bool TAB, bool CODE = false>
 __device__ __noinline__ void dp2_rows_band() {
-    static_assert(!CODE || (NP == 2 && ABL == 0), "move codes: four cells per lane -> one dword per lane and row");
+    static_assert(!CODE || NP == 2, "move codes: four cells per lane -> one dword per lane and row");
     constexpr int NTH = 64, WB = 128 * NP, LPC = 2 * NP;       // window columns, columns per lane
     const int t = threadIdx.x & 63, lane = t;
     const Ctx c = ctx_load<Block4>();
@@ -250,23 +230,9 @@ __device__ __noinline__ void dp2_rows_band() {
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
 
     // the window moves to new_off before row i is computed
-    constexpr bool kBatch = (RCN_STORE_MODE & 2) != 0 && NP == 2 && ABL == 0 && !CODE, kNT = (RCN_STORE_MODE & 1) != 0;
-    // batched row stores: rows [first, last] (all still in the register window, all written under the current window
-    // offset) go out back to back
-    auto flush_rows = [&](int first, int last) {
-        const int woff = cold_get(&cold->woff);
-#pragma unroll
-        for (int w = 0; w < R; ++w) {
-            const int r = (last & ~(R - 1)) + w - ((w > (last & (R - 1))) ? R : 0);     // the row held in slot w
-            if (r >= first && r <= last)
-                row_store2<kNT>(H + static_cast<int64_t>(r) * hs2 + (woff >> 1) + t * NP, win[w * NP], win[w * NP + 1]);
-        }
-    };
-    int flushed = 0;                            // rows <= flushed are in HBM (batched mode)
     auto shift_to = [&](int i_in, int new_off) {
         int i = i_in, Vs = V;
         asm volatile("; window shift (rare): nothing of it is carried in the row loop" : "+s"(i), "+s"(Vs));
-        if (kBatch) { flush_rows(flushed + 1, i - 1); flushed = i - 1; }
         flush_edge();
         const int woff = cold_get(&cold->woff);
         const int delta = new_off - woff, dl = delta / LPC;
@@ -364,7 +330,7 @@ __device__ __noinline__ void dp2_rows_band() {
             // the row just finished enters the register window here, at ONE place: the copies of the row tail below then
             // only hand over `prev` (with the window written in each of them the compiler copies all sixteen registers
             // per row to reconcile the copies)
-            if (!kBatch && ABL != 4) {
+            {
                 __builtin_amdgcn_sched_barrier(0);       // (the two indexed writes back to back: one register-index mode region, not two)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) win[((i - 1) & (R - 1)) * NP + q] = prev[q];
@@ -402,13 +368,13 @@ __device__ __noinline__ void dp2_rows_band() {
                     Aq[q] = pk_mad(gt, pk_sub(Q, Aq[q]), Aq[q]);
                 }
             };
-            if (ABL == 6 || __builtin_expect_with_probability((meta & (1 << 13)) != 0, 1, 0.98)) {
+            if (__builtin_expect_with_probability((meta & (1 << 13)) != 0, 1, 0.98)) {
                 // ---- chain and fast rows (98 % of the rows): every predecessor is in the register window (always in current
                 //      coordinates).  The first predecessor is one indexed register read whatever its distance (a chain row
                 //      has distance 1), a second one follows in line, only a third / fourth loop; rows with one predecessor
                 //      and rows with several each run through their own copy of the row tail ----
-                const unsigned int dd = ABL == 6 ? 1u : static_cast<unsigned int>(meta) >> 16;
-                const int npf = ABL == 6 ? 1 : (meta >> 9) & 7;
+                const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
+                const int npf = (meta >> 9) & 7;
                 {
                     const int wi = ((i - static_cast<int>(dd & 15)) & (R - 1)) * NP;
 #pragma unroll
@@ -577,7 +543,6 @@ __device__ __noinline__ void dp2_rows_band() {
             }
         }
     }
-    if (kBatch && !bfail) flush_rows(flushed + 1, V);
     flush_edge();
     // ---- certificate: no recorded cell may be alive at T = the best end score found ----
     int ev = max(static_cast<int>(emaxV) >> 16, static_cast<int>(emaxV << 16) >> 16);

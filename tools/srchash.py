@@ -3,12 +3,14 @@ import hashlib
 import os
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_FILES = ["poa_core.hpp", "poa_kernel.hpp", "poa_kernel2.hpp", "poa_band.hpp", "poa_band_row_tail.inc", "engine.hip", "Makefile"]
+def _files():
+    d = os.path.join(_ROOT, "racon_amd", "csrc")
+    return sorted(f for f in os.listdir(d) if f.endswith((".hpp", ".inc", ".hip")) or f == "Makefile")
 
 
 def kernel_source_hash() -> str:
     h = hashlib.sha256()
-    for f in _FILES:
+    for f in _files():
         with open(os.path.join(_ROOT, "racon_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
