@@ -122,6 +122,31 @@ def product_polish(paths, window, scores, threads, expect=None, reps=2, batches=
                     % (paths["contig"], threads, reps)}
 
 
+def product_cli(paths, window, scores, threads, expect=None, reps=2, batches=1):
+    """The same through the drop-in BINARY (racon_amd/host/racon_hip, the reference's command line): the interval is the
+    Logger's own line, "[racon::Polisher::polish] generated consensus <s> s" (reference src/polisher.cpp:539-543)."""
+    import re
+    import subprocess
+    m, x, g = scores
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    best, runs, same = None, [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-t", str(threads), "-w", str(window), "-m", str(m), "-x", str(x), "-g", str(g), "-c", str(batches),
+                            paths["reads"], paths["sam"], paths["targets"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        mt = re.search(r"\[racon::Polisher::polish\] generated consensus (\d+\.\d+) s", r.stderr.decode(errors="replace"))
+        if r.returncode != 0 or not mt:
+            return {"error": "racon_hip exit %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-200:])}
+        sec = float(mt.group(1))
+        runs.append({"wall_s": round(wall, 3), "polish_s": sec})
+        best = sec if best is None else min(best, sec)
+        if expect is not None:
+            same = b"".join(r.stdout.split(b"\n")[1::2]) == expect
+    nw = sum((int(l) + window - 1) // window for l in [len(x) for x in open(paths["targets"], "rb").read().split(b"\n")[1::2]])
+    return {"windows": nw, "polish_s": best, "windows_per_s": nw / best, "runs": runs, "fasta_matches_kernel_leg": same}
+
+
 def pick_workload(config: str, contig: int, rank: int, world: int):
     """(contig bp on this rank, seed, scaling, name) of the seeded ONT-like workloads:
     N = 1: cfg2 (1 Mbp, seed 20260921).  N > 1: cfg3, the 50 Mbp / 100 000-window job cut into N equal stretches, rank r
@@ -321,6 +346,8 @@ def main():
                     same_windows = name in ("cfg2", "cfg3")             # (the packed batch of this run holds the same windows)
                     out["product_polish"][name] = product_polish(paths, a.window, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
                                                                  reps=1 if name == "cfg3" else 2, batches=a.product_batches)
+                    out["product_polish"][name]["cli"] = product_cli(paths, a.window, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
+                                                                     reps=1 if name == "cfg3" else 2, batches=a.product_batches)
                 out["value_product_polish"] = out["product_polish"][pfiles[0][0]]["windows_per_s"]
                 if "cfg3_share" in out["product_polish"]:
                     out["value_product_polish_12k"] = out["product_polish"]["cfg3_share"]["windows_per_s"]

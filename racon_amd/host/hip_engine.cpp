@@ -228,6 +228,7 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
     if (rc == RCN_OK && run) rc = a.run(handle_);
     rcn_result r{};
     if (rc == RCN_OK) rc = a.result(handle_, &r);
+    last_rc_ = rc;
     if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::consensus] error: ") + a.strerror_(rc) + "!");
     rcn_run_stats st{};
     if (a.stats(handle_, &st) == RCN_OK) last_kernel_ms_ = st.kernel_ms;

@@ -90,6 +90,7 @@ public:
                    uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                    std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
     double last_kernel_ms() const { return last_kernel_ms_; }
+    int last_rc() const { return last_rc_; }      // return code of the ABI call behind the last consensus() (RCN_OK, RCN_E_*)
     // Only windows [first, last) of the next consensus() calls are copied into strings (the others come back empty):
     // a shard of a device-built job owns a range of the windows its engine returns.  (0, ~0) = all.
     void set_fetch_range(uint64_t first, uint64_t last) { fetch_first_ = first; fetch_last_ = last; }
@@ -100,6 +101,7 @@ private:
     void fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run = true);
     rcn_engine* handle_ = nullptr;
     double last_kernel_ms_ = 0;
+    int last_rc_ = 0;
     uint64_t fetch_first_ = 0, fetch_last_ = ~uint64_t(0);
 };
 

@@ -11,6 +11,7 @@
 
 #include "fatal.hpp"
 #include "hip_engine.hpp"
+#include "nw_path.hpp"
 #include "overlap.hpp"
 #include "parsers.hpp"
 #include "sequence.hpp"
@@ -610,11 +611,45 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
                 auto engine = engines_[static_cast<size_t>(device)];
                 engine->set_fetch_range(wa, wb);                       // the strings of its own windows only
                 std::vector<std::string> c; std::vector<uint8_t> pl, ch;
+                bool aligned_on_device = false;
+                std::vector<uint8_t> host_cigar; std::vector<uint64_t> host_cigar_off; std::vector<uint32_t> host_q_start;
                 if (device_align_) {
                     rcn_pair_set ps{};
                     ps.n_pairs = so.n_overlaps; ps.q_id = so.q_id; ps.t_id = so.t_id; ps.strand = so.strand;
                     ps.q_begin = p_q_begin; ps.q_end = p_q_end; ps.t_begin = p_t_begin; ps.t_end = p_t_end;
-                    engine->consensus(sr, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                    try {
+                        if (getenv("RACON_HIP_FORCE_ALIGN_FALLBACK")) throw FatalError("forced");      // (tests)
+                        engine->consensus(sr, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                        aligned_on_device = true;
+                    } catch (const FatalError&) {
+                        // The device aligner holds one op byte per row + column of every overlap and a per-wave scratch sized
+                        // for the longest read: an input it has no room for (RCN_E_CAPACITY / RCN_E_NOMEM; also a read beyond
+                        // its 3 Mbp limit) is aligned HERE instead, by the host's edlib-equivalent (reference
+                        // src/overlap.cpp:205-224) -- same paths, hence the same windows -- and goes on through the CIGAR path.
+                        if (!getenv("RACON_HIP_FORCE_ALIGN_FALLBACK") && engine->last_rc() != RCN_E_CAPACITY && engine->last_rc() != RCN_E_NOMEM) throw;
+                        static const struct Comp { char t[256]; Comp() { for (int i = 0; i < 256; ++i) t[i] = static_cast<char>(i); t['A'] = 'T'; t['T'] = 'A'; t['C'] = 'G'; t['G'] = 'C'; } } comp;
+                        const uint64_t n = so.n_overlaps;
+                        std::vector<std::string> cg(n);
+                        host_q_start.resize(n);
+                        parallel_for(n, num_threads_, [&](uint64_t k) {
+                            const uint64_t qa = sr.seq_off[so.q_id[k]], ql = sr.seq_off[so.q_id[k] + 1] - qa, ta = sr.seq_off[so.t_id[k]];
+                            std::string q(reinterpret_cast<const char*>(sr.bases + qa + p_q_begin[k]), p_q_end[k] - p_q_begin[k]);
+                            if (so.strand[k]) { std::reverse(q.begin(), q.end()); for (char& ch_ : q) ch_ = comp.t[static_cast<unsigned char>(ch_)]; }
+                            cg[k] = nwpath::align_cigar(q.data(), static_cast<uint32_t>(q.size()), reinterpret_cast<const char*>(sr.bases + ta + p_t_begin[k]), p_t_end[k] - p_t_begin[k]);
+                            host_q_start[k] = so.strand[k] ? static_cast<uint32_t>(ql - p_q_end[k]) : p_q_begin[k];       // reference src/overlap.cpp:241-242
+                        });
+                        host_cigar_off.assign(1, 0);
+                        for (const auto& s_ : cg) { host_cigar.insert(host_cigar.end(), s_.begin(), s_.end()); host_cigar_off.push_back(host_cigar.size()); }
+                    }
+                }
+                if (device_align_ && !aligned_on_device) {
+                    rcn_cigar_set a{};
+                    static const uint8_t kNoCigar = 0;
+                    a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
+                    a.q_start = host_q_start.empty() ? &kNoWord : host_q_start.data(); a.t_begin = p_t_begin; a.t_end = p_t_end;
+                    a.cigar_off = host_cigar_off.data(); a.cigar = host_cigar.empty() ? &kNoCigar : host_cigar.data();
+                    engine->consensus(sr, a, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
+                } else if (device_align_) {
                 } else if (device_cigars_) {
                     rcn_cigar_set a{};
                     a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;

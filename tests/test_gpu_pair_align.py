@@ -180,3 +180,22 @@ def test_cli_with_device_alignment(P, oracle, ovl, tmp_path_factory):
     out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
     assert out == ref
+
+
+def test_cli_device_alignment_falls_back_to_the_host_aligner(P, oracle, tmp_path_factory):
+    """An overlap set the device aligner has no room for (RCN_E_CAPACITY / RCN_E_NOMEM) is aligned by the host's
+    edlib-equivalent instead and goes on through the device's CIGAR path: same FASTA.  RACON_HIP_FORCE_ALIGN_FALLBACK takes
+    that road for every shard."""
+    import subprocess
+    from racon_amd.synth import simulate_files
+    d = str(tmp_path_factory.mktemp("e2e4"))
+    paths, _ = simulate_files(d, contig_len=15000, coverage=20.0, read_len=3000, n_contigs=2)
+    p = P.Polisher(paths["reads"], paths["paf"], paths["targets"], "kC", 500, 10.0, 0.3, True, 3, -5, -4, num_threads=4)
+    p.initialize()
+    ref = p.assemble(oracle.consensus(p.windows(), 3, -5, -4, True, 0), True)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "racon_amd", "host", "racon_hip")
+    for shards in ("1", "3"):
+        env = dict(os.environ, RACON_HIP_DEVICE_WINDOWS="3", RACON_HIP_FORCE_ALIGN_FALLBACK="1", RACON_HIP_DEVICE_SHARDS=shards)
+        out = subprocess.run([exe, "-t", "4", paths["reads"], paths["paf"], paths["targets"]], check=True, env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
+        assert out == ref, shards

@@ -94,6 +94,28 @@ if has cfg5; then
   timeout 2400 python tools/cfg5_at_size.py --scale ${CFG5_SCALE:-0.125} > "$OUT/cfg5_at_size.json" 2> "$OUT/cfg5_at_size.err"
   echo "cfg5 exit $?"; cat "$OUT/cfg5_at_size.json"; tail -5 "$OUT/cfg5_at_size.err"
 fi
+if has winprof; then
+  # per-window phase clocks (RCN_PROF_WIN build): where the deepest windows of the bench batch spend their time
+  make -s -C racon_amd/csrc prof
+  for C in "" "--config cfg4"; do
+    T=$(echo "$C" | tr -d ' -' ); T=${T:-cfg2}
+    RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_prof.so timeout 600 python bench.py $C --steps 1 --warmup 1 --no-cpu --no-product --no-upload-leg > "$OUT/winprof_${T}_bench.json" 2> "$OUT/winprof_$T.txt"
+    echo "== winprof $T"; grep -v amdgpu.ids "$OUT/winprof_$T.txt" | tail -12
+  done
+fi
+if has others; then
+  # the other workloads of BASELINE.json through the same kernel (bench lines with roofline + cpu_baseline)
+  for C in cfg4 w1000 cfg5x0.004; do
+    timeout 900 python bench.py --config $C --steps 5 --warmup 1 > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err"
+    echo "== $C exit $?"; python - "$OUT/bench_$C.json" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = j["roofline"]; c = j.get("cpu_baseline") or {}
+print("%s | %.0f windows/s, step %.2f ms, frac %.3f, cpu %.0f (%s threads) -> %.1fx" % (j["config"]["workload"][:70], j["value"], r["step_kernel_ms"], r["frac"], c.get("value", 0), c.get("cores"), j["value"] / max(1, c.get("value", 1))))
+PY
+  done
+  timeout 900 python bench.py --contig 4000000 --steps 3 --warmup 1 --no-cpu --no-product > "$OUT/bench_4mbp.json" 2> "$OUT/bench_4mbp.err"; python -c "
+import json; j=json.loads(open('$OUT/bench_4mbp.json').read().strip().splitlines()[-1]); print('4 Mbp: %.0f windows/s frac %.3f' % (j['value'], j['roofline']['frac']))"
+fi
 BENCH_PROF="python bench.py --steps 3 --warmup 1 --no-cpu --no-upload-leg --no-product"
 if has prof; then
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- $BENCH_PROF > "$OUT/prof_bench.json" 2> "$OUT/prof.err"

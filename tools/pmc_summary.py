@@ -28,16 +28,27 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 per_kernel.setdefault(kn, {})[cn] = total / n
 # traffic.json: HBM bytes per launch of the consensus kernel.  Raw units are KB (rocprofv3 derived counters);
 # FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) prescribes for gfx950 wide reads, WRITE_SIZE is uncalibrated.
+# A step of bench.py is one launch of the kernel, or -- split launch -- two concurrent ones on disjoint CU sets: the bench line
+# of the counter pass says which (roofline.launches_per_step); the traffic quoted next to the roofline is per STEP.
+lps = 1
+for name in ("pmc_FETCH_SIZE.json", "prof_bench.json"):
+    try:
+        line = open(os.path.join(out, name)).read().strip().splitlines()[-1]
+        lps = int(json.loads(line)["roofline"].get("launches_per_step", 1))
+        break
+    except Exception:
+        pass
 for kn, c in per_kernel.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        fetch = c["FETCH_SIZE"] * 1024.0 * 2.0
-        write = c["WRITE_SIZE"] * 1024.0
+        fetch = c["FETCH_SIZE"] * 1024.0 * 2.0 * lps
+        write = c["WRITE_SIZE"] * 1024.0 * lps
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from srchash import kernel_source_hash
         import time
         json.dump({"kernel": kn, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
-                   "bytes_per_launch": fetch + write, "kernel_source_hash": kernel_source_hash(),
+                   "bytes_per_launch": fetch + write, "launches_per_step": lps, "kernel_source_hash": kernel_source_hash(),
                    "measured": "%s, %s" % (os.path.basename(os.path.normpath(out)), time.strftime("%Y-%m-%d")),
-                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 (gfx950 correction)"},
+                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 (gfx950 correction); per bench step "
+                           "= per dispatch x launches_per_step (the split launch is two concurrent dispatches of the kernel)"},
                   open(os.path.join(out, "traffic.json"), "w"))
         print("traffic.json:", fetch + write, "bytes per launch")
