@@ -114,3 +114,32 @@ def test_malformed_inputs_are_reported(P, tmp_path):
     with pytest.raises(P.RaconError) as e:
         p.initialize()
     assert "invalid FASTQ record" in str(e.value)
+
+
+def test_records_much_longer_than_a_block(P, tmp_path, monkeypatch):
+    """A FASTA record of 40 MB (ten inflate blocks; a chromosome-scale contig is 250 MB) next to small ones: framed once
+    per doubling of the carried text, not once per block (parsers.cpp read_batches), with and without line breaks inside
+    the record -- the same windows as a serial run, and in time that is linear in the file."""
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    big = acgt[rng.integers(0, 4, 40_000_000)].tobytes()
+    small = acgt[rng.integers(0, 4, 3000)].tobytes()
+    targets = tmp_path / "targets.fasta"
+    with open(targets, "wb") as f:
+        f.write(b">small1\n" + small + b"\n>big unwrapped\n" + big + b"\n>big_wrapped\n")
+        f.write(b"\n".join(big[k:k + 60_000] for k in range(0, len(big), 60_000)) + b"\n>small2\n" + small[::-1] + b"\n")
+    reads = tmp_path / "reads.fasta"
+    with open(reads, "wb") as f:
+        for k in range(40):
+            a = 1000 * k
+            f.write(b">r%d\n" % k + big[a:a + 2500] + b"\n")
+    paf = tmp_path / "ovl.paf"
+    with open(paf, "wb") as f:
+        for k in range(40):
+            f.write(b"r%d\t2500\t0\t2500\t+\tbig\t%d\t%d\t%d\t2500\t2500\t60\n" % (k, len(big), 1000 * k, 1000 * k + 2500))
+    t = time.perf_counter()
+    wp, tp = _windows(P, str(reads), str(paf), str(targets), "kC", 8, False, monkeypatch)
+    ws, ts = _windows(P, str(reads), str(paf), str(targets), "kC", 8, True, monkeypatch)
+    _same(ws, wp)
+    assert wp.n_windows == 2 * (40_000_000 // 500) + 2 * 6
+    assert tp < 20.0, tp          # (quadratic re-framing of a 40 MB record was ~10 rescans of up to 40 MB each: still seconds; the bound catches a regression on CI-sized boxes)
