@@ -107,7 +107,12 @@ public:
     }
 private:
     HostPool() {
-        const unsigned n = std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
+        // fifteen helpers feed one device (a batch is packed by up to sixteen threads); a process that drives several
+        // devices -- every one with two engines packing their chunks at once -- gets twelve more per further device
+        int devices = 1;
+        if (hipGetDeviceCount(&devices) != hipSuccess || devices < 1) devices = 1;
+        const unsigned want = 15u + 12u * static_cast<unsigned>(devices - 1);
+        const unsigned n = std::min(want, std::max(2u, std::thread::hardware_concurrency()) - 1u);
         for (unsigned t = 0; t < n; ++t) threads_.emplace_back([this]() { loop(); });
     }
     ~HostPool() {

@@ -31,9 +31,13 @@ def test_bench_single_rank_line():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["achieved"] > 0 and abs(j["value"] - 200 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    # the step is one launch or two concurrent ones (split launch): the interval they cover is what the bytes are divided by
+    assert r["launches_per_step"] == len(r["launch_ms"]) in (1, 2) and r["step_kernel_ms"] >= max(r["launch_ms"]) * 0.999
+    assert r["step_kernel_ms"] <= j["ms_per_step"] * 1.001 and abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["step_kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "windows/s" and c["sample"]
     assert c["matches_gpu"] is True and max(c["thread_sweep_windows_per_s"].values()) == c["value"]
+    assert c["host"]["sched_affinity"] >= 1 and "cgroup_cpus" in c["host"]          # what "all host cores" is on this box
     # the upload-inclusive rate (pack + H2D + kernel + D2H per step) is reported next to `value`, never instead of it
     assert 0 < j["value_incl_upload"] <= j["value"] * 1.05 and j["ms_per_step_incl_upload"] > 0
 
@@ -47,3 +51,16 @@ def test_bench_two_ranks_on_one_gpu():
     j = _line(out)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak"
     assert abs(j["value"] - 2 * 200 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6      # whole-job aggregate over both ranks
+
+
+def test_bench_product_legs_on_the_default_workload():
+    """The default line (cfg2) also carries the PRODUCT: the same workload as files through racon_amd/host's Polisher -- the
+    Logger-bracketed polish() interval, in-process and through the binary -- with the FASTA checked against the kernel leg."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--product-contig", "0"],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT).stdout
+    j = _line(out)
+    p = j["product_polish"]["cfg2"]
+    assert p["windows"] == 2000 and p["fasta_matches_kernel_leg"] is True and 0 < p["polish_s"] < 1.0
+    assert p["cli"]["windows"] == 2000 and p["cli"]["fasta_matches_kernel_leg"] is True and 0 < p["cli"]["polish_s"] < 1.0
+    assert abs(j["value_product_polish"] - 2000 / p["polish_s"]) < 1e-6 * j["value_product_polish"]
+    assert j["config"]["windows_per_gpu"] == 2000 and "cfg2" in j["config"]["workload"]
