@@ -432,9 +432,9 @@ void Polisher::reserve_for_windows() {
     // chunk needs -- later chunks are shallower and fit in the same buffers -- and an engine without a chunk gets nothing
     FatalThrowsScope scope;
     try {
-        WindowRefs refs;
-        for (size_t k = 0; k < engines_.size() && k < chunks_.size(); ++k) {
-            refs.clear();
+        planned_refs_.assign(std::min(engines_.size(), chunks_.size()), WindowRefs());
+        for (size_t k = 0; k < planned_refs_.size(); ++k) {
+            WindowRefs& refs = planned_refs_[k];
             for (uint64_t i = chunks_[k].first; i < chunks_[k].second; ++i) refs.add(*windows_[rank_[i]]);
             engines_[k]->reserve(refs, chunks_.size() > 1);
         }
@@ -703,10 +703,13 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
             std::vector<std::string> c; std::vector<uint8_t> p, h;
             for (size_t ci = k; ci < chunks.size(); ci = cursor.fetch_add(1)) {
                 const double t_a = seconds_since(polish_begin);
-                refs.clear();
-                for (uint64_t i = chunks[ci].first; i < chunks[ci].second; ++i) refs.add(*windows_[rank[i]]);
+                const bool planned = ci < planned_refs_.size() && planned_refs_[ci].n_windows() == chunks[ci].second - chunks[ci].first;
+                if (!planned) {
+                    refs.clear();
+                    for (uint64_t i = chunks[ci].first; i < chunks[ci].second; ++i) refs.add(*windows_[rank[i]]);
+                }
                 const double t_b = seconds_since(polish_begin);
-                engine->consensus(refs, queued, trim_, &c, &p, &h);
+                engine->consensus(planned ? planned_refs_[ci] : refs, queued, trim_, &c, &p, &h);
                 const double t_c = seconds_since(polish_begin);
                 for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { const uint32_t w = rank[i]; cons[w].swap(c[j]); pol[w] = p[j]; chim[w] = h[j]; }
                 if (timing) fprintf(stderr, "[racon::Polisher::polish] timing: engine %u chunk %zu (%lu windows): start %.1f ms, refs %.1f, engine done %.1f (kernel %.1f), stored %.1f\n",

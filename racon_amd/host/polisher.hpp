@@ -25,6 +25,7 @@ class Sequence;
 class Overlap;
 class HipEngine;
 struct PackedBatch;
+struct WindowRefs;
 
 enum class PolisherType { kC, kF };   // contig polishing / fragment error correction
 
@@ -150,6 +151,7 @@ protected:
     std::vector<uint32_t> rank_;
     std::vector<std::pair<uint64_t, uint64_t>> chunks_;     // [first, last) positions in rank_
     void plan_chunks();
+    std::vector<WindowRefs> planned_refs_;                   // the pointer tables of the first chunks (built for the dry run, used by polish())
 public:
     double polish_seconds() const { return polish_seconds_; }
 };
