@@ -169,6 +169,7 @@ struct rcn_engine {
     hipStream_t deep_stream = nullptr, rest_stream = nullptr;
     int split_cus = 0;
     bool warmed = false;                            // rcn_engine_reserve ran its warm-up launch
+    int caps_level = 0;                             // first_pass_caps: raised when a batch needed many retries
     bool stats_pending = false;                     // the last run's device counters have not been read yet (rcn_engine_stats)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
@@ -243,19 +244,23 @@ Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast
 
 // first-pass capacities of a set of windows: typical graph growth (a window that outgrows them is re-run by the retry
 // pass with worst-case capacities)
+// `level`: 0 = the estimates below; raised by collect() when a batch sent more than 2 % of its windows to the retry pass
+// (reads noisier than the 10-15 % the estimates leave room for): every step gives the graph and the matrix more room
+// for the NEXT batch -- a node per 3, then 2 layer bases, a matrix row per 4, then 2.
 template <class It>
-Caps first_pass_caps(It first, It last, bool fast) {
+Caps first_pass_caps(It first, It last, bool fast, int level = 0) {
     // The graph arrays (~230 B per node) for a node per four layer bases; the DP matrix -- one row of 1 or 2 KB per node,
     // nine tenths of a slot -- for one per six: cfg2's windows end with a node per ~12 layer bases (10 % read error, most
     // errors shared by no other read), so both leave room, and the arena (slots x slot bytes, tens of GB that the driver
     // has to find and clear) shrinks by a third.  RCN_HROWS_DIV overrides the divisor (tests: a small matrix forces retries).
     const char* hd = getenv("RCN_HROWS_DIV");
-    const int hdiv = hd ? std::max(1, atoi(hd)) : 6;
+    const int hdiv = hd ? std::max(1, atoi(hd)) : (level <= 0 ? 6 : level == 1 ? 4 : 2);
+    const int ndiv = level <= 0 ? 4 : level == 1 ? 3 : 2;
     int32_t ncap = 0, hrows = 0, lmax = 1, nsym = 2;
     for (It it = first; it != last; ++it) {
         const WinShape& s = *it;
         const int64_t worst = static_cast<int64_t>(s.L) + s.sum_l + 8;
-        const int64_t est = static_cast<int64_t>(s.L) + s.sum_l / 4 + 256;
+        const int64_t est = static_cast<int64_t>(s.L) + s.sum_l / ndiv + 256;
         ncap = std::max<int32_t>(ncap, static_cast<int32_t>(std::min(worst, est)));
         hrows = std::max<int32_t>(hrows, static_cast<int32_t>(std::min(worst + 1, static_cast<int64_t>(s.L) + s.sum_l / hdiv + 129)));
         lmax = std::max(lmax, s.lmax); nsym = std::max(nsym, s.nsym);
@@ -864,6 +869,7 @@ static int collect(rcn_engine* e) {
         }
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->stats.n_retried = static_cast<uint32_t>(retry.size());
+        if (retry.size() * 50 > nw && nw >= 50 && e->caps_level < 2) ++e->caps_level;
     }
 
     e->stats_pending = true;                      // the device counters of this run: fetched by rcn_engine_stats on demand
@@ -991,7 +997,7 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
     sh.reserve(pp.cut[c + 1] - pp.cut[c]);
     for (uint32_t k = pp.cut[c]; k < pp.cut[c + 1]; ++k) sh.push_back(e->shapes[e->lpt[k]]);
     Launch& L = pp.L[c];
-    L.c = first_pass_caps(sh.begin(), sh.end(), fast);
+    L.c = first_pass_caps(sh.begin(), sh.end(), fast, e->caps_level);
     L.n_work = pp.cut[c + 1] - pp.cut[c]; L.work_base = pp.cut[c]; L.out_base = pp.cut[c]; L.ctr = c;
     if (sp.on) {
         L.stream = c == 0 ? e->deep_stream : e->rest_stream;
@@ -1068,7 +1074,7 @@ int rcn_engine_run(rcn_engine* e) {
             return collect(e);
         }
     }
-    const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), fast);
+    const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), fast, e->caps_level);
     if ((rc = run_pass(e, c1, ids, nw))) return rc;
     return collect(e);
 }
@@ -1423,7 +1429,7 @@ int rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* h) {
     sh.sum_l = static_cast<int32_t>(std::min<uint64_t>(deepest > L ? deepest - L : 0, 1u << 30));
     sh.lmax = static_cast<int32_t>(h->max_layer_length ? h->max_layer_length : L + (3 * L + 9) / 10);
     sh.nsym = 5;
-    const Caps c = first_pass_caps(&sh, &sh + 1, !getenv("RCN_WIDE_ONLY"));
+    const Caps c = first_pass_caps(&sh, &sh + 1, !getenv("RCN_WIDE_ONLY"), e->caps_level);
     const uint64_t slots = std::min<uint64_t>(nw, e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint64_t>(e->n_cu) * 8u);
     { size_t fr = 0, tot = 0; HIP_TRY(hipMemGetInfo(&fr, &tot)); e->free_mem = fr + e->d_scratch.cap; }
     const uint64_t want = std::min<uint64_t>(slots * c.slot_bytes, scratch_budget(e));

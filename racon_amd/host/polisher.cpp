@@ -430,15 +430,25 @@ void Polisher::reserve_for_windows() {
     plan_chunks();
     // engine k takes chunk k first (the shared cursor of polish() hands them out in this order): each gets exactly what that
     // chunk needs -- later chunks are shallower and fit in the same buffers -- and an engine without a chunk gets nothing
-    FatalThrowsScope scope;
-    try {
-        planned_refs_.assign(std::min(engines_.size(), chunks_.size()), WindowRefs());
-        for (size_t k = 0; k < planned_refs_.size(); ++k) {
+    // (one thread per engine: pinned staging costs 0.23 ms per MB and an arena can wait a second for the driver's page
+    //  clearing -- sixteen engines on an eight-GPU node must not pay that one after the other)
+    planned_refs_.assign(std::min(engines_.size(), chunks_.size()), WindowRefs());
+    std::vector<std::string> errors(planned_refs_.size());
+    auto reserve_one = [&](size_t k) {
+        FatalThrowsScope scope;
+        try {
             WindowRefs& refs = planned_refs_[k];
             for (uint64_t i = chunks_[k].first; i < chunks_[k].second; ++i) refs.add(*windows_[rank_[i]]);
             engines_[k]->reserve(refs, chunks_.size() > 1);
-        }
-    } catch (const std::exception& e) { engines_error_ = e.what(); engines_.clear(); }
+        } catch (const std::exception& e) { errors[k] = e.what(); }
+    };
+    if (planned_refs_.size() == 1) reserve_one(0);
+    else {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < planned_refs_.size(); ++k) pool.emplace_back(reserve_one, k);
+        for (auto& t : pool) t.join();
+    }
+    for (const auto& e : errors) if (!e.empty()) { engines_error_ = e; engines_.clear(); planned_refs_.clear(); break; }
     if (timing) fprintf(stderr, "[racon::Polisher::initialize] timing: %zu chunk(s) planned, engines reserved in %.1f ms\n", chunks_.size(), 1e3 * seconds_since(t0));
 }
 

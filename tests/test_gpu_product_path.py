@@ -172,3 +172,22 @@ def test_matrix_rows_smaller_than_the_graph(Engine, mid, mid_ref, monkeypatch):
     got = eng.consensus(sub)
     assert eng.stats()["n_retried"] > 48
     assert got.consensus == mid_ref.consensus[:96] and list(got.polished) == list(mid_ref.polished[:96])
+
+
+def test_noisy_reads_raise_the_capacity_estimates(Engine, oracle):
+    """Reads at 25 % error add a node per ~4 layer bases -- beyond what the first-pass estimates leave room for (a node per
+    four, a matrix row per six): many windows go to the retry pass, the results do not change, and the engine gives the NEXT
+    batch more room (engine.hip: caps_level)."""
+    b = simulate_windows(100_000, 500, 30.0, 10000, seed=78, sub=0.08, ins=0.08, dele=0.09)
+    ref = oracle.consensus(b, 3, -5, -4, True, 0, simd=True)
+    eng = Engine(3, -5, -4, True)
+    assert_same(eng.consensus(b), ref, "25 % error, first batch")
+    first = eng.stats()["n_retried"]
+    assert_same(eng.consensus_refs(b), ref, "25 % error, second batch")
+    second = eng.stats()["n_retried"]
+    assert_same(eng.consensus(b), ref, "25 % error, third batch")
+    third = eng.stats()["n_retried"]
+    print("windows sent to the retry pass: %d, %d, %d of %d" % (first, second, third, b.n_windows))
+    assert third <= second <= first, (first, second, third)
+    if first > b.n_windows // 50:                       # the estimates were too small: they must have grown
+        assert third < first, (first, second, third)
