@@ -382,7 +382,8 @@ void Polisher::create_engines() {
     // RACON_HIP_FAKE_DEVICES=n: drive n logical devices (engine k belongs to logical device k mod n, which is physical device
     // (k mod n) mod the real count): the multi-device code paths on a one-GPU box (tests)
     if (const char* fd = getenv("RACON_HIP_FAKE_DEVICES")) n_devices_ = std::max(1, atoi(fd));
-    const uint32_t engines_per_device = 2 * hip_batches_;
+    uint32_t engines_per_device = 2 * hip_batches_;
+    if (const char* ed = getenv("RACON_HIP_ENGINES_PER_DEVICE")) engines_per_device = static_cast<uint32_t>(std::max(1, atoi(ed)));   // experiments
     const uint32_t sharing = engines_per_device * static_cast<uint32_t>((n_devices_ + real_devices - 1) / real_devices);
     std::vector<std::shared_ptr<HipEngine>> engines;
     for (uint32_t k = 0; k < static_cast<uint32_t>(n_devices_) * engines_per_device; ++k) {
@@ -414,7 +415,7 @@ void Polisher::plan_chunks() {
     }
     std::stable_sort(rank_.begin(), rank_.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
     uint64_t target = std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (nw + 2 * n_engines - 1) / (2 * n_engines)));
-    if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) target = std::max(1, atoi(cw));       // tests: many small chunks
+    if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) { if (atoi(cw) > 0) target = static_cast<uint64_t>(atoi(cw)); }   // tests: many small chunks
     for (uint64_t a = 0; a < nw;) {
         uint64_t b = a, sum = 0;
         while (b < nw && b - a < target && sum < kMaxChunkBases) sum += bases[rank_[b++]];

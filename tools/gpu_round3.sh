@@ -69,6 +69,20 @@ j=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=j.get('product_polish
 print('-c $c:', {k:(round(v['polish_s']*1e3,1), round(v['windows_per_s'])) if isinstance(v,dict) and 'polish_s' in v else v for k,v in p.items()}, 'value', round(j['value']))"
   done 2>&1 | tee "$OUT/product_batches.txt"
 fi
+if has chunksweep; then
+  # engines per device x chunk size on one GPU's share of cfg3 (12 500 windows): the polish() interval of the binary
+  F=/tmp/racon_amd_cache/files_6250000_30_20260922
+  [ -d "$F" ] || python -c "
+import os,sys; sys.path.insert(0, os.getcwd()); import bench; bench.product_files(6_250_000, 30.0, 20260922, 32)"
+  { for E in 2 3 4; do for CW in 0 1600 2100 3200 4200 6300; do
+      best=999
+      for k in 1 2; do
+        t=$(RACON_HIP_ENGINES_PER_DEVICE=$E RACON_HIP_CHUNK_WINDOWS=$CW racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2>&1 >/dev/null | grep "generated consensus" | sed 's/.*consensus \([0-9.]*\) s/\1/')
+        best=$(python -c "print(min($best, float('$t')))")
+      done
+      echo "engines $E chunk $CW: polish $best s"
+    done; done; } 2>&1 | tee "$OUT/chunksweep.txt"
+fi
 if has malloc; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/malloc_time tools/probe/malloc_time.hip && /tmp/malloc_time > "$OUT/malloc_time.txt" 2>&1; cat "$OUT/malloc_time.txt"
   /tmp/malloc_time > "$OUT/malloc_time_second_process.txt" 2>&1; head -3 "$OUT/malloc_time_second_process.txt"
