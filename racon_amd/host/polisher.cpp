@@ -414,7 +414,11 @@ void Polisher::plan_chunks() {
         rank_[i] = static_cast<uint32_t>(i);
     }
     std::stable_sort(rank_.begin(), rank_.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-    uint64_t target = std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (nw + 2 * n_engines - 1) / (2 * n_engines)));
+    // three chunks per two engines (two engines: thirds).  Sweep on one GPU's share of cfg3, 12 500 windows, polish() of the binary
+    // (profiles/r03/j_chunksweep.txt): chunks of 1600 / 2100 / 3200 / 4200 / 6300 windows 111 / 110 / 98 / 92 / 99 ms with two
+    // engines, 108 / 104 / 98 / 95 / 95 with three, 116 / 113 / 96 / 95 / 94 with four: fewer, larger chunks -- every chunk's launch
+    // has a tail of its own -- and the number of engines beyond two does not matter
+    uint64_t target = std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (2 * nw + 3 * n_engines - 1) / (3 * n_engines)));
     if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) { if (atoi(cw) > 0) target = static_cast<uint64_t>(atoi(cw)); }   // tests: many small chunks
     for (uint64_t a = 0; a < nw;) {
         uint64_t b = a, sum = 0;
