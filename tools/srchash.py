@@ -5,7 +5,9 @@ import os
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _files():
     d = os.path.join(_ROOT, "racon_amd", "csrc")
-    return sorted(f for f in os.listdir(d) if f.endswith((".hpp", ".inc", ".hip")) or f == "Makefile")
+    # the consensus kernel's sources (the window-construction and pair-alignment kernels live in the same library but do not
+    # touch the traffic of poa_window_kernel2)
+    return sorted(f for f in os.listdir(d) if (f.startswith("poa_") and f.endswith((".hpp", ".inc"))) or f in ("engine.hip", "Makefile"))
 
 
 def kernel_source_hash() -> str:
