@@ -74,6 +74,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the HIP engine)")
+    # One HIP runtime per process: PyTorch-ROCm brings its own libamdhip64 (same SONAME as /opt/rocm's).  Whoever loads first
+    # wins for both, and a process that loaded this library first and torch second was seen to end up without a usable device
+    # (`python __graft_entry__.py smoke` = build() then smoke()).  torch first, always -- it is what bench.py does anyway.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.rcn_engine_create.argtypes = [C.POINTER(RcnEngineConfig), C.POINTER(C.c_void_p)]
     lib.rcn_engine_destroy.argtypes = [C.c_void_p]
