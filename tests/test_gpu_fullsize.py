@@ -200,3 +200,49 @@ def test_four_ranks_on_one_gpu_gather_to_rank_zero():
     b = simulate_windows(400_000, 500, 30.0, 10000, seed=20260922)
     one = HipEngine(3, -5, -4, True).consensus(b)
     assert n == b.n_windows == 800 and digest == _digest(one.consensus) and npol == int(one.polished.sum())
+
+
+def test_cfg3_one_gpu_share_through_the_product(oracle, tmp_path_factory):
+    """BASELINE configs[2] at one GPU's share (50 Mbp / 8 = 6.25 Mbp, 12 500 windows) through the PRODUCT: files ->
+    racon_amd/host Polisher -> initialize -> polish (three deepest-first chunks over two engines) -- the FASTA the oracle gives
+    on the windows initialize() built, byte for byte; the windows themselves are the packed workload of bench.py
+    (tests/test_synth_files.py).  (The whole 100 000-window job on one GPU, every window against the oracle:
+    `bench.py --config cfg3 --verify`, profiles/r03/h_bench_cfg3_1gpu.json.)"""
+    from racon_amd import polisher as P
+    from racon_amd.synth import simulate_window_files
+    P.build()
+    d = str(tmp_path_factory.mktemp("cfg3share"))
+    paths = simulate_window_files(d, 6_250_000, 30.0, 10000, seed=20260922, workers=16)
+
+    def make():
+        return P.Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", 500, 10.0, 0.3, True, 3, -5, -4, num_threads=16)
+    p = make(); p.initialize()
+    b = p.windows()
+    assert b.n_windows == 12500
+    ref = p.assemble(oracle.consensus(b, 3, -5, -4, True, 0, simd=True), True)
+    p.close()
+    p = make(); p.initialize()
+    got = p.polish(True)
+    sec = p.polish_seconds()
+    p.close()
+    assert got == ref
+    assert 0.0 < sec < 2.0, sec                   # (95-110 ms on an idle box; the bound only catches a product that fell off the fast path)
+
+
+def test_cfg5_share_through_the_binary():
+    """BASELINE configs[4] (`-f`, dual overlaps) at 2.5 % -- 2500 reads, ~50 000 windows, ~120 000 overlaps to align -- through
+    `racon_hip -f` with everything on the device: the FASTA equals the engine's consensus on the device-built windows, a 5 %
+    sample of those windows equals the oracle.  (One GPU's share, 12.5 % = 250 000 windows, plus the host-aligned modes at
+    1 %: tools/cfg5_at_size.py, profiles/r03/e_cfg5_at_size_x0.125.json.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "cfg5_at_size.py"), "--scale", "0.025", "--cross-scale", "0", "--threads", "16"],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root).stdout
+    j = json.loads(out.decode().strip().splitlines()[-1])
+    assert j["device_everything"]["rc"] == 0 and 40000 < j["windows"] < 60000
+    assert j["fasta_equals_engine_consensus"] is True
+    assert j["oracle_sample"]["differ"] == 0 and j["oracle_sample"]["windows"] >= 2000
+    assert j["consensus_kernel"]["n_retried"] == 0
