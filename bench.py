@@ -351,6 +351,11 @@ def main():
                 out["value_product_polish"] = out["product_polish"][pfiles[0][0]]["windows_per_s"]
                 if "cfg3_share" in out["product_polish"]:
                     out["value_product_polish_12k"] = out["product_polish"]["cfg3_share"]["windows_per_s"]
+                # ... and through the drop-in binary (the Logger's own line)
+                for name, key in ((pfiles[0][0], "value_product_polish_cli"), ("cfg3_share", "value_product_polish_12k_cli")):
+                    cli = out["product_polish"].get(name, {}).get("cli", {})
+                    if "windows_per_s" in cli:
+                        out[key] = cli["windows_per_s"]
             except Exception as e:                       # the headline line must not die with the product leg
                 out["product_polish"] = {"error": repr(e)}
         if not a.no_cpu and world == 1:
