@@ -741,6 +741,7 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         }
     }
     for (const auto& e : errors) if (e) fatal_from(e);
+    planned_refs_.clear();                          // (borrowed pointers into the windows assemble() is about to release)
 
     for (uint64_t i = 0; i < nw; ++i)
         if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
