@@ -169,6 +169,7 @@ struct rcn_engine {
     hipStream_t deep_stream = nullptr, rest_stream = nullptr;
     int split_cus = 0;
     bool warmed = false;                            // rcn_engine_reserve ran its warm-up launch
+    bool lds_optin = false;                         // a work-group may ask for more than 64 KB of LDS (fewer than three per CU)
     int caps_level = 0;                             // first_pass_caps: raised when a batch needed many retries
     bool stats_pending = false;                     // the last run's device counters have not been read yet (rcn_engine_stats)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -297,7 +298,7 @@ bool deepest_rules(const rcn_engine* e) {
     return static_cast<double>(e->t_max) > 1.25 * even;
 }
 uint32_t wg_per_cu(const rcn_engine* e) {
-    if (const char* v = getenv("RCN_WG_PER_CU")) return static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));   // experiments
+    if (const char* v = getenv("RCN_WG_PER_CU")) return static_cast<uint32_t>(std::min(8, std::max(e->lds_optin ? 1 : 3, atoi(v))));   // experiments
     if (e->queued) return 8u;                       // the caller keeps the device busy with further batches: a long queue
     return deepest_rules(e) ? 6u : 8u;
 }
@@ -330,6 +331,7 @@ SplitPlan split_plan(const rcn_engine* e, uint32_t nw, bool fast) {
     sp.deep_per_cu = 1; sp.rest_per_cu = 8;
     if (const char* v = getenv("RCN_SPLIT_DEEP_PER_CU")) sp.deep_per_cu = static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));
     if (const char* v = getenv("RCN_SPLIT_REST_PER_CU")) sp.rest_per_cu = static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));
+    if (!e->lds_optin) sp.deep_per_cu = std::max(sp.deep_per_cu, 3u);      // (residency is set through the LDS request: 64 KB at most without the opt-in)
     sp.n_deep = cus * sp.deep_per_cu;
     if (const char* v = getenv("RCN_SPLIT_DEEP")) sp.n_deep = static_cast<uint32_t>(std::max(1, atoi(v)));
     sp.n_deep = std::min(sp.n_deep, nw - 1);
@@ -599,7 +601,7 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
             e->split_cus = e->deep_stream ? cus : 0;
         }
         // fewer than eight work-groups per CU are enforced through the LDS request (lds_bytes_for): up to the whole LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e->lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
     }
     int rc = e->d_ctr.reserve(kCtrBytes);
