@@ -325,7 +325,7 @@ SplitPlan split_plan(const rcn_engine* e, uint32_t nw, bool fast) {
     if (!fast || !e->deep_stream || !e->rest_stream || e->cfg.max_slots || (sw && atoi(sw) == 0)) return sp;
     const bool forced = sw && atoi(sw) == 1;
     const uint32_t cus = static_cast<uint32_t>(e->split_cus);
-    if (!forced && (e->queued || !deepest_rules(e) || nw < 4 * cus || nw > static_cast<uint32_t>(e->n_cu) * 8u)) return sp;
+    if (!forced && (e->queued || !deepest_rules(e) || nw < 256u || nw > static_cast<uint32_t>(e->n_cu) * 8u)) return sp;
     if (nw < 2) return sp;
     sp.on = true;
     sp.deep_per_cu = 1; sp.rest_per_cu = 8;
@@ -346,6 +346,7 @@ struct Launch {
     const uint32_t* d_ids = nullptr;    // work item -> device window, or nullptr: work_base + work item
     uint32_t n_work = 0, work_base = 0, out_base = 0, slots = 0;
     uint32_t per_cu = 0;                // work-groups per CU of the fast kernel (0: wg_per_cu)
+    int32_t heavy_ns = -1;              // KParams::heavy_ns of this pass (-1: the engine's)
     bool host_out = true;               // results go straight into the pinned result block (first pass); false: d_out_* (retry pass)
     uint64_t scratch_off = 0;
     int ctr = 0;                        // which work-queue counter of d_ctr
@@ -380,7 +381,7 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.win_ids = L.d_ids; P.n_work = L.n_work; P.work_base = L.work_base;
     P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : win_flags;
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
-    P.heavy_ns = e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
+    P.heavy_ns = L.heavy_ns >= 0 ? L.heavy_ns : e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
     P.force_tie = getenv("RCN_FORCE_TIE") ? atoi(getenv("RCN_FORCE_TIE")) : 0;
     P.force_slow_tb = getenv("RCN_FORCE_SLOW_TB") ? 1 : 0;
     // the band's exactness certificate (poa_band.hpp: a cell is alive when H' + m (len - j) >= T) assumes that a remaining
@@ -584,9 +585,12 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     for (auto& evs : e->sub_ev) for (auto& ev : evs) HIP_TRY(hipEventCreate(&ev));
     {
         // the CU-masked stream pair of the split launch (split_plan); a runtime that refuses masks leaves them null
-        // 64 of the 256 CUs for the deep launch: A/B on cfg2 (profiles/r03/a_split_ab.txt) 20.81 ms per step against 21.22
-        // with 96, 23.3 with 128 (the other launch then lacks CUs) and 21.62 without the split
-        int cus = 64;
+        // 32 of the 256 CUs for the deep launch.  cfg2 (profiles/r03/o_split_sweep.txt): the deep launch lasts as long as the
+        // deepest window's own chain whatever it is given (19.3-19.5 ms with 16, 24, 32 or 64 CUs), the other launch gets
+        // shorter the more CUs it keeps (19.6 ms on 192, 17.3 on 224): 19.3-19.5 ms per step with 16-32, 19.6 with 64,
+        // 20.4 without the split.  (Masks of 40, 48, 56 or 72 bits ran the deep launch in TWO rounds -- 29 ms: fewer CUs
+        // than bits took its work-groups -- so the count stays one of those measured.)
+        int cus = 32;
         if (const char* v = getenv("RCN_SPLIT_CUS")) cus = atoi(v);
         cus = (cus / 8) * 8;                                   // an even slice of the eight XCDs
         const char* sw = getenv("RCN_SPLIT");
@@ -912,7 +916,15 @@ static int collect(rcn_engine* e) {
       for (int k = 0; k < 3 && k < (int)tot.size(); ++k) { int w = tot[k].second; fprintf(stderr, "  work item %d (%u seqs): total %.3g | sub %.3g desc %.3g dp %.3g tb %.3g add %.3g merge %.3g cons %.3g | tiles %llu boxes %llu slow %llu\n", w,
           e->h_win_seq_off[e->lpt[w] + 1] - e->h_win_seq_off[e->lpt[w]], (double)tot[k].first, (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6], wc[w][7] >> 40, (wc[w][7] >> 20) & 0xfffff, wc[w][7] & 0xfffff); }
       { int w = tot[tot.size() / 2].second; fprintf(stderr, "  median work item %d: total %.3g | sub %.3g desc %.3g dp %.3g tb %.3g add %.3g merge %.3g cons %.3g\n", w, (double)tot[tot.size() / 2].first,
-          (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6]); } }
+          (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6]); }
+      { unsigned long long wt_[8]; HIP_TRY(hipMemcpyFromSymbol(wt_, HIP_SYMBOL(rcn::g_wtie), sizeof(wt_)));
+        fprintf(stderr, "[racon_hip] sink ties since load: %llu alignments, %.0f clocks each; %llu past the rule, %llu closure sweeps, %llu full DFS\n", wt_[0], (double)wt_[1] / std::max(1ull, wt_[0]), wt_[2], wt_[3], wt_[4]); }
+      if (getenv("RCN_PROF_LAYERS")) {
+          static unsigned long long wl[4][128][5]; HIP_TRY(hipMemcpyFromSymbol(wl, HIP_SYMBOL(rcn::g_wlay), sizeof(wl)));
+          for (int w = 0; w < 4; ++w) for (int j = 1; j < 128; ++j) if (wl[w][j][0])
+              fprintf(stderr, "  item %d layer %3d: V %4llu len %4llu | dp %8llu tie %8llu tb %8llu | tied %llu level %llu band-flags %llu\n", w, j, wl[w][j][4] >> 32, wl[w][j][4] & 0xffffffffull,
+                      wl[w][j][0], wl[w][j][1], wl[w][j][2], wl[w][j][3] >> 16, (wl[w][j][3] >> 8) & 255, wl[w][j][3] & 255);
+      } }
 #endif
 
     e->cons_off.assign(static_cast<size_t>(nw) + 1, 0);
@@ -1004,6 +1016,7 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
     if (sp.on) {
         L.stream = c == 0 ? e->deep_stream : e->rest_stream;
         L.per_cu = c == 0 ? sp.deep_per_cu : sp.rest_per_cu;
+        if (c == 0 && getenv("RCN_SPLIT_DEEP_WIDE")) L.heavy_ns = atoi(getenv("RCN_SPLIT_DEEP_WIDE"));
         const uint32_t cus = c == 0 ? static_cast<uint32_t>(e->split_cus) : static_cast<uint32_t>(e->n_cu - e->split_cus);
         L.slots = std::min(L.n_work, cus * L.per_cu);
     } else {

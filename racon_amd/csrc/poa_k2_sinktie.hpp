@@ -12,7 +12,8 @@ namespace rcn {
 //      backbone nodes and their aligned rings) is appended before anything else, ring of backbone node b_p at
 //      start p as (b_p, aligned list of b_p = ascending id).  A sink without aligned nodes and id >= L is in
 //      nobody's closure: it is appended exactly when the start loop reaches its own id.  Hence the key
-//      (p, id) for sinks whose ring holds a backbone node, (inf, id) for lone non-backbone sinks.
+//      (p, id) for sinks whose ring holds a backbone node, (inf, id) for lone non-backbone sinks, and
+//      (inf, smallest id of the ring, position behind it) for rings of non-backbone nodes without out-edges.
 //  (2) the tied sinks include rings of non-backbone nodes: mark the backbone closure (= Subgraph(0, L-1), the
 //      parallel sweep) as done and run the exact DFS only over the few nodes outside it.
 //  (3) otherwise the full exact DFS.
@@ -37,8 +38,37 @@ __device__ __noinline__ void phase_sink_tie_rule() {
             for (int a = 0; a < na; ++a) rm = min(rm, g.al_nodes[v * g.ring + a]);
             long long key;
             if (rm < c.bblen) key = (static_cast<long long>(rm) << 32) | static_cast<unsigned int>(v);
-            else if (na == 0) key = (0x7ffffffell << 32) | static_cast<unsigned int>(v);
-            else { classified = false; break; }
+            else if (v >= (1 << 25)) { classified = false; break; }
+            else if (na == 0) key = (0x7ffffffell << 32) | (static_cast<unsigned int>(v) << 6);
+            else {
+                // a ring of non-backbone nodes none of which has an out-edge (alternative last bases past the backbone's
+                // end: every later layer that stops short of them ties there): nothing is appended because of them and
+                // nobody's DFS reaches them, so the start loop finds the ring at its smallest id m and appends m, then
+                // m's aligned list in list order -> key (m, position).  (Measured on cfg2: 240 of 241 ties the rule
+                // above left open, ~440 k clocks each through the closure sweep, eleven layers in a row of the window
+                // that ended the launch.)
+                bool closed = true;
+                for (int a = -1; a < na && closed; ++a) {
+                    const int u = a < 0 ? v : g.al_nodes[v * g.ring + a];
+                    if (sub && !g.inc[u]) continue;
+                    for (int e = g.out_head[u]; e >= 0 && closed; e = g.e_nout[e]) if (!sub || g.inc[g.e_head[e]]) closed = false;
+                }
+                if (!closed) { classified = false; break; }
+                int pos = 0;
+                if (v != rm) {
+                    if (sub && !g.inc[rm]) { classified = false; break; }      // (a non-backbone ring is inside the subgraph as a whole)
+                    const int nm = g.al_cnt[rm];
+                    pos = -1;
+                    for (int a = 0, q = 0; a < nm; ++a) {
+                        const int u = g.al_nodes[rm * g.ring + a];
+                        if (sub && !g.inc[u]) continue;
+                        ++q;
+                        if (u == v) { pos = q; break; }
+                    }
+                    if (pos < 0 || pos >= 64) { classified = false; break; }
+                }
+                key = (0x7ffffffell << 32) | (static_cast<unsigned int>(rm) << 6) | static_cast<unsigned int>(pos);
+            }
             if (key < bestkey) { bestkey = key; pick = v; }
         }
         if (classified) { o->best_row = nr[pick] + 1; status = 0; }

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 }
             }
             RCN_PHASE2(2);
+#ifdef RCN_PROF_WIN
+            const long long tl0__ = clock64();
+            const int tl_tied__ = bcast0(ctx->tied), tl_bf__ = bcast0(ctx->band_fail) | (bcast0(ctx->coded) ? 0 : 2);
+            int tl_lvl__ = 0, tl_route__ = 0;
+#endif
             if (bcast0(ctx->tied) > 1) {
                 if (wv == 0) phase_sink_tie_rule();
                 Block4::sync();
@@ -193,9 +198,15 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     Block4::sync();
                 }
                 if (st == 1) {
+#ifdef RCN_PROF_WIN
+                    tl_route__ = 1;
+#endif
                     if (wv == 0) phase_sink_tie_starts();
                     Block4::sync();
                     st = bcast0(ctx->tb_n);
+#ifdef RCN_PROF_WIN
+                    if (st == 3) tl_route__ = 2;
+#endif
                     if (st == 3) {
                         // marks of what spoa's DFS has finished before the deciding start: the closure of backbone
                         // node p* - 1 (of L - 1 when no candidate is in the backbone closure) = a Subgraph sweep in
@@ -226,8 +237,29 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     }
                 }
                 if (st == 2) { if (wv == 0) phase_sink_tie_full(); Block4::sync(); }
+#ifdef RCN_PROF_WIN
+                tl_lvl__ = 1 + st;
+                if (t == 0) {
+                    // all windows: tie events, clocks, events that went past the rule / into the closure sweep / into the full DFS
+                    atomicAdd(&g_wtie[0], 1ull); atomicAdd(&g_wtie[1], static_cast<unsigned long long>(clock64() - tl0__));
+                    if (tl_route__ >= 1) atomicAdd(&g_wtie[2], 1ull);
+                    if (tl_route__ >= 2) atomicAdd(&g_wtie[3], 1ull);
+                    if (st == 2) atomicAdd(&g_wtie[4], 1ull);
+                }
+#endif
             }
+#ifdef RCN_PROF_WIN
+            const long long tl1__ = clock64();
+#endif
             if (bcast0(ctx->coded)) phase_traceback_code(); else phase_traceback3();
+#ifdef RCN_PROF_WIN
+            if (t == 0 && wi < 4 && P.work_base == 0 && jl < 128) {
+                g_wlay[wi][jl][0] = static_cast<unsigned long long>(tl0__ - tck);       // (tck: end of the DP)
+                g_wlay[wi][jl][1] = static_cast<unsigned long long>(tl1__ - tl0__); g_wlay[wi][jl][2] = static_cast<unsigned long long>(clock64() - tl1__);
+                g_wlay[wi][jl][3] = (static_cast<unsigned long long>(tl_tied__) << 16) | ((tl_lvl__ + 16 * tl_route__) << 8) | tl_bf__;
+                g_wlay[wi][jl][4] = (static_cast<unsigned long long>(bcast0(ctx->V)) << 32) | static_cast<unsigned int>(len);
+            }
+#endif
             RCN_PHASE2(3);
             overflow = bcast0(ctx->overflow);
             if (!overflow) {

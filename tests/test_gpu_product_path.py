@@ -72,7 +72,7 @@ def test_split_launch_on_and_off(Engine, mid, mid_ref, monkeypatch, cus, per_cu)
     on = Engine(3, -5, -4, True)
     r = on.consensus(mid)                               # streamed: piece 0 is the deep launch
     st = on.stats()
-    assert st["split_deep"] > 0 and st["n_launches"] == 2 and st["split_cus"] == (int(cus) if cus else 64)
+    assert st["split_deep"] > 0 and st["n_launches"] == 2 and st["split_cus"] == (int(cus) if cus else 32)
     assert st["launch_ms"][0] > 0 and st["launch_ms"][1] > 0 and st["kernel_ms"] >= max(st["launch_ms"]) * 0.999
     assert_same(r, mid_ref, "split, streamed")
     assert_same(on.run(), mid_ref, "split, resident batch (deepest-first layout)")
