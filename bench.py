@@ -334,7 +334,7 @@ def main():
                          "full_matrix": {"algorithmic_bytes_per_launch": alg_bytes - st["dp_bytes"] + st["dp_bytes_full"],
                                          "achieved": (alg_bytes - st["dp_bytes"] + st["dp_bytes_full"]) / step_s / 1e9,
                                          "gcups": st["dp_cells_full"] / step_s / 1e9},
-                         "banded_alignments": st["n_banded"], "band_redone": st["n_band_redone"], "band_redo_why": st["band_redo_why"],
+                         "banded_alignments": st["n_banded"], "code_wave_alignments": st["n_code_wave"], "band_redone": st["n_band_redone"], "band_redo_why": st["band_redo_why"],
                          "phase_clocks": st["phase_clocks"], "work_groups_per_cu": st["wg_per_cu"]},
         }
         if do_product:

@@ -100,6 +100,8 @@ typedef struct rcn_run_stats {
     uint32_t split_deep_per_cu;/* work-groups per CU of the deep launch                                                    */
     double   launch_ms[2];     /* HIP-event durations of the (up to two, concurrent) launches of the first pass; kernel_ms is
                                   the interval they cover together                                                         */
+    uint64_t n_code_wave;      /* banded alignments whose move codes were assembled by waves 1-3 of the work-group next to the DP
+                                  wave (windows with a CU and its LDS to themselves: the deep launch; poa_band.hpp)          */
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */

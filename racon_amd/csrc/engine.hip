@@ -392,6 +392,8 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.scratch = e->d_scratch.as<uint8_t>() + L.scratch_off; P.slot_bytes = L.c.slot_bytes;
     P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride; P.hrows = L.c.hrows;
     P.out_base = L.out_base;
+    P.lds_extra = L.c.fast ? static_cast<int32_t>(lds_bytes_for(L.per_cu ? L.per_cu : wg_per_cu(e)) - (rcn::kLdsBytes + rcn::kCtxBytes)) : 0;
+    P.no_help = getenv("RCN_NO_CODE_WAVE") ? 1 : 0;
     if (L.host_out) {
         // The first pass writes lengths, flags and consensus bytes straight into pinned host memory (hipHostMalloc memory is
         // device-visible): ~1 KB per window over PCIe from the kernel's own stores, and no device-to-host copy afterwards -- a
@@ -919,6 +921,8 @@ static int collect(rcn_engine* e) {
           (double)wc[w][0], (double)wc[w][1], (double)wc[w][2], (double)wc[w][3], (double)wc[w][4], (double)wc[w][5], (double)wc[w][6]); }
       { unsigned long long wt_[8]; HIP_TRY(hipMemcpyFromSymbol(wt_, HIP_SYMBOL(rcn::g_wtie), sizeof(wt_)));
         fprintf(stderr, "[racon_hip] sink ties since load: %llu alignments, %.0f clocks each; %llu past the rule, %llu closure sweeps, %llu full DFS\n", wt_[0], (double)wt_[1] / std::max(1ull, wt_[0]), wt_[2], wt_[3], wt_[4]); }
+      { unsigned long long wh_[8]; HIP_TRY(hipMemcpyFromSymbol(wh_, HIP_SYMBOL(rcn::g_whelp), sizeof(wh_)));
+        fprintf(stderr, "[racon_hip] code waves since load: %llu lap checks of wave 0 with %llu polls; %llu waits of the code waves with %llu polls\n", wh_[0], wh_[1], wh_[2], wh_[3]); }
       if (getenv("RCN_PROF_LAYERS")) {
           static unsigned long long wl[4][128][5]; HIP_TRY(hipMemcpyFromSymbol(wl, HIP_SYMBOL(rcn::g_wlay), sizeof(wl)));
           for (int w = 0; w < 4; ++w) for (int j = 1; j < 128; ++j) if (wl[w][j][0])
@@ -1468,7 +1472,7 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         // engine's own non-blocking stream (a plain hipMemcpy runs on the null stream and waits for every blocking stream of
         // the process -- the CU-masked launch streams of the device's other engine among them)
         HIP_TRY(hipSetDevice(e->cfg.device));
-        unsigned long long st[24] = {0};
+        unsigned long long st[25] = {0};
         HIP_TRY(hipMemcpyAsync(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
@@ -1476,6 +1480,7 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         e->stats.n_sink_ties = st[11];
         e->stats.dp_cells_full = st[12]; e->stats.dp_bytes_full = st[13]; e->stats.n_banded = st[14]; e->stats.n_band_redone = st[15];
         for (int k = 0; k < 8; ++k) e->stats.band_redo_why[k] = st[16 + k];
+        e->stats.n_code_wave = st[24];
         e->stats_pending = false;
     }
     *out = e->stats;

@@ -46,6 +46,31 @@ __host__ __device__ constexpr int dp2_ring_rows_band(int np, bool tab) {
     return (kLdsBytes - 64 - kBandSeq - (tab ? 4 * 4 * 64 * np : 0)) / (4 * 64 * np) - 1;
 }
 
+// ---- the code wave (HELP) ----
+// A window that has a CU to itself (the deep launch of engine.hip's split: one work-group per CU, enforced by asking for
+// the CU's whole LDS) is as slow as its DP wave issues instructions, and three SIMDs idle next to it.  With the large LDS
+// at hand the DP wave (wave 0) leaves the move codes of the chain / fast rows -- 98 % of the rows; 12 of a chain row's 82
+// instructions, 20-30 of a row with several predecessors (the running first-argmax included) -- to waves 1-3: the finished
+// rows go into a ring of kHelpRows rows behind the context instead of the ~27 of the work area, wave 0 counts them in a
+// mailbox word, and the code waves follow at their own pace, each taking every third row (re-deriving a row's inputs costs
+// more instructions than wave 0 saves, but nothing in it waits for the previous row): they re-read the row and its
+// predecessor rows from the ring, recombine them (same arithmetic, first-argmax included), and store the code word.
+// Window shifts they replay from the row offsets; rows of the other classes (general, medium, sink: 2 %) keep their
+// codes in wave 0.  Wave 0 checks once per 64 rows that no code wave is 128 rows behind (the ring holds 256).  Every wait
+// is bounded: a wave that waits too long reports the alignment as failed and the caller redoes it on full rows, like a
+// failed certificate.
+constexpr int kHelpRows = 256;                                   // rows of the large ring (NP = 2: 512 bytes each)
+constexpr int kHelpRingBytes = kHelpRows * 64 * 2 * 4;
+constexpr int kHelpLdsBytes = kHelpRingBytes + 64 * 4 + 16;      // + progress words (one per lane of wave 0) + {rows done by waves 1-3, failure flag}
+constexpr int kHelpSpin = 1 << 18;                               // polls (s_sleep 1 each) before a wait gives up
+__device__ __forceinline__ uint32_t* help_ring() { return reinterpret_cast<uint32_t*>(lds_words2() + (kLdsBytes + kCtxBytes) / 4); }
+__device__ __forceinline__ uint32_t* help_prog() { return help_ring() + kHelpRingBytes / 4; }        // [64] rows finished by wave 0, x 0x00010001; 0xffffffff = gave up
+__device__ __forceinline__ uint32_t* help_done() { return help_prog() + 64; }                        // [0..2] rows waves 1-3 are through with, [3] one of them gave up
+__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) {
+    const uint32_t a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));
+    asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {        // saturating a - b per half (v_pk_sub_i16 clamp)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
@@ -109,9 +134,10 @@ __device__ unsigned long long g_rowprof[256][16];
 // phase_traceback_code.  A quarter of the bytes of the full int16 row, and the traceback neither re-reads scores nor
 // compares them.  Rows with more than EIGHT in-edges (three bits name a predecessor) are left to the score-matrix path
 // (band_fail); the seventh and eighth are not in the row descriptor, the traceback finds them on the in-edge list.
-template <int NP, bool TAB, bool CODE = false>
+template <int NP, bool TAB, bool CODE = false, bool HELP = false>
 __device__ __noinline__ void dp2_rows_band() {
     static_assert(!CODE || NP == 2, "move codes: four cells per lane -> one dword per lane and row");
+    static_assert(!HELP || CODE, "the code wave assembles move codes");
     constexpr int NTH = 64, WB = 128 * NP, LPC = 2 * NP;       // window columns, columns per lane
     const int t = threadIdx.x & 63, lane = t;
     const Ctx c = ctx_load<Block4>();
@@ -130,11 +156,13 @@ __device__ __noinline__ void dp2_rows_band() {
     const int hs = c.hstride, hs2 = hs >> 1;
     constexpr int kTab = TAB ? 4 * 4 * NTH * NP : 0;
     constexpr int KT = (kLdsBytes - 64 - kBandSeq - kTab) / (4 * NTH * NP);
-    constexpr int K = KT - 1;
-    static_assert(K == dp2_ring_rows_band(NP, TAB), "phase_desc2 classifies rows with the same ring depth");
-    static_assert(K >= 8 && K <= 63, "ring depth");
-    uint32_t* ring = reinterpret_cast<uint32_t*>(Block4::work());          // [KT][NTH][NP]
-    uint32_t* ptab = ring + KT * NTH * NP;                                    // [4][NTH][NP] (TAB)
+    // HELP: the ring is the large one behind the context (phase_desc2 classifies rows for the small one: conservative)
+    constexpr int K = HELP ? kHelpRows : KT - 1;
+    static_assert(KT - 1 == dp2_ring_rows_band(NP, TAB), "phase_desc2 classifies rows with the same ring depth");
+    static_assert(KT - 1 >= 8 && KT - 1 <= 63, "ring depth");
+    uint32_t* ring0 = reinterpret_cast<uint32_t*>(Block4::work());         // [KT][NTH][NP]
+    uint32_t* ring = HELP ? help_ring() : ring0;
+    uint32_t* ptab = ring0 + KT * NTH * NP;                                   // [4][NTH][NP] (TAB)
     uint8_t* lseq = reinterpret_cast<uint8_t*>(ptab + kTab / 4);             // [kBandSeq]
     for (int k = t; k < len; k += NTH) lseq[k] = seq[k];
     // this lane's slice of the profile table as an LDS byte address held in a VGPR: table slot -> address is one add
@@ -149,6 +177,8 @@ __device__ __noinline__ void dp2_rows_band() {
     asm volatile("; constants live in VGPRs" : "+v"(MG), "+v"(XM), "+v"(ONE));
     uint32_t tie_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&Block4::ctx()->tie_rows[0]));
     asm volatile("" : "+s"(tie_base));
+    uint32_t prog_l = HELP ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>(help_prog() + t)) : 0u;   // this lane's progress word
+    if (HELP) asm volatile("" : "+v"(prog_l));
 
     // ---- window state ----
     // State that only the rare rows touch (window shifts, general rows) lives in LDS, behind the layer's bases: kept in
@@ -281,6 +311,21 @@ __device__ __noinline__ void dp2_rows_band() {
 
 #pragma unroll 1
     for (int rbase = 0; rbase < V && !bfail; rbase += 64) {
+        if (HELP && rbase >= 128) {
+            // the rows of this block overwrite ring rows rbase - 255 ...: the code waves must be through with block rbase - 128
+            int spins = 0;
+            for (;;) {
+                const int d0 = static_cast<int>(__builtin_amdgcn_readfirstlane(lds_poll(help_done()))), d1 = static_cast<int>(__builtin_amdgcn_readfirstlane(lds_poll(help_done() + 1)));
+                const int d2 = static_cast<int>(__builtin_amdgcn_readfirstlane(lds_poll(help_done() + 2)));
+                if (min(min(d0, d1), d2) >= rbase - 128) break;
+                if (++spins > kHelpSpin || __builtin_amdgcn_readfirstlane(lds_poll(help_done() + 3)) != 0u) { bfail |= 256; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#ifdef RCN_PROF_WIN
+            if (lane == 0) { atomicAdd(&g_whelp[0], 1ull); atomicAdd(&g_whelp[1], static_cast<unsigned long long>(spins)); }
+#endif
+            if (bfail) break;
+        }
         {
             RowDesc d; d.erest = -1; d.meta = 1 << 9;
 #pragma unroll
@@ -388,7 +433,7 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
                         for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
                         __builtin_amdgcn_sched_barrier(0);
-                        if (CODE) arg_step(zq, 1);
+                        if (CODE && !HELP) arg_step(zq, 1);
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
                     }
@@ -400,7 +445,7 @@ __device__ __noinline__ void dp2_rows_band() {
 #pragma unroll
                         for (int q = 0; q < NP; ++q) zq[q] = win[wi + q];
                         __builtin_amdgcn_sched_barrier(0);
-                        if (CODE) arg_step(zq, e);
+                        if (CODE && !HELP) arg_step(zq, e);
 #pragma unroll
                         for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], zq[q]);
                     }
@@ -543,6 +588,7 @@ __device__ __noinline__ void dp2_rows_band() {
             }
         }
     }
+    if (HELP && bfail) lds_store(help_prog() + t, 0xffffffffu);       // left early: the code waves must not wait for the rest
     flush_edge();
     // ---- certificate: no recorded cell may be alive at T = the best end score found ----
     int ev = max(static_cast<int>(emaxV) >> 16, static_cast<int>(emaxV << 16) >> 16);
@@ -552,6 +598,7 @@ __device__ __noinline__ void dp2_rows_band() {
     const int lim = best + len * c.gp - c.m * len;          // T - m len, with T = Z + len g at column len
     // why (statistics): 1 source row off the left edge, 2 predecessor older than the ring, 4 / 16 more than two window shifts
     // inside the ring, 8 more than six in-edges, 32 no end cell, 64 an alive last window cell, 128 an alive dropped cell
+    // (256: the code wave fell too far behind -- not counted by reason)
     const int why = bfail | (!have_best ? 32 : 0) | ((have_best && edgeS >= lim) ? 64 : 0) | ((have_best && ev >= lim) ? 128 : 0);
     const int fail = (why || c.tie_pad[0] == 2) ? 1 : 0;
     Ctx* o = Block4::ctx();
@@ -576,6 +623,145 @@ __device__ __noinline__ void dp2_rows_band() {
         }
     }
     Wave0Of4::sync();
+}
+
+// ---- a code wave (waves 1-3 of the work-group, next to dp2_rows_band<NP, TAB, true, true> on wave 0) ----
+// For every chain / fast row, in row order and as soon as wave 0 has counted it: the row and its predecessor rows from the
+// large ring (a predecessor written under an older window offset is read dl lanes further right, -inf beyond lane 63: what
+// the re-based register window of wave 0 holds), the combined predecessor row M with its first-argmax, the diagonal and
+// vertical candidates, and the code word -- the arithmetic of the row tail (poa_band_row_tail.inc), on values that are
+// bit-identical to the ones wave 0 worked with.
+template <int NP, bool TAB>
+__device__ __noinline__ void dp2_band_codes(const int hw) {        // hw = 0, 1, 2: this wave takes the rows i with i % 3 == hw
+    static_assert(NP == 2, "move codes: four cells per lane -> one dword per lane and row");
+    constexpr int NTH = 64, LPC = 2 * NP, K = kHelpRows;
+    constexpr int kTab = TAB ? 4 * 4 * NTH * NP : 0;
+    constexpr int KT = (kLdsBytes - 64 - kBandSeq - kTab) / (4 * NTH * NP);
+    const int t = threadIdx.x & 63;
+    const Ctx c = ctx_load<Block4>();
+    Win g = ctx_win(c);
+    RCN_G const RowDesc* desc = g.desc.ptr();
+    RCN_G const int32_t* roff = g.pred.ptr();
+    RCN_G uint8_t* cbase = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr());
+    const int V = c.V, len = c.len, hs = c.hstride;
+    const uint32_t* ring = help_ring();
+    const uint8_t* lseq = reinterpret_cast<const uint8_t*>(reinterpret_cast<uint32_t*>(Block4::work()) + KT * NTH * NP + kTab / 4);
+    const uint32_t* prog = help_prog() + t;
+    const int mg = c.m - c.gp, xg = c.x - c.gp;
+    const uint32_t MG = pack2(mg, mg), XM = pack2(xg - mg, xg - mg), ONE = 0x00010001u;
+    const uint32_t GG = pack2(c.gp, c.gp), NEGP = pack2(kNeg16, kNeg16);
+    uint32_t sqx[NP];
+    auto set_columns = [&](int woff) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int j0 = woff + t * LPC + 2 * q, j1 = j0 + 1;
+            const int l0 = lseq[min(max(j0 - 1, 0), kBandSeq - 1)], l1 = lseq[min(max(j1 - 1, 0), kBandSeq - 1)];
+            const int s0 = (j0 >= 1 && j0 <= len) ? l0 : 0x100, s1 = (j1 >= 1 && j1 <= len) ? l1 : 0x100;
+            sqx[q] = pack2(s0, s1);
+        }
+    };
+    int have = 0;                               // rows wave 0 is known to have finished
+    bool gone = false;                          // wave 0 left early, or this wave waited too long
+    auto wait_for = [&](int i) {
+        int spins = 0;
+        while (have < i) {
+            const uint32_t v = __builtin_amdgcn_readfirstlane(lds_poll(prog));
+            if (v == 0xffffffffu) { gone = true; return; }
+            have = static_cast<int>(v & 0xffffu);
+            if (have >= i) break;
+            if (++spins > kHelpSpin) { gone = true; lds_store(help_done() + 3, 1u); return; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#ifdef RCN_PROF_WIN
+        if (t == 0) { atomicAdd(&g_whelp[2], 1ull); atomicAdd(&g_whelp[3], static_cast<unsigned long long>(spins)); }
+#endif
+    };
+    wait_for(1);                                // (the layer's bases are in LDS before wave 0 counts its first row)
+    int woff = 0;                               // the window offset sqx[] was made for
+    if (!gone) set_columns(0);
+    // A row's window offset is roff[row - 1]: wave 0 moves its window exactly where that value changes (phase_desc2 marks
+    // those rows).  64 offsets and descriptor words per block, one per lane; the previous block's offsets for predecessors
+    // across the block edge.
+    int dl_off_prev = 0;
+    static_assert((K & (K - 1)) == 0, "ring slots by mask");
+#pragma unroll 1
+    for (int rbase = 0; rbase < V && !gone; rbase += 64) {
+        int dl_meta = 1 << 9, dl_off = 0;
+        if (rbase + t < V) { dl_meta = desc[rbase + t].meta; dl_off = roff[rbase + t]; }
+        const int nrow = min(V, rbase + 64) - rbase;
+        int k0 = hw - rbase % 3; if (k0 < 0) k0 += 3;                // rows i = rbase + k + 1 with (i - 1) % 3 == hw
+#pragma unroll 1
+        for (int k = k0; k < nrow; k += 3) {
+            const int i = rbase + k + 1;
+            const int meta = __builtin_amdgcn_readlane(dl_meta, k);
+            if (!(meta & (1 << 13))) continue;                          // wave 0 keeps the codes of this row
+            if (have < i) { wait_for(i); if (gone) break; }
+            const int wi = __builtin_amdgcn_readlane(dl_off, k);
+            if (wi != woff) { woff = wi; set_columns(woff); }
+            const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
+            const int npf = (meta >> 9) & 7;
+            const int slot = i & (K - 1);
+            uint32_t acc[NP], M[NP], Aq[NP];
+            {
+                const uint32_t* src = ring + (slot * NTH + t) * NP;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { acc[q] = src[q]; Aq[q] = 0u; }
+            }
+            // predecessor e: distance d rows up, read dlp lanes further right when it was written under an older offset
+            auto pred_row = [&](int e, uint32_t (&zq)[NP]) {
+                const int d = static_cast<int>((dd >> (4 * e)) & 15);
+                const int kp = k - d;
+                const int wp = kp >= 0 ? __builtin_amdgcn_readlane(dl_off, kp & 63) : __builtin_amdgcn_readlane(dl_off_prev, (kp + 64) & 63);
+                const uint32_t* base = ring + (((slot - d) & (K - 1)) * NTH) * NP;
+                if (__builtin_expect(wp == wi, 1)) {
+                    const uint32_t* src = base + t * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) zq[q] = src[q];
+                } else {
+                    const int dlp = (wi - wp) / LPC;
+                    const bool keep = t + dlp < 64;
+                    const uint32_t* src = base + min(t + dlp, 63) * NP;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) { const uint32_t v = src[q]; zq[q] = keep ? v : NEGP; }
+                }
+            };
+            pred_row(0, M);
+            for (int e = 1; e < npf; ++e) {
+                uint32_t zq[NP];
+                pred_row(e, zq);
+                const uint32_t Q = pack2(e, e);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const uint32_t gt = pk_minu(pk_sub(pk_max(M[q], zq[q]), M[q]), ONE);
+                    Aq[q] = pk_mad(gt, pk_sub(Q, Aq[q]), Aq[q]);
+                    M[q] = pk_max(M[q], zq[q]);
+                }
+            }
+            // (lane 0: -inf, the cell left of the window)
+            const uint32_t mprev = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(kNeg16) << 16, M[NP - 1], 0x138, 0xf, 0xf, false);
+            const uint32_t sy = meta & 255, symsym = sy | (sy << 16);
+            uint32_t nd[NP], nu[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
+                const uint32_t DPv = pk_add(D, pk_profile(sqx[q], symsym, ONE, XM, MG)), Uv = pk_add(M[q], GG);
+                nd[q] = pk_minu(pk_sub(acc[q], DPv), ONE); nu[q] = pk_minu(pk_sub(acc[q], Uv), ONE);
+            }
+            const uint32_t bnd = __builtin_amdgcn_perm(nd[1], nd[0], 0x06040200u), bnu = __builtin_amdgcn_perm(nu[1], nu[0], 0x06040200u);
+            uint32_t word = (bnu << 1) | bnd;
+            if (npf > 1) {
+                const uint32_t bA = __builtin_amdgcn_perm(Aq[1], Aq[0], 0x06040200u);
+                const uint32_t bAl = __builtin_amdgcn_update_dpp(0u, bA, 0x138, 0xf, 0xf, true);
+                const uint32_t bAsh = __builtin_amdgcn_alignbit(bA, bAl, 24);
+                word = (bA << 5) | word;
+                word = (bAsh << 2) | word;
+            }
+            __builtin_nontemporal_store(word, reinterpret_cast<RCN_G uint32_t*>(cbase + (static_cast<uint32_t>(i) * static_cast<uint32_t>(hs) + static_cast<uint32_t>(wi) + 4u * static_cast<uint32_t>(t))));
+        }
+        dl_off_prev = dl_off;
+        const int rend = rbase + nrow;
+        if (!gone) lds_store(help_done() + hw, static_cast<uint32_t>(rend));
+    }
 }
 
 }  // namespace rcn

@@ -160,6 +160,7 @@ __device__ unsigned long long g_dbg[8];          // code traceback: clocks of a 
 #endif
 __device__ unsigned long long g_wtb2[4096][8];   // ... boxes left because: tile edge, origin, columns used up, climbed 1-2 box heights, fell below the skew line, climbed more; cells walked
 __device__ unsigned long long g_wtb[4096][8];    // per work item, code traceback: clocks of tile load issue / wait / walk, tiles, box decode / walk / emit, boxes
+__device__ unsigned long long g_whelp[8];           // code waves: lap checks of wave 0, polls spent in them; waits of the code waves, polls spent in them
 __device__ unsigned long long g_wtie[8];            // sink ties, all windows: events, clocks, past the rule, closure sweeps, full DFS
 __device__ unsigned long long g_wlay[4][128][5];   // work items 0-3 of the first launch, per layer: clocks dp, tie, traceback; {tied, tie level, band}; {V, len}
 __device__ unsigned long long g_wclk[4096][8];   // per work item: phase clocks     // per wave: cycles in row bodies, cycles in barriers

@@ -49,6 +49,10 @@ struct KParams {
     // per-slot scratch
     uint8_t* scratch; uint64_t slot_bytes; int32_t ncap, ecap, ring, lmax, hstride;
     int32_t hrows;                // rows of a slot's DP matrix (win_bind); poa_window_kernel2 flags a window whose alignment needs more
+    int32_t lds_extra;            // poa_window_kernel2: bytes of dynamic LDS behind the work area + context (a launch with fewer than eight
+                                  // work-groups per CU asks for more LDS to get there; with >= kHelpLdsBytes of it the banded DP runs with its
+                                  // code wave, poa_band.hpp)
+    int32_t no_help;              // tests / A-B (env RCN_NO_CODE_WAVE): never the code wave
     // outputs
     // outputs, indexed by out_base + work item: consensus bytes at out_cons + out_off[k], capacity out_off[k + 1] - out_off[k]
     // (a consensus that does not fit is flagged kFlagOverflow and redone by the retry pass)
@@ -416,6 +420,8 @@ struct Ctx {
     unsigned int n_banded, n_band_fail;
     unsigned int band_why, band_whyn[8];            // reasons of the redos (bit k of dp2_rows_band's `why`), counted
     int32_t hrows;                                  // KParams::hrows
+    unsigned int n_help;                            // banded alignments done with the code waves
+    int32_t big;                                    // the work-group owns the large LDS ring + mailbox of the code wave (KParams::lds_extra)
 };
 static_assert(sizeof(Ctx) % 4 == 0 && sizeof(Ctx) <= 512, "Ctx must fit its LDS slot");
 constexpr int kCtxBytes = 512;

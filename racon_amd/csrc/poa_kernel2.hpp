@@ -53,10 +53,12 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
     if (t == 0) {
         ctx->scratch = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
         ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride; ctx->hrows = P.hrows;
+        ctx->big = (P.lds_extra >= kHelpLdsBytes && !P.no_help) ? 1 : 0;
         ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
         ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
         ctx->cells_full = 0; ctx->bytes_full = 0; ctx->n_banded = 0; ctx->n_band_fail = 0; ctx->band = 0; ctx->band_fail = 0;
         ctx->band_why = 0; for (int k = 0; k < 8; ++k) ctx->band_whyn[k] = 0;
+        ctx->n_help = 0;
         ctx->dbg_tiles = 0; ctx->dbg_boxes = 0; ctx->dbg_slow = 0;
     }
     for (;;) {
@@ -144,12 +146,23 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             if (bnp) {
                 // exact banded DP (poa_band.hpp); an alignment whose certificate fails is redone on full rows right below
                 const bool coded = P.band != 3;
+                const bool help = coded && bcast0(ctx->big) != 0;            // a CU's LDS to itself: waves 1-3 assemble the move codes
+                if (help) {
+                    if (t < 64) help_prog()[t] = 0u;
+                    if (t < 4) help_done()[t] = 0u;
+                    Block4::sync();
+                }
                 if (wv == 0) {
                     const bool tab = bcast0(ctx->tie_pad[1]) != 0;
-                    if (coded) { if (tab) dp2_rows_band<2, true, true>(); else dp2_rows_band<2, false, true>(); }
+                    if (help) { if (tab) dp2_rows_band<2, true, true, true>(); else dp2_rows_band<2, false, true, true>(); }
+                    else if (coded) { if (tab) dp2_rows_band<2, true, true>(); else dp2_rows_band<2, false, true>(); }
                     else { if (tab) dp2_rows_band<2, true>(); else dp2_rows_band<2, false>(); }
+                } else if (help) {
+                    if (bcast0(ctx->tie_pad[1]) != 0) dp2_band_codes<2, true>(wv - 1); else dp2_band_codes<2, false>(wv - 1);
                 }
                 Block4::sync();
+                if (help && t == 0 && help_done()[3] != 0u && ctx->band_fail == 0) { ctx->band_fail = 1; ctx->n_band_fail += 1; }   // (the code wave gave up)
+                if (help) { if (t == 0 && ctx->band_fail == 0) ctx->n_help += 1; Block4::sync(); }
                 dp_done = bcast0(ctx->band_fail) == 0;
                 if (t == 0) ctx->coded = (dp_done && coded) ? 1 : 0;
                 Block4::sync();
@@ -326,6 +339,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
         atomicAdd(&P.stats[12], ctx->cells_full); atomicAdd(&P.stats[13], ctx->bytes_full);
         atomicAdd(&P.stats[14], static_cast<unsigned long long>(ctx->n_banded)); atomicAdd(&P.stats[15], static_cast<unsigned long long>(ctx->n_band_fail));
         for (int k = 0; k < 8; ++k) if (ctx->band_whyn[k]) atomicAdd(&P.stats[16 + k], static_cast<unsigned long long>(ctx->band_whyn[k]));
+        if (ctx->n_help) atomicAdd(&P.stats[24], static_cast<unsigned long long>(ctx->n_help));
     }
 }
 

@@ -5,6 +5,7 @@
 * the split launch (engine.hip: split_plan): deepest windows on CUs of their own, forced on, forced off, other CU counts;
 * rcn_engine_reserve ahead of the first batch, too small and too large;
 * rcn_engine_export_batch after a streamed batch (device layout is deepest first, the copy is in caller order);
+* the code waves of a window that has a CU to itself (poa_band.hpp), in the deep launch and with every window alone on a CU;
 * Polisher::polish on files: engines created by initialize()'s warm-up thread, chunks in deepest-first order over two
   engines, the Logger-bracketed interval reported through the C ABI -- same FASTA as host layer + oracle.
 """
@@ -191,3 +192,40 @@ def test_noisy_reads_raise_the_capacity_estimates(Engine, oracle):
     assert third <= second <= first, (first, second, third)
     if first > b.n_windows // 50:                       # the estimates were too small: they must have grown
         assert third < first, (first, second, third)
+
+
+def test_code_waves_of_the_deep_launch(Engine, mid, mid_ref, oracle, monkeypatch):
+    """A window with a CU (and its LDS) to itself runs the banded DP with code waves (poa_band.hpp: waves 1-3 assemble the
+    move codes of the chain / fast rows from the large LDS ring): same bytes as without them, in the deep launch of the
+    split and with EVERY window alone on a CU -- ONT-like windows (window shifts, predecessors written under older
+    offsets), noisy backbones, forced failures of the certificate, forced sink-tie levels."""
+    monkeypatch.setenv("RCN_SPLIT", "1")
+    eng = Engine(3, -5, -4, True)
+    assert_same(eng.consensus(mid), mid_ref, "deep launch with code waves")
+    st = eng.stats()
+    assert st["split_deep"] > 0 and st["n_code_wave"] > 20 * st["split_deep"]      # ~30 banded alignments per deep window
+    monkeypatch.setenv("RCN_NO_CODE_WAVE", "1")
+    off = Engine(3, -5, -4, True)
+    assert_same(off.consensus(mid), mid_ref, "deep launch without")
+    assert off.stats()["n_code_wave"] == 0 and off.stats()["n_banded"] == st["n_banded"]
+    monkeypatch.delenv("RCN_NO_CODE_WAVE")
+    # every window alone on a CU: every banded alignment goes through the code waves
+    monkeypatch.setenv("RCN_SPLIT", "0")
+    monkeypatch.setenv("RCN_WG_PER_CU", "1")
+    one = Engine(3, -5, -4, True)
+    assert_same(one.consensus(mid), mid_ref, "one work-group per CU")
+    s1 = one.stats()
+    assert s1["wg_per_cu"] == 1 and s1["n_code_wave"] == s1["n_banded"] == st["n_banded"]
+    for name, b, (m, x, g) in synthetic_sets():
+        ref = oracle.consensus(b, m, x, g, True, 0, simd=True)
+        e = Engine(m, x, g, True)
+        assert_same(e.consensus(b), ref, name)
+        if name.startswith("ont_w500") or name == "noisy_backbone":
+            assert e.stats()["n_code_wave"] == e.stats()["n_banded"] > 0, name
+    for var, val in (("RCN_FORCE_BAND_FAIL", "1"), ("RCN_FORCE_TIE", "2"), ("RCN_FORCE_TIE", "3"), ("RCN_FORCE_SLOW_TB", "1")):
+        monkeypatch.setenv(var, val)
+        sub = mid.select(list(range(0, mid.n_windows, 7)))
+        r = Engine(3, -5, -4, True).consensus(sub)
+        for k, i in enumerate(range(0, mid.n_windows, 7)):
+            assert r.consensus[k] == mid_ref.consensus[i], (var, val, i)
+        monkeypatch.delenv(var)
