@@ -193,8 +193,12 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                     default: dp2_rows<4, 4>(); break;
                 }
             }
+#ifdef RCN_PROF_WIN
+            const unsigned long long dp0__ = ph[2];
+#endif
             RCN_PHASE2(2);
 #ifdef RCN_PROF_WIN
+            const unsigned long long dpc__ = ph[2] - dp0__;
             const long long tl0__ = clock64();
             const int tl_tied__ = bcast0(ctx->tied), tl_bf__ = bcast0(ctx->band_fail) | (bcast0(ctx->coded) ? 0 : 2);
             int tl_lvl__ = 0, tl_route__ = 0;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             if (bcast0(ctx->coded)) phase_traceback_code(); else phase_traceback3();
 #ifdef RCN_PROF_WIN
             if (t == 0 && wi < 4 && P.work_base == 0 && jl < 128) {
-                g_wlay[wi][jl][0] = static_cast<unsigned long long>(tl0__ - tck);       // (tck: end of the DP)
+                g_wlay[wi][jl][0] = dpc__;
                 g_wlay[wi][jl][1] = static_cast<unsigned long long>(tl1__ - tl0__); g_wlay[wi][jl][2] = static_cast<unsigned long long>(clock64() - tl1__);
                 g_wlay[wi][jl][3] = (static_cast<unsigned long long>(tl_tied__) << 16) | ((tl_lvl__ + 16 * tl_route__) << 8) | tl_bf__;
                 g_wlay[wi][jl][4] = (static_cast<unsigned long long>(bcast0(ctx->V)) << 32) | static_cast<unsigned int>(len);
