@@ -10,7 +10,7 @@
 //   2. stable radix sort of the kept pairs by window id (hipCUB): inside a window the layers keep overlap order, which
 //      is the order the serial loop calls add_layer in (the engine's std::sort emulation depends on it)
 //   3. exclusive scans -> win_seq_off, seq_off; k_seq_table writes one source descriptor per sequence of the batch
-//   4. k_gather       : one wave per sequence copies (or reverse-complements) bases and qualities into the packed batch
+//   4. k_gather       : sixteen lanes per sequence copy (or reverse-complement) bases and qualities into the packed batch
 // Everything is integer / byte work bounded by HBM traffic; the only floating point is the reference's own
 // `q1 - q0 < 0.02 * w` and `mean quality < threshold` comparisons, evaluated in double exactly as there.
 #pragma once
@@ -135,33 +135,44 @@ struct GatherParams {
     uint8_t* bases; uint8_t* quals; uint64_t n_seqs;
 };
 
-// one wave per sequence, 256 consecutive bytes per step: four bytes per lane through (unaligned) dword accesses, the tail
-// byte by byte.  Reverse strand: base k of the layer is the complement of base (rlen - 1 - (q0 + k)) of the read, its
-// quality the quality of that base (Sequence::create_reverse_complement).
+// Sixteen lanes per sequence, 512 consecutive bytes per step: two (unaligned) 16-byte accesses per lane and array, the tail
+// byte by byte -- a layer of a w = 500 window is one step, a wave has four layers' loads in flight at once and a 256-thread
+// work-group sixteen (one wave per sequence and a dword per lane moved 2.5-2.7 TB/s, half a wave and 16 bytes per lane
+// 3.5: the 300 000 short copies of a batch are latency, not bandwidth).  Reverse strand: base k of the layer is the complement of base (rlen - 1 - (q0 + k))
+// of the read, its quality the quality of that base (Sequence::create_reverse_complement).
 __device__ __forceinline__ uint32_t comp_byte(uint32_t b) { return b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'C' ? 'G' : b == 'G' ? 'C' : b; }
+__device__ __forceinline__ uint32_t comp_dword_reversed(uint32_t v) {           // bytes reversed, each complemented
+    v = __builtin_bswap32(v);
+    return comp_byte(v & 255) | (comp_byte((v >> 8) & 255) << 8) | (comp_byte((v >> 16) & 255) << 16) | (comp_byte(v >> 24) << 24);
+}
 
+constexpr int kGatherLanes = 16;          // lanes per sequence: 32 bytes per lane and step (two 16-byte accesses per array)
 __global__ __launch_bounds__(256) void k_gather(GatherParams G) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t s = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int hl = threadIdx.x & (kGatherLanes - 1);
+    const uint64_t s = static_cast<uint64_t>(blockIdx.x) * (256 / kGatherLanes) + threadIdx.x / kGatherLanes;
     if (s >= G.n_seqs) return;
     const uint64_t dst = G.seq_off[s], len = G.seq_off[s + 1] - dst;
     const uint32_t id = G.src_id[s], pos = G.src_pos[s], fl = G.src_flags[s];
     const uint64_t a = G.read_off[id], rlen = G.read_off[id + 1] - a;
     const bool rev = (fl & 1) != 0, real_q = !(fl & 2) && G.has_qual[s] != 0;
-    const uint64_t len4 = len & ~3ull;
-    for (uint64_t k = 4ull * lane; k < len4; k += 256) {
-        // forward: bytes src .. src + 3; reverse: the four bytes ending at the mirrored position, reversed
-        const uint64_t src = a + (rev ? rlen - 4 - (pos + k) : pos + k);
-        uint32_t vb = *reinterpret_cast<const uint32_t*>(G.read_bases + src);
-        uint32_t vq = real_q ? *reinterpret_cast<const uint32_t*>(G.read_quals + src) : 0x21212121u;
-        if (rev) {
-            vb = __builtin_bswap32(vb); vq = __builtin_bswap32(vq);
-            vb = comp_byte(vb & 255) | (comp_byte((vb >> 8) & 255) << 8) | (comp_byte((vb >> 16) & 255) << 16) | (comp_byte(vb >> 24) << 24);
-        }
-        *reinterpret_cast<uint32_t*>(G.bases + dst + k) = vb;
-        *reinterpret_cast<uint32_t*>(G.quals + dst + k) = vq;
+    const uint64_t len16 = len & ~15ull;
+    const uint4 noq = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
+    auto rc16 = [](uint4 v) { return make_uint4(comp_dword_reversed(v.w), comp_dword_reversed(v.z), comp_dword_reversed(v.y), comp_dword_reversed(v.x)); };
+    auto rv16 = [](uint4 v) { return make_uint4(__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x)); };
+    for (uint64_t k = 32ull * hl; k < len16; k += 32ull * kGatherLanes) {
+        // forward: bytes src .. src + 15; reverse: the sixteen bytes ending at the mirrored position, reversed
+        const bool two = k + 16 < len16;
+        const uint64_t k1 = two ? k + 16 : k;
+        const uint64_t s0 = a + (rev ? rlen - 16 - (pos + k) : pos + k), s1 = a + (rev ? rlen - 16 - (pos + k1) : pos + k1);
+        uint4 b0 = *reinterpret_cast<const uint4*>(G.read_bases + s0), b1 = *reinterpret_cast<const uint4*>(G.read_bases + s1);
+        uint4 q0 = noq, q1 = noq;
+        if (real_q) { q0 = *reinterpret_cast<const uint4*>(G.read_quals + s0); q1 = *reinterpret_cast<const uint4*>(G.read_quals + s1); }
+        if (rev) { b0 = rc16(b0); b1 = rc16(b1); q0 = rv16(q0); q1 = rv16(q1); }
+        *reinterpret_cast<uint4*>(G.bases + dst + k) = b0;
+        *reinterpret_cast<uint4*>(G.quals + dst + k) = q0;
+        if (two) { *reinterpret_cast<uint4*>(G.bases + dst + k1) = b1; *reinterpret_cast<uint4*>(G.quals + dst + k1) = q1; }
     }
-    for (uint64_t k = len4 + lane; k < len; k += 64) {
+    for (uint64_t k = len16 + hl; k < len; k += kGatherLanes) {
         const uint64_t src = a + (rev ? rlen - 1 - (pos + k) : pos + k);
         uint32_t b8 = G.read_bases[src];
         if (rev) b8 = comp_byte(b8);
@@ -528,7 +539,7 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     G.seq_off = e->d_seq_off.as<uint64_t>(); G.src_id = T.src_id; G.src_pos = T.src_pos; G.src_flags = T.src_flags; G.has_qual = T.has_qual;
     G.bases = e->d_bases.as<uint8_t>(); G.quals = e->d_quals.as<uint8_t>(); G.n_seqs = ns;
     HIP_TRY(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(k_gather, dim3((ns + 3) / 4), dim3(256), 0, st, G);
+    hipLaunchKernelGGL(k_gather, dim3((ns + 256 / kGatherLanes - 1) / (256 / kGatherLanes)), dim3(256), 0, st, G);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], st));
 
