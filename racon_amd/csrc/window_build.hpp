@@ -280,20 +280,36 @@ __global__ __launch_bounds__(256) void k_cigar_breaking_points(CigarParams C) {
 }
 
 // The same walk with one WAVE per overlap: 64 bytes of CIGAR text per step, no divergence.  Lanes holding an operation
-// character parse the number in front of it (the digits sit in the lanes before it, or in the carry of the previous
-// step), two wave scans turn the operation lengths into target / query start positions, and every match run writes its
-// candidates for "first match column" (min) and "last + 1" (max) of the windows it covers with 64-bit atomics on packed
-// (target << 32 | query) keys -- inside one overlap both coordinates grow together, so the packed order is the walk
-// order.  A window counts only once the walk has passed its end (the reference pushes a pair when it closes a window).
+// character get the number in front of it from one weighted prefix sum over the digits (which sit in the lanes before it,
+// or in the carry of the previous step), prefix sums turn the operation lengths into target / query start positions (all
+// sums in six DPP steps each: the first version walked the digits with ds_bpermute and scanned 64-bit values with
+// __shfl_up, 1.09 ms for 24 000 overlaps), and every match run writes its
+// "first match column" and "last + 1" of the windows it covers as packed (target << 32 | query) keys -- inside one overlap
+// both coordinates grow together, so the first run that reaches a window holds its first column and the last one its last.  A window counts only once the walk has passed its end (the reference pushes a pair when it closes a window).
 struct CigarWaveParams {
     CigarParams c;
     unsigned long long* first_key;                // [slots] initialised to ~0
     unsigned long long* last_key;                 // [slots] initialised to 0
 };
 
+// wave-wide inclusive sum in six DPP steps (lanes without a source add 0)
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_cigar_breaking_points_wave(CigarWaveParams P) {
     const CigarParams& C = P.c;
     const int lane = threadIdx.x & 63;
+    // 10^k mod 2^32, k = 0 .. 64: a number is the sum of its digits times these (the reference parses into uint32_t, n = n * 10 + d)
+    __shared__ uint32_t p10[65];
+    if (threadIdx.x < 65) { uint32_t v = 1; for (unsigned k = 0; k < threadIdx.x; ++k) v *= 10u; p10[threadIdx.x] = v; }
+    __syncthreads();
     const uint64_t o = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (o >= C.n_overlaps) return;
     const uint64_t W = C.W;
@@ -303,58 +319,78 @@ __global__ __launch_bounds__(256) void k_cigar_breaking_points_wave(CigarWavePar
     auto end_of = [&](uint64_t k) -> uint64_t { return k + 1 < n_slots ? (wb + 1 + k) * W - 1 : t_end - 1; };
     const uint64_t a = C.cigar_off[o], z = C.cigar_off[o + 1];
     uint64_t t_run = t_begin, q_run = C.q_start[o];                    // next target / query position to be consumed
-    uint64_t carry = 0;                                               // value of the digits pending from the previous step
+    uint32_t carry = 0;                                               // value of the digits pending from the previous step
+    long long kdone = -1;                                             // last window a match run of the previous steps reached
     const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t c_next = a + lane < z ? C.cigar[a + lane] : '0';           // (the next step's text is in flight while this one is worked on)
     for (uint64_t p0 = a; p0 < z; p0 += 64) {
-        const uint64_t p = p0 + lane;
-        const uint32_t c = p < z ? C.cigar[p] : '0';                  // padding = digits that never meet an operation
+        const uint32_t c = c_next;                                    // padding = digits that never meet an operation
+        c_next = p0 + 64 + lane < z ? C.cigar[p0 + 64 + lane] : '0';
         const bool is_digit = c >= '0' && c <= '9';
         const unsigned long long opmask = __ballot(!is_digit);
-        // the number in front of this lane's operation: lanes (prev operation, lane) exclusive
+        // Every digit weighs 10^(digits between it and the operation its number belongs to) -- trailing digits, whose
+        // operation is in the next step: up to the end of this one -- and one wave-wide sum gives every operation its
+        // number as a difference of two prefix sums, all mod 2^32.
+        const unsigned long long above = lane < 63 ? (opmask >> (lane + 1)) : 0ull;
+        const int nxt = above ? lane + 1 + __builtin_ctzll(above) : 64;
+        const uint32_t wgt = is_digit ? (c - '0') * p10[nxt - 1 - lane] : 0u;
+        const uint32_t S = wave_incl_add(wgt);
         const unsigned long long before = opmask & below;
-        const int first_digit = before ? 64 - __builtin_clzll(before) : 0;   // lane after the previous operation
-        const int ndig = lane - first_digit;
-        unsigned long long n = 0;
-        const int maxdig = __reduce_max_sync(~0ull, is_digit ? 0 : ndig);
-        for (int d = 0; d < maxdig; ++d) {
-            const uint32_t dc = __shfl(c, (first_digit + d) & 63);
-            if (!is_digit && d < ndig) n = n * 10 + (dc - '0');
+        const int prev_op = before ? 63 - __builtin_clzll(before) : -1;
+        const uint32_t Sprev = static_cast<uint32_t>(__shfl(static_cast<int>(S), prev_op < 0 ? 0 : prev_op));
+        uint32_t n = 0;
+        if (!is_digit) {
+            n = S - (prev_op < 0 ? 0u : Sprev);
+            if (prev_op < 0) n += carry * p10[lane];                   // the number started in the previous step(s)
         }
-        if (!is_digit && first_digit == 0 && carry) {                 // the number started in the previous step
-            unsigned long long scale = 1;
-            for (int d = 0; d < ndig; ++d) scale *= 10;
-            n += carry * scale;
+        {   // carry out: the digits behind the last operation of this step (everything, if there is none)
+            const uint32_t S63 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(S), 63));
+            if (opmask) carry = S63 - static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(S), 63 - __builtin_clzll(opmask)));
+            else carry = carry * p10[64] + S63;
         }
-        // carry out: the digits behind the last operation of this step (everything, if there is none)
-        {
-            const int tail0 = opmask ? 64 - __builtin_clzll(opmask) : 0;
-            unsigned long long v = opmask ? 0 : carry;
-            for (int d = tail0; d < 64 && p0 + d < z; ++d) v = v * 10 + (__shfl(c, d) - '0');
-            carry = v;
-        }
-        n = static_cast<uint32_t>(n);                                  // the reference parses into uint32
         const bool isM = !is_digit && (c == 'M' || c == '=' || c == 'X');
-        const unsigned long long dt = (isM || (!is_digit && (c == 'D' || c == 'N'))) ? n : 0;
-        const unsigned long long dq = (isM || (!is_digit && c == 'I')) ? n : 0;
-        unsigned long long st = dt, sq = dq;                          // inclusive scans
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long vt = __shfl_up(st, d), vq = __shfl_up(sq, d);
-            if (lane >= d) { st += vt; sq += vq; }
-        }
+        const uint32_t dt = (isM || (!is_digit && (c == 'D' || c == 'N'))) ? n : 0u;
+        const uint32_t dq = (isM || (!is_digit && c == 'I')) ? n : 0u;
+        // inclusive 64-bit sums from 16-bit halves (64 x 65535 fits a dword)
+        const unsigned long long st = wave_incl_add(dt & 0xffffu) + (static_cast<unsigned long long>(wave_incl_add(dt >> 16)) << 16);
+        const unsigned long long sq = wave_incl_add(dq & 0xffffu) + (static_cast<unsigned long long>(wave_incl_add(dq >> 16)) << 16);
         const uint64_t ts = t_run + (st - dt), qs = q_run + (sq - dq);
+        // This lane's match run covers the windows kf .. kl of the overlap.  Positions only grow along the walk, so a
+        // window's first match column comes from the FIRST run that reaches it and its last one from the LAST: a run
+        // writes "first" only for the windows no earlier run (of this step, or of the steps before: kdone) reached,
+        // and "last" only for those the next run of this step does not reach as well -- plain stores, later steps
+        // overwrite "last" (the slots belong to this overlap alone; one atomic pair per run and window was 34 M
+        // 64-bit atomics for 24 000 overlaps, and their rate at the L2 was the kernel's time).
+        const uint64_t te = ts + n;                                   // match columns ts .. te - 1
+        long long kf = 0, kl = -1;
         if (isM && n > 0) {
-            const uint64_t te = ts + n;                               // match columns ts .. te - 1
-            for (uint64_t k = ts / W - wb; k < n_slots; ++k) {
-                const uint64_t wstart = k == 0 ? t_begin : (wb + k) * W, wend = end_of(k);
-                if (wstart >= te) break;
+            // (window numbers by 32-bit division where the positions allow it: a 64-bit division is ~100 instructions)
+            uint64_t wf, wl;
+            if ((te >> 32) == 0) { wf = static_cast<uint32_t>(ts) / static_cast<uint32_t>(W); wl = static_cast<uint32_t>(te - 1) / static_cast<uint32_t>(W); }
+            else { wf = ts / W; wl = (te - 1) / W; }
+            if (wf - wb < n_slots && !(wf - wb == n_slots - 1 && ts >= t_end)) {
+                kf = static_cast<long long>(wf - wb);
+                kl = static_cast<long long>(wl - wb);
+                if (kl > static_cast<long long>(n_slots) - 1) kl = static_cast<long long>(n_slots) - 1;
+            }
+        }
+        const unsigned long long runs = __ballot(kl >= kf);
+        const unsigned long long rb = runs & below, ra = lane < 63 ? (runs >> (lane + 1)) : 0ull;
+        const long long kl_prev = __shfl(kl, rb ? 63 - __builtin_clzll(rb) : 0), kf_next = __shfl(kf, ra ? lane + 1 + __builtin_ctzll(ra) : 0);
+        if (kl >= kf) {
+            const long long reached = rb ? kl_prev : kdone;           // windows up to here have their first match column
+            const long long lf = kf > reached + 1 ? kf : reached + 1; // "first": windows lf .. kl
+            const long long ll = (ra && kf_next - 1 < kl) ? kf_next - 1 : kl;     // "last": windows kf .. ll
+            for (long long k = kf; k <= kl; ++k) {
+                const uint64_t wstart = k == 0 ? t_begin : (wb + k) * W, wend = end_of(static_cast<uint64_t>(k));
                 const uint64_t f = ts > wstart ? ts : wstart, l = te < wend + 1 ? te : wend + 1;
                 if (f < l) {
-                    atomicMin(&P.first_key[slot0 + k], (f << 32) | (qs + (f - ts)));
-                    atomicMax(&P.last_key[slot0 + k], (l << 32) | (qs + (l - ts)));
+                    if (k >= lf) P.first_key[slot0 + k] = (f << 32) | (qs + (f - ts));
+                    if (k <= ll) P.last_key[slot0 + k] = (l << 32) | (qs + (l - ts));
                 }
             }
         }
+        if (runs) kdone = __shfl(kl, 63 - __builtin_clzll(runs));
         t_run += __shfl(st, 63); q_run += __shfl(sq, 63);
     }
     __threadfence();
