@@ -387,17 +387,7 @@ __device__ __noinline__ void dp2_rows_band() {
             if ((meta & ((1 << 13) | 256)) == 256) row_cls = 7;
 #endif
             meta_next = __builtin_amdgcn_readlane(dl_meta, i & 63);
-            if (__builtin_expect((meta & (1 << 12)) != 0, 0)) {
-                // special row: the window may move here (all on-chip state is re-based, the profile of this row redone)
-                const int new_off = __builtin_amdgcn_readlane(dl_off, k);
-#ifdef RCN_PROF_ROWS
-                if (new_off != cold_get(&cold->woff)) row_cls = 6;
-#endif
-                if (new_off != cold_get(&cold->woff)) { shift_to(i, new_off); profile_now(meta); }
-            }
             uint32_t P[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) P[q] = Pn[q];
 
             uint32_t M[NP];
             uint32_t Aq[NP];                        // CODE: per cell, the first predecessor (in-edge order) that attains M
@@ -413,7 +403,147 @@ __device__ __noinline__ void dp2_rows_band() {
                     Aq[q] = pk_mad(gt, pk_sub(Q, Aq[q]), Aq[q]);
                 }
             };
-            if (__builtin_expect_with_probability((meta & (1 << 13)) != 0, 1, 0.98)) {
+            // ONE test for the ordinary fast row (98 % of the rows: bit 13 set, bit 12 clear): a branch, taken or not, is what
+            // a lone wave pays most for (a not-taken one ~15 clocks, a taken one ~70; plain scalar instructions next to
+            // nothing: profiles/r03/r_row_sections.txt), so the special rows and the other classes share the first one and
+            // sort themselves out behind it
+            if (__builtin_expect((meta & ((1 << 13) | (1 << 12))) != (1 << 13), 0)) {
+                if (meta & (1 << 12)) {
+                    // special row: the window may move here (all on-chip state is re-based, the profile of this row redone)
+                    const int new_off = __builtin_amdgcn_readlane(dl_off, k);
+#ifdef RCN_PROF_ROWS
+                    if (new_off != cold_get(&cold->woff)) row_cls = 6;
+#endif
+                    if (new_off != cold_get(&cold->woff)) { shift_to(i, new_off); profile_now(meta); }
+                }
+                if (!(meta & (1 << 13))) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) P[q] = Pn[q];
+                    if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
+                        // ---- medium row whose predecessors all share this row's window: LDS ring, reads in flight together ----
+                        const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
+                        const int npf = (meta >> 9) & 7;
+                        uint32_t hp[4][NP];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int d = (dd >> (4 * (e < npf ? e : 0))) & 15;
+                            int sp = slot - d; if (sp < 0) sp += K;
+                            const uint32_t* src = ring + (sp * NTH + t) * NP;
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) hp[e][q] = src[q];
+                        }
+                        if (CODE) {
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) M[q] = hp[0][q];
+#pragma unroll
+                            for (int e = 1; e < 4; ++e) {           // unused slots repeat predecessor 0: never strictly greater
+                                arg_step(hp[e], e);
+#pragma unroll
+                                for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[e][q]);
+                            }
+                        } else {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
+                        }
+                        pred_rows += npf;
+                    } else {
+                        // ---- general row: any number of predecessors from the LDS ring, each in the coordinates it was
+                        //      written in (window offsets of the last two shifts are kept) ----
+                        const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
+                        const int er = __builtin_amdgcn_readlane(dl_er, k);
+                        const int woff = cold_get(&cold->woff), s_row1 = cold_get(&cold->s_row1), s_row2 = cold_get(&cold->s_row2), s_row3 = cold_get(&cold->s_row3);
+                        const int off1 = cold_get(&cold->off1), off2 = cold_get(&cold->off2);
+                        const int np = (meta >> 9) & 7;
+                        bool first = true;
+                        int nq = 0;                          // ordinal of the predecessor being combined (= its index in the descriptor)
+                        auto combine = [&](int p) {
+                            uint32_t hp[NP];
+                            if (p == 0) {
+                                if (woff > 0) bfail |= 1;                     // (c)
+#pragma unroll
+                                for (int q = 0; q < NP; ++q) hp[q] = 0u;
+                            } else if (i - p < K - 1) {
+                                int sp = slot - (i - p); if (sp < 0) sp += K;
+                                int delta = 0;
+                                if (p < s_row1) {
+                                    if (p >= s_row2) delta = woff - off1;
+                                    else if (p >= s_row3) delta = woff - off2;
+                                    else { bfail |= 4; }
+                                }
+                                if (delta > 8 * kBandG) { bfail |= 16; delta = 0; }
+                                const int dlp = delta / LPC;
+                                if (dlp == 0) {
+                                    const uint32_t* src = ring + (sp * NTH + t) * NP;
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) hp[q] = src[q];
+                                } else {
+                                    // (b) for a ring row: its dlp leftmost lanes fall off
+                                    const uint32_t* old = ring + (sp * NTH + t) * NP;
+                                    const uint32_t dthr = pack2(mg * delta, mg * delta);
+                                    uint32_t ev = pack2(-32768, -32768);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) {
+                                        uint32_t ov = old[q];
+                                        asm volatile("" : "+v"(ov));          // (loaded by every lane: no exec-masked region in the row loop)
+                                        ev = pk_max(ev, pk_subs(ov, pk_sub(thrv[q], dthr)));
+                                    }
+                                    {
+                                        uint32_t cand = pk_max(emaxV, ev);
+                                        asm volatile("" : "+v"(cand));         // computed by every lane, then selected: no exec-masked region
+                                        emaxV = lane < dlp ? cand : emaxV;
+                                    }
+                                    const uint32_t* src = ring + (sp * NTH + min(t + dlp, 63)) * NP;
+                                    const bool keep = t + dlp < 64;
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) { uint32_t v = src[q]; asm volatile("" : "+v"(v)); hp[q] = keep ? v : NEGP; }
+                                }
+                            } else {
+                                bfail |= 2;                                    // (d)
+#pragma unroll
+                                for (int q = 0; q < NP; ++q) hp[q] = NEGP;
+                            }
+                            if (first) {
+#pragma unroll
+                                for (int q = 0; q < NP; ++q) M[q] = hp[q];
+                                first = false;
+                            } else {
+                                if (CODE) arg_step(hp, nq);
+#pragma unroll
+                                for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[q]);
+                            }
+                            ++pred_rows; ++nq;
+                        };
+                        combine(p0);
+                        if (np > 1) {
+                            const int q1 = __builtin_amdgcn_readlane(dl_p1, k), q2 = __builtin_amdgcn_readlane(dl_p2, k);
+                            const int q3 = __builtin_amdgcn_readlane(dl_p3, k), q4 = __builtin_amdgcn_readlane(dl_p4, k);
+                            const int q5 = __builtin_amdgcn_readlane(dl_p5, k);
+#pragma unroll 1
+                            for (int q = 1; q < np; ++q) combine(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
+                        }
+                        for (int e = er; e >= 0; e = e_nin[e]) {          // more than six in-edges: the rest of the list
+                            const int tl = e_tail[e];
+                            if (sub && !inc[tl]) continue;
+                            combine(nr[tl] + 1);
+                        }
+                        if (CODE && nq > 8) bfail |= 8;                   // move codes name predecessors 0..7 (three bits)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
+                    }
+
+                    {
+#define RCN_TAIL_MULTI 2
+#define RCN_TAIL_SINK 1
+#include "poa_band_row_tail.inc"
+#undef RCN_TAIL_MULTI
+#undef RCN_TAIL_SINK
+                    }
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) P[q] = Pn[q];
+            {
                 // ---- chain and fast rows (98 % of the rows): every predecessor is in the register window (always in current
                 //      coordinates).  The first predecessor is one indexed register read whatever its distance (a chain row
                 //      has distance 1), a second one follows in line, only a third / fourth loop; rows with one predecessor
@@ -466,125 +596,6 @@ __device__ __noinline__ void dp2_rows_band() {
 #undef RCN_TAIL_SINK
                 }
                 continue;
-            }
-            if ((meta & ((1 << 14) | (1 << 12))) == (1 << 14)) {
-                // ---- medium row whose predecessors all share this row's window: LDS ring, reads in flight together ----
-                const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
-                const int npf = (meta >> 9) & 7;
-                uint32_t hp[4][NP];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int d = (dd >> (4 * (e < npf ? e : 0))) & 15;
-                    int sp = slot - d; if (sp < 0) sp += K;
-                    const uint32_t* src = ring + (sp * NTH + t) * NP;
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) hp[e][q] = src[q];
-                }
-                if (CODE) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) M[q] = hp[0][q];
-#pragma unroll
-                    for (int e = 1; e < 4; ++e) {           // unused slots repeat predecessor 0: never strictly greater
-                        arg_step(hp[e], e);
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[e][q]);
-                    }
-                } else {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) M[q] = pk_max(pk_max(hp[0][q], hp[1][q]), pk_max(hp[2][q], hp[3][q]));
-                }
-                pred_rows += npf;
-            } else {
-                // ---- general row: any number of predecessors from the LDS ring, each in the coordinates it was
-                //      written in (window offsets of the last two shifts are kept) ----
-                const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
-                const int er = __builtin_amdgcn_readlane(dl_er, k);
-                const int woff = cold_get(&cold->woff), s_row1 = cold_get(&cold->s_row1), s_row2 = cold_get(&cold->s_row2), s_row3 = cold_get(&cold->s_row3);
-                const int off1 = cold_get(&cold->off1), off2 = cold_get(&cold->off2);
-                const int np = (meta >> 9) & 7;
-                bool first = true;
-                int nq = 0;                          // ordinal of the predecessor being combined (= its index in the descriptor)
-                auto combine = [&](int p) {
-                    uint32_t hp[NP];
-                    if (p == 0) {
-                        if (woff > 0) bfail |= 1;                     // (c)
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) hp[q] = 0u;
-                    } else if (i - p < K - 1) {
-                        int sp = slot - (i - p); if (sp < 0) sp += K;
-                        int delta = 0;
-                        if (p < s_row1) {
-                            if (p >= s_row2) delta = woff - off1;
-                            else if (p >= s_row3) delta = woff - off2;
-                            else { bfail |= 4; }
-                        }
-                        if (delta > 8 * kBandG) { bfail |= 16; delta = 0; }
-                        const int dlp = delta / LPC;
-                        if (dlp == 0) {
-                            const uint32_t* src = ring + (sp * NTH + t) * NP;
-#pragma unroll
-                            for (int q = 0; q < NP; ++q) hp[q] = src[q];
-                        } else {
-                            // (b) for a ring row: its dlp leftmost lanes fall off
-                            const uint32_t* old = ring + (sp * NTH + t) * NP;
-                            const uint32_t dthr = pack2(mg * delta, mg * delta);
-                            uint32_t ev = pack2(-32768, -32768);
-#pragma unroll
-                            for (int q = 0; q < NP; ++q) {
-                                uint32_t ov = old[q];
-                                asm volatile("" : "+v"(ov));          // (loaded by every lane: no exec-masked region in the row loop)
-                                ev = pk_max(ev, pk_subs(ov, pk_sub(thrv[q], dthr)));
-                            }
-                            {
-                                uint32_t cand = pk_max(emaxV, ev);
-                                asm volatile("" : "+v"(cand));         // computed by every lane, then selected: no exec-masked region
-                                emaxV = lane < dlp ? cand : emaxV;
-                            }
-                            const uint32_t* src = ring + (sp * NTH + min(t + dlp, 63)) * NP;
-                            const bool keep = t + dlp < 64;
-#pragma unroll
-                            for (int q = 0; q < NP; ++q) { uint32_t v = src[q]; asm volatile("" : "+v"(v)); hp[q] = keep ? v : NEGP; }
-                        }
-                    } else {
-                        bfail |= 2;                                    // (d)
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) hp[q] = NEGP;
-                    }
-                    if (first) {
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) M[q] = hp[q];
-                        first = false;
-                    } else {
-                        if (CODE) arg_step(hp, nq);
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], hp[q]);
-                    }
-                    ++pred_rows; ++nq;
-                };
-                combine(p0);
-                if (np > 1) {
-                    const int q1 = __builtin_amdgcn_readlane(dl_p1, k), q2 = __builtin_amdgcn_readlane(dl_p2, k);
-                    const int q3 = __builtin_amdgcn_readlane(dl_p3, k), q4 = __builtin_amdgcn_readlane(dl_p4, k);
-                    const int q5 = __builtin_amdgcn_readlane(dl_p5, k);
-#pragma unroll 1
-                    for (int q = 1; q < np; ++q) combine(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
-                }
-                for (int e = er; e >= 0; e = e_nin[e]) {          // more than six in-edges: the rest of the list
-                    const int tl = e_tail[e];
-                    if (sub && !inc[tl]) continue;
-                    combine(nr[tl] + 1);
-                }
-                if (CODE && nq > 8) bfail |= 8;                   // move codes name predecessors 0..7 (three bits)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
-            }
-
-            {
-#define RCN_TAIL_MULTI 2
-#define RCN_TAIL_SINK 1
-#include "poa_band_row_tail.inc"
-#undef RCN_TAIL_MULTI
-#undef RCN_TAIL_SINK
             }
         }
     }
