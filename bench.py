@@ -322,7 +322,7 @@ def main():
                        "windows_per_gpu": batch.n_windows, "parallelism": "windows sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "poa_window_kernel2", "step_kernel_ms": step_s * 1e3, "avg_launch_ms": sum(per_launch_ms) / len(per_launch_ms),
+                         "kernel": "poa_window_kernel2" + (" + poa_window_kernel2_deep (the instance for the deep launch)" if st["split_deep"] else ""), "step_kernel_ms": step_s * 1e3, "avg_launch_ms": sum(per_launch_ms) / len(per_launch_ms),
                          "launches_per_step": len(per_launch_ms), "launch_ms": per_launch_ms,
                          "split_launch": None if not st["split_deep"] else
                              {"deep_windows": st["split_deep"], "deep_cus": st["split_cus"], "deep_work_groups_per_cu": st["split_deep_per_cu"],

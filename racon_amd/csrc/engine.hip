@@ -411,7 +411,10 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] pass of %u windows on %u slots, %u work-groups per CU (deepest window %llu bases, all %llu)\n", L.n_work, L.slots,
                                      L.c.fast ? per_cu : 8u, (unsigned long long)e->t_max, (unsigned long long)e->t_sum);
     if (L.c.fast) e->stats.wg_per_cu = per_cu;
-    if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(per_cu), L.stream, P);
+    // one work-group per CU with the CU's whole LDS: the instance of the kernel that runs the banded DP with code waves
+    const bool deep_kernel = L.c.fast && P.lds_extra >= rcn::kHelpLdsBytes && !P.no_help;
+    if (deep_kernel) hipLaunchKernelGGL(rcn::poa_window_kernel2_deep, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(per_cu), L.stream, P);
+    else if (L.c.fast) hipLaunchKernelGGL(rcn::poa_window_kernel2, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(per_cu), L.stream, P);
     else hipLaunchKernelGGL(rcn::poa_window_kernel, dim3(L.slots), dim3(64), rcn::kLdsBytes + rcn::kCtxBytes, L.stream, P);
     HIP_TRY(hipGetLastError());
     return RCN_OK;
@@ -608,6 +611,7 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
         }
         // fewer than eight work-groups per CU are enforced through the LDS request (lds_bytes_for): up to the whole LDS
         e->lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        e->lds_optin = e->lds_optin && hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2_deep), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
     }
     int rc = e->d_ctr.reserve(kCtrBytes);

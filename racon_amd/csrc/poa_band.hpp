@@ -135,7 +135,7 @@ __device__ unsigned long long g_rowprof[256][16];
 // compares them.  Rows with more than EIGHT in-edges (three bits name a predecessor) are left to the score-matrix path
 // (band_fail); the seventh and eighth are not in the row descriptor, the traceback finds them on the in-edge list.
 template <int NP, bool TAB, bool CODE = false, bool HELP = false>
-__device__ __noinline__ void dp2_rows_band() {
+__device__ __forceinline__ void dp2_rows_band_body() {
     static_assert(!CODE || NP == 2, "move codes: four cells per lane -> one dword per lane and row");
     static_assert(!HELP || CODE, "the code wave assembles move codes");
     constexpr int NTH = 64, WB = 128 * NP, LPC = 2 * NP;       // window columns, columns per lane
@@ -635,6 +635,14 @@ __device__ __noinline__ void dp2_rows_band() {
     }
     Wave0Of4::sync();
 }
+
+// The instances as functions of their own.  Those with code waves (HELP) only exist in the kernel instance that has a CU to
+// itself (poa_window_kernel2_deep, compiled in a translation unit of its own -- engine_deep.hip -- at two waves per SIMD:
+// none of its functions is held to the 64 VGPRs that eight work-groups per CU leave a wave).
+template <int NP, bool TAB, bool CODE = false>
+__device__ __noinline__ void dp2_rows_band() { dp2_rows_band_body<NP, TAB, CODE, false>(); }
+template <bool TAB>
+__device__ __noinline__ void dp2_rows_band_help() { dp2_rows_band_body<2, TAB, true, true>(); }
 
 // ---- a code wave (waves 1-3 of the work-group, next to dp2_rows_band<NP, TAB, true, true> on wave 0) ----
 // For every chain / fast row, in row order and as soon as wave 0 has counted it: the row and its predecessor rows from the

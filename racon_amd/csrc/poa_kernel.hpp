@@ -705,6 +705,7 @@ __device__ __noinline__ void phase_consensus(uint8_t* out_in, uint64_t out_cap, 
     S::sync();
 }
 
+#ifndef RCN_DEEP_TU
 __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
     const int lane = threadIdx.x;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub, desc, dp, traceback, add, merge, consensus, other
@@ -803,5 +804,6 @@ __global__ __launch_bounds__(64, 2) void poa_window_kernel(KParams P) {
         atomicAdd(&P.stats[12], ctx->cells_full); atomicAdd(&P.stats[13], ctx->bytes_full);
     }
 }
+#endif  // RCN_DEEP_TU
 
 }  // namespace rcn

@@ -44,7 +44,11 @@
 
 namespace rcn {
 
-__global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
+// The body of the kernel.  DEEP: the instance for work-groups that have a CU and its LDS to themselves (the deep launch of
+// engine.hip's split) -- the only one that runs the banded DP with code waves, so that those functions have one caller,
+// launched at one work-group per CU, and are not held to the 64 VGPRs of eight work-groups per CU.
+template <bool DEEP>
+__device__ __forceinline__ void poa_window_body(const KParams& P) {
     const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sub, desc, dp, traceback, add, merge, consensus, other
     long long tck = clock64();
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
     if (t == 0) {
         ctx->scratch = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
         ctx->ncap = P.ncap; ctx->ecap = P.ecap; ctx->ring = P.ring; ctx->lmax = P.lmax; ctx->hstride = P.hstride; ctx->hrows = P.hrows;
-        ctx->big = (P.lds_extra >= kHelpLdsBytes && !P.no_help) ? 1 : 0;
+        ctx->big = (DEEP && P.lds_extra >= kHelpLdsBytes && !P.no_help) ? 1 : 0;
         ctx->m = P.m; ctx->x = P.x; ctx->gp = P.g; ctx->trim = P.trim;
         ctx->cells = 0; ctx->pred = 0; ctx->bytes = 0; ctx->ties = 0;
         ctx->cells_full = 0; ctx->bytes_full = 0; ctx->n_banded = 0; ctx->n_band_fail = 0; ctx->band = 0; ctx->band_fail = 0;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
             if (bnp) {
                 // exact banded DP (poa_band.hpp); an alignment whose certificate fails is redone on full rows right below
                 const bool coded = P.band != 3;
-                const bool help = coded && bcast0(ctx->big) != 0;            // a CU's LDS to itself: waves 1-3 assemble the move codes
+                const bool help = DEEP && coded && bcast0(ctx->big) != 0;            // a CU's LDS to itself: waves 1-3 assemble the move codes
                 if (help) {
                     if (t < 64) help_prog()[t] = 0u;
                     if (t < 4) help_done()[t] = 0u;
@@ -154,11 +158,11 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
                 }
                 if (wv == 0) {
                     const bool tab = bcast0(ctx->tie_pad[1]) != 0;
-                    if (help) { if (tab) dp2_rows_band<2, true, true, true>(); else dp2_rows_band<2, false, true, true>(); }
+                    if (DEEP && help) { if constexpr (DEEP) { if (tab) dp2_rows_band_help<true>(); else dp2_rows_band_help<false>(); } }
                     else if (coded) { if (tab) dp2_rows_band<2, true, true>(); else dp2_rows_band<2, false, true>(); }
                     else { if (tab) dp2_rows_band<2, true>(); else dp2_rows_band<2, false>(); }
-                } else if (help) {
-                    if (bcast0(ctx->tie_pad[1]) != 0) dp2_band_codes<2, true>(wv - 1); else dp2_band_codes<2, false>(wv - 1);
+                } else if (DEEP && help) {
+                    if constexpr (DEEP) { if (bcast0(ctx->tie_pad[1]) != 0) dp2_band_codes<2, true>(wv - 1); else dp2_band_codes<2, false>(wv - 1); }
                 }
                 Block4::sync();
                 if (help && t == 0 && help_done()[3] != 0u && ctx->band_fail == 0) { ctx->band_fail = 1; ctx->n_band_fail += 1; }   // (the code wave gave up)
@@ -347,5 +351,19 @@ __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) {
     }
 }
 
-}  // namespace rcn
+// Two instances, two translation units (functions compiled for a kernel that runs eight work-groups per CU are held to 64
+// VGPRs, and the compiler gives a function ONE register budget, its most generous caller's): engine.hip has the kernel
+// for eight work-groups per CU, engine_deep.hip (RCN_DEEP_TU) the one for a work-group that has a CU to itself, two waves
+// per SIMD at most.  RCN_ONE_TU (profiling builds, whose device-side counters must exist once): both here, same bounds.
+#ifdef RCN_DEEP_TU
+__global__ __launch_bounds__(kThreads2, 2) void poa_window_kernel2_deep(KParams P) { poa_window_body<true>(P); }
+#else
+__global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) { poa_window_body<false>(P); }
+#ifdef RCN_ONE_TU
+__global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2_deep(KParams P) { poa_window_body<true>(P); }
+#else
+__global__ void poa_window_kernel2_deep(KParams P);
+#endif
+#endif
 
+}  // namespace rcn
