@@ -53,3 +53,11 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
                 src += open(os.path.join(root, f), errors="ignore").read()
     assert "oracle_lib" not in src and "liboracle" not in src and "poa_oracle" not in src
+
+
+def test_library_holds_both_instances_of_the_consensus_kernel():
+    """The consensus kernel is built twice, in two translation units (racon_amd/csrc/poa_kernel2.hpp): the instance for eight
+    work-groups per CU and the one for a work-group that has a CU to itself (engine_deep.hip); and the int32 fallback kernel."""
+    blob = open(os.path.join(ROOT, "racon_amd", "csrc", "libracon_hip.so"), "rb").read()
+    for name in (b"_ZN3rcn18poa_window_kernel2ENS_7KParamsE", b"_ZN3rcn23poa_window_kernel2_deepENS_7KParamsE", b"_ZN3rcn17poa_window_kernelENS_7KParamsE"):
+        assert name in blob, name
