@@ -19,6 +19,8 @@ static long long g_hist[8] = {0};   // pred distance: 1, 2, 3-4, 5-8, 9-16, 17-3
 static long long g_rows = 0, g_row0 = 0;
 static long long g_align_maxin[4] = {0};   // alignments whose widest row has <= 6, 7..8, > 8 in-edges; [3] = by window depth >= 40: 7+
 static int g_cur_maxin = 0;
+static int g_max_nodes = 0, g_max_indeg = 0, g_max_ring = 0, g_max_edges = 0;   // per process: the largest graph, in-degree, aligned ring
+static long long g_indeg_hist[8] = {0};
 
 // scalar DP over `rank` (any valid topological order); returns the row of the best sink
 // and how many sinks tie at the best score.
@@ -327,6 +329,11 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
             int nr_ = graph_toposort(g, g.rank_x.ptr(), false, g.stack.ptr());
             if (nr_ != g.n_nodes) return -3;
         }
+        g_max_nodes = std::max(g_max_nodes, g.n_nodes); g_max_edges = std::max(g_max_edges, g.n_edges);
+        for (int v = 0; v < g.n_nodes; ++v) {
+            int k = 0; for (int e = g.in_head[v]; e >= 0; e = g.e_nin[e]) ++k;
+            g_max_indeg = std::max(g_max_indeg, k); g_max_ring = std::max(g_max_ring, (int)g.al_cnt[v]); ++g_indeg_hist[std::min(k, 7)];
+        }
         for (int r = 0; r < g.n_nodes; ++r) g.n2r_x[g.rank_x[r]] = r;
         std::vector<int32_t> cn(g.n_nodes);
         int k = graph_consensus(g, g.rank_x.ptr(), g.n2r_x, cn.data());
@@ -345,5 +352,7 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
     if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] tracebacks over move codes checked against the ones over scores: %lld (%lld alignments with a row of more than eight in-edges not coded)\n", g_code_paths, g_code_skipped);
     if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] Subgraph sweeps checked against the DFS: %lld (%lld chunks, %lld chain runs)\n", g_sweeps, g_sweep_chunks, g_sweep_runs);
     if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] alignments %d, sink ties %d rows %lld row0 %lld hist", g_aligns, g_ties, g_rows, g_row0); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_hist[i]); fprintf(stderr, " | alignments by widest row: <=6 in-edges %lld, 7-8 %lld, >8 %lld (7+ in windows of >= 40 sequences: %lld)\n", g_align_maxin[0], g_align_maxin[1], g_align_maxin[2], g_align_maxin[3]); }
+    if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] largest graph %d nodes %d edges, widest in-list %d, largest aligned ring %d; nodes by in-degree", g_max_nodes, g_max_edges, g_max_indeg, g_max_ring + 1);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_indeg_hist[i]); fprintf(stderr, "\n"); }
     return 0;
 }
