@@ -322,7 +322,7 @@ def main():
                        "windows_per_gpu": batch.n_windows, "parallelism": "windows sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "poa_window_kernel2" + (" + poa_window_kernel2_deep (the instance for the deep launch)" if st["split_deep"] else ""), "step_kernel_ms": step_s * 1e3, "avg_launch_ms": sum(per_launch_ms) / len(per_launch_ms),
+                         "kernel": ("poa_window_kernel_small (+ poa_window_kernel2 for the windows it sent back)" if st["n_small"] else "poa_window_kernel2") + (" + poa_window_kernel2_deep (the instance for the deep launch)" if st["split_deep"] else ""), "step_kernel_ms": step_s * 1e3, "avg_launch_ms": sum(per_launch_ms) / len(per_launch_ms),
                          "launches_per_step": len(per_launch_ms), "launch_ms": per_launch_ms,
                          "split_launch": None if not st["split_deep"] else
                              {"deep_windows": st["split_deep"], "deep_cus": st["split_cus"], "deep_work_groups_per_cu": st["split_deep_per_cu"],
@@ -335,7 +335,10 @@ def main():
                                          "achieved": (alg_bytes - st["dp_bytes"] + st["dp_bytes_full"]) / step_s / 1e9,
                                          "gcups": st["dp_cells_full"] / step_s / 1e9},
                          "banded_alignments": st["n_banded"], "code_wave_alignments": st["n_code_wave"], "band_redone": st["n_band_redone"], "band_redo_why": st["band_redo_why"],
-                         "phase_clocks": st["phase_clocks"], "work_groups_per_cu": st["wg_per_cu"]},
+                         "phase_clocks": st["phase_clocks"], "work_groups_per_cu": st["wg_per_cu"],
+                         # the small-window kernel (one wave per window, graph in LDS): windows it polished / sent back to
+                         # poa_window_kernel2 (the retry pass is inside step_kernel_ms) and why
+                         "small_windows": st["n_small"], "small_bailed": st["n_small_bailed"], "small_bail_why": st["small_bail_why"]},
         }
         if do_product:
             # the product on the same workload (same seed -> the same windows, tests/test_synth_files.py)

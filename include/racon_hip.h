@@ -102,6 +102,11 @@ typedef struct rcn_run_stats {
                                   the interval they cover together                                                         */
     uint64_t n_code_wave;      /* banded alignments whose move codes were assembled by waves 1-3 of the work-group next to the DP
                                   wave (windows with a CU and its LDS to themselves: the deep launch; poa_band.hpp)          */
+    uint64_t n_small;          /* windows polished by the small-window kernel (one wave per window, graph in LDS: poa_small.hpp) */
+    uint64_t n_small_bailed;   /* windows that kernel sent back (outside its shape) and poa_window_kernel2 polished instead       */
+    uint64_t small_bail_why[9];/* ... by reason: graph capacity, fifth in-edge, predecessor > 16 rows back, aligned ring (or a symbol
+                                  besides A/C/G/T), int16 range, layer > 255 bases, sink tie beyond the id rule, consensus scratch,
+                                  internal inconsistency (must be zero)                                                           */
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */

@@ -24,6 +24,7 @@
 
 #include "../../include/racon_hip.h"
 #include "poa_kernel2.hpp"
+#include "poa_small.hpp"
 
 namespace {
 
@@ -154,8 +155,38 @@ void host_parallel(size_t n, unsigned threads, F fn) {
 
 }  // namespace
 
+// Experiment and test switches, read ONCE when the engine is created and only when RCN_EXPERIMENT=1 is set (tests/conftest.py
+// sets it; tools/exp scripts do): a stray RCN_* variable in a user's environment cannot change the product's kernel path.
+// RCN_DEBUG (host timeline on stderr, no effect on results) is the one switch that needs no gate.
+struct Knobs {
+    bool debug = false, no_ptab = false, force_exact = false, force_slow_tb = false, no_band = false, force_band_fail = false,
+         band_scores = false, no_code_wave = false, wide_only = false, no_stream = false, no_small = false, force_small = false, prof_layers = false;
+    int force_tie = 0, wg_per_cu = 0, split = -1, split_deep_per_cu = 0, split_rest_per_cu = 0, split_deep = 0, split_deep_wide = -1,
+        split_cus = 0, hrows_div = 0, small_per_cu = 0;
+    double heavy_pct = 1.0;
+};
+static Knobs read_knobs() {
+    Knobs k;
+    k.debug = getenv("RCN_DEBUG") != nullptr;
+    const char* gate = getenv("RCN_EXPERIMENT");
+    if (!gate || atoi(gate) == 0) return k;
+    auto flag = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+    k.no_ptab = flag("RCN_NO_PTAB"); k.force_exact = flag("RCN_FORCE_EXACT"); k.force_slow_tb = flag("RCN_FORCE_SLOW_TB");
+    k.no_band = flag("RCN_NO_BAND"); k.force_band_fail = flag("RCN_FORCE_BAND_FAIL"); k.band_scores = flag("RCN_BAND_SCORES");
+    k.no_code_wave = flag("RCN_NO_CODE_WAVE"); k.wide_only = flag("RCN_WIDE_ONLY"); k.no_stream = flag("RCN_NO_STREAM");
+    k.no_small = flag("RCN_NO_SMALL"); k.force_small = flag("RCN_FORCE_SMALL"); k.prof_layers = flag("RCN_PROF_LAYERS");
+    k.force_tie = num("RCN_FORCE_TIE", 0); k.wg_per_cu = num("RCN_WG_PER_CU", 0); k.split = num("RCN_SPLIT", -1);
+    k.split_deep_per_cu = num("RCN_SPLIT_DEEP_PER_CU", 0); k.split_rest_per_cu = num("RCN_SPLIT_REST_PER_CU", 0);
+    k.split_deep = num("RCN_SPLIT_DEEP", 0); k.split_deep_wide = num("RCN_SPLIT_DEEP_WIDE", -1); k.split_cus = num("RCN_SPLIT_CUS", 0);
+    k.hrows_div = num("RCN_HROWS_DIV", 0); k.small_per_cu = num("RCN_SMALL_PER_CU", 0);
+    if (const char* v = getenv("RCN_HEAVY_PCT")) k.heavy_pct = atof(v);
+    return k;
+}
+
 struct rcn_engine {
     rcn_engine_config cfg{};
+    Knobs knobs;
     hipStream_t stream = nullptr;                   // main stream: resident-batch launches, retry pass, result copies
     hipStream_t copy_stream = nullptr;              // H2D of a streamed batch (rcn_engine_polish)
     // sub-launches of a streamed batch: each on its own stream so that they overlap.  Two pieces, three streams in use
@@ -171,6 +202,8 @@ struct rcn_engine {
     bool warmed = false;                            // rcn_engine_reserve ran its warm-up launch
     bool lds_optin = false;                         // a work-group may ask for more than 64 KB of LDS (fewer than three per CU)
     int caps_level = 0;                             // first_pass_caps: raised when a batch needed many retries
+    bool small_off = false;                         // the small-window kernel sent too many windows back: not for this engine's next batches
+    bool pass_small = false;                        // the first pass of the current batch ran (partly) on the small-window kernel
     bool stats_pending = false;                     // the last run's device counters have not been read yet (rcn_engine_stats)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
@@ -227,7 +260,7 @@ int upload_vec(DevBuf& d, const void* src, size_t bytes, hipStream_t s) {
     return RCN_OK;
 }
 
-struct Caps { int32_t ncap, ecap, ring, lmax, hstride, hrows; uint64_t slot_bytes; bool fast; };
+struct Caps { int32_t ncap, ecap, ring, lmax, hstride, hrows; uint64_t slot_bytes; bool fast; bool small = false; uint32_t lds = 0, per_cu = 0; };
 
 // fast = poa_window_kernel2 (4 waves per window, int16 Z matrix); else poa_window_kernel (1 wave, int32 H)
 // hrows: rows of the DP matrix (0 = ncap + 1, one per node the graph arrays can hold)
@@ -243,19 +276,30 @@ Caps make_caps(int32_t ncap, int32_t ecap, int32_t ring, int32_t lmax, bool fast
     return c;
 }
 
+// ---- the small-window kernel (poa_small.hpp): one wave per window, the graph in LDS ----
+// A pass takes it when EVERY window of the pass has the shape: backbone and growth within the LDS layout, layers of at most
+// 255 bases (what is not known before the bases are read -- symbols besides A, C, G, T -- and what only shows while the
+// graph grows is the kernel's own business: it flags such a window and collect() re-runs it with poa_window_kernel2).
+// Node capacity = backbone + the larger of 64 and 3/8 of it + 13 (BASELINE configs[3], 200-base windows at 60x: graphs end
+// at 221 nodes, the largest of 5000 at ~270; 288 nodes = 10 080 bytes of LDS = sixteen windows per CU).
+inline int small_ncap(int L) { return std::max<int>(rcn::kSmMinCap, (L + std::max(64, (3 * L) / 8 + 13) + 7) & ~7); }
+inline bool small_shape(const WinShape& s) { return s.L >= 1 && small_ncap(s.L) <= rcn::kSmMaxCap && s.lmax <= rcn::kSmLen; }
+template <class It>
+bool small_caps(const rcn_engine* e, It first, It last, Caps& out);
+
 // first-pass capacities of a set of windows: typical graph growth (a window that outgrows them is re-run by the retry
 // pass with worst-case capacities)
 // `level`: 0 = the estimates below; raised by collect() when a batch sent more than 2 % of its windows to the retry pass
 // (reads noisier than the 10-15 % the estimates leave room for): every step gives the graph and the matrix more room
-// for the NEXT batch -- a node per 3, then 2 layer bases, a matrix row per 4, then 2.
+// for the NEXT batch -- a node per 3, then 2 layer bases, a matrix row per 4, then 2.  `hrows_div` (tests, Knobs::hrows_div: a
+// small matrix forces retries) overrides the matrix divisor.
 template <class It>
-Caps first_pass_caps(It first, It last, bool fast, int level = 0) {
+Caps first_pass_caps(It first, It last, bool fast, int level = 0, int hrows_div = 0) {
     // The graph arrays (~230 B per node) for a node per four layer bases; the DP matrix -- one row of 1 or 2 KB per node,
     // nine tenths of a slot -- for one per six: cfg2's windows end with a node per ~12 layer bases (10 % read error, most
     // errors shared by no other read), so both leave room, and the arena (slots x slot bytes, tens of GB that the driver
-    // has to find and clear) shrinks by a third.  RCN_HROWS_DIV overrides the divisor (tests: a small matrix forces retries).
-    const char* hd = getenv("RCN_HROWS_DIV");
-    const int hdiv = hd ? std::max(1, atoi(hd)) : (level <= 0 ? 6 : level == 1 ? 4 : 2);
+    // has to find and clear) shrinks by a third.
+    const int hdiv = hrows_div > 0 ? hrows_div : (level <= 0 ? 6 : level == 1 ? 4 : 2);
     const int ndiv = level <= 0 ? 4 : level == 1 ? 3 : 2;
     int32_t ncap = 0, hrows = 0, lmax = 1, nsym = 2;
     for (It it = first; it != last; ++it) {
@@ -274,6 +318,29 @@ Caps first_pass_caps(It first, It last, bool fast, int level = 0) {
 inline uint64_t first_pass_out_cap(const WinShape& s) {
     const uint64_t worst = static_cast<uint64_t>(s.L) + s.sum_l + 8;
     return (std::min<uint64_t>(worst, 2ull * s.L + 64) + 15) & ~uint64_t(15);
+}
+
+// capacities of a pass on the small-window kernel, false when some window of [first, last) does not have the shape
+template <class It>
+bool small_caps(const rcn_engine* e, It first, It last, Caps& out) {
+    if (first == last || e->knobs.no_small || e->knobs.wide_only || (e->small_off && !e->knobs.force_small) || e->cfg.gap >= 0) return false;
+    int32_t Lmax = 1;
+    for (It it = first; it != last; ++it) {
+        if (!small_shape(*it)) return false;
+        Lmax = std::max(Lmax, it->L);
+    }
+    Caps c{};
+    c.ncap = small_ncap(Lmax); c.ecap = 0; c.ring = rcn::kSmRing; c.lmax = rcn::kSmLen; c.hstride = 256; c.hrows = c.ncap + 1;
+    c.fast = true; c.small = true;
+    c.slot_bytes = rcn::small_slot_bytes(c.ncap);
+    c.lds = rcn::small_layout(c.ncap).end;
+    // LDS is handed out in 1280-byte granules, 128 per CU; sixteen one-wave work-groups (four per SIMD) are what the kernel's
+    // register budget admits
+    const uint32_t granules = (c.lds + 1279u) / 1280u;
+    c.per_cu = std::max(1u, std::min(16u, 128u / granules));
+    if (e->knobs.small_per_cu > 0) c.per_cu = static_cast<uint32_t>(std::min(32, e->knobs.small_per_cu));
+    out = c;
+    return true;
 }
 
 uint64_t scratch_budget(const rcn_engine* e) {
@@ -298,7 +365,7 @@ bool deepest_rules(const rcn_engine* e) {
     return static_cast<double>(e->t_max) > 1.25 * even;
 }
 uint32_t wg_per_cu(const rcn_engine* e) {
-    if (const char* v = getenv("RCN_WG_PER_CU")) return static_cast<uint32_t>(std::min(8, std::max(e->lds_optin ? 1 : 3, atoi(v))));   // experiments
+    if (e->knobs.wg_per_cu > 0) return static_cast<uint32_t>(std::min(8, std::max(e->lds_optin ? 1 : 3, e->knobs.wg_per_cu)));   // experiments
     if (e->queued) return 8u;                       // the caller keeps the device busy with further batches: a long queue
     return deepest_rules(e) ? 6u : 8u;
 }
@@ -321,19 +388,18 @@ uint32_t lds_bytes_for(uint32_t per_cu) {
 struct SplitPlan { bool on = false; uint32_t n_deep = 0, deep_per_cu = 1, rest_per_cu = 8; };
 SplitPlan split_plan(const rcn_engine* e, uint32_t nw, bool fast) {
     SplitPlan sp;
-    const char* sw = getenv("RCN_SPLIT");
-    if (!fast || !e->deep_stream || !e->rest_stream || e->cfg.max_slots || (sw && atoi(sw) == 0)) return sp;
-    const bool forced = sw && atoi(sw) == 1;
+    if (!fast || !e->deep_stream || !e->rest_stream || e->cfg.max_slots || e->knobs.split == 0) return sp;
+    const bool forced = e->knobs.split == 1;
     const uint32_t cus = static_cast<uint32_t>(e->split_cus);
     if (!forced && (e->queued || !deepest_rules(e) || nw < 256u || nw > static_cast<uint32_t>(e->n_cu) * 8u)) return sp;
     if (nw < 2) return sp;
     sp.on = true;
     sp.deep_per_cu = 1; sp.rest_per_cu = 8;
-    if (const char* v = getenv("RCN_SPLIT_DEEP_PER_CU")) sp.deep_per_cu = static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));
-    if (const char* v = getenv("RCN_SPLIT_REST_PER_CU")) sp.rest_per_cu = static_cast<uint32_t>(std::min(8, std::max(1, atoi(v))));
+    if (e->knobs.split_deep_per_cu > 0) sp.deep_per_cu = static_cast<uint32_t>(std::min(8, e->knobs.split_deep_per_cu));
+    if (e->knobs.split_rest_per_cu > 0) sp.rest_per_cu = static_cast<uint32_t>(std::min(8, e->knobs.split_rest_per_cu));
     if (!e->lds_optin) sp.deep_per_cu = std::max(sp.deep_per_cu, 3u);      // (residency is set through the LDS request: 64 KB at most without the opt-in)
     sp.n_deep = cus * sp.deep_per_cu;
-    if (const char* v = getenv("RCN_SPLIT_DEEP")) sp.n_deep = static_cast<uint32_t>(std::max(1, atoi(v)));
+    if (e->knobs.split_deep > 0) sp.n_deep = static_cast<uint32_t>(e->knobs.split_deep);
     sp.n_deep = std::min(sp.n_deep, nw - 1);
     return sp;
 }
@@ -379,21 +445,22 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     if (!L.host_out) P.out_off = e->d_retry_off.as<uint64_t>();         // a retry pass numbers its outputs by its own work items
     P.bases = e->d_bases.as<uint8_t>(); P.quals = e->d_quals.as<uint8_t>();
     P.win_ids = L.d_ids; P.n_work = L.n_work; P.work_base = L.work_base;
-    P.win_flags = getenv("RCN_NO_PTAB") ? nullptr : win_flags;
+    const Knobs& K = e->knobs;
+    P.win_flags = (K.no_ptab && !L.c.small) ? nullptr : win_flags;
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
-    P.heavy_ns = L.heavy_ns >= 0 ? L.heavy_ns : e->heavy_ns; P.force_exact = getenv("RCN_FORCE_EXACT") ? 1 : 0;
-    P.force_tie = getenv("RCN_FORCE_TIE") ? atoi(getenv("RCN_FORCE_TIE")) : 0;
-    P.force_slow_tb = getenv("RCN_FORCE_SLOW_TB") ? 1 : 0;
+    P.heavy_ns = L.heavy_ns >= 0 ? L.heavy_ns : e->heavy_ns; P.force_exact = K.force_exact ? 1 : 0;
+    P.force_tie = K.force_tie;
+    P.force_slow_tb = K.force_slow_tb ? 1 : 0;
     // the band's exactness certificate (poa_band.hpp: a cell is alive when H' + m (len - j) >= T) assumes that a remaining
     // base adds at most m: any -m/-x/-g is legal on the command line (reference src/main.cpp:51-53,91-99), so score sets
     // with x > m or g > m take full rows
     const bool band_sound = e->cfg.match >= e->cfg.mismatch && e->cfg.match >= e->cfg.gap;
-    P.band = (!band_sound || getenv("RCN_NO_BAND")) ? 0 : (getenv("RCN_FORCE_BAND_FAIL") ? 2 : (getenv("RCN_BAND_SCORES") ? 3 : 1));
+    P.band = (!band_sound || K.no_band) ? 0 : (K.force_band_fail ? 2 : (K.band_scores ? 3 : 1));
     P.scratch = e->d_scratch.as<uint8_t>() + L.scratch_off; P.slot_bytes = L.c.slot_bytes;
     P.ncap = L.c.ncap; P.ecap = L.c.ecap; P.ring = L.c.ring; P.lmax = L.c.lmax; P.hstride = L.c.hstride; P.hrows = L.c.hrows;
     P.out_base = L.out_base;
-    P.lds_extra = L.c.fast ? static_cast<int32_t>(lds_bytes_for(L.per_cu ? L.per_cu : wg_per_cu(e)) - (rcn::kLdsBytes + rcn::kCtxBytes)) : 0;
-    P.no_help = getenv("RCN_NO_CODE_WAVE") ? 1 : 0;
+    P.lds_extra = (L.c.fast && !L.c.small) ? static_cast<int32_t>(lds_bytes_for(L.per_cu ? L.per_cu : wg_per_cu(e)) - (rcn::kLdsBytes + rcn::kCtxBytes)) : 0;
+    P.no_help = K.no_code_wave ? 1 : 0;
     if (L.host_out) {
         // The first pass writes lengths, flags and consensus bytes straight into pinned host memory (hipHostMalloc memory is
         // device-visible): ~1 KB per window over PCIe from the kernel's own stores, and no device-to-host copy afterwards -- a
@@ -407,10 +474,16 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     }
     P.next = e->d_ctr.as<unsigned int>() + L.ctr;
     P.stats = reinterpret_cast<unsigned long long*>(e->d_ctr.as<uint8_t>() + kStatsOff);
-    const uint32_t per_cu = L.per_cu ? L.per_cu : wg_per_cu(e);
-    if (getenv("RCN_DEBUG")) fprintf(stderr, "[racon_hip] pass of %u windows on %u slots, %u work-groups per CU (deepest window %llu bases, all %llu)\n", L.n_work, L.slots,
-                                     L.c.fast ? per_cu : 8u, (unsigned long long)e->t_max, (unsigned long long)e->t_sum);
+    const uint32_t per_cu = L.c.small ? L.c.per_cu : (L.per_cu ? L.per_cu : wg_per_cu(e));
+    if (K.debug) fprintf(stderr, "[racon_hip] pass of %u windows on %u slots, %u work-groups per CU%s (deepest window %llu bases, all %llu)\n", L.n_work, L.slots,
+                         L.c.fast ? per_cu : 8u, L.c.small ? " (small-window kernel)" : "", (unsigned long long)e->t_max, (unsigned long long)e->t_sum);
     if (L.c.fast) e->stats.wg_per_cu = per_cu;
+    if (L.c.small) {
+        // one wave per window, the graph in LDS (poa_small.hpp); a window outside its shape comes back flagged (collect())
+        hipLaunchKernelGGL(rcn::poa_window_kernel_small, dim3(L.slots), dim3(64), L.c.lds, L.stream, P);
+        HIP_TRY(hipGetLastError());
+        return RCN_OK;
+    }
     // one work-group per CU with the CU's whole LDS: the instance of the kernel that runs the banded DP with code waves
     const bool deep_kernel = L.c.fast && P.lds_extra >= rcn::kHelpLdsBytes && !P.no_help;
     if (deep_kernel) hipLaunchKernelGGL(rcn::poa_window_kernel2_deep, dim3(L.slots), dim3(rcn::kThreads2), lds_bytes_for(per_cu), L.stream, P);
@@ -422,7 +495,7 @@ int launch_pass(rcn_engine* e, const Launch& L) {
 
 // resident slots for a pass of n_work windows within the scratch budget (0: not even one slot fits)
 uint32_t slots_for(const rcn_engine* e, const Caps& c, uint32_t n_work, uint64_t budget) {
-    uint32_t slots = std::min(e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e), n_work);
+    uint32_t slots = std::min(e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * (c.small ? c.per_cu : wg_per_cu(e)), n_work);
     while (slots > 1 && static_cast<uint64_t>(slots) * c.slot_bytes > budget) slots = (slots + 1) / 2;
     return static_cast<uint64_t>(slots) * c.slot_bytes > budget ? 0 : slots;
 }
@@ -575,6 +648,7 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     struct Guard { rcn_engine* e; ~Guard() { if (e) rcn_engine_destroy(e); } } guard{new rcn_engine()};
     rcn_engine* e = guard.e;
     e->cfg = *cfg;
+    e->knobs = read_knobs();
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
     e->n_cu = prop.multiProcessorCount;
@@ -596,10 +670,9 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
         // 20.4 without the split.  (Masks of 40, 48, 56 or 72 bits ran the deep launch in TWO rounds -- 29 ms: fewer CUs
         // than bits took its work-groups -- so the count stays one of those measured.)
         int cus = 32;
-        if (const char* v = getenv("RCN_SPLIT_CUS")) cus = atoi(v);
+        if (e->knobs.split_cus > 0) cus = e->knobs.split_cus;
         cus = (cus / 8) * 8;                                   // an even slice of the eight XCDs
-        const char* sw = getenv("RCN_SPLIT");
-        if (cus >= 8 && cus <= e->n_cu - 8 && e->n_cu <= 256 && !(sw && atoi(sw) == 0)) {
+        if (cus >= 8 && cus <= e->n_cu - 8 && e->n_cu <= 256 && e->knobs.split != 0) {
             uint32_t deep[8] = {0}, rest[8] = {0};
             for (int b = 0; b < e->n_cu; ++b) (b < cus ? deep : rest)[b >> 5] |= 1u << (b & 31);
             const uint32_t words = static_cast<uint32_t>((e->n_cu + 31) / 32);
@@ -612,6 +685,7 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
         // fewer than eight work-groups per CU are enforced through the LDS request (lds_bytes_for): up to the whole LDS
         e->lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         e->lds_optin = e->lds_optin && hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2_deep), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel_small), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipGetLastError();
     }
     int rc = e->d_ctr.reserve(kCtrBytes);
@@ -822,7 +896,7 @@ int rcn_engine_export_batch(rcn_engine* e, uint32_t* win_seq_off, uint8_t* win_t
 // per-window results in caller order.
 static int collect(rcn_engine* e) {
     const uint32_t nw = e->n_windows;
-    const bool dbg = getenv("RCN_DEBUG") != nullptr;
+    const bool dbg = e->knobs.debug;
     const auto c0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count(); };
     const uint64_t cons_bytes = e->out_off[nw];
@@ -842,46 +916,71 @@ static int collect(rcn_engine* e) {
     std::vector<uint32_t> out_len(nw), item_of(nw);
     std::vector<uint8_t> flags(nw);
     for (uint32_t wi = 0; wi < nw; ++wi) { const uint32_t w = e->lpt[wi]; out_len[w] = len_item[wi]; flags[w] = flag_item[wi]; item_of[w] = wi; }
-    // retry pass with worst-case capacities for windows that overflowed
+    // Windows the first pass flagged are re-run on the GPU, never on the CPU: a window the small-window kernel sent back
+    // (outside its shape: poa_small.hpp) goes to poa_window_kernel2 with first-pass capacities, what that one flags -- or
+    // what it flagged in the first place -- to the int32 kernel with worst-case capacities.
     std::vector<uint32_t> retry;
     for (uint32_t w = 0; w < nw; ++w) {
         if (flags[w] & rcn::kFlagError) { fprintf(stderr, "[racon_hip] internal error on window %u\n", w); return RCN_E_STATE; }
         if (flags[w] & rcn::kFlagOverflow) retry.push_back(w);
     }
-    std::vector<std::string> retry_cons(retry.size());
-    if (!retry.empty()) {
-        int32_t n2 = 0, l2 = 1, nsym = 2;
-        std::vector<uint32_t> ids(retry.size());
-        std::vector<uint64_t> off2(retry.size() + 1, 0);
-        for (size_t k = 0; k < retry.size(); ++k) {
-            const uint32_t w = retry[k];
-            const auto& s = e->shapes[w];
-            n2 = std::max<int32_t>(n2, s.L + s.sum_l + 8); l2 = std::max(l2, s.lmax); nsym = std::max(nsym, s.nsym);
-            ids[k] = e->lpt_layout ? item_of[w] : w;                          // device window id
-            off2[k + 1] = off2[k] + ((static_cast<uint64_t>(s.L) + s.sum_l + 8 + 15) & ~uint64_t(15));
+    std::vector<std::string> retry_cons;
+    std::vector<uint32_t> retry_win;                 // windows whose bytes are in retry_cons, ascending
+    {
+        std::vector<std::pair<uint32_t, std::string>> redone;
+        const uint32_t n_first = static_cast<uint32_t>(retry.size());
+        for (int tier = e->pass_small ? 0 : 1; tier < 2 && !retry.empty(); ++tier) {
+            int32_t n2 = 0, l2 = 1, nsym = 2;
+            const uint32_t nr = static_cast<uint32_t>(retry.size());
+            std::vector<uint32_t> ids(nr);
+            std::vector<uint64_t> off2(nr + 1, 0);
+            std::vector<WinShape> sh(nr);
+            for (size_t k = 0; k < nr; ++k) {
+                const uint32_t w = retry[k];
+                const auto& sw = e->shapes[w];
+                sh[k] = sw;
+                n2 = std::max<int32_t>(n2, sw.L + sw.sum_l + 8); l2 = std::max(l2, sw.lmax); nsym = std::max(nsym, sw.nsym);
+                ids[k] = e->lpt_layout ? item_of[w] : w;                          // device window id
+                off2[k + 1] = off2[k] + ((static_cast<uint64_t>(sw.L) + sw.sum_l + 8 + 15) & ~uint64_t(15));
+            }
+            const Caps c2 = tier == 0 ? first_pass_caps(sh.begin(), sh.end(), true, e->caps_level, e->knobs.hrows_div)
+                                      : make_caps(n2, n2 + 8, std::max(1, nsym - 1), l2, false);     // int32 kernel, worst-case capacities
+            // first-pass bytes are already on the host; a retry pass indexes its outputs by its own work items
+            if ((rc = e->d_out_cons.reserve(off2[nr] + 16)) || (rc = e->d_out_len.reserve(4ull * nr)) || (rc = e->d_out_flags.reserve(nr))) return rc;
+            if ((rc = upload_vec(e->d_retry_off, off2.data(), 8ull * (nr + 1), e->stream))) return rc;
+            if ((rc = upload_vec(e->d_win_ids, ids.data(), 4ull * nr, e->stream))) return rc;
+            if ((rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr, /*host_out=*/false))) return rc;
+            std::vector<uint32_t> len2(nr);
+            std::vector<uint8_t> fl2(nr);
+            HIP_TRY(hipMemcpyAsync(len2.data(), e->d_out_len.p, 4ull * nr, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync(fl2.data(), e->d_out_flags.p, nr, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            std::vector<uint32_t> again;
+            const size_t first_new = redone.size();
+            for (size_t k = 0; k < nr; ++k) {
+                const uint32_t w = retry[k];
+                if (fl2[k] & rcn::kFlagError) { fprintf(stderr, "[racon_hip] internal error on window %u (retry pass)\n", w); return RCN_E_STATE; }
+                if (fl2[k] & rcn::kFlagOverflow) { if (tier == 1) return RCN_E_CAPACITY; again.push_back(w); continue; }
+                redone.emplace_back(w, std::string(len2[k], '\0'));
+                out_len[w] = len2[k]; flags[w] = fl2[k];
+            }
+            for (size_t k = 0, j = first_new; k < nr; ++k) {
+                if (fl2[k] & rcn::kFlagOverflow) continue;
+                if (len2[k]) HIP_TRY(hipMemcpyAsync(&redone[j].second[0], e->d_out_cons.as<uint8_t>() + off2[k], len2[k], hipMemcpyDeviceToHost, e->stream));
+                ++j;
+            }
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (tier == 0) e->stats.n_small_bailed = nr;
+            retry.swap(again);
         }
-        Caps c2 = make_caps(n2, n2 + 8, std::max(1, nsym - 1), l2, false);     // int32 kernel, worst-case capacities
-        const uint32_t nr = static_cast<uint32_t>(retry.size());
-        // first-pass bytes are already on the host; the retry pass indexes its outputs by its own work items
-        if ((rc = e->d_out_cons.reserve(off2[nr] + 16)) || (rc = e->d_out_len.reserve(4ull * nr)) || (rc = e->d_out_flags.reserve(nr))) return rc;
-        if ((rc = upload_vec(e->d_retry_off, off2.data(), 8ull * (nr + 1), e->stream))) return rc;
-        if ((rc = upload_vec(e->d_win_ids, ids.data(), 4ull * nr, e->stream))) return rc;
-        if ((rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr, /*host_out=*/false))) return rc;
-        std::vector<uint32_t> len2(nr);
-        std::vector<uint8_t> fl2(nr);
-        HIP_TRY(hipMemcpyAsync(len2.data(), e->d_out_len.p, 4ull * nr, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipMemcpyAsync(fl2.data(), e->d_out_flags.p, nr, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        for (size_t k = 0; k < retry.size(); ++k) {
-            const uint32_t w = retry[k];
-            if (fl2[k] & (rcn::kFlagOverflow | rcn::kFlagError)) return RCN_E_CAPACITY;
-            retry_cons[k].resize(len2[k]);
-            if (len2[k]) HIP_TRY(hipMemcpyAsync(&retry_cons[k][0], e->d_out_cons.as<uint8_t>() + off2[k], len2[k], hipMemcpyDeviceToHost, e->stream));
-            out_len[w] = len2[k]; flags[w] = fl2[k];
-        }
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        e->stats.n_retried = static_cast<uint32_t>(retry.size());
-        if (retry.size() * 50 > nw && nw >= 50 && e->caps_level < 2) ++e->caps_level;
+        std::sort(redone.begin(), redone.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (auto& r : redone) { retry_win.push_back(r.first); retry_cons.push_back(std::move(r.second)); }
+        e->stats.n_retried = static_cast<uint32_t>(retry_win.size());
+        if (e->pass_small) {
+            // a batch whose windows keep leaving the small-window kernel (noisy reads on short windows: graphs that outgrow
+            // the LDS) pays for them twice: not for this engine's next batches
+            if (n_first * 8 > nw && nw >= 64) e->small_off = true;
+        } else if (n_first * 50 > nw && nw >= 50 && e->caps_level < 2) ++e->caps_level;
     }
 
     e->stats_pending = true;                      // the device counters of this run: fetched by rcn_engine_stats on demand
@@ -927,7 +1026,7 @@ static int collect(rcn_engine* e) {
         fprintf(stderr, "[racon_hip] sink ties since load: %llu alignments, %.0f clocks each; %llu past the rule, %llu closure sweeps, %llu full DFS\n", wt_[0], (double)wt_[1] / std::max(1ull, wt_[0]), wt_[2], wt_[3], wt_[4]); }
       { unsigned long long wh_[8]; HIP_TRY(hipMemcpyFromSymbol(wh_, HIP_SYMBOL(rcn::g_whelp), sizeof(wh_)));
         fprintf(stderr, "[racon_hip] code waves since load: %llu lap checks of wave 0 with %llu polls; %llu waits of the code waves with %llu polls\n", wh_[0], wh_[1], wh_[2], wh_[3]); }
-      if (getenv("RCN_PROF_LAYERS")) {
+      if (e->knobs.prof_layers) {
           static unsigned long long wl[4][128][5]; HIP_TRY(hipMemcpyFromSymbol(wl, HIP_SYMBOL(rcn::g_wlay), sizeof(wl)));
           for (int w = 0; w < 4; ++w) for (int j = 1; j < 128; ++j) if (wl[w][j][0])
               fprintf(stderr, "  item %d layer %3d: V %4llu len %4llu | dp %8llu tie %8llu tb %8llu | tied %llu level %llu band-flags %llu\n", w, j, wl[w][j][4] >> 32, wl[w][j][4] & 0xffffffffull,
@@ -942,7 +1041,7 @@ static int collect(rcn_engine* e) {
     size_t rk = 0;
     for (uint32_t w = 0; w < nw; ++w) {
         uint8_t* dst = e->cons.data() + e->cons_off[w];
-        if (rk < retry.size() && retry[rk] == w) { std::memcpy(dst, retry_cons[rk].data(), out_len[w]); ++rk; }
+        if (rk < retry_win.size() && retry_win[rk] == w) { std::memcpy(dst, retry_cons[rk].data(), out_len[w]); ++rk; }
         else std::memcpy(dst, raw + e->out_off[item_of[w]], out_len[w]);
         e->polished[w] = (flags[w] & rcn::kFlagPolished) ? 1 : 0;
         e->chimeric[w] = (flags[w] & rcn::kFlagChimeric) ? 1 : 0;
@@ -961,12 +1060,12 @@ static int begin_run(rcn_engine* e) {
     int rc;
     if ((rc = e->h_out.reserve(result_layout(nw).off_cons + e->out_off[nw] + 16))) return rc;
     e->stats_pending = false;
+    e->pass_small = false;
     HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, kCtrBytes, e->stream));
     {
         // windows in the top tail of the depth distribution can be given the 4-wave DP (RCN_HEAVY_PCT; off by default:
         // measured slower).  Threshold = a percentile of sequences per window.
-        const char* pe = getenv("RCN_HEAVY_PCT");
-        const double pct = pe ? atof(pe) : 1.0;
+        const double pct = e->knobs.heavy_pct;
         e->heavy_ns = 0;
         if (pct < 1.0 && nw) {
             std::vector<uint32_t> depth(nw);
@@ -1019,12 +1118,17 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
     sh.reserve(pp.cut[c + 1] - pp.cut[c]);
     for (uint32_t k = pp.cut[c]; k < pp.cut[c + 1]; ++k) sh.push_back(e->shapes[e->lpt[k]]);
     Launch& L = pp.L[c];
-    L.c = first_pass_caps(sh.begin(), sh.end(), fast, e->caps_level);
+    const bool small = fast && !sp.on && small_caps(e, sh.begin(), sh.end(), L.c);
+    if (!small) L.c = first_pass_caps(sh.begin(), sh.end(), fast, e->caps_level, e->knobs.hrows_div);
     L.n_work = pp.cut[c + 1] - pp.cut[c]; L.work_base = pp.cut[c]; L.out_base = pp.cut[c]; L.ctr = c;
-    if (sp.on) {
+    if (small) {
+        e->pass_small = true;
+        L.stream = e->sub_stream[c]; L.per_cu = L.c.per_cu;
+        L.slots = std::min(L.n_work, slots_left);
+    } else if (sp.on) {
         L.stream = c == 0 ? e->deep_stream : e->rest_stream;
         L.per_cu = c == 0 ? sp.deep_per_cu : sp.rest_per_cu;
-        if (c == 0 && getenv("RCN_SPLIT_DEEP_WIDE")) L.heavy_ns = atoi(getenv("RCN_SPLIT_DEEP_WIDE"));
+        if (c == 0 && e->knobs.split_deep_wide >= 0) L.heavy_ns = e->knobs.split_deep_wide;
         const uint32_t cus = c == 0 ? static_cast<uint32_t>(e->split_cus) : static_cast<uint32_t>(e->n_cu - e->split_cus);
         L.slots = std::min(L.n_work, cus * L.per_cu);
     } else {
@@ -1046,7 +1150,7 @@ int finish_pieces(rcn_engine* e, const PassPlan& pp, hipEvent_t ref) {
         HIP_TRY(hipEventElapsedTime(&a0, ref, e->sub_ev[c][1]));
         HIP_TRY(hipEventElapsedTime(&a1, ref, e->sub_ev[c][2]));
         if (!have) { span0 = a0; span1 = a1; have = true; } else { span0 = std::min(span0, a0); span1 = std::max(span1, a1); }
-        if (getenv("RCN_DEBUG")) {
+        if (e->knobs.debug) {
             float cp = 0; if (pp.copied) (void)hipEventElapsedTime(&cp, ref, e->sub_ev[c][0]);
             fprintf(stderr, "[racon_hip] piece %d: work items [%u, %u) slots %u (%u per CU) ncap %d lmax %d | copy done %.2f ms, kernel %.2f .. %.2f ms\n",
                     c, pp.cut[c], pp.cut[c + 1], pp.L[c].slots, pp.L[c].per_cu, pp.L[c].c.ncap, pp.L[c].c.lmax, cp, a0, a1);
@@ -1077,8 +1181,16 @@ int rcn_engine_run(rcn_engine* e) {
     }
     int rc;
     if ((rc = begin_run(e))) return rc;
-    const bool fast = !getenv("RCN_WIDE_ONLY");
+    const bool fast = !e->knobs.wide_only;
     const uint32_t* ids = e->lpt_layout ? nullptr : e->d_lpt_ids.as<uint32_t>();
+    {
+        Caps cs;
+        if (fast && small_caps(e, e->shapes.begin(), e->shapes.end(), cs)) {
+            e->pass_small = true;
+            if ((rc = run_pass(e, cs, ids, nw))) return rc;
+            return collect(e);
+        }
+    }
     const SplitPlan sp = split_plan(e, nw, fast);
     if (sp.on) {
         // the split pair: deepest windows on their own CUs, everything else on the rest of the chip
@@ -1097,7 +1209,7 @@ int rcn_engine_run(rcn_engine* e) {
             return collect(e);
         }
     }
-    const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), fast, e->caps_level);
+    const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), fast, e->caps_level, e->knobs.hrows_div);
     if ((rc = run_pass(e, c1, ids, nw))) return rc;
     return collect(e);
 }
@@ -1162,11 +1274,11 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         e->queued = (v.flags & RCN_REFS_QUEUED) != 0;
         return rc ? rc : rcn_engine_run(e);
     };
-    const bool fast = !getenv("RCN_WIDE_ONLY");
-    if (nw < 64 || getenv("RCN_NO_STREAM")) return dry ? RCN_OK : plain();
+    const bool fast = !e->knobs.wide_only;
+    if (nw < 64 || e->knobs.no_stream) return dry ? RCN_OK : plain();
     e->uploaded = false; e->ran = false;
     e->n_windows = nw; e->n_seqs = ns; e->n_bases = v.seq_off[ns];
-    const bool dbg = getenv("RCN_DEBUG") != nullptr;
+    const bool dbg = e->knobs.debug;
     const auto h0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count(); };
     EventPair t;
@@ -1191,8 +1303,17 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     if (dbg) fprintf(stderr, "[racon_hip] polish: pinned staging (%.1f MB) at %.2f ms\n", total / 1e6, since());
     if ((rc = e->d_meta.reserve(ml.end + kDmaCopyBytes)) || (rc = e->d_bases.reserve(nb + 16)) || (rc = e->d_quals.reserve(nb + 16))) return rc;
     if (dbg) fprintf(stderr, "[racon_hip] polish: device inputs reserved at %.2f ms\n", since());
-    const SplitPlan sp = split_plan(e, nw, fast);
-    const uint32_t slots_total = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e);
+    SplitPlan sp = split_plan(e, nw, fast);
+    uint32_t slots_total = e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * wg_per_cu(e);
+    {
+        // a batch of small windows: no split (its windows are a few ms each, the launch does not hang on one of them), the
+        // pieces go to the small-window kernel (plan_piece) with its own residency
+        Caps cs;
+        if (fast && small_caps(e, e->shapes.begin(), e->shapes.end(), cs)) {
+            sp = SplitPlan{};
+            if (!e->cfg.max_slots) slots_total = static_cast<uint32_t>(e->n_cu) * cs.per_cu;
+        }
+    }
     if (dry) {
         // the launches' scratch as polish_view will lay it out (usual alphabet: A, C, G, T and one more symbol), and the pinned
         // result buffer of collect()
@@ -1452,7 +1573,7 @@ int rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* h) {
     sh.sum_l = static_cast<int32_t>(std::min<uint64_t>(deepest > L ? deepest - L : 0, 1u << 30));
     sh.lmax = static_cast<int32_t>(h->max_layer_length ? h->max_layer_length : L + (3 * L + 9) / 10);
     sh.nsym = 5;
-    const Caps c = first_pass_caps(&sh, &sh + 1, !getenv("RCN_WIDE_ONLY"), e->caps_level);
+    const Caps c = first_pass_caps(&sh, &sh + 1, !e->knobs.wide_only, e->caps_level, e->knobs.hrows_div);
     const uint64_t slots = std::min<uint64_t>(nw, e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint64_t>(e->n_cu) * 8u);
     { size_t fr = 0, tot = 0; HIP_TRY(hipMemGetInfo(&fr, &tot)); e->free_mem = fr + e->d_scratch.cap; }
     const uint64_t want = std::min<uint64_t>(slots * c.slot_bytes, scratch_budget(e));
@@ -1476,7 +1597,7 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         // engine's own non-blocking stream (a plain hipMemcpy runs on the null stream and waits for every blocking stream of
         // the process -- the CU-masked launch streams of the device's other engine among them)
         HIP_TRY(hipSetDevice(e->cfg.device));
-        unsigned long long st[25] = {0};
+        unsigned long long st[35] = {0};
         HIP_TRY(hipMemcpyAsync(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
@@ -1485,6 +1606,8 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         e->stats.dp_cells_full = st[12]; e->stats.dp_bytes_full = st[13]; e->stats.n_banded = st[14]; e->stats.n_band_redone = st[15];
         for (int k = 0; k < 8; ++k) e->stats.band_redo_why[k] = st[16 + k];
         e->stats.n_code_wave = st[24];
+        e->stats.n_small = st[25];
+        for (int k = 0; k < 9; ++k) e->stats.small_bail_why[k] = st[26 + k];
         e->stats_pending = false;
     }
     *out = e->stats;

@@ -355,7 +355,9 @@ __device__ __forceinline__ void poa_window_body(const KParams& P) {
 // VGPRs, and the compiler gives a function ONE register budget, its most generous caller's): engine.hip has the kernel
 // for eight work-groups per CU, engine_deep.hip (RCN_DEEP_TU) the one for a work-group that has a CU to itself, two waves
 // per SIMD at most.  RCN_ONE_TU (profiling builds, whose device-side counters must exist once): both here, same bounds.
-#ifdef RCN_DEEP_TU
+#if defined(RCN_SMALL_TU)
+// (engine_small.hip: the helpers of this file, none of its kernels)
+#elif defined(RCN_DEEP_TU)
 __global__ __launch_bounds__(kThreads2, 2) void poa_window_kernel2_deep(KParams P) { poa_window_body<true>(P); }
 #else
 __global__ __launch_bounds__(kThreads2, 8) void poa_window_kernel2(KParams P) { poa_window_body<false>(P); }

@@ -34,7 +34,8 @@ class RcnRunStats(C.Structure):
                 ("dp_bytes", C.c_uint64), ("phase_clocks", C.c_uint64 * 8), ("n_sink_ties", C.c_uint64),
                 ("dp_cells_full", C.c_uint64), ("dp_bytes_full", C.c_uint64), ("n_banded", C.c_uint64), ("n_band_redone", C.c_uint64),
                 ("band_redo_why", C.c_uint64 * 8), ("wg_per_cu", C.c_uint32), ("split_deep", C.c_uint32), ("split_cus", C.c_uint32),
-                ("split_deep_per_cu", C.c_uint32), ("launch_ms", C.c_double * 2), ("n_code_wave", C.c_uint64)]
+                ("split_deep_per_cu", C.c_uint32), ("launch_ms", C.c_double * 2), ("n_code_wave", C.c_uint64),
+                ("n_small", C.c_uint64), ("n_small_bailed", C.c_uint64), ("small_bail_why", C.c_uint64 * 9)]
 
 
 class RcnWindowDesc(C.Structure):
@@ -170,6 +171,7 @@ class HipEngine:
         d["phase_clocks"] = list(s.phase_clocks)
         d["band_redo_why"] = list(s.band_redo_why)
         d["launch_ms"] = list(s.launch_ms)
+        d["small_bail_why"] = list(s.small_bail_why)
         return d
 
     def consensus(self, batch: WindowBatch) -> ConsensusResult:

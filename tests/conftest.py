@@ -12,6 +12,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _experiment_gate(monkeypatch):
+    """The engine reads its RCN_* test / experiment switches once, at creation, and only with this gate set
+    (engine.hip: read_knobs): a stray variable in a user's environment cannot change the product's kernel path."""
+    monkeypatch.setenv("RCN_EXPERIMENT", "1")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle_lib

@@ -1,0 +1,127 @@
+"""-m gpu: the small-window kernel (racon_amd/csrc/poa_small.hpp: one wave per window, the graph in LDS) against the CPU
+oracle and against poa_window_kernel2 -- BASELINE configs[3] (150-bp reads at 60x, -w 200: reference src/window.cpp:99-107,
+the Subgraph branch nearly every layer takes) and every way a window can leave that kernel and come back through the
+retry tier."""
+import numpy as np
+import pytest
+
+from racon_amd.batch import WindowBatch
+from racon_amd.synth import config_windows, simulate_windows
+from helpers import assert_same, edge_case_batch, q
+
+pytestmark = pytest.mark.gpu
+
+SHORT = dict(sub=0.003, ins=0.0005, dele=0.0005, phred_mean=30, phred_sd=0)
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from racon_amd.engine import HipEngine
+    return HipEngine
+
+
+def _no_bug(st):
+    assert st["small_bail_why"][8] == 0, st["small_bail_why"]          # internal inconsistencies: never
+
+
+def test_cfg4_share_through_the_small_kernel(Engine, oracle):
+    b = config_windows("cfg4", 0.04)                                    # 200 windows of ~140 layers
+    ref = oracle.consensus(b, 3, -5, -4, True, 0)
+    eng = Engine(3, -5, -4, True)
+    got = eng.consensus(b)
+    st = eng.stats()
+    assert_same(got, ref, "cfg4 share")
+    _no_bug(st)
+    assert st["n_small"] + st["n_small_bailed"] == b.n_windows and st["n_small"] >= 0.9 * b.n_windows, st
+    assert_same(eng.run(), ref, "resident batch again")
+    assert_same(eng.consensus_refs(b), ref, "refs")
+
+
+def test_small_kernel_equals_the_four_wave_kernel(Engine, monkeypatch):
+    b = simulate_windows(30_000, 200, 60.0, 150, seed=41, **SHORT)
+    eng = Engine(3, -5, -4, True)
+    a = eng.consensus(b)
+    assert eng.stats()["n_small"] > 0
+    _no_bug(eng.stats())
+    monkeypatch.setenv("RCN_NO_SMALL", "1")
+    off = Engine(3, -5, -4, True)
+    r = off.consensus(b)
+    assert off.stats()["n_small"] == 0
+    assert_same(a, r, "small kernel vs poa_window_kernel2")
+
+
+@pytest.mark.parametrize("scores", [(3, -5, -4), (5, -4, -8), (1, -1, -1), (4, -6, -100)])
+def test_scores_and_exact_consensus_order(Engine, oracle, monkeypatch, scores):
+    b = simulate_windows(12_000, 200, 40.0, 150, seed=43, **SHORT)
+    ref = oracle.consensus(b, *scores, True, 0)
+    eng = Engine(*scores, True)
+    assert_same(eng.consensus(b), ref, f"{scores}")
+    _no_bug(eng.stats())
+    monkeypatch.setenv("RCN_FORCE_EXACT", "1")                           # every window: spoa's own DFS order, then the bundle over it
+    ex = Engine(*scores, True)
+    assert_same(ex.consensus(b), ref, f"{scores}, exact order")
+    _no_bug(ex.stats())
+
+
+def test_tgs_trim_noisy_reads_and_the_way_back(Engine, oracle):
+    """kTGS windows (coverage trim: the coverage atomics), reads noisy enough that graphs outgrow the LDS, get a fifth
+    in-edge or a far predecessor: those windows come back flagged and poa_window_kernel2 polishes them."""
+    b = simulate_windows(16_000, 200, 30.0, 2000, seed=45)              # ONT-like errors on 200-base windows
+    ref = oracle.consensus(b, 3, -5, -4, True, 0)
+    eng = Engine(3, -5, -4, True)
+    got = eng.consensus(b)
+    st = eng.stats()
+    assert_same(got, ref, "noisy short windows")
+    _no_bug(st)
+    assert st["n_small_bailed"] > 0 and st["n_retried"] >= st["n_small_bailed"], st
+    mild = simulate_windows(16_000, 200, 30.0, 2000, seed=46, sub=0.01, ins=0.005, dele=0.005)
+    refm = oracle.consensus(mild, 3, -5, -4, True, 0)
+    e2 = Engine(3, -5, -4, True)
+    assert_same(e2.consensus(mild), refm, "mild TGS windows, trimmed")
+    _no_bug(e2.stats())
+    assert e2.stats()["n_small"] > 0
+    notrim = Engine(3, -5, -4, False)
+    assert_same(notrim.consensus(mild), oracle.consensus(mild, 3, -5, -4, False, 0), "mild TGS windows, no trim")
+
+
+def test_no_quality_other_symbols_and_corner_windows(Engine, oracle):
+    nq = simulate_windows(10_000, 200, 40.0, 150, seed=47, with_quality=False, **SHORT)
+    eng = Engine(3, -5, -4, True)
+    assert_same(eng.consensus(nq), oracle.consensus(nq, 3, -5, -4, True, 0), "no qualities")
+    _no_bug(eng.stats())
+    assert eng.stats()["n_small"] > 0
+    # the hand-made corner windows (fewer than three sequences, begin ties, chimeric, lower case / N: other symbols leave the kernel)
+    b = edge_case_batch()
+    e2 = Engine(3, -5, -4, True)
+    assert_same(e2.consensus(b), oracle.consensus(b, 3, -5, -4, True, 2), "edge cases")
+    _no_bug(e2.stats())
+    # a window with an N in one layer among ACGT windows
+    wins = []
+    rng = np.random.default_rng(5)
+    for k in range(70):
+        bb = bytes(rng.choice(list(b"ACGT"), 120).astype(np.uint8))
+        lay = bb[10:110]
+        seqs = [(bb, q(bb, 20), 0, 0)] + [(lay, q(lay, 25), 10, 109) for _ in range(4)] + [(bb, q(bb, 30), 0, 119)]
+        if k == 13:
+            withn = lay[:50] + b"N" + lay[51:]
+            seqs[2] = (withn, q(withn, 25), 10, 109)
+        wins.append({"type": 0, "seqs": seqs})
+    wb = WindowBatch.from_windows(wins)
+    e3 = Engine(3, -5, -4, True)
+    assert_same(e3.consensus(wb), oracle.consensus(wb, 3, -5, -4, True, 2), "one window with an N")
+    st = e3.stats()
+    _no_bug(st)
+    assert st["n_small_bailed"] >= 1 and st["small_bail_why"][3] >= 1, st
+
+
+def test_long_queue_and_slot_counts(Engine, oracle):
+    b = config_windows("cfg4", 0.02)
+    big = b.select(list(range(b.n_windows)) * 50)                        # 5000 windows: more than the resident slots
+    ref = oracle.consensus(b, 3, -5, -4, True, 0)
+    eng = Engine(3, -5, -4, True)
+    got = eng.consensus(big)
+    _no_bug(eng.stats())
+    for k in range(big.n_windows):
+        assert got.consensus[k] == ref.consensus[k % b.n_windows], k
+    few = Engine(3, -5, -4, True, max_slots=5)
+    assert_same(few.consensus(b), ref, "five slots")
