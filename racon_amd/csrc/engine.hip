@@ -334,10 +334,10 @@ bool small_caps(const rcn_engine* e, It first, It last, Caps& out) {
     c.fast = true; c.small = true;
     c.slot_bytes = rcn::small_slot_bytes(c.ncap);
     c.lds = rcn::small_layout(c.ncap).end;
-    // LDS is handed out in 1280-byte granules, 128 per CU; sixteen one-wave work-groups (four per SIMD) are what the kernel's
-    // register budget admits
+    // LDS is handed out in 1280-byte granules, 128 per CU; twelve one-wave work-groups (three per SIMD) are what the kernel's
+    // register budget admits (__launch_bounds__(64, 3): up to 168 VGPRs, nothing spilled)
     const uint32_t granules = (c.lds + 1279u) / 1280u;
-    c.per_cu = std::max(1u, std::min(16u, 128u / granules));
+    c.per_cu = std::max(1u, std::min(12u, 128u / granules));
     if (e->knobs.small_per_cu > 0) c.per_cu = static_cast<uint32_t>(std::min(32, e->knobs.small_per_cu));
     out = c;
     return true;
@@ -494,8 +494,17 @@ int launch_pass(rcn_engine* e, const Launch& L) {
 }
 
 // resident slots for a pass of n_work windows within the scratch budget (0: not even one slot fits)
+// A queue of a few windows per slot ends when the slot with one window more than the others is done: for the small-window
+// kernel (whose windows are alike) the slots are cut down to what fills whole rounds -- 5000 windows on 4096 slots are two
+// rounds for 904 slots and one for the rest; on 2500 slots they are two rounds for all, each window with fewer neighbours.
+inline uint32_t balanced_slots(uint32_t n_work, uint32_t max_slots) {
+    if (max_slots == 0 || n_work <= max_slots) return n_work;
+    const uint32_t rounds = (n_work + max_slots - 1) / max_slots;
+    return rounds > 8 ? max_slots : (n_work + rounds - 1) / rounds;
+}
 uint32_t slots_for(const rcn_engine* e, const Caps& c, uint32_t n_work, uint64_t budget) {
     uint32_t slots = std::min(e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * (c.small ? c.per_cu : wg_per_cu(e)), n_work);
+    if (c.small && !e->cfg.max_slots) slots = balanced_slots(n_work, slots);
     while (slots > 1 && static_cast<uint64_t>(slots) * c.slot_bytes > budget) slots = (slots + 1) / 2;
     return static_cast<uint64_t>(slots) * c.slot_bytes > budget ? 0 : slots;
 }
@@ -1124,7 +1133,7 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
     if (small) {
         e->pass_small = true;
         L.stream = e->sub_stream[c]; L.per_cu = L.c.per_cu;
-        L.slots = std::min(L.n_work, slots_left);
+        L.slots = e->cfg.max_slots ? std::min(L.n_work, slots_left) : balanced_slots(L.n_work, slots_left);
     } else if (sp.on) {
         L.stream = c == 0 ? e->deep_stream : e->rest_stream;
         L.per_cu = c == 0 ? sp.deep_per_cu : sp.rest_per_cu;
@@ -1597,7 +1606,7 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         // engine's own non-blocking stream (a plain hipMemcpy runs on the null stream and waits for every blocking stream of
         // the process -- the CU-masked launch streams of the device's other engine among them)
         HIP_TRY(hipSetDevice(e->cfg.device));
-        unsigned long long st[35] = {0};
+        unsigned long long st[40] = {0};
         HIP_TRY(hipMemcpyAsync(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
@@ -1608,6 +1617,7 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         e->stats.n_code_wave = st[24];
         e->stats.n_small = st[25];
         for (int k = 0; k < 9; ++k) e->stats.small_bail_why[k] = st[26 + k];
+        for (int k = 0; k < 5; ++k) e->stats.small_work[k] = st[35 + k];
         e->stats_pending = false;
     }
     *out = e->stats;

@@ -33,30 +33,34 @@
 
 namespace rcn {
 
-constexpr int kSmIn = 4;            // in-edge tails kept per node
+constexpr int kSmIn = 8;            // in-edge tails kept per node (move codes name a predecessor with three bits)
 constexpr int kSmRing = 3;          // aligned-ring members of a node besides itself
 constexpr int kSmLen = 255;         // longest layer (256 columns: two packed VGPRs per lane)
 constexpr int kSmWin = 16;          // rows of the register window = farthest predecessor row
 constexpr int kSmMinCap = 256, kSmMaxCap = 1024;     // node capacities the LDS layout is made for
 constexpr int kSmPosBytes = 512;    // per-position area: int16 x 256
 constexpr int kSmRow0 = 1 << 12;    // row descriptor: the only predecessor is the virtual start row
+constexpr int kSmWide = 1 << 13;    // row descriptor: five to eight predecessors, their distances in the side table
+constexpr int kSmWideRows = 16;     // rows of that kind per alignment (more: the window leaves the kernel)
 
 // LDS layout (byte offsets from the work-group's dynamic LDS) for a graph of up to `ncap` nodes.
 //   persistent for the window: code, alcnt, ink [ncap] u8; rank, n2r [ncap] u16; intail [ncap][4] u16; ring [ncap][3] u16
-//   per layer:   inc, mark [ncap] u8; rsub, nsub [ncap] u16; desc [ncap] u32; post [256] i16; misc: 16 words
+//   per layer:   inc, mark [ncap] u8; rsub, nsub [ncap] u16; desc [ncap] u32; post [256] i16; misc: 32 words (rows of the tied
+//                sinks, wide-row counter, distances of the wide rows); lseq [2][256] u8: the bases of this layer and
+//                (prefetched) of the next one; lqual [256]: this layer's qualities
 //   (phases that run after the traceback re-use inc .. desc: see sm_add / sm_consensus)
-struct SmLayout { uint32_t code, alcnt, ink, rank, n2r, intail, ring, inc, mark, rsub, nsub, desc, post, misc, end; };
+struct SmLayout { uint32_t code, alcnt, ink, rank, n2r, intail, ring, inc, mark, rsub, nsub, desc, post, misc, lseq, lqual, end; };
 __host__ __device__ inline SmLayout small_layout(int ncap) {
     const uint32_t n = static_cast<uint32_t>((ncap + 7) & ~7);
     SmLayout l;
     l.code = 0; l.alcnt = l.code + n; l.ink = l.alcnt + n; l.rank = l.ink + n; l.n2r = l.rank + 2 * n;
     l.intail = l.n2r + 2 * n; l.ring = l.intail + 2 * kSmIn * n;
     l.inc = l.ring + 2 * kSmRing * n; l.mark = l.inc + n; l.rsub = l.mark + n; l.nsub = l.rsub + 2 * n; l.desc = l.nsub + 2 * n;
-    l.post = l.desc + 4 * n; l.misc = l.post + kSmPosBytes; l.end = l.misc + 64;
+    l.post = l.desc + 4 * n; l.misc = l.post + kSmPosBytes; l.lseq = l.misc + 128; l.lqual = l.lseq + 512; l.end = l.lqual + 256;
     return l;
 }
-// HBM slot of a resident window: weights [ncap][4] u32, coverage [ncap] u32, then the move codes (256 bytes per DP row)
-__host__ __device__ inline uint64_t small_slot_codes(int ncap) { return (static_cast<uint64_t>(ncap) * 20 + 255) & ~uint64_t(255); }
+// HBM slot of a resident window: weights [ncap][8] u32, coverage [ncap] u32, then the move codes (256 bytes per DP row)
+__host__ __device__ inline uint64_t small_slot_codes(int ncap) { return (static_cast<uint64_t>(ncap) * (4 * kSmIn + 4) + 255) & ~uint64_t(255); }
 __host__ __device__ inline uint64_t small_slot_bytes(int ncap) { return small_slot_codes(ncap) + 256ull * (static_cast<uint64_t>(ncap) + 2); }
 
 #ifndef RCN_SMALL_TU
@@ -64,7 +68,14 @@ __global__ void poa_window_kernel_small(KParams P);        // defined in engine_
 #else
 template <class T> using sm_lds = __attribute__((address_space(3))) T*;
 template <class T> __device__ __forceinline__ sm_lds<T> sm_at(uint32_t byte_addr) { return reinterpret_cast<sm_lds<T>>(byte_addr); }
-__device__ __forceinline__ void sm_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0xc07f); }   // lgkmcnt(0): this wave's LDS traffic is done
+// Phase boundary of the one-wave work-group: this wave's LDS traffic is done (LDS operations of a wave execute in order; the
+// clobber keeps the compiler from moving LDS accesses across).  NOT a fence of the memory model: a workgroup- or agent-scope
+// fence also waits for the wave's outstanding global stores and atomics (vmcnt), and at agent scope writes the L2 back
+// (buffer_wbl2) -- per layer, that was most of the 64 % of their time the waves spent parked (profiles/r04/c_sq_cfg4_summary.txt).
+__device__ __forceinline__ void sm_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// this wave's global stores / atomics have been performed at the L2 (all a later access of the SAME wave's CU needs: the
+// L2 of its XCD is where its atomics execute and where its sc1 loads read)
+__device__ __forceinline__ void sm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Why a window left the kernel (statistics, stats[25 + why]): 1 graph capacity, 2 fifth in-edge, 3 far predecessor, 4 ring,
 // 5 int16 range, 6 layer too long, 7 sink tie, 8 consensus scratch, 9 internal inconsistency (a bug: tests assert it is zero)
@@ -75,7 +86,8 @@ struct SmPtrs {
     sm_lds<uint16_t> rank, n2r, intail, ring, rsub, nsub;
     sm_lds<uint32_t> desc;
     sm_lds<int16_t> post;
-    sm_lds<int32_t> misc;       // [0..7] rows of the tied sinks
+    sm_lds<int32_t> misc;       // [0..7] rows of the tied sinks, [8] wide rows of this alignment, [16..31] their distance words
+    sm_lds<uint8_t> lseq, lqual;   // [2][256], [256]
 };
 __device__ __forceinline__ SmPtrs sm_ptrs(uint32_t base, const SmLayout& l) {
     SmPtrs p;
@@ -84,6 +96,7 @@ __device__ __forceinline__ SmPtrs sm_ptrs(uint32_t base, const SmLayout& l) {
     p.rank = sm_at<uint16_t>(base + l.rank); p.n2r = sm_at<uint16_t>(base + l.n2r); p.intail = sm_at<uint16_t>(base + l.intail);
     p.ring = sm_at<uint16_t>(base + l.ring); p.rsub = sm_at<uint16_t>(base + l.rsub); p.nsub = sm_at<uint16_t>(base + l.nsub);
     p.desc = sm_at<uint32_t>(base + l.desc); p.post = sm_at<int16_t>(base + l.post); p.misc = sm_at<int32_t>(base + l.misc);
+    p.lseq = sm_at<uint8_t>(base + l.lseq); p.lqual = sm_at<uint8_t>(base + l.lqual);
     return p;
 }
 
@@ -91,7 +104,7 @@ __device__ __forceinline__ SmPtrs sm_ptrs(uint32_t base, const SmLayout& l) {
 // spoa's ExtractSubgraph(end, begin) = nodes with id >= begin backward-reachable from `end` over in-edges and aligned
 // links = one descending sweep over the RING BLOCKS of the ring-contiguous topological order (see phase_subgraph2).
 // Fills inc[] (by node), rsub / nsub (the subgraph's own order and its inverse); returns its size.
-__device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, int end, int lane) {
+__device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, int end, int lane, unsigned int& n_chunks) {
     sm_lds<uint8_t> pend = reinterpret_cast<sm_lds<uint8_t>>(g.desc);             // [n] pending / included, by rank
     int top;
     {
@@ -100,12 +113,13 @@ __device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, in
         for (int a = 0; a < na; ++a) r = max(r, static_cast<int>(g.n2r[g.ring[end * kSmRing + a]]));
         top = bcast0(r);
     }
-    for (int r = lane; r < n; r += 64) pend[r] = 0;
+    for (int r = lane; r <= top; r += 64) pend[r] = 0;          // (nothing above `top` is looked at: tails and ring mates rank below their node's block end)
     sm_fence();
     if (lane == 0) pend[g.n2r[end]] = 1;
     sm_fence();
     int hi = top, minpend = bcast0(static_cast<int>(g.n2r[end]));
     while (hi >= 0 && minpend <= hi) {
+        ++n_chunks;
         const int base = hi - 63;
         const int r = base + lane;
         const bool have = r >= 0;
@@ -113,7 +127,15 @@ __device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, in
         const int k = have ? g.ink[v] : 0;
         int tr[kSmIn];
 #pragma unroll
-        for (int q = 0; q < kSmIn; ++q) { const int tn = g.intail[v * kSmIn + q]; tr[q] = q < k ? static_cast<int>(g.n2r[tn < n ? tn : 0]) : -1; }
+        for (int q = 0; q < kSmIn; ++q) tr[q] = -1;
+        // (a third in-edge is rare, a fifth rarer: whole chunks skip those loads)
+        auto tails = [&](int q0, int q1) {
+#pragma unroll
+            for (int q = 0; q < kSmIn; ++q) if (q >= q0 && q < q1) { const int tn = g.intail[v * kSmIn + q]; tr[q] = q < k ? static_cast<int>(g.n2r[tn < n ? tn : 0]) : -1; }
+        };
+        tails(0, 2);
+        if (__ballot(k > 2)) tails(2, 4);
+        if (__ballot(k > 4)) tails(4, 8);
         const int na = have ? g.alcnt[v] : 0;
         int rb = r;
 #pragma unroll
@@ -175,12 +197,12 @@ __device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, in
     // inclusion flags by node and the subgraph's own order
     int nv = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int b0 = 0; b0 < n; b0 += 64) {
+    for (int b0 = 0; b0 <= top; b0 += 64) {
         const int r = b0 + lane;
-        const int v = r < n ? g.rank[r] : 0;
-        const bool in = r < n && r <= top && pend[r] != 0;
+        const int v = r <= top ? g.rank[r] : 0;
+        const bool in = r <= top && pend[r] != 0;
         const unsigned long long mk = __ballot(in);
-        if (r < n) g.inc[v] = in ? 1 : 0;
+        if (r <= top) g.inc[v] = in ? 1 : 0;
         if (in) { const int pos = nv + __popcll(mk & lt); g.rsub[pos] = static_cast<uint16_t>(v); g.nsub[v] = static_cast<uint16_t>(pos); }
         nv += __popcll(mk);
     }
@@ -190,12 +212,14 @@ __device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, in
 
 // ---- row descriptors: one word per DP row ----
 // bits 0-7 symbol, 8 sink (no successor inside the (sub)graph), 9-11 number of predecessors (1..4), 12 the only predecessor
-// is the virtual start row, 16-31 four 4-bit distances to the predecessor rows in in-edge order (16 is stored as 0).
+// is the virtual start row, 16-31 four 4-bit distances to the predecessor rows in in-edge order (16 is stored as 0); a row
+// with five to eight predecessors (bit 13): 16-19 its entry of the side table (eight distance nibbles), 20-23 their number.
 // Also leaves mark[r] = row r has a successor.  Returns a bail reason or 0.
 __device__ __forceinline__ int sm_desc(const SmPtrs& g, int V, bool partial, int lane) {
     const sm_lds<uint16_t> rk = partial ? g.rsub : g.rank;
     const sm_lds<uint16_t> nr = partial ? g.nsub : g.n2r;
     for (int r = lane; r < V; r += 64) g.mark[r] = 0;
+    if (lane == 0) g.misc[8] = 0;
     sm_fence();
     int bad = 0;
     for (int r = lane; r < V; r += 64) {
@@ -216,8 +240,15 @@ __device__ __forceinline__ int sm_desc(const SmPtrs& g, int V, bool partial, int
                 }
             }
         }
-        uint32_t meta = static_cast<uint32_t>(g.code[v]) | (dd << 16);
-        meta |= np == 0 ? (static_cast<uint32_t>(kSmRow0) | (1u << 9)) : (static_cast<uint32_t>(np) << 9);
+        uint32_t meta = static_cast<uint32_t>(g.code[v]);
+        if (np == 0) meta |= static_cast<uint32_t>(kSmRow0) | (1u << 9);
+        else if (np <= 4) meta |= (static_cast<uint32_t>(np) << 9) | (dd << 16);
+        else {
+            // five to eight predecessors (rare): the eight distance nibbles go to the side table
+            const int idx = __hip_atomic_fetch_add(g.misc + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (idx >= kSmWideRows) bad = kSmInDeg;
+            else { g.misc[16 + idx] = static_cast<int32_t>(dd); meta |= static_cast<uint32_t>(kSmWide) | (static_cast<uint32_t>(idx) << 16) | (static_cast<uint32_t>(np) << 20); }
+        }
         g.desc[r] = meta;
     }
     sm_fence();
@@ -231,7 +262,7 @@ __device__ __forceinline__ int sm_desc(const SmPtrs& g, int V, bool partial, int
 // ---- NW DP (window.cpp:95-97,104-106), Z domain, packed int16, move codes out ----
 struct SmDpOut { int best, best_row, tied; unsigned int pred_rows; };
 template <int NP>
-__device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, RCN_G const uint8_t* seq, RCN_G uint8_t* cmat, int m, int x, int gp, int lane) {
+__device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds<uint8_t> seq, RCN_G uint8_t* cmat, int m, int x, int gp, int lane) {
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
     constexpr int LPC = 2 * NP;                 // columns per lane
     constexpr uint32_t rowb = 128u * NP;        // bytes of a code row
@@ -243,7 +274,8 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, RCN_G 
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int j0 = lane * LPC + 2 * q, j1 = j0 + 1;
-        const int s0 = (j0 >= 1 && j0 <= len) ? seq[j0 - 1] : 0x100, s1 = (j1 >= 1 && j1 <= len) ? seq[j1 - 1] : 0x100;
+        const int l0 = seq[min(max(j0 - 1, 0), 255)], l1 = seq[min(max(j1 - 1, 0), 255)];
+        const int s0 = (j0 >= 1 && j0 <= len) ? l0 : 0x100, s1 = (j1 >= 1 && j1 <= len) ? l1 : 0x100;
         sqx[q] = pack2(s0, s1);
     }
     u32x16 w0, w1;
@@ -260,7 +292,7 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, RCN_G 
         uint32_t dmeta = (1u << 9) | static_cast<uint32_t>(kSmRow0);
         if (rbase + lane < V) dmeta = g.desc[rbase + lane];
         {
-            int npl = rbase + lane < V ? static_cast<int>((dmeta >> 9) & 7) : 0;
+            int npl = rbase + lane < V ? static_cast<int>((dmeta & kSmWide) ? ((dmeta >> 20) & 15) : ((dmeta >> 9) & 7)) : 0;
 #pragma unroll
             for (int sh = 32; sh >= 1; sh >>= 1) npl += __shfl_xor(npl, sh);
             pred_rows += static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(npl));
@@ -275,8 +307,12 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, RCN_G 
             uint32_t P[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) P[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
-            const uint32_t dd = meta >> 16;
-            const int npf = static_cast<int>((meta >> 9) & 7);
+            uint32_t dd = meta >> 16;
+            int npf = static_cast<int>((meta >> 9) & 7);
+            if (__builtin_expect((meta & kSmWide) != 0u, 0)) {
+                npf = static_cast<int>((meta >> 20) & 15);
+                dd = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(g.misc[16 + ((meta >> 16) & 15)]));
+            }
             uint32_t M[NP], Aq[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) Aq[q] = 0u;
@@ -441,7 +477,7 @@ __device__ __forceinline__ int sm_sink_tie(const SmPtrs& g, int tied, int best_r
 // gather of the box a purely diagonal walk reaches next is issued before the current box is decoded.  Returns 0, or
 // kSmBug when the codes lead nowhere.
 template <int NP>
-__device__ __forceinline__ int sm_traceback(const SmPtrs& g, int best_row, int len, RCN_G const uint8_t* cmat, int lane) {
+__device__ __forceinline__ int sm_traceback(const SmPtrs& g, int best_row, int len, RCN_G const uint8_t* cmat, int lane, unsigned int& n_boxes, unsigned int& n_regather) {
     constexpr uint32_t rowb = 128u * NP;
     const int a = lane >> 3, b = lane & 7;
     auto gather = [&](int ci, int cj) -> int {
@@ -451,10 +487,13 @@ __device__ __forceinline__ int sm_traceback(const SmPtrs& g, int best_row, int l
         return cmat[o];
     };
     int i = best_row, j = len;
-    int code = gather(i, j);
+    // the boxes a purely diagonal walk visits are 8 rows and 8 columns apart: their gathers are kept four deep in flight (a
+    // gather is an L2 round trip, a box's decode and walk a few hundred clocks); a walk that leaves the diagonal starts over
+    int c0 = gather(i, j), c1 = gather(i - 8, j - 8), c2 = gather(i - 16, j - 16), c3 = gather(i - 24, j - 24);
     int guard = 0;
     while (!(i == 0 && j == 0)) {
-        const int code_next = gather(i - 8, j - 8);
+        ++n_boxes;
+        const int code = c0;
         const int ii = i - a - b, jj = j - b;
         const bool inside = ii >= 0 && jj >= 0;
         const uint32_t meta = (inside && ii >= 1) ? g.desc[ii - 1] : 0u;
@@ -463,9 +502,13 @@ __device__ __forceinline__ int sm_traceback(const SmPtrs& g, int best_row, int l
         const bool up = !row0 && !dg && !(code & 2);
         int mv = dg ? kMvDiag : up ? kMvUp : jpos ? kMvLeft : kMvInvalid;
         const int q = dg ? ((code >> 2) & 7) : up ? (code >> 5) : 0;
-        const int dist = ((static_cast<int>(meta >> (16 + 4 * (q & 3))) - 1) & 15) + 1;
+        const bool wide = (meta & kSmWide) != 0u;
+        const uint32_t ddw = static_cast<uint32_t>(g.misc[16 + ((meta >> 16) & 15)]);      // (read by every lane: no exec-masked region)
+        const uint32_t ddq = wide ? ddw : (meta >> 16);
+        const int npq = wide ? static_cast<int>((meta >> 20) & 15) : static_cast<int>((meta >> 9) & 7);
+        const int dist = ((static_cast<int>(ddq >> (4 * q)) - 1) & 15) + 1;
         int pi = (meta & kSmRow0) ? 0 : ii - dist;
-        if (q >= static_cast<int>((meta >> 9) & 7)) pi = -1;                  // a predecessor number the row does not have
+        if (q >= npq) pi = -1;                                                 // a predecessor number the row does not have
         mv = (!inside || (mv != kMvLeft && pi < 0)) ? kMvInvalid : mv;
         const int ni = mv == kMvLeft ? ii : pi, nj = jj - (mv == kMvUp ? 0 : 1);
         const int nb = j - nj, na = i - ni - nb;
@@ -484,7 +527,8 @@ __device__ __forceinline__ int sm_traceback(const SmPtrs& g, int best_row, int l
         int ti, tj;
         if (nxt == kNxInvalid) { if (idx == 0) return kSmBug; ti = __builtin_amdgcn_readlane(ii, idx); tj = __builtin_amdgcn_readlane(jj, idx); }
         else { ti = __builtin_amdgcn_readlane(ni, idx); tj = __builtin_amdgcn_readlane(nj, idx); }
-        code = (ti == i - 8 && tj == j - 8) ? code_next : gather(ti, tj);
+        if (ti == i - 8 && tj == j - 8) { c0 = c1; c1 = c2; c2 = c3; c3 = gather(ti - 24, tj - 24); }
+        else if (!(ti == 0 && tj == 0)) { ++n_regather; c0 = gather(ti, tj); c1 = gather(ti - 8, tj - 8); c2 = gather(ti - 16, tj - 16); c3 = gather(ti - 24, tj - 24); }
         i = ti; j = tj;
         if (++guard > 4 * (kSmMaxCap + kSmLen)) return kSmBug;
     }
@@ -497,7 +541,7 @@ __device__ __forceinline__ int sm_traceback(const SmPtrs& g, int best_row, int l
 // once, so positions are independent up to the node numbering (prefix count) and the order anchors (prefix max); distinct
 // positions touch distinct nodes, rings and in-records.  Work arrays over the dead inc / mark / nsub / desc areas.
 struct SmAddOut { int n, why; };
-__device__ __forceinline__ SmAddOut sm_add(const SmPtrs& g, int n_old, int ncap, bool partial, int len, RCN_G const uint8_t* seq, RCN_G const uint8_t* qual,
+__device__ __forceinline__ SmAddOut sm_add(const SmPtrs& g, int n_old, int ncap, bool partial, int len, sm_lds<uint8_t> seq, sm_lds<uint8_t> qual, bool has_qual,
                                            RCN_G uint32_t* wgt, RCN_G uint32_t* cov, int lane) {
     const sm_lds<uint16_t> rk = partial ? g.rsub : g.rank;
     const sm_lds<uint16_t> curr = reinterpret_cast<sm_lds<uint16_t>>(g.desc);             // [len] node that carries the base
@@ -576,7 +620,9 @@ __device__ __forceinline__ SmAddOut sm_add(const SmPtrs& g, int n_old, int ncap,
     for (int pos = lane; pos < len; pos += 64) {
         if (pos >= 1) {
             const int tail = curr[pos - 1], head = curr[pos];
-            const uint32_t w = static_cast<uint32_t>(pair_weight(qual, pos));
+            // weights[pos - 1] + weights[pos] (uint32 arithmetic on (char)quality - 33; no quality: 1 + 1), as pair_weight of poa_core.hpp
+            const uint32_t w = has_qual ? static_cast<uint32_t>(static_cast<int32_t>(static_cast<signed char>(qual[pos - 1])) - 33) +
+                                          static_cast<uint32_t>(static_cast<int32_t>(static_cast<signed char>(qual[pos])) - 33) : 2u;
             const int k = g.ink[head];
             int slot = -1;
 #pragma unroll
@@ -838,7 +884,7 @@ __device__ __forceinline__ SmConsOut sm_consensus(const SmPtrs& g, int n, int nc
 }
 
 // ---- the kernel ----
-__global__ __launch_bounds__(64, 4) void poa_window_kernel_small(KParams P) {
+__global__ __launch_bounds__(64, 3) void poa_window_kernel_small(KParams P) {
     extern __shared__ int4 lds_dyn[];
     const int lane = threadIdx.x;
     const uint32_t lbase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_dyn));
@@ -851,7 +897,7 @@ __global__ __launch_bounds__(64, 4) void poa_window_kernel_small(KParams P) {
     RCN_G uint8_t* cmat = slot + small_slot_codes(ncap);                                 // move codes, rows of 128 or 256 bytes
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // sub, desc, dp, traceback, add (+ merge), -, consensus, other
     unsigned long long st_cells = 0, st_pred = 0, st_bytes = 0, st_ties = 0;
-    unsigned int st_done = 0;
+    unsigned int st_done = 0, st_boxes = 0, st_regather = 0, st_chunks = 0, st_rows = 0, st_aligns = 0;
     long long tck = clock64();
 #define RCN_PHASE_S(k) do { const long long now__ = clock64(); ph[k] += now__ - tck; tck = now__; } while (0)
     for (;;) {
@@ -882,10 +928,12 @@ __global__ __launch_bounds__(64, 4) void poa_window_kernel_small(KParams P) {
         if (!why) {
             // ---- backbone -> graph (window.cpp:73-77); every weight / coverage word of the slot starts at its final-or-zero value ----
             RCN_G const uint8_t* q0 = P.seq_has_qual[s0] ? gcast(P.quals + P.seq_off[s0]) : nullptr;
+            static_assert(kSmIn == 8, "two 16-byte stores per node");
             for (int i = lane; i < ncap; i += 64) {
                 uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+                reinterpret_cast<RCN_G uint4*>(wgt)[2 * i + 1] = w4;
                 if (i >= 1 && i < L) w4.x = static_cast<uint32_t>(pair_weight(q0, i));
-                reinterpret_cast<RCN_G uint4*>(wgt)[i] = w4;
+                reinterpret_cast<RCN_G uint4*>(wgt)[2 * i] = w4;
                 cov[i] = (i < L && L >= 2) ? 1u : 0u;
             }
             for (int i = lane; i < L; i += 64) {
@@ -893,22 +941,58 @@ __global__ __launch_bounds__(64, 4) void poa_window_kernel_small(KParams P) {
                 g.intail[i * kSmIn] = static_cast<uint16_t>(i > 0 ? i - 1 : 0);
                 g.rank[i] = static_cast<uint16_t>(i); g.n2r[i] = static_cast<uint16_t>(i);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_s_waitcnt(0);              // the plain stores above are ordered before every later atomic
+            sm_fence(); sm_drain();                     // the plain stores above are ordered before every later atomic
         }
+        // Layer metadata and bytes run one layer ahead of their use: the scalar loads of layer jl + 1 are issued at the top of
+        // layer jl, its bases / qualities go into registers behind the Subgraph sweep and into the other half of lseq / lqual
+        // after the traceback -- no phase of a layer waits for HBM on its own behalf.
+        struct LayerMeta { uint32_t si; int len; bool partial, has_qual; int begin, end; uint64_t off; };
+        auto load_meta = [&](int jl_) {
+            LayerMeta m_;
+            m_.si = s0 + P.order[s0 + jl_];
+            m_.off = P.seq_off[m_.si];
+            m_.len = static_cast<int>(P.seq_off[m_.si + 1] - m_.off);
+            m_.partial = P.seq_full[m_.si] == 0; m_.has_qual = P.seq_has_qual[m_.si] != 0;
+            m_.begin = static_cast<int>(P.seq_begin[m_.si]); m_.end = static_cast<int>(P.seq_end[m_.si]);
+            return m_;
+        };
+        uint32_t pre_s = 0, pre_q = 0;                  // bytes lane, lane + 64, lane + 128, lane + 192 of the prefetched layer
+        auto load_bytes = [&](const LayerMeta& m_) {
+            RCN_G const uint8_t* sp = gcast(P.bases + m_.off);
+            RCN_G const uint8_t* qp = gcast(P.quals + m_.off);
+            pre_s = 0; pre_q = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pos = lane + 64 * k;
+                const bool act = pos < m_.len && pos <= kSmLen;
+                const uint32_t sb = act ? sp[pos] : 0u, qb = (act && m_.has_qual) ? qp[pos] : 0u;
+                pre_s |= sb << (8 * k); pre_q |= qb << (8 * k);
+            }
+        };
+        auto store_seq = [&](int half) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g.lseq[half * 256 + lane + 64 * k] = static_cast<uint8_t>(pre_s >> (8 * k));
+        };
+        auto store_qual = [&]() {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g.lqual[lane + 64 * k] = static_cast<uint8_t>(pre_q >> (8 * k));
+        };
+        LayerMeta nxt = load_meta(1);
+        if (!why) { load_bytes(nxt); store_seq(1); store_qual(); sm_fence(); }
         for (int jl = 1; jl < ns && !why; ++jl) {
-            const uint32_t si = s0 + P.order[s0 + jl];
-            const int len = static_cast<int>(P.seq_off[si + 1] - P.seq_off[si]);
-            const bool partial = P.seq_full[si] == 0;
-            RCN_G const uint8_t* seq = gcast(P.bases + P.seq_off[si]);
-            RCN_G const uint8_t* qual = P.seq_has_qual[si] ? gcast(P.quals + P.seq_off[si]) : nullptr;
+            const LayerMeta cur = nxt;
+            if (jl + 1 < ns) nxt = load_meta(jl + 1);
+            const int len = cur.len;
+            const bool partial = cur.partial;
+            const sm_lds<uint8_t> seq = g.lseq + (jl & 1) * 256, qual = g.lqual;
             if (len > kSmLen || len < 1) { why = kSmLong; break; }
             int V = n;
             if (partial) {
-                const int begin = static_cast<int>(P.seq_begin[si]), end = static_cast<int>(P.seq_end[si]);
+                const int begin = cur.begin, end = cur.end;
                 if (end >= n || begin > end) { why = kSmBug; break; }
-                V = sm_subgraph(g, n, begin, end, lane);
+                V = sm_subgraph(g, n, begin, end, lane, st_chunks);
             }
+            if (jl + 1 < ns) load_bytes(nxt);           // (in flight through the descriptors, the DP and the traceback)
             RCN_PHASE_S(0);
             const int np_regs = len + 1 <= 128 ? 1 : 2;
             {
@@ -937,19 +1021,20 @@ __global__ __launch_bounds__(64, 4) void poa_window_kernel_small(KParams P) {
                 if (best_row == 0) { why = kSmTie; break; }
                 ++st_ties;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_s_waitcnt(0);              // the code rows are in memory before the traceback gathers them
-            why = np_regs == 1 ? sm_traceback<1>(g, best_row, len, cmat, lane) : sm_traceback<2>(g, best_row, len, cmat, lane);
+            sm_drain();                                 // the code rows are in memory before the traceback gathers them
+            why = np_regs == 1 ? sm_traceback<1>(g, best_row, len, cmat, lane, st_boxes, st_regather) : sm_traceback<2>(g, best_row, len, cmat, lane, st_boxes, st_regather);
+            st_rows += static_cast<unsigned int>(V); ++st_aligns;
+            if (jl + 1 < ns) store_seq((jl + 1) & 1);
             RCN_PHASE_S(3);
             if (why) break;
-            const SmAddOut ao = sm_add(g, n, ncap, partial, len, seq, qual, wgt, cov, lane);
+            const SmAddOut ao = sm_add(g, n, ncap, partial, len, seq, qual, cur.has_qual, wgt, cov, lane);
+            if (jl + 1 < ns) { sm_fence(); store_qual(); }        // (the one quality buffer is this layer's until its edges are in)
             RCN_PHASE_S(4);
             why = ao.why;
             n = ao.n;
         }
         if (!why) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_s_waitcnt(0);              // every weight / coverage atomic of this window has been performed
+            sm_drain();                                 // every weight / coverage atomic of this window has been performed
             const uint64_t wbases = P.seq_off[s0 + ns] - P.seq_off[s0];
             if (wbases * 444ull >= 0x7fffffffull) why = kSmRange;
             else {
@@ -970,6 +1055,10 @@ __global__ __launch_bounds__(64, 4) void poa_window_kernel_small(KParams P) {
         atomicAdd(&P.stats[11], st_ties);
         atomicAdd(&P.stats[12], st_cells); atomicAdd(&P.stats[13], st_bytes);
         atomicAdd(&P.stats[25], static_cast<unsigned long long>(st_done));
+        // work counters: alignments, DP rows, Subgraph sweep chunks, traceback boxes, boxes whose gather had to start over
+        atomicAdd(&P.stats[35], static_cast<unsigned long long>(st_aligns)); atomicAdd(&P.stats[36], static_cast<unsigned long long>(st_rows));
+        atomicAdd(&P.stats[37], static_cast<unsigned long long>(st_chunks)); atomicAdd(&P.stats[38], static_cast<unsigned long long>(st_boxes));
+        atomicAdd(&P.stats[39], static_cast<unsigned long long>(st_regather));
     }
 }
 

@@ -35,7 +35,8 @@ class RcnRunStats(C.Structure):
                 ("dp_cells_full", C.c_uint64), ("dp_bytes_full", C.c_uint64), ("n_banded", C.c_uint64), ("n_band_redone", C.c_uint64),
                 ("band_redo_why", C.c_uint64 * 8), ("wg_per_cu", C.c_uint32), ("split_deep", C.c_uint32), ("split_cus", C.c_uint32),
                 ("split_deep_per_cu", C.c_uint32), ("launch_ms", C.c_double * 2), ("n_code_wave", C.c_uint64),
-                ("n_small", C.c_uint64), ("n_small_bailed", C.c_uint64), ("small_bail_why", C.c_uint64 * 9)]
+                ("n_small", C.c_uint64), ("n_small_bailed", C.c_uint64), ("small_bail_why", C.c_uint64 * 9),
+                ("small_work", C.c_uint64 * 5)]
 
 
 class RcnWindowDesc(C.Structure):
@@ -172,6 +173,7 @@ class HipEngine:
         d["band_redo_why"] = list(s.band_redo_why)
         d["launch_ms"] = list(s.launch_ms)
         d["small_bail_why"] = list(s.small_bail_why)
+        d["small_work"] = list(s.small_work)
         return d
 
     def consensus(self, batch: WindowBatch) -> ConsensusResult:

@@ -14,7 +14,7 @@ has() { [[ " $WHAT " == *" $1 "* ]]; }
 benchline() { python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
-print('%s: %.0f windows/s  step %.2f ms  frac %.3f  gcups %.0f  small %s bailed %s why %s  phase %s' % ('$1', j['value'], r['step_kernel_ms'], r['frac'], r.get('gcups',0), r.get('small_windows'), r.get('small_bailed'), r.get('small_bail_why'), [round(c/1e9,1) for c in r.get('phase_clocks',[])]))"; }
+print('%s: %.0f windows/s  step %.2f ms  frac %.3f  gcups %.0f  small %s bailed %s why %s work %s phase %s' % ('$1', j['value'], r['step_kernel_ms'], r['frac'], r.get('gcups',0), r.get('small_windows'), r.get('small_bailed'), r.get('small_bail_why'), r.get('small_work'), [round(c/1e9,1) for c in r.get('phase_clocks',[])]))"; }
 
 if has small; then
   timeout 1500 python -m pytest tests/test_gpu_small.py -m gpu -q -x --durations=8 > "$OUT/pytest_small.log" 2>&1
@@ -43,3 +43,26 @@ fi
 if has w1000; then
   timeout 900 python bench.py --config w1000 --steps 5 --warmup 1 --no-product --no-upload-leg 2> "$OUT/bench_w1000.err" | tee "$OUT/bench_w1000.json" | benchline w1000
 fi
+# ---- issue / LDS counters (SURVEY 8(d) secondary ceilings): rocprofv3 --pmc passes of SQ counters, 8 per pass ----
+# usage: ... sq           -> cfg4 (small-window kernel) and cfg2 (poa_window_kernel2 + the deep instance)
+sqpasses() {   # $1 = label, rest = bench arguments
+  local label=$1; shift
+  local n=0
+  for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
+             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_I8 SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+    n=$((n + 1))
+    timeout 600 rocprofv3 --pmc $SET --output-format csv -d "$OUT/sq_${label}_$n" -o pmc -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu --no-product --no-upload-leg > "$OUT/sq_${label}_$n.json" 2> "$OUT/sq_${label}_$n.err"
+    echo "sq $label pass $n exit $?"; tail -2 "$OUT/sq_${label}_$n.err" | cut -c1-200
+  done
+  python tools/sq_summary.py "$OUT" "$label" > "$OUT/sq_${label}_summary.txt" 2>&1; cat "$OUT/sq_${label}_summary.txt"
+}
+if has sq; then
+  rocprofv3 -L > "$OUT/counters_list.txt" 2>&1; grep -c "SQ_" "$OUT/counters_list.txt"
+  sqpasses cfg4 --config cfg4
+  sqpasses cfg2
+fi
+if has sq4; then sqpasses cfg4 --config cfg4; fi
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+find "$OUT" -name "*.db" -delete 2>/dev/null
+du -sh "$OUT" | tail -1
