@@ -147,6 +147,41 @@ def product_cli(paths, window, scores, threads, expect=None, reps=2, batches=1):
     return {"windows": nw, "polish_s": best, "windows_per_s": nw / best, "runs": runs, "fasta_matches_kernel_leg": same}
 
 
+def product_multi_device(paths, window, scores, threads, n_devices, fake=False):
+    """THE PRODUCT ON SEVERAL DEVICES: one racon_hip process drives every visible device (racon_amd/host/polisher.cpp: two
+    engines per device pulling deepest-first chunks off one cursor -- the reference's organisation, src/cuda/cudapolisher.cpp:
+    228-240, 254-276), against the same files on ONE device: polish() windows/s of both and whether the FASTA is the same.
+    `fake`: RACON_HIP_FAKE_DEVICES (several logical devices on one GPU: the code path, not a speed-up)."""
+    import hashlib
+    import re
+    import subprocess
+    m, x, g = scores
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    out = {"devices": n_devices, "fake_devices": bool(fake)}
+    md5 = {}
+    for label, env_add in (("one_device", {"RACON_HIP_FAKE_DEVICES": "1"} if fake else {"HIP_VISIBLE_DEVICES": "0"}),
+                           ("all_devices", {"RACON_HIP_FAKE_DEVICES": str(n_devices)} if fake else {})):
+        env = dict(os.environ)
+        for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "RACON_HIP_FAKE_DEVICES"):
+            env.pop(k, None)
+        env.update(env_add)
+        best = None
+        for _ in range(2):
+            r = subprocess.run([exe, "-t", str(threads), "-w", str(window), "-m", str(m), "-x", str(x), "-g", str(g),
+                                paths["reads"], paths["sam"], paths["targets"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            mt = re.search(r"\[racon::Polisher::polish\] generated consensus (\d+\.\d+) s", r.stderr.decode(errors="replace"))
+            if r.returncode != 0 or not mt:
+                return {"error": "racon_hip (%s) exit %d: %s" % (label, r.returncode, r.stderr.decode(errors="replace")[-300:])}
+            sec = float(mt.group(1))
+            best = sec if best is None else min(best, sec)
+            md5[label] = hashlib.md5(r.stdout).hexdigest()
+        nw = sum((int(l) + window - 1) // window for l in [len(t) for t in open(paths["targets"], "rb").read().split(b"\n")[1::2]])
+        out[label] = {"polish_s": best, "windows_per_s": nw / best, "windows": nw, "fasta_md5": md5[label]}
+    out["fasta_identical"] = md5["one_device"] == md5["all_devices"]
+    out["speedup"] = out["all_devices"]["windows_per_s"] / out["one_device"]["windows_per_s"]
+    return out
+
+
 def pick_workload(config: str, contig: int, rank: int, world: int):
     """(contig bp on this rank, seed, scaling, name) of the seeded ONT-like workloads:
     N = 1: cfg2 (1 Mbp, seed 20260921).  N > 1: cfg3, the 50 Mbp / 100 000-window job cut into N equal stretches, rank r
@@ -183,11 +218,22 @@ def main():
     ap.add_argument("--product-batches", type=int, default=1, help="-c of the product legs: batch objects (pairs of engines) per device")
     ap.add_argument("--verify", action="store_true", help="also check every window against the oracle (untimed)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (code-path test with several ranks on ONE GPU)")
+    ap.add_argument("--product-multi-contig", type=int, default=0, help="N > 1: contig bp of the product leg that ONE racon_hip process polishes on all N devices "
+                                                                         "(default: 6.25 Mbp per device, 50 Mbp = cfg3 at N = 8)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: one rank per GPU through torch.distributed.run, as the driver does it
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if a.gpus != world:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a line for the wrong N" % (a.gpus, world))
     m, x, g = [int(v) for v in a.scores.split(",")]
 
     from racon_amd.engine import HipEngine
@@ -221,6 +267,9 @@ def main():
         pfiles.append(("cfg2", product_files(1_000_000, a.coverage, 20260921, workers)))
         if a.product_contig > 1_000_000:
             pfiles.append(("cfg3_share", product_files(a.product_contig, a.coverage, 20260922, workers)))
+    pmulti = None
+    if world > 1 and not a.no_product and a.window == 500 and not a.config and rank == 0:
+        pmulti = product_files(a.product_multi_contig or min(50_000_000, 6_250_000 * world), a.coverage, 20260922, workers)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.dist_backend == "nccl":
@@ -362,6 +411,14 @@ def main():
                         out[key] = cli["windows_per_s"]
             except Exception as e:                       # the headline line must not die with the product leg
                 out["product_polish"] = {"error": repr(e)}
+        if pmulti is not None:
+            # N > 1: the product is ONE process on all N devices (the other ranks idle at the barrier below)
+            try:
+                th = max(1, min(32 * world, len(os.sched_getaffinity(0))))
+                out["product_multi_device"] = product_multi_device(pmulti, a.window, (m, x, g), th, world)
+                out["value_product_polish"] = out["product_multi_device"]["all_devices"]["windows_per_s"]
+            except Exception as e:
+                out["product_multi_device"] = {"error": repr(e)}
         if not a.no_cpu and world == 1:
             # CPU baseline on this box's host cores (rank 0 at N = 1 only): the oracle's AVX2 int16 variant (the scheme of spoa's SIMD
             # engine: row vectors + log-step prefix max), whole batch; the thread count is swept and the box's best is what the
@@ -398,6 +455,19 @@ def main():
                                              % (cb.n_windows, cores, ncpu, lim.get("cgroup_cpus"), best_dt, n_s, min(ncpu, cores), n_s / dts),
                                    "thread_sweep_windows_per_s": sweep, "host": lim,
                                    "matches_gpu": bool(ok)}
+        # THE METRIC AS SURVEY.md 8(d) DEFINES IT, first class: windows/s on the polish() interval of the product (files ->
+        # Polisher; in-process and through the binary), next to the resident-input kernel leg (`value`), each against the CPU
+        # number of this line
+        cpu_v = out.get("cpu_baseline", {}).get("value")
+        if out.get("value_product_polish"):
+            out["product"] = {"metric": "polished windows/s on the Polisher::polish() interval (reference src/polisher.cpp:493 -> :539-543)",
+                              "value": out["value_product_polish"], "value_cli": out.get("value_product_polish_cli"), "unit": "windows/s",
+                              "workload": pfiles[0][0] if pfiles else ("%d devices, one process" % world),
+                              "fraction_of_kernel_leg": out["value_product_polish"] / out["value"] if world == 1 else None,
+                              "vs_cpu_baseline": (out["value_product_polish"] / cpu_v) if cpu_v else None,
+                              "vs_cpu_baseline_cli": (out["value_product_polish_cli"] / cpu_v) if (cpu_v and out.get("value_product_polish_cli")) else None}
+        if cpu_v:
+            out["cpu_baseline"]["gpu_kernel_leg_over_cpu"] = out["value"] / cpu_v
         if a.verify:
             from oracle import oracle_lib
             ref = oracle_lib.consensus(batch, m, x, g, True, 0, simd=True)

@@ -38,10 +38,15 @@ namespace {
         }                                                                                   \
     } while (0)
 
+// tests (Knobs::fail_alloc_above, RCN_FAIL_ALLOC_ABOVE behind RCN_EXPERIMENT=1): device allocations above this many bytes fail like
+// an exhausted device -- the way the callers survive RCN_E_NOMEM can be exercised on a box with 288 GB
+static std::atomic<uint64_t> g_fail_alloc_above{0};
+
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap && p) return RCN_OK;
+        { const uint64_t lim = g_fail_alloc_above.load(std::memory_order_relaxed); if (lim && bytes > lim) return RCN_E_NOMEM; }
         if (p) { if (hipFree(p) != hipSuccess) return RCN_E_HIP; p = nullptr; cap = 0; }
         size_t want = std::max<size_t>(bytes, 256);
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return RCN_E_NOMEM; }
@@ -164,6 +169,7 @@ struct Knobs {
     int force_tie = 0, wg_per_cu = 0, split = -1, split_deep_per_cu = 0, split_rest_per_cu = 0, split_deep = 0, split_deep_wide = -1,
         split_cus = 0, hrows_div = 0, small_per_cu = 0;
     double heavy_pct = 1.0;
+    unsigned long long fail_alloc_above = 0;
 };
 static Knobs read_knobs() {
     Knobs k;
@@ -181,6 +187,7 @@ static Knobs read_knobs() {
     k.split_deep = num("RCN_SPLIT_DEEP", 0); k.split_deep_wide = num("RCN_SPLIT_DEEP_WIDE", -1); k.split_cus = num("RCN_SPLIT_CUS", 0);
     k.hrows_div = num("RCN_HROWS_DIV", 0); k.small_per_cu = num("RCN_SMALL_PER_CU", 0);
     if (const char* v = getenv("RCN_HEAVY_PCT")) k.heavy_pct = atof(v);
+    if (const char* v = getenv("RCN_FAIL_ALLOC_ABOVE")) k.fail_alloc_above = strtoull(v, nullptr, 10);
     return k;
 }
 
@@ -343,8 +350,13 @@ bool small_caps(const rcn_engine* e, It first, It last, Caps& out) {
     return true;
 }
 
+// What a pass may take for its slots: 80 % of what is free NOW (+ the scratch this engine already holds: free_mem is refreshed at
+// the start of every run), and never more than the caller's arena.  (An arena fixed when the engine was created -- the host
+// layer splits a device's free memory between its engines then -- says nothing about what reads, overlaps and other engines
+// have taken since: sized from it alone, a pass asked hipMalloc for memory that was no longer there.)
 uint64_t scratch_budget(const rcn_engine* e) {
-    return e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>(e->free_mem * 0.80);
+    const uint64_t now = static_cast<uint64_t>(e->free_mem * 0.80);
+    return e->cfg.arena_bytes ? std::min<uint64_t>(e->cfg.arena_bytes, now) : now;
 }
 uint32_t max_slots(const rcn_engine* e) {
     return e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint32_t>(e->n_cu) * 8u;    // 8 work-groups per CU (20 KiB LDS each) at most
@@ -658,6 +670,7 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
     rcn_engine* e = guard.e;
     e->cfg = *cfg;
     e->knobs = read_knobs();
+    g_fail_alloc_above.store(e->knobs.fail_alloc_above);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
     e->n_cu = prop.multiProcessorCount;
@@ -1520,7 +1533,9 @@ int rcn_engine_polish(rcn_engine* e, const rcn_batch* b) {
     v.nw = b->n_windows; v.ns = ns; v.win_seq_off = b->win_seq_off; v.win_type = b->win_type; v.seq_off = b->seq_off;
     v.seq = sp.data(); v.qual = qp.data(); v.begin = b->seq_begin; v.end = b->seq_end;
     if (v.nw == 0) { HIP_TRY(hipSetDevice(e->cfg.device)); const int rc = rcn_engine_upload(e, b); return rc ? rc : rcn_engine_run(e); }
-    return polish_view(e, v);
+    const int rc = polish_view(e, v);
+    if (rc) (void)hipDeviceSynchronize();           // (a failed call may have launches in flight: the caller may retry with less)
+    return rc;
 }
 
 int rcn_engine_polish_refs(rcn_engine* e, const rcn_window_refs* w) {
@@ -1534,7 +1549,9 @@ int rcn_engine_polish_refs(rcn_engine* e, const rcn_window_refs* w) {
         const int rc = rcn_engine_upload(e, &hb.b);
         return rc ? rc : rcn_engine_run(e);
     }
-    return polish_view(e, v);
+    const int rc = polish_view(e, v);
+    if (rc) (void)hipDeviceSynchronize();           // (a failed call may have launches in flight: the caller may retry with less)
+    return rc;
 }
 
 int rcn_engine_reserve_refs(rcn_engine* e, const rcn_window_refs* w) {

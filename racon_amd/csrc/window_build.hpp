@@ -691,7 +691,9 @@ inline int align_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set&
     HIP_TRY(hipMemsetAsync(A[kACtr].p, 0, 64, st));
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
-    const uint64_t budget = e->cfg.arena_bytes ? e->cfg.arena_bytes : static_cast<uint64_t>((fr + A[kAScratch].cap) * 0.8);
+    // (80 % of what is free now, within the caller's arena: see scratch_budget)
+    const uint64_t free_now = static_cast<uint64_t>((fr + A[kAScratch].cap) * 0.8);
+    const uint64_t budget = e->cfg.arena_bytes ? std::min<uint64_t>(e->cfg.arena_bytes, free_now) : free_now;
     uint64_t slots = std::min<uint64_t>(std::max<uint64_t>(n, 1), static_cast<uint64_t>(e->n_cu) * 16);
     while (slots > 1 && slots * slot_bytes > budget) slots = (slots + 1) / 2;
     if (slots * slot_bytes > budget) return RCN_E_CAPACITY;

@@ -173,6 +173,7 @@ void Polisher::initialize() {
         return;
     }
     logger_->log();
+    rank_.clear(); chunks_.clear(); planned_refs_.clear();       // (plans belong to one set of windows)
     if (!device_warmup_.joinable() && engines_.empty() && getenv("RACON_HIP_NO_WARMUP") == nullptr)
         device_warmup_ = std::thread([this] {
             FatalThrowsScope scope;
@@ -403,6 +404,7 @@ void Polisher::create_engines() {
 void Polisher::plan_chunks() {
     const uint64_t nw = windows_.size();
     const uint64_t n_engines = std::max<size_t>(1, engines_.size());
+    if (nw > 0xffffffffull) fatal("[racon::Polisher::polish] error: more than 2^32 windows!");
     rank_.resize(nw);
     chunks_.clear();
     std::vector<uint64_t> cost(nw), bases(nw);
@@ -453,7 +455,13 @@ void Polisher::reserve_for_windows() {
         for (size_t k = 0; k < planned_refs_.size(); ++k) pool.emplace_back(reserve_one, k);
         for (auto& t : pool) t.join();
     }
-    for (const auto& e : errors) if (!e.empty()) { engines_error_ = e; engines_.clear(); planned_refs_.clear(); break; }
+    // a reservation that failed (a device short of memory at this moment) is not an error yet: polish() sizes its calls as it
+    // goes and halves a chunk the device has no room for
+    for (const auto& e : errors) if (!e.empty()) {
+        fprintf(stderr, "[racon::Polisher::initialize] warning: could not reserve device buffers ahead of polish() (%s)\n", e.c_str());
+        planned_refs_.clear();
+        break;
+    }
     if (timing) fprintf(stderr, "[racon::Polisher::initialize] timing: %zu chunk(s) planned, engines reserved in %.1f ms\n", chunks_.size(), 1e3 * seconds_since(t0));
 }
 
@@ -492,6 +500,7 @@ void Polisher::assemble(const std::function<const std::string&(uint64_t)>& conse
     // (src/polisher.cpp:532,545-546).  For one GPU's share of cfg3 that is ~400 MB in ~40 000 heap blocks -- 30 ms of
     // free() in a 110 ms polish() -- and nobody waits for it: a helper thread does it while the caller goes on with the
     // polished sequences (joined by the destructor / the next call).
+    rank_.clear(); chunks_.clear(); planned_refs_.clear();       // (planned for the windows that are released here)
     if (cleanup_.joinable()) cleanup_.join();
     auto* old_windows = new std::vector<std::shared_ptr<Window>>(std::move(windows_));
     auto* old_sequences = new std::vector<std::unique_ptr<Sequence>>(std::move(sequences_));
@@ -716,17 +725,39 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
             auto& engine = engines_[k];
             WindowRefs refs;
             std::vector<std::string> c; std::vector<uint8_t> p, h;
+            // A chunk the device has no room for (RCN_E_NOMEM / RCN_E_CAPACITY: other engines, reads and overlaps share its
+            // memory) is polished in halves, on the GPU: the reference completes its run when a batch fails
+            // (src/cuda/cudapolisher.cpp:357-373 redoes those windows); there is no CPU path to fall back to here.
+            std::function<void(uint64_t, uint64_t)> polish_range = [&](uint64_t a, uint64_t b) {
+                refs.clear();
+                for (uint64_t i = a; i < b; ++i) refs.add(*windows_[rank[i]]);
+                try {
+                    engine->consensus(refs, queued, trim_, &c, &p, &h);
+                } catch (const FatalError&) {
+                    if ((engine->last_rc() != RCN_E_NOMEM && engine->last_rc() != RCN_E_CAPACITY) || b - a < 2) throw;
+                    fprintf(stderr, "[racon::Polisher::polish] warning: no room on the device for %lu windows at once, polishing them in halves\n", static_cast<unsigned long>(b - a));
+                    const uint64_t mid = a + (b - a) / 2;
+                    polish_range(a, mid); polish_range(mid, b);
+                    return;
+                }
+                for (uint64_t i = a, j = 0; i < b; ++i, ++j) { const uint32_t w = rank[i]; cons[w].swap(c[j]); pol[w] = p[j]; chim[w] = h[j]; }
+            };
             for (size_t ci = k; ci < chunks.size(); ci = cursor.fetch_add(1)) {
                 const double t_a = seconds_since(polish_begin);
                 const bool planned = ci < planned_refs_.size() && planned_refs_[ci].n_windows() == chunks[ci].second - chunks[ci].first;
-                if (!planned) {
-                    refs.clear();
-                    for (uint64_t i = chunks[ci].first; i < chunks[ci].second; ++i) refs.add(*windows_[rank[i]]);
-                }
                 const double t_b = seconds_since(polish_begin);
-                engine->consensus(planned ? planned_refs_[ci] : refs, queued, trim_, &c, &p, &h);
+                bool done = false;
+                if (planned) {
+                    try {
+                        engine->consensus(planned_refs_[ci], queued, trim_, &c, &p, &h);
+                        for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { const uint32_t w = rank[i]; cons[w].swap(c[j]); pol[w] = p[j]; chim[w] = h[j]; }
+                        done = true;
+                    } catch (const FatalError&) {
+                        if (engine->last_rc() != RCN_E_NOMEM && engine->last_rc() != RCN_E_CAPACITY) throw;
+                    }
+                }
+                if (!done) polish_range(chunks[ci].first, chunks[ci].second);
                 const double t_c = seconds_since(polish_begin);
-                for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { const uint32_t w = rank[i]; cons[w].swap(c[j]); pol[w] = p[j]; chim[w] = h[j]; }
                 if (timing) fprintf(stderr, "[racon::Polisher::polish] timing: engine %u chunk %zu (%lu windows): start %.1f ms, refs %.1f, engine done %.1f (kernel %.1f), stored %.1f\n",
                                     k, ci, static_cast<unsigned long>(chunks[ci].second - chunks[ci].first), 1e3 * t_a, 1e3 * t_b, 1e3 * t_c, engine->last_kernel_ms(), 1e3 * seconds_since(polish_begin));
             }

@@ -122,3 +122,20 @@ def test_cli_on_three_logical_devices(P, oracle, data, ovl, mode):
     out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
     assert out == ref
+
+
+@pytest.mark.gpu
+def test_cli_survives_a_device_short_of_memory(tmp_path):
+    """A chunk the device has no room for is polished in halves, on the GPU (racon_amd/host/polisher.cpp; the reference
+    completes its run when a batch fails: src/cuda/cudapolisher.cpp:357-373).  RCN_FAIL_ALLOC_ABOVE (a test switch behind
+    RCN_EXPERIMENT=1) makes every device allocation above 1 GB fail like an exhausted device: 1000 windows want ~8 GB of
+    scratch at once, the run completes in pieces of 125 with the FASTA of the unrestricted run."""
+    from racon_amd.synth import simulate_window_files
+    paths = simulate_window_files(str(tmp_path), 500_000, 30.0, 10000, seed=20260931, workers=4)
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    cmd = [exe, "-t", "8", paths["reads"], paths["sam"], paths["targets"]]
+    free = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    env = dict(os.environ, RCN_EXPERIMENT="1", RCN_FAIL_ALLOC_ABOVE=str(1 << 30))
+    tight = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert tight.stdout == free.stdout and tight.stdout.count(b">") == 1
+    assert b"polishing them in halves" in tight.stderr and b"polishing them in halves" not in free.stderr

@@ -46,11 +46,39 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--contig", "100000", "--no-cpu", "--dist-backend", "gloo"],
+                          "--contig", "100000", "--no-cpu", "--dist-backend", "gloo", "--product-multi-contig", "300000"],
                          check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, env=env).stdout
     j = _line(out)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak"
     assert abs(j["value"] - 2 * 200 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6      # whole-job aggregate over both ranks
+    # N > 1 also carries the PRODUCT: one racon_hip process on every visible device against the same files on one device
+    pm = j["product_multi_device"]
+    assert pm["devices"] == 2 and pm["fasta_identical"] is True and pm["all_devices"]["windows"] == 600, pm
+    assert j["product"]["value"] == pm["all_devices"]["windows_per_s"]
+
+
+def test_gpus_flag_spawns_its_ranks_or_refuses():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks; a launcher that started another number of ranks
+    than --gpus says is an error, not a line for the wrong N."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--contig", "100000",
+                          "--no-cpu", "--no-product", "--dist-backend", "gloo"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}).stdout
+    assert _line(out)["n_gpus"] == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--contig", "100000", "--no-cpu", "--no-product"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and b"refusing" in bad.stderr and b'{"metric"' not in bad.stdout
+
+
+def test_product_on_eight_logical_devices():
+    """The N > 1 product leg before an 8-GPU node ever sees it: one racon_hip process over RACON_HIP_FAKE_DEVICES=8 (eight logical
+    devices on this one GPU: racon_amd/host/polisher.cpp drives each with its own engines off one cursor, reference
+    src/cuda/cudapolisher.cpp:228-240, 254-276) prints the FASTA of the one-device run."""
+    sys.path.insert(0, ROOT)
+    import bench
+    files = bench.product_files(400_000, 30.0, 20260977, 8)
+    r = bench.product_multi_device(files, 500, (3, -5, -4), 16, 8, fake=True)
+    assert "error" not in r, r
+    assert r["fasta_identical"] is True and r["all_devices"]["windows"] == r["one_device"]["windows"] == 800
 
 
 def test_bench_product_legs_on_the_default_workload():
@@ -63,4 +91,7 @@ def test_bench_product_legs_on_the_default_workload():
     assert p["windows"] == 2000 and p["fasta_matches_kernel_leg"] is True and 0 < p["polish_s"] < 1.0
     assert p["cli"]["windows"] == 2000 and p["cli"]["fasta_matches_kernel_leg"] is True and 0 < p["cli"]["polish_s"] < 1.0
     assert abs(j["value_product_polish"] - 2000 / p["polish_s"]) < 1e-6 * j["value_product_polish"]
+    # ... first class: the metric on the interval SURVEY.md 8(d) defines it on, next to the kernel leg
+    assert j["product"]["value"] == j["value_product_polish"] and j["product"]["value_cli"] == p["cli"]["windows_per_s"]
+    assert 0 < j["product"]["fraction_of_kernel_leg"] <= 1.05
     assert j["config"]["windows_per_gpu"] == 2000 and "cfg2" in j["config"]["workload"]
