@@ -355,6 +355,27 @@ def main():
                     traffic_src = "profiles/traffic.json is stale (kernel sources changed since it was measured)"
             except Exception:
                 traffic = None
+        # secondary ceilings ("the kernel may be issue-bound before it is HBM-bound"): vector / scalar issue and
+        # LDS-array occupancy of the dominant kernel from the rocprofv3 SQ-counter passes of THIS command (tools/gpu_round4.sh sq
+        # -> tools/sq_summary.py), committed as profiles/issue_<workload>.json and stamped like traffic.json
+        secondary = None
+        wl = a.config if a.config else ("cfg2" if (world == 1 and a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0) else None)
+        jf = os.path.join(ROOT, "profiles", "issue_%s.json" % wl) if wl else None
+        if jf and os.path.exists(jf):
+            try:
+                ij = json.load(open(jf))
+                from tools.srchash import kernel_source_hash
+                if ij.get("kernel_source_hash") == kernel_source_hash():
+                    ks = ij["kernels"]
+                    dom = max(ks, key=lambda k: ks[k].get("wave_instructions", 0))
+                    secondary = {k: ks[dom].get(k) for k in ("valu_issue_frac", "scalar_issue_frac", "lds_frac", "lds_conflict_share", "wave_time_issuing",
+                                                            "wave_time_parked_waitcnt", "wave_time_issue_stalled", "cycles_per_instruction_per_simd")}
+                    secondary.update({"kernel": dom, "source": "profiles/issue_%s.json (%s)" % (wl, ij.get("measured", "?")),
+                                      "note": "valu/scalar_issue_frac = SQ_ACTIVE_INST_* x 4 / (dispatch cycles x 1024 SIMDs); lds_frac = SQ_LDS_IDX_ACTIVE / (dispatch cycles x 256 CUs)"})
+                else:
+                    secondary = {"source": "profiles/issue_%s.json is stale (kernel sources changed since it was measured)" % wl}
+            except Exception:
+                secondary = None
         achieved = alg_bytes / step_s / 1e9
         out = {
             "metric": "polished windows/sec (500 bp, 30x cov)",
@@ -370,7 +391,7 @@ def main():
             "config": {"workload": "%s, scores %s, %d windows/GPU" % (what, a.scores, batch.n_windows),
                        "windows_per_gpu": batch.n_windows, "parallelism": "windows sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "secondary": secondary,
                          "kernel": ("poa_window_kernel_small (+ poa_window_kernel2 for the windows it sent back)" if st["n_small"] else "poa_window_kernel2") + (" + poa_window_kernel2_deep (the instance for the deep launch)" if st["split_deep"] else ""), "step_kernel_ms": step_s * 1e3, "avg_launch_ms": sum(per_launch_ms) / len(per_launch_ms),
                          "launches_per_step": len(per_launch_ms), "launch_ms": per_launch_ms,
                          "split_launch": None if not st["split_deep"] else

@@ -79,6 +79,12 @@ struct PairLane {                    // what a lane keeps of its word between th
     unsigned long long Pv, Mv;
 };
 
+// What one lane of the wave stored, another lane of the SAME wave loads next: the stores must have been performed, nothing
+// else -- a work-group-scope fence (its waves share the CU's vector L1, which takes write hits: s_waitcnt only).  The
+// agent-scope __threadfence() that stood here wrote the L2 back and invalidated the caches (buffer_wbl2 sc1 + buffer_inv sc1)
+// after every 64-word pass of every sub-problem.
+__device__ __forceinline__ void pair_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
 __device__ __forceinline__ int pair_shr1(int fill, int v) {      // lane l <- lane l - 1, lane 0 <- fill
     return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
 }
@@ -172,7 +178,7 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
         uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
         unsigned long long Pv, Mv;
         pair_pass<NPL>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv);
-        __threadfence();                               // the carries of this pass are read (by other lanes) in the next one
+        pair_wave_fence();                             // the carries of this pass are read (by other lanes) in the next one
         // scores of this pass's rows: running sum of the vertical deltas down the last column
         const int rows_here = lane < nwp ? min(64, m - (w0 + lane) * 64) : 0;
         const unsigned long long vmask = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
@@ -188,7 +194,7 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
         }
         carry += __shfl(incl, 63);
     }
-    __threadfence();                                   // out[] is read by other lanes than the ones that wrote it
+    pair_wave_fence();                                 // out[] is read by other lanes than the ones that wrote it
     return carry;
 }
 
@@ -207,7 +213,7 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
             uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
             unsigned long long Pv, Mv;
             pair_pass<NPL>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv);
-            __threadfence();
+            pair_wave_fence();
             off += static_cast<int64_t>(n + nwp - 1) * nwp;
         }
     }

@@ -66,3 +66,10 @@ if has sq4; then sqpasses cfg4 --config cfg4; fi
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
 find "$OUT" -name "*.db" -delete 2>/dev/null
 du -sh "$OUT" | tail -1
+if has align; then
+  timeout 600 python tools/align_bench.py > "$OUT/align_bench.json" 2> "$OUT/align_bench.err"; echo "align exit $?"; tail -3 "$OUT/align_bench.json" | cut -c1-600
+fi
+if has testsq; then   # quick subset: the suites touched this round
+  timeout 1500 python -m pytest tests/test_gpu_small.py tests/test_gpu_pair_align.py tests/test_gpu_bench_contract.py tests/test_cli_e2e.py -m gpu -q -x --durations=8 > "$OUT/pytest_subset.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_subset.log"; tail -15 "$OUT/pytest_subset.log"
+fi

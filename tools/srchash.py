@@ -7,7 +7,7 @@ def _files():
     d = os.path.join(_ROOT, "racon_amd", "csrc")
     # the consensus kernel's sources (the window-construction and pair-alignment kernels live in the same library but do not
     # touch the traffic of poa_window_kernel2)
-    return sorted(f for f in os.listdir(d) if (f.startswith("poa_") and f.endswith((".hpp", ".inc"))) or f in ("engine.hip", "engine_deep.hip", "Makefile"))
+    return sorted(f for f in os.listdir(d) if (f.startswith("poa_") and f.endswith((".hpp", ".inc"))) or f in ("engine.hip", "engine_deep.hip", "engine_small.hip", "Makefile"))
 
 
 def kernel_source_hash() -> str:
