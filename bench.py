@@ -481,7 +481,7 @@ def main():
         # number of this line
         cpu_v = out.get("cpu_baseline", {}).get("value")
         if out.get("value_product_polish"):
-            out["product"] = {"metric": "polished windows/s on the Polisher::polish() interval (reference src/polisher.cpp:493 -> :539-543)",
+            out["product"] = {"definition": "polished windows/s on the Polisher::polish() interval (reference src/polisher.cpp:493 -> :539-543)",
                               "value": out["value_product_polish"], "value_cli": out.get("value_product_polish_cli"), "unit": "windows/s",
                               "workload": pfiles[0][0] if pfiles else ("%d devices, one process" % world),
                               "fraction_of_kernel_leg": out["value_product_polish"] / out["value"] if world == 1 else None,
