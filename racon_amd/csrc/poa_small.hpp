@@ -42,6 +42,7 @@ constexpr int kSmPosBytes = 512;    // per-position area: int16 x 256
 constexpr int kSmRow0 = 1 << 12;    // row descriptor: the only predecessor is the virtual start row
 constexpr int kSmWide = 1 << 13;    // row descriptor: five to eight predecessors, their distances in the side table
 constexpr int kSmWideRows = 16;     // rows of that kind per alignment (more: the window leaves the kernel)
+constexpr int kSmChain = 1 << 14;   // row descriptor: one predecessor, the row right above (the DP reads it from registers)
 
 // LDS layout (byte offsets from the work-group's dynamic LDS) for a graph of up to `ncap` nodes.
 //   persistent for the window: code, alcnt, ink [ncap] u8; rank, n2r [ncap] u16; intail [ncap][4] u16; ring [ncap][3] u16
@@ -242,7 +243,7 @@ __device__ __forceinline__ int sm_desc(const SmPtrs& g, int V, bool partial, int
         }
         uint32_t meta = static_cast<uint32_t>(g.code[v]);
         if (np == 0) meta |= static_cast<uint32_t>(kSmRow0) | (1u << 9);
-        else if (np <= 4) meta |= (static_cast<uint32_t>(np) << 9) | (dd << 16);
+        else if (np <= 4) meta |= (static_cast<uint32_t>(np) << 9) | (dd << 16) | ((np == 1 && dd == 1u) ? static_cast<uint32_t>(kSmChain) : 0u);
         else {
             // five to eight predecessors (rare): the eight distance nibbles go to the side table
             const int idx = __hip_atomic_fetch_add(g.misc + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -261,6 +262,39 @@ __device__ __forceinline__ int sm_desc(const SmPtrs& g, int V, bool partial, int
 
 // ---- NW DP (window.cpp:95-97,104-106), Z domain, packed int16, move codes out ----
 struct SmDpOut { int best, best_row, tied; unsigned int pred_rows; };
+// One step of the move-code assembly of the PREVIOUS row, issued between two steps of the current row's prefix scan: a DPP
+// read needs two wait states after the VALU write of its source, and the s_nop the compiler would put there costs the wave
+// an issue slot all the same (the kernel is issue-bound: profiles/r04/f_sq_cfg4_summary.txt).  bit 0 clear = a diagonal move
+// reproduces the cell, bit 1 clear = a vertical one does (poa_band.hpp); the predecessor numbers of a row with several
+// predecessors are added behind the scan (rare).
+template <int NP, int STEP>
+__device__ __forceinline__ void sm_code_step(const uint32_t (&accp)[NP], const uint32_t (&dpvp)[NP], const uint32_t (&uvp)[NP], uint32_t (&td)[NP], uint32_t (&tu)[NP],
+                                             uint32_t& word, uint32_t ONE) {
+    if constexpr (STEP == 0) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) td[q] = pk_sub(accp[q], dpvp[q]);
+    } else if constexpr (STEP == 1) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) tu[q] = pk_sub(accp[q], uvp[q]);
+    } else if constexpr (STEP == 2) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) td[q] = pk_minu(td[q], ONE);
+    } else if constexpr (STEP == 3) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) tu[q] = pk_minu(tu[q], ONE);
+    } else if constexpr (STEP == 4) {
+        if constexpr (NP == 2) { td[0] = __builtin_amdgcn_perm(td[NP - 1], td[0], 0x06040200u); tu[0] = __builtin_amdgcn_perm(tu[NP - 1], tu[0], 0x06040200u); }
+        else { td[0] = __builtin_amdgcn_perm(0u, td[0], 0x0c0c0200u); tu[0] = __builtin_amdgcn_perm(0u, tu[0], 0x0c0c0200u); }
+    } else {
+        word = (tu[0] << 1) | td[0];
+    }
+    // (a use right here: without it the steps are sunk out of the gaps into the block that consumes the word)
+    if constexpr (STEP == 0 || STEP == 2) { for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(td[q])); }
+    else if constexpr (STEP == 1 || STEP == 3) { for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(tu[q])); }
+    else if constexpr (STEP == 4) asm volatile("" : "+v"(td[0]), "+v"(tu[0]));
+    else asm volatile("" : "+v"(word));
+}
+
 template <int NP>
 __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds<uint8_t> seq, RCN_G uint8_t* cmat, int m, int x, int gp, int lane) {
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
@@ -286,7 +320,31 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds
     const int own_lane = (len / LPC) & 63, own_q = (len % LPC) >> 1, own_hi = len & 1;
     int best = 0, best_row = 0, have_best = 0, tied = 0;
     unsigned int pred_rows = 0;
-    uint32_t coff = rowb + static_cast<uint32_t>(LPC) * static_cast<uint32_t>(lane);       // this lane's codes of row 1
+    // the row just finished: what a chain row (its only predecessor is the row right above: most rows) reads without an
+    // indexed register access, and what its move codes are made from one row later (sm_code_step)
+    uint32_t accp[NP], dpvp[NP], uvp[NP], aqp[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { accp[q] = NEGP; dpvp[q] = NEGP; uvp[q] = NEGP; aqp[q] = 0u; }
+    int npfp = 1;                                // predecessors of that row
+    uint32_t coff = static_cast<uint32_t>(LPC) * static_cast<uint32_t>(lane);       // this lane's codes of the row just finished (row 0: nothing is stored)
+    auto store_codes = [&](uint32_t word) {
+        if (__builtin_expect(npfp > 1, 0)) {
+            // bits 2-4 / 5-7: the first predecessor in in-edge order that attains the maximum at the previous / at this column
+            uint32_t bA, bAsh;
+            if constexpr (NP == 2) {
+                bA = __builtin_amdgcn_perm(aqp[NP - 1], aqp[0], 0x06040200u);
+                const uint32_t bAl = __builtin_amdgcn_update_dpp(0u, bA, 0x138, 0xf, 0xf, true);
+                bAsh = __builtin_amdgcn_alignbit(bA, bAl, 24);
+            } else {
+                bA = __builtin_amdgcn_perm(0u, aqp[0], 0x0c0c0200u);
+                const uint32_t bAl = __builtin_amdgcn_update_dpp(0u, bA, 0x138, 0xf, 0xf, true);
+                bAsh = ((bA << 8) | (bAl >> 8)) & 0xffffu;
+            }
+            word = (bA << 5) | (bAsh << 2) | word;
+        }
+        if constexpr (NP == 2) *reinterpret_cast<RCN_G uint32_t*>(cmat + coff) = word;
+        else *reinterpret_cast<RCN_G uint16_t*>(cmat + coff) = static_cast<uint16_t>(word);
+    };
 #pragma unroll 1
     for (int rbase = 0; rbase < V; rbase += 64) {
         uint32_t dmeta = (1u << 9) | static_cast<uint32_t>(kSmRow0);
@@ -307,25 +365,30 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds
             uint32_t P[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) P[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
-            uint32_t dd = meta >> 16;
-            int npf = static_cast<int>((meta >> 9) & 7);
-            if (__builtin_expect((meta & kSmWide) != 0u, 0)) {
-                npf = static_cast<int>((meta >> 20) & 15);
-                dd = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(g.misc[16 + ((meta >> 16) & 15)]));
-            }
             uint32_t M[NP], Aq[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) Aq[q] = 0u;
-            {
-                const int wi = (i - static_cast<int>(dd & 15)) & 15;
-                M[0] = w0[wi];
-                if (NP > 1) M[NP - 1] = w1[wi];
-                if (meta & kSmRow0) {
+            int npf = 1;
+            if (__builtin_expect((meta & kSmChain) != 0u, 1)) {
+                // ---- chain row: the row right above, still in registers ----
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) M[q] = 0u;           // row 0 is identically zero in the Z domain
+                for (int q = 0; q < NP; ++q) M[q] = accp[q];
+            } else {
+                uint32_t dd = meta >> 16;
+                npf = static_cast<int>((meta >> 9) & 7);
+                if (__builtin_expect((meta & kSmWide) != 0u, 0)) {
+                    npf = static_cast<int>((meta >> 20) & 15);
+                    dd = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(g.misc[16 + ((meta >> 16) & 15)]));
                 }
-            }
-            if (__builtin_expect(npf > 1, 0)) {
+                {
+                    const int wi = (i - static_cast<int>(dd & 15)) & 15;
+                    M[0] = w0[wi];
+                    if (NP > 1) M[NP - 1] = w1[wi];
+                    if (meta & kSmRow0) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) M[q] = 0u;           // row 0 is identically zero in the Z domain
+                    }
+                }
 #pragma unroll 1
                 for (int e = 1; e < npf; ++e) {
                     const int wi = (i - static_cast<int>((dd >> (4 * e)) & 15)) & 15;
@@ -356,48 +419,28 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds
 #pragma unroll
             for (int q = 1; q < NP; ++q) acc[q] = pk_max_bhi(acc[q], acc[q - 1]);
             int sc = static_cast<int>(acc[NP - 1]) >> 16;
+            uint32_t td[NP], tu[NP], wordp = 0u;
             {
                 constexpr int I = static_cast<int>(0x80000000u);
-                sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
-                sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
-                sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
-                sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
-                sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
-                sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
+#define RCN_SM_GAP(k) do { __builtin_amdgcn_sched_barrier(0); sm_code_step<NP, (k)>(accp, dpvp, uvp, td, tu, wordp, ONE); __builtin_amdgcn_sched_barrier(0); } while (0)
+                RCN_SM_GAP(0); sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
+                RCN_SM_GAP(1); sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
+                RCN_SM_GAP(2); sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
+                RCN_SM_GAP(3); sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
+                RCN_SM_GAP(4); sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
+                RCN_SM_GAP(5); sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
+                __builtin_amdgcn_sched_barrier(0);
+#undef RCN_SM_GAP
             }
+            store_codes(wordp);                  // (before the first row: a word of row 0, which nobody reads)
+            coff += rowb;
             zsh = dpp_or<0x138, 0xf>(zsh, sc);
             const int zex = max(zsh, kNeg16);
 #pragma unroll
             for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
-            {
-                // move codes (poa_band.hpp): bit 0 clear = a diagonal move reproduces the cell, bit 1 clear = a vertical one does,
-                // bits 2-4 / 5-7 = first predecessor in in-edge order attaining the maximum at the previous / at this column
-                uint32_t nd[NP], nu[NP];
 #pragma unroll
-                for (int q = 0; q < NP; ++q) { nd[q] = pk_minu(pk_sub(acc[q], DPv[q]), ONE); nu[q] = pk_minu(pk_sub(acc[q], Uv[q]), ONE); }
-                if (NP == 2) {
-                    const uint32_t bnd = __builtin_amdgcn_perm(nd[NP - 1], nd[0], 0x06040200u), bnu = __builtin_amdgcn_perm(nu[NP - 1], nu[0], 0x06040200u);
-                    uint32_t word = (bnu << 1) | bnd;
-                    if (npf > 1) {
-                        const uint32_t bA = __builtin_amdgcn_perm(Aq[NP - 1], Aq[0], 0x06040200u);
-                        const uint32_t bAl = __builtin_amdgcn_update_dpp(0u, bA, 0x138, 0xf, 0xf, true);
-                        const uint32_t bAsh = __builtin_amdgcn_alignbit(bA, bAl, 24);
-                        word = (bA << 5) | (bAsh << 2) | word;
-                    }
-                    *reinterpret_cast<RCN_G uint32_t*>(cmat + coff) = word;
-                } else {
-                    const uint32_t bnd = __builtin_amdgcn_perm(0u, nd[0], 0x0c0c0200u), bnu = __builtin_amdgcn_perm(0u, nu[0], 0x0c0c0200u);
-                    uint32_t word = (bnu << 1) | bnd;
-                    if (npf > 1) {
-                        const uint32_t bA = __builtin_amdgcn_perm(0u, Aq[0], 0x0c0c0200u);
-                        const uint32_t bAl = __builtin_amdgcn_update_dpp(0u, bA, 0x138, 0xf, 0xf, true);
-                        const uint32_t bAsh = ((bA << 8) | (bAl >> 8)) & 0xffffu;
-                        word = (bA << 5) | (bAsh << 2) | word;
-                    }
-                    *reinterpret_cast<RCN_G uint16_t*>(cmat + coff) = static_cast<uint16_t>(word);
-                }
-                coff += rowb;
-            }
+            for (int q = 0; q < NP; ++q) { accp[q] = acc[q]; dpvp[q] = DPv[q]; uvp[q] = Uv[q]; aqp[q] = Aq[q]; }
+            npfp = npf;
             {
                 const int wi = i & 15;
                 w0[wi] = acc[0];
@@ -416,6 +459,14 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds
                 }
             }
         }
+    }
+    {
+        // the codes of the last row
+        uint32_t td[NP], tu[NP], wordp = 0u;
+        sm_code_step<NP, 0>(accp, dpvp, uvp, td, tu, wordp, ONE); sm_code_step<NP, 1>(accp, dpvp, uvp, td, tu, wordp, ONE);
+        sm_code_step<NP, 2>(accp, dpvp, uvp, td, tu, wordp, ONE); sm_code_step<NP, 3>(accp, dpvp, uvp, td, tu, wordp, ONE);
+        sm_code_step<NP, 4>(accp, dpvp, uvp, td, tu, wordp, ONE); sm_code_step<NP, 5>(accp, dpvp, uvp, td, tu, wordp, ONE);
+        store_codes(wordp);
     }
     SmDpOut o; o.best = best; o.best_row = have_best ? best_row : 0; o.tied = tied; o.pred_rows = pred_rows;
     return o;
