@@ -90,6 +90,20 @@ def test_w1000_full_size_against_the_oracle(oracle):
     _all_windows_vs_oracle(oracle, b, (3, -5, -4), "w1000 full size, scores 3/-5/-4")
 
 
+def test_cfg3_whole_job_on_one_gpu_against_the_oracle(oracle):
+    """BASELINE configs[2] at its stated size on ONE device: the 50 Mbp / 100 000-window job (the windows bench.py polishes with
+    `--config cfg3`), every window against the oracle -- one launch over a queue fifty times the resident slots.  (Eight devices
+    polish an eighth of these windows each: windows are independent, reference src/polisher.cpp:496-503.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    b = bench.cached_windows(50_000_000, 500, 30.0, 10000, 20260922, max(1, min(32, (os.cpu_count() or 8))))
+    assert b.n_windows == 100_000
+    st = _all_windows_vs_oracle(oracle, b, (3, -5, -4), "cfg3 whole, one GPU")
+    assert st["n_retried"] < 100 and st["dp_cells_full"] > 1.0e12
+
+
 def test_batch_larger_than_the_resident_slots(oracle):
     """9000 windows in one batch: more work items than the 2048 resident slots, so the deepest-first work queue, the
     work-item -> window indirection of the outputs and slot re-use between windows are all on the path."""
