@@ -409,7 +409,7 @@ def main():
                          # the small-window kernel (one wave per window, graph in LDS): windows it polished / sent back to
                          # poa_window_kernel2 (the retry pass is inside step_kernel_ms) and why
                          "small_windows": st["n_small"], "small_bailed": st["n_small_bailed"], "small_bail_why": st["small_bail_why"],
-                         "small_work": dict(zip(("alignments", "dp_rows", "subgraph_chunks", "traceback_boxes", "traceback_regathers"), st["small_work"]))},
+                         "small_work": dict(zip(("alignments", "dp_rows", "subgraph_chunks", "traceback_boxes", "traceback_regathers", "subgraph_intervals"), st["small_work"]))},
         }
         if do_product:
             # the product on the same workload (same seed -> the same windows, tests/test_synth_files.py)

@@ -107,8 +107,8 @@ typedef struct rcn_run_stats {
     uint64_t small_bail_why[9];/* ... by reason: graph capacity, fifth in-edge, predecessor > 16 rows back, aligned ring (or a symbol
                                   besides A/C/G/T), int16 range, layer > 255 bases, sink tie beyond the id rule, consensus scratch,
                                   internal inconsistency (must be zero)                                                           */
-    uint64_t small_work[5];    /* work of that kernel: alignments, DP rows, Subgraph sweep chunks, traceback boxes, boxes whose gather
-                                  pipeline had to start over (the walk left the diagonal)                                         */
+    uint64_t small_work[6];    /* work of that kernel: alignments, DP rows, Subgraph sweep chunks, traceback boxes, boxes whose gather
+                                  pipeline had to start over (the walk left the diagonal), Subgraph masks that were a rank interval */
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */

@@ -1623,7 +1623,7 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         // engine's own non-blocking stream (a plain hipMemcpy runs on the null stream and waits for every blocking stream of
         // the process -- the CU-masked launch streams of the device's other engine among them)
         HIP_TRY(hipSetDevice(e->cfg.device));
-        unsigned long long st[40] = {0};
+        unsigned long long st[41] = {0};
         HIP_TRY(hipMemcpyAsync(st, e->d_ctr.as<uint8_t>() + kStatsOff, sizeof(st), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->stats.dp_cells = st[0]; e->stats.dp_pred_cells = st[1]; e->stats.dp_bytes = st[2];
@@ -1634,7 +1634,7 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         e->stats.n_code_wave = st[24];
         e->stats.n_small = st[25];
         for (int k = 0; k < 9; ++k) e->stats.small_bail_why[k] = st[26 + k];
-        for (int k = 0; k < 5; ++k) e->stats.small_work[k] = st[35 + k];
+        for (int k = 0; k < 6; ++k) e->stats.small_work[k] = st[35 + k];
         e->stats_pending = false;
     }
     *out = e->stats;

@@ -105,14 +105,59 @@ __device__ __forceinline__ SmPtrs sm_ptrs(uint32_t base, const SmLayout& l) {
 // spoa's ExtractSubgraph(end, begin) = nodes with id >= begin backward-reachable from `end` over in-edges and aligned
 // links = one descending sweep over the RING BLOCKS of the ring-contiguous topological order (see phase_subgraph2).
 // Fills inc[] (by node), rsub / nsub (the subgraph's own order and its inverse); returns its size.
-__device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, int end, int lane, unsigned int& n_chunks) {
+__device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, int end, int lane, unsigned int& n_chunks, unsigned int& n_intervals) {
     sm_lds<uint8_t> pend = reinterpret_cast<sm_lds<uint8_t>>(g.desc);             // [n] pending / included, by rank
-    int top;
+    int top, lo, end_lo;
     {
-        int r = g.n2r[end];
+        int r = g.n2r[end], rl = r;
         const int na = g.alcnt[end];
-        for (int a = 0; a < na; ++a) r = max(r, static_cast<int>(g.n2r[g.ring[end * kSmRing + a]]));
-        top = bcast0(r);
+        for (int a = 0; a < na; ++a) { const int q = g.n2r[g.ring[end * kSmRing + a]]; r = max(r, q); rl = min(rl, q); }
+        top = bcast0(r); end_lo = bcast0(rl);
+        int b = g.n2r[begin];
+        const int nb = g.alcnt[begin];
+        for (int a = 0; a < nb; ++a) b = min(b, static_cast<int>(g.n2r[g.ring[begin * kSmRing + a]]));
+        lo = bcast0(b);
+    }
+    // ---- the common case on clean reads: the mask IS the rank interval [lo, top] ----
+    // (first rank of begin's ring block .. last rank of end's): exactly so when every ring block of the interval below end's
+    // own has a member with a successor inside the interval -- then, top down, every block is an ancestor of `end` -- and no
+    // node of the interval has an in-edge from a NON-backbone node ranked below it (such a tail has id >= begin and would be
+    // included; backbone nodes before `begin` rank below the interval and are cut by the id rule).  Two passes of LDS traffic
+    // instead of the sweep; tests/emul/emul_main.cpp (clean_interval) checks the rule against the DFS on every partial layer of
+    // the CPU test sets: 89 % of the layers of BASELINE configs[3] take it, ~half of ONT-like ones.
+    if (lo <= top) {
+        for (int r = lo + lane; r <= top; r += 64) g.mark[r] = 0;
+        sm_fence();
+        int bad = 0;
+        for (int r = lo + lane; r <= top; r += 64) {
+            const int v = g.rank[r];
+            const int k = g.ink[v];
+#pragma unroll
+            for (int q = 0; q < kSmIn; ++q) {
+                if (q < k) {
+                    const int t = g.intail[v * kSmIn + q];
+                    const int tr = g.n2r[t];
+                    if (tr >= lo) g.mark[tr] = 1;
+                    else if (t >= begin) bad = 1;
+                    else g.inc[t] = 0;                              // (a backbone node before `begin`: the descriptors ask)
+                }
+            }
+        }
+        sm_fence();
+        if (!__ballot(bad != 0)) {
+            for (int r = lo + lane; r <= top; r += 64) {
+                const int v = g.rank[r];
+                bool ok = r >= end_lo || g.mark[r] != 0;
+                if (!ok) {
+                    const int na = g.alcnt[v];
+                    for (int a = 0; a < na; ++a) ok = ok || g.mark[g.n2r[g.ring[v * kSmRing + a]]] != 0;
+                }
+                if (!ok) bad = 1;
+                g.inc[v] = 1; g.rsub[r - lo] = static_cast<uint16_t>(v); g.nsub[v] = static_cast<uint16_t>(r - lo);
+            }
+            sm_fence();
+            if (!__ballot(bad != 0)) { ++n_intervals; return top - lo + 1; }
+        }
     }
     for (int r = lane; r <= top; r += 64) pend[r] = 0;          // (nothing above `top` is looked at: tails and ring mates rank below their node's block end)
     sm_fence();
@@ -139,8 +184,10 @@ __device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, in
         if (__ballot(k > 4)) tails(4, 8);
         const int na = have ? g.alcnt[v] : 0;
         int rb = r;
+        if (__ballot(na > 0)) {                                      // (most chunks of a clean graph have no aligned ring at all)
 #pragma unroll
-        for (int a = 0; a < kSmRing; ++a) { const int u = g.ring[v * kSmRing + a]; if (a < na) rb = min(rb, static_cast<int>(g.n2r[u < n ? u : 0])); }
+            for (int a = 0; a < kSmRing; ++a) { const int u = g.ring[v * kSmRing + a]; if (a < na) rb = min(rb, static_cast<int>(g.n2r[u < n ? u : 0])); }
+        }
         const int off = r - rb, bsz = na + 1;
         const bool mine = have && r - off >= base && r - off >= 0;       // lanes whose ring block starts below the chunk wait for the next chunk
         const unsigned long long minemask = __ballot(mine);
@@ -948,7 +995,7 @@ __global__ __launch_bounds__(64, 3) void poa_window_kernel_small(KParams P) {
     RCN_G uint8_t* cmat = slot + small_slot_codes(ncap);                                 // move codes, rows of 128 or 256 bytes
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // sub, desc, dp, traceback, add (+ merge), -, consensus, other
     unsigned long long st_cells = 0, st_pred = 0, st_bytes = 0, st_ties = 0;
-    unsigned int st_done = 0, st_boxes = 0, st_regather = 0, st_chunks = 0, st_rows = 0, st_aligns = 0;
+    unsigned int st_done = 0, st_boxes = 0, st_regather = 0, st_chunks = 0, st_rows = 0, st_aligns = 0, st_intervals = 0;
     long long tck = clock64();
 #define RCN_PHASE_S(k) do { const long long now__ = clock64(); ph[k] += now__ - tck; tck = now__; } while (0)
     for (;;) {
@@ -1041,7 +1088,7 @@ __global__ __launch_bounds__(64, 3) void poa_window_kernel_small(KParams P) {
             if (partial) {
                 const int begin = cur.begin, end = cur.end;
                 if (end >= n || begin > end) { why = kSmBug; break; }
-                V = sm_subgraph(g, n, begin, end, lane, st_chunks);
+                V = sm_subgraph(g, n, begin, end, lane, st_chunks, st_intervals);
             }
             if (jl + 1 < ns) load_bytes(nxt);           // (in flight through the descriptors, the DP and the traceback)
             RCN_PHASE_S(0);
@@ -1110,6 +1157,7 @@ __global__ __launch_bounds__(64, 3) void poa_window_kernel_small(KParams P) {
         atomicAdd(&P.stats[35], static_cast<unsigned long long>(st_aligns)); atomicAdd(&P.stats[36], static_cast<unsigned long long>(st_rows));
         atomicAdd(&P.stats[37], static_cast<unsigned long long>(st_chunks)); atomicAdd(&P.stats[38], static_cast<unsigned long long>(st_boxes));
         atomicAdd(&P.stats[39], static_cast<unsigned long long>(st_regather));
+        atomicAdd(&P.stats[40], static_cast<unsigned long long>(st_intervals));
     }
 }
 

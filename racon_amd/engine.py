@@ -36,7 +36,7 @@ class RcnRunStats(C.Structure):
                 ("band_redo_why", C.c_uint64 * 8), ("wg_per_cu", C.c_uint32), ("split_deep", C.c_uint32), ("split_cus", C.c_uint32),
                 ("split_deep_per_cu", C.c_uint32), ("launch_ms", C.c_double * 2), ("n_code_wave", C.c_uint64),
                 ("n_small", C.c_uint64), ("n_small_bailed", C.c_uint64), ("small_bail_why", C.c_uint64 * 9),
-                ("small_work", C.c_uint64 * 5)]
+                ("small_work", C.c_uint64 * 6)]
 
 
 class RcnWindowDesc(C.Structure):

@@ -231,6 +231,37 @@ static void sweep_subgraph_mask(const Win& g, int begin, int end, std::vector<ui
     for (int r = 0; r < n; ++r) inc_out[g.rank_full[r]] = pend[r];
 }
 
+// The small-window kernel's shortcut for the Subgraph (racon_amd/csrc/poa_small.hpp, sm_subgraph): the mask is the rank interval
+// [first rank of begin's ring block, last rank of end's ring block] exactly when (1) every ring block of the interval below
+// end's own has a member with a successor inside the interval (then, top down, every block is an ancestor of `end`) and
+// (2) no node of the interval has an in-edge from a NON-backbone node ranked below the interval (such a tail has id >=
+// begin and would be included: backbone nodes below `begin` rank below the interval and are cut by the id rule).
+// Returns true when the shortcut applies; the caller checks interval == DFS mask.
+static long long g_clean = 0, g_clean_of = 0;
+static bool clean_interval(const Win& g, int begin, int end, int& lo, int& top) {
+    auto block_lo = [&](int v) { int r = g.n2r[v]; for (int a = 0; a < g.al_cnt[v]; ++a) r = std::min(r, (int)g.n2r[g.al_nodes[v * g.ring + a]]); return r; };
+    auto block_hi = [&](int v) { int r = g.n2r[v]; for (int a = 0; a < g.al_cnt[v]; ++a) r = std::max(r, (int)g.n2r[g.al_nodes[v * g.ring + a]]); return r; };
+    lo = block_lo(begin); top = block_hi(end);
+    const int end_lo = block_lo(end);
+    if (lo > top) return false;
+    std::vector<uint8_t> succ(top + 1, 0);
+    for (int r = lo; r <= top; ++r) {
+        const int v = g.rank_full[r];
+        for (int e = g.in_head[v]; e >= 0; e = g.e_nin[e]) {
+            const int t = g.e_tail[e], tr = g.n2r[t];
+            if (tr >= lo) succ[tr] = 1;
+            else if (t >= begin) return false;            // a non-backbone ancestor below the interval
+        }
+    }
+    for (int r = lo; r < end_lo; ++r) {
+        const int v = g.rank_full[r];
+        bool any = succ[r] != 0;
+        for (int a = 0; a < g.al_cnt[v]; ++a) any = any || succ[g.n2r[g.al_nodes[v * g.ring + a]]] != 0;
+        if (!any) return false;
+    }
+    return true;
+}
+
 extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int trim,
                                   uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint8_t* polished) {
     uint64_t out = 0;
@@ -273,6 +304,17 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
                     for (int v = 0; v < g.n_nodes; ++v) if ((swept[v] != 0) != (g.inc[v] != 0)) {
                         fprintf(stderr, "emul: Subgraph sweep and DFS disagree on node %d (sweep %d, dfs %d), window %u layer %u [%u, %u]\n", v, swept[v], g.inc[v], w, j, bg, en);
                         return -5;
+                    }
+                }
+                {
+                    int lo_ = 0, top_ = 0;
+                    ++g_clean_of;
+                    if (clean_interval(g, (int)bg, (int)en, lo_, top_)) {
+                        ++g_clean;
+                        for (int r = 0; r < g.n_nodes; ++r) if ((g.inc[g.rank_full[r]] != 0) != (r >= lo_ && r <= top_)) {
+                            fprintf(stderr, "emul: clean-interval shortcut and DFS disagree at rank %d, window %u layer %u [%u, %u] (interval %d..%d)\n", r, w, j, bg, en, lo_, top_);
+                            return -7;
+                        }
                     }
                 }
                 V = 0;
@@ -352,6 +394,7 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
     if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] tracebacks over move codes checked against the ones over scores: %lld (%lld alignments with a row of more than eight in-edges not coded)\n", g_code_paths, g_code_skipped);
     if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] Subgraph sweeps checked against the DFS: %lld (%lld chunks, %lld chain runs)\n", g_sweeps, g_sweep_chunks, g_sweep_runs);
     if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] alignments %d, sink ties %d rows %lld row0 %lld hist", g_aligns, g_ties, g_rows, g_row0); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_hist[i]); fprintf(stderr, " | alignments by widest row: <=6 in-edges %lld, 7-8 %lld, >8 %lld (7+ in windows of >= 40 sequences: %lld)\n", g_align_maxin[0], g_align_maxin[1], g_align_maxin[2], g_align_maxin[3]); }
+    if (getenv("RCN_EMUL_VERBOSE")) fprintf(stderr, "[emul] Subgraph = rank interval (clean-interval shortcut applies and equals the DFS mask): %lld of %lld partial layers\n", g_clean, g_clean_of);
     if (getenv("RCN_EMUL_VERBOSE")) { fprintf(stderr, "[emul] largest graph %d nodes %d edges, widest in-list %d, largest aligned ring %d; nodes by in-degree", g_max_nodes, g_max_edges, g_max_indeg, g_max_ring + 1);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", g_indeg_hist[i]); fprintf(stderr, "\n"); }
     return 0;
