@@ -368,22 +368,24 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds
     int best = 0, best_row = 0, have_best = 0, tied = 0;
     unsigned int pred_rows = 0;
     // the row just finished: what a chain row (its only predecessor is the row right above: most rows) reads without an
-    // indexed register access, and what its move codes are made from one row later (sm_code_step)
-    uint32_t accp[NP], dpvp[NP], uvp[NP], aqp[NP];
+    // indexed register access, and what its move codes are made from one row later (sm_code_step).  Two sets, used in
+    // turn by the two rows of a loop trip: no copies on the back-edge.
+    struct RowRegs { uint32_t acc[NP], dpv[NP], uv[NP], aq[NP]; int npf; };
+    RowRegs A, B;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) { accp[q] = NEGP; dpvp[q] = NEGP; uvp[q] = NEGP; aqp[q] = 0u; }
-    int npfp = 1;                                // predecessors of that row
-    uint32_t coff = static_cast<uint32_t>(LPC) * static_cast<uint32_t>(lane);       // this lane's codes of the row just finished (row 0: nothing is stored)
-    auto store_codes = [&](uint32_t word) {
-        if (__builtin_expect(npfp > 1, 0)) {
+    for (int q = 0; q < NP; ++q) { A.acc[q] = NEGP; A.dpv[q] = NEGP; A.uv[q] = NEGP; A.aq[q] = 0u; }
+    A.npf = 1;
+    uint32_t coff = static_cast<uint32_t>(LPC) * static_cast<uint32_t>(lane);       // this lane's codes of the row just finished (row 0: nothing is read there)
+    auto store_codes = [&](const RowRegs& pv, uint32_t word) __attribute__((always_inline)) {
+        if (__builtin_expect(pv.npf > 1, 0)) {
             // bits 2-4 / 5-7: the first predecessor in in-edge order that attains the maximum at the previous / at this column
             uint32_t bA, bAsh;
             if constexpr (NP == 2) {
-                bA = __builtin_amdgcn_perm(aqp[NP - 1], aqp[0], 0x06040200u);
+                bA = __builtin_amdgcn_perm(pv.aq[NP - 1], pv.aq[0], 0x06040200u);
                 const uint32_t bAl = __builtin_amdgcn_update_dpp(0u, bA, 0x138, 0xf, 0xf, true);
                 bAsh = __builtin_amdgcn_alignbit(bA, bAl, 24);
             } else {
-                bA = __builtin_amdgcn_perm(0u, aqp[0], 0x0c0c0200u);
+                bA = __builtin_amdgcn_perm(0u, pv.aq[0], 0x0c0c0200u);
                 const uint32_t bAl = __builtin_amdgcn_update_dpp(0u, bA, 0x138, 0xf, 0xf, true);
                 bAsh = ((bA << 8) | (bAl >> 8)) & 0xffffu;
             }
@@ -392,6 +394,102 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds
         if constexpr (NP == 2) *reinterpret_cast<RCN_G uint32_t*>(cmat + coff) = word;
         else *reinterpret_cast<RCN_G uint16_t*>(cmat + coff) = static_cast<uint16_t>(word);
     };
+    // one DP row: PV_ is the row above (its codes are assembled and stored here), CU_ receives this row.  A macro, expanded
+    // twice per loop trip: as a lambda the register window it indexes (w0 / w1) ends up in scratch memory.
+#define RCN_SM_GAP(PV_, k) do { __builtin_amdgcn_sched_barrier(0); sm_code_step<NP, (k)>(PV_.acc, PV_.dpv, PV_.uv, td, tu, wordp, ONE); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RCN_SM_ROW(I_, META_, PV_, CU_) do { \
+        const int i__ = (I_); const uint32_t meta__ = (META_); \
+        const uint32_t sy = meta__ & 255u, symsym = sy | (sy << 16); \
+        uint32_t P[NP]; \
+_Pragma("unroll") \
+        for (int q = 0; q < NP; ++q) P[q] = pk_profile(sqx[q], symsym, ONE, XM, MG); \
+        uint32_t M[NP]; \
+_Pragma("unroll") \
+        for (int q = 0; q < NP; ++q) CU_.aq[q] = 0u; \
+        int npf = 1; \
+        if (__builtin_expect((meta__ & kSmChain) != 0u, 1)) { \
+_Pragma("unroll") \
+            for (int q = 0; q < NP; ++q) M[q] = PV_.acc[q]; \
+        } else { \
+            uint32_t dd = meta__ >> 16; \
+            npf = static_cast<int>((meta__ >> 9) & 7); \
+            if (__builtin_expect((meta__ & kSmWide) != 0u, 0)) { \
+                npf = static_cast<int>((meta__ >> 20) & 15); \
+                dd = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(g.misc[16 + ((meta__ >> 16) & 15)])); \
+            } \
+            { \
+                const int wi = (i__ - static_cast<int>(dd & 15)) & 15; \
+                M[0] = w0[wi]; \
+                if (NP > 1) M[NP - 1] = w1[wi]; \
+                if (meta__ & kSmRow0) { \
+_Pragma("unroll") \
+                    for (int q = 0; q < NP; ++q) M[q] = 0u; \
+                } \
+            } \
+_Pragma("unroll 1") \
+            for (int e = 1; e < npf; ++e) { \
+                const int wi = (i__ - static_cast<int>((dd >> (4 * e)) & 15)) & 15; \
+                uint32_t zq[NP]; \
+                zq[0] = w0[wi]; \
+                if (NP > 1) zq[NP - 1] = w1[wi]; \
+                const uint32_t Q = pack2(e, e); \
+_Pragma("unroll") \
+                for (int q = 0; q < NP; ++q) { \
+                    const uint32_t gt = pk_minu(pk_sub(pk_max(M[q], zq[q]), M[q]), ONE); \
+                    CU_.aq[q] = pk_mad(gt, pk_sub(Q, CU_.aq[q]), CU_.aq[q]); \
+                    M[q] = pk_max(M[q], zq[q]); \
+                } \
+            } \
+        } \
+        CU_.npf = npf; \
+        const uint32_t mprev = mpv = __builtin_amdgcn_update_dpp(mpv, M[NP - 1], 0x138, 0xf, 0xf, false); \
+        uint32_t acc[NP]; \
+_Pragma("unroll") \
+        for (int q = 0; q < NP; ++q) { \
+            const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16); \
+            CU_.dpv[q] = pk_add(D, P[q]); CU_.uv[q] = pk_add(M[q], GG); \
+            acc[q] = pk_max(CU_.dpv[q], CU_.uv[q]); \
+        } \
+_Pragma("unroll") \
+        for (int q = 0; q < NP; ++q) acc[q] = pk_chain_pair(acc[q]); \
+_Pragma("unroll") \
+        for (int q = 1; q < NP; ++q) acc[q] = pk_max_bhi(acc[q], acc[q - 1]); \
+        int sc = static_cast<int>(acc[NP - 1]) >> 16; \
+        uint32_t td[NP], tu[NP], wordp = 0u; \
+        { \
+            constexpr int I = static_cast<int>(0x80000000u); \
+            RCN_SM_GAP(PV_, 0); sc = max(sc, dpp_or<0x111, 0xf>(I, sc)); \
+            RCN_SM_GAP(PV_, 1); sc = max(sc, dpp_or<0x112, 0xf>(I, sc)); \
+            RCN_SM_GAP(PV_, 2); sc = max(sc, dpp_or<0x114, 0xf>(I, sc)); \
+            RCN_SM_GAP(PV_, 3); sc = max(sc, dpp_or<0x118, 0xf>(I, sc)); \
+            RCN_SM_GAP(PV_, 4); sc = max(sc, dpp_or<0x142, 0xa>(I, sc)); \
+            RCN_SM_GAP(PV_, 5); sc = max(sc, dpp_or<0x143, 0xc>(I, sc)); \
+            __builtin_amdgcn_sched_barrier(0); \
+        } \
+        store_codes(PV_, wordp); \
+        coff += rowb; \
+        zsh = dpp_or<0x138, 0xf>(zsh, sc); \
+        const int zex = max(zsh, kNeg16); \
+_Pragma("unroll") \
+        for (int q = 0; q < NP; ++q) { acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex)); CU_.acc[q] = acc[q]; } \
+        { \
+            const int wi = i__ & 15; \
+            w0[wi] = acc[0]; \
+            if (NP > 1) w1[wi] = acc[NP - 1]; \
+        } \
+        if (__builtin_expect((meta__ & 256u) != 0u, 0)) { \
+            uint32_t fv = acc[0]; \
+_Pragma("unroll") \
+            for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q]; \
+            const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16); \
+            const int val = __builtin_amdgcn_readlane(v16, own_lane); \
+            if (!have_best || best < val) { have_best = 1; best = val; best_row = i__; tied = 1; } \
+            else if (best == val) { \
+                if (tied < 8 && lane == 0) g.misc[tied] = i__; \
+                ++tied; \
+            } \
+        } \
+    } while (0)
 #pragma unroll 1
     for (int rbase = 0; rbase < V; rbase += 64) {
         uint32_t dmeta = (1u << 9) | static_cast<uint32_t>(kSmRow0);
@@ -404,117 +502,30 @@ __device__ __forceinline__ SmDpOut sm_dp(const SmPtrs& g, int V, int len, sm_lds
         }
         const int rend = min(V, rbase + 64);
         uint32_t meta_next = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dmeta), 0));
+        int i = rbase + 1;
 #pragma unroll 1
-        for (int i = rbase + 1; i <= rend; ++i) {
-            const uint32_t meta = meta_next;
-            meta_next = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dmeta), i & 63));
-            const uint32_t sy = meta & 255u, symsym = sy | (sy << 16);
-            uint32_t P[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) P[q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
-            uint32_t M[NP], Aq[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) Aq[q] = 0u;
-            int npf = 1;
-            if (__builtin_expect((meta & kSmChain) != 0u, 1)) {
-                // ---- chain row: the row right above, still in registers ----
-#pragma unroll
-                for (int q = 0; q < NP; ++q) M[q] = accp[q];
-            } else {
-                uint32_t dd = meta >> 16;
-                npf = static_cast<int>((meta >> 9) & 7);
-                if (__builtin_expect((meta & kSmWide) != 0u, 0)) {
-                    npf = static_cast<int>((meta >> 20) & 15);
-                    dd = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(g.misc[16 + ((meta >> 16) & 15)]));
-                }
-                {
-                    const int wi = (i - static_cast<int>(dd & 15)) & 15;
-                    M[0] = w0[wi];
-                    if (NP > 1) M[NP - 1] = w1[wi];
-                    if (meta & kSmRow0) {
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) M[q] = 0u;           // row 0 is identically zero in the Z domain
-                    }
-                }
-#pragma unroll 1
-                for (int e = 1; e < npf; ++e) {
-                    const int wi = (i - static_cast<int>((dd >> (4 * e)) & 15)) & 15;
-                    uint32_t zq[NP];
-                    zq[0] = w0[wi];
-                    if (NP > 1) zq[NP - 1] = w1[wi];
-                    const uint32_t Q = pack2(e, e);
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) {
-                        // running "first argmax": predecessor e replaces the holder where it is strictly greater
-                        const uint32_t gt = pk_minu(pk_sub(pk_max(M[q], zq[q]), M[q]), ONE);
-                        Aq[q] = pk_mad(gt, pk_sub(Q, Aq[q]), Aq[q]);
-                        M[q] = pk_max(M[q], zq[q]);
-                    }
-                }
-            }
-            // diagonal sources = the combined predecessor row shifted right by one column (lane 0: -inf left of column 0)
-            const uint32_t mprev = mpv = __builtin_amdgcn_update_dpp(mpv, M[NP - 1], 0x138, 0xf, 0xf, false);
-            uint32_t acc[NP], DPv[NP], Uv[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const uint32_t D = __builtin_amdgcn_alignbit(M[q], q == 0 ? mprev : M[q - 1], 16);
-                DPv[q] = pk_add(D, P[q]); Uv[q] = pk_add(M[q], GG);
-                acc[q] = pk_max(DPv[q], Uv[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < NP; ++q) acc[q] = pk_chain_pair(acc[q]);
-#pragma unroll
-            for (int q = 1; q < NP; ++q) acc[q] = pk_max_bhi(acc[q], acc[q - 1]);
-            int sc = static_cast<int>(acc[NP - 1]) >> 16;
-            uint32_t td[NP], tu[NP], wordp = 0u;
-            {
-                constexpr int I = static_cast<int>(0x80000000u);
-#define RCN_SM_GAP(k) do { __builtin_amdgcn_sched_barrier(0); sm_code_step<NP, (k)>(accp, dpvp, uvp, td, tu, wordp, ONE); __builtin_amdgcn_sched_barrier(0); } while (0)
-                RCN_SM_GAP(0); sc = max(sc, dpp_or<0x111, 0xf>(I, sc));
-                RCN_SM_GAP(1); sc = max(sc, dpp_or<0x112, 0xf>(I, sc));
-                RCN_SM_GAP(2); sc = max(sc, dpp_or<0x114, 0xf>(I, sc));
-                RCN_SM_GAP(3); sc = max(sc, dpp_or<0x118, 0xf>(I, sc));
-                RCN_SM_GAP(4); sc = max(sc, dpp_or<0x142, 0xa>(I, sc));
-                RCN_SM_GAP(5); sc = max(sc, dpp_or<0x143, 0xc>(I, sc));
-                __builtin_amdgcn_sched_barrier(0);
-#undef RCN_SM_GAP
-            }
-            store_codes(wordp);                  // (before the first row: a word of row 0, which nobody reads)
-            coff += rowb;
-            zsh = dpp_or<0x138, 0xf>(zsh, sc);
-            const int zex = max(zsh, kNeg16);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) acc[q] = pk_max_blo(acc[q], static_cast<uint32_t>(zex));
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { accp[q] = acc[q]; dpvp[q] = DPv[q]; uvp[q] = Uv[q]; aqp[q] = Aq[q]; }
-            npfp = npf;
-            {
-                const int wi = i & 15;
-                w0[wi] = acc[0];
-                if (NP > 1) w1[wi] = acc[NP - 1];
-            }
-            if (__builtin_expect((meta & 256u) != 0u, 0)) {
-                uint32_t fv = acc[0];
-#pragma unroll
-                for (int q = 1; q < NP; ++q) if (own_q == q) fv = acc[q];
-                const int v16 = own_hi ? (static_cast<int>(fv) >> 16) : (static_cast<int>(fv << 16) >> 16);
-                const int val = __builtin_amdgcn_readlane(v16, own_lane);
-                if (!have_best || best < val) { have_best = 1; best = val; best_row = i; tied = 1; }
-                else if (best == val) {
-                    if (tied < 8 && lane == 0) g.misc[tied] = i;
-                    ++tied;
-                }
-            }
+        for (; i + 1 <= rend; i += 2) {
+            const uint32_t m0 = meta_next;
+            const uint32_t m1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dmeta), i & 63));
+            meta_next = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dmeta), (i + 1) & 63));
+            RCN_SM_ROW(i, m0, A, B);
+            RCN_SM_ROW(i + 1, m1, B, A);
+        }
+        if (i <= rend) {                          // an odd row at the end of the block
+            RCN_SM_ROW(i, meta_next, A, B);
+            A = B;
         }
     }
     {
         // the codes of the last row
         uint32_t td[NP], tu[NP], wordp = 0u;
-        sm_code_step<NP, 0>(accp, dpvp, uvp, td, tu, wordp, ONE); sm_code_step<NP, 1>(accp, dpvp, uvp, td, tu, wordp, ONE);
-        sm_code_step<NP, 2>(accp, dpvp, uvp, td, tu, wordp, ONE); sm_code_step<NP, 3>(accp, dpvp, uvp, td, tu, wordp, ONE);
-        sm_code_step<NP, 4>(accp, dpvp, uvp, td, tu, wordp, ONE); sm_code_step<NP, 5>(accp, dpvp, uvp, td, tu, wordp, ONE);
-        store_codes(wordp);
+        sm_code_step<NP, 0>(A.acc, A.dpv, A.uv, td, tu, wordp, ONE); sm_code_step<NP, 1>(A.acc, A.dpv, A.uv, td, tu, wordp, ONE);
+        sm_code_step<NP, 2>(A.acc, A.dpv, A.uv, td, tu, wordp, ONE); sm_code_step<NP, 3>(A.acc, A.dpv, A.uv, td, tu, wordp, ONE);
+        sm_code_step<NP, 4>(A.acc, A.dpv, A.uv, td, tu, wordp, ONE); sm_code_step<NP, 5>(A.acc, A.dpv, A.uv, td, tu, wordp, ONE);
+        store_codes(A, wordp);
     }
+#undef RCN_SM_ROW
+#undef RCN_SM_GAP
     SmDpOut o; o.best = best; o.best_row = have_best ? best_row : 0; o.tied = tied; o.pred_rows = pred_rows;
     return o;
 }
@@ -612,8 +623,10 @@ __device__ __forceinline__ int sm_traceback(const SmPtrs& g, int best_row, int l
         const int nb = j - nj, na = i - ni - nb;
         const bool leaves = (ni == 0 && nj == 0) || na < 0 || na >= 8 || nb >= 8;
         const int nx = mv == kMvInvalid ? kNxInvalid : leaves ? kNxExit : na * 8 + nb;
-        int idx = 0, nxt = kNxInvalid;
-        unsigned long long vis = 0ull;
+        // the walk starts on the box's first row (lane b is cell b of it) and mostly stays there: one diagonal step per column,
+        // predecessor one row up.  That leading run is taken in one go (a ballot instead of a v_readlane round trip per step)
+        int idx = __builtin_ctzll(~__ballot(lane < 8 && nx == lane + 1) | 0x80ull), nxt = kNxInvalid;
+        unsigned long long vis = (1ull << idx) - 1ull;
         for (;;) {
             nxt = __builtin_amdgcn_readlane(nx, idx);
             if (nxt >= 64) break;
