@@ -85,13 +85,17 @@ def cpu_limits():
     return out
 
 
-def product_files(contig, coverage, seed, workers):
-    """The workload as racon input files in the scratch cache (generated in forked workers: call before HIP exists)."""
+def product_files(contig, coverage, seed, workers, short_reads=False):
+    """The workload as racon input files in the scratch cache (generated in forked workers: call before HIP exists).
+    `short_reads`: the cfg4 shape (150-base reads, 0.3 % substitutions, 0.05 % insertions / deletions, phred 30)."""
     from racon_amd.synth import simulate_window_files
-    d = os.path.join(CACHE, "files_%d_%g_%d" % (contig, coverage, seed))
+    d = os.path.join(CACHE, "files_%d_%g_%d%s" % (contig, coverage, seed, "_short" if short_reads else ""))
     t0 = time.perf_counter()
     if not all(os.path.exists(os.path.join(d, n)) for n in ("targets.fasta", "reads.fastq", "overlaps.sam", ".done")):
-        simulate_window_files(d, contig, coverage, 10000, seed=seed, workers=workers)
+        if short_reads:
+            simulate_window_files(d, contig, coverage, 150, seed=seed, piece=125_000, workers=workers, sub=0.003, ins=0.0005, dele=0.0005, phred=(30.0, 0.0, 30, 30))
+        else:
+            simulate_window_files(d, contig, coverage, 10000, seed=seed, workers=workers)
         open(os.path.join(d, ".done"), "w").close()
     return {"targets": os.path.join(d, "targets.fasta"), "reads": os.path.join(d, "reads.fastq"), "sam": os.path.join(d, "overlaps.sam"),
             "contig": contig, "files_s": round(time.perf_counter() - t0, 1)}
@@ -259,9 +263,13 @@ def main():
         what = "%s: synthetic %d bp contig/GPU, %gx ONT-error reads (3%% sub, 3%% ins, 4%% del), -w %d" % (cfg_name, contig, a.coverage, a.window)
     a.contig = contig
     # the product leg's input files (same seeds -> the same windows as the packed batches; generated in forked workers too)
-    do_product = not a.no_product and world == 1 and a.window == 500 and ((not a.config and contig == 1_000_000) or a.config == "cfg3")
+    do_product = not a.no_product and world == 1 and ((a.window == 500 and ((not a.config and contig == 1_000_000) or a.config == "cfg3")) or a.config == "cfg4")
     pfiles = []
-    if do_product and a.config == "cfg3":
+    pwindow = 200 if a.config == "cfg4" else a.window
+    if do_product and a.config == "cfg4":
+        # the same SHAPE as files (1 Mbp, 150-base reads at 60x, -w 200): the product's polish() interval on short reads
+        pfiles.append(("cfg4_files", product_files(1_000_000, 60.0, 20260923, workers, short_reads=True)))
+    elif do_product and a.config == "cfg3":
         pfiles.append(("cfg3", product_files(50_000_000, a.coverage, 20260922, workers)))       # the whole 100 000-window job as files
     elif do_product:
         pfiles.append(("cfg2", product_files(1_000_000, a.coverage, 20260921, workers)))
@@ -418,9 +426,9 @@ def main():
                 out["product_polish"] = {}
                 for name, paths in pfiles:
                     same_windows = name in ("cfg2", "cfg3")             # (the packed batch of this run holds the same windows)
-                    out["product_polish"][name] = product_polish(paths, a.window, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
+                    out["product_polish"][name] = product_polish(paths, pwindow, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
                                                                  reps=1 if name == "cfg3" else 2, batches=a.product_batches)
-                    out["product_polish"][name]["cli"] = product_cli(paths, a.window, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
+                    out["product_polish"][name]["cli"] = product_cli(paths, pwindow, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
                                                                      reps=1 if name == "cfg3" else 2, batches=a.product_batches)
                 out["value_product_polish"] = out["product_polish"][pfiles[0][0]]["windows_per_s"]
                 if "cfg3_share" in out["product_polish"]:

@@ -1599,8 +1599,13 @@ int rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* h) {
     sh.sum_l = static_cast<int32_t>(std::min<uint64_t>(deepest > L ? deepest - L : 0, 1u << 30));
     sh.lmax = static_cast<int32_t>(h->max_layer_length ? h->max_layer_length : L + (3 * L + 9) / 10);
     sh.nsym = 5;
-    const Caps c = first_pass_caps(&sh, &sh + 1, !e->knobs.wide_only, e->caps_level, e->knobs.hrows_div);
-    const uint64_t slots = std::min<uint64_t>(nw, e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint64_t>(e->n_cu) * 8u);
+    Caps c = first_pass_caps(&sh, &sh + 1, !e->knobs.wide_only, e->caps_level, e->knobs.hrows_div);
+    uint64_t slots = std::min<uint64_t>(nw, e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint64_t>(e->n_cu) * 8u);
+    {
+        // windows of the small-window kernel's shape: its slots (a few tens of KB each), not poa_window_kernel2's
+        Caps cs;
+        if (small_caps(e, &sh, &sh + 1, cs)) { c = cs; slots = std::min<uint64_t>(nw, e->cfg.max_slots ? e->cfg.max_slots : static_cast<uint64_t>(e->n_cu) * cs.per_cu); }
+    }
     { size_t fr = 0, tot = 0; HIP_TRY(hipMemGetInfo(&fr, &tot)); e->free_mem = fr + e->d_scratch.cap; }
     const uint64_t want = std::min<uint64_t>(slots * c.slot_bytes, scratch_budget(e));
     if ((rc = e->d_scratch.reserve(want))) return rc;

@@ -139,3 +139,27 @@ def test_cli_survives_a_device_short_of_memory(tmp_path):
     tight = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert tight.stdout == free.stdout and tight.stdout.count(b">") == 1
     assert b"polishing them in halves" in tight.stderr and b"polishing them in halves" not in free.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_cli_short_reads_through_the_small_window_kernel(P, oracle, tmp_path_factory, mode):
+    """racon's short-read use (kNGS windows: reference src/polisher.cpp:229-230 picks the type from the mean read length) with
+    `-w 200`: 150-base reads at 60x on two contigs.  The windows have the small-window kernel's shape
+    (racon_amd/csrc/poa_small.hpp: one wave per window, graph in LDS) whether the host builds them (mode 0) or the device does
+    (1: windows, 2: CIGAR walk too) -- the FASTA of host layer + oracle, byte for byte."""
+    d = str(tmp_path_factory.mktemp("short"))
+    paths, _ = simulate_files(d, contig_len=30000, coverage=60.0, read_len=150, n_contigs=2, sub=0.004, ins=0.0005, dele=0.0005, backbone_errors=0.01)
+    p = P.Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", 200, 10.0, 0.3, True, 3, -5, -4, num_threads=4)
+    p.initialize()
+    b = p.windows()
+    assert b.n_windows == 2 * 150 and int(b.win_type.max()) == 0          # kNGS
+    ref = p.assemble(oracle.consensus(b, 3, -5, -4, True, 0), True)
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    env = dict(os.environ, RCN_DEBUG="1")
+    if mode != "0":
+        env["RACON_HIP_DEVICE_WINDOWS"] = mode
+    r = subprocess.run([exe, "-t", "4", "-w", "200", paths["reads"], paths["sam"], paths["targets"]], check=True, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.stdout == ref
+    assert b"small-window kernel" in r.stderr                               # (the engine's debug line of the pass)
