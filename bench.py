@@ -352,15 +352,15 @@ def main():
         # profiles/traffic.json and stamped with the hash of the kernel sources it was measured on: a stale file
         # (sources changed since) is reported as null, not quoted
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and world == 1 and not a.config and a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0:
+        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config if a.config else "traffic.json")
+        if os.path.exists(tf) and world == 1 and (a.config or (a.contig == 1_000_000 and a.window == 500 and a.coverage == 30.0)):
             try:
                 tj = json.load(open(tf))
                 from tools.srchash import kernel_source_hash
                 if tj.get("kernel_source_hash") == kernel_source_hash():
-                    traffic, traffic_src = tj["bytes_per_launch"], "profiles/traffic.json (%s)" % tj.get("measured", "?")
+                    traffic, traffic_src = tj["bytes_per_launch"], "profiles/%s (%s)" % (os.path.basename(tf), tj.get("measured", "?"))
                 else:
-                    traffic_src = "profiles/traffic.json is stale (kernel sources changed since it was measured)"
+                    traffic_src = "profiles/%s is stale (kernel sources changed since it was measured)" % os.path.basename(tf)
             except Exception:
                 traffic = None
         # secondary ceilings ("the kernel may be issue-bound before it is HBM-bound"): vector / scalar issue and

@@ -125,3 +125,26 @@ def test_long_queue_and_slot_counts(Engine, oracle):
         assert got.consensus[k] == ref.consensus[k % b.n_windows], k
     few = Engine(3, -5, -4, True, max_slots=5)
     assert_same(few.consensus(b), ref, "five slots")
+
+
+@pytest.mark.parametrize("seed,scores", [(11, (3, -5, -4)), (12, (5, -4, -8)), (13, (1, -1, -1))])
+def test_fuzz_small_windows(Engine, oracle, monkeypatch, seed, scores):
+    """The tie-break stress windows of test_gpu_fuzz.py in the alphabets the kernel keeps (A/C/G/T and subsets: low-complexity
+    backbones, co-optimal alignments, sink ties, weight ties in the heaviest bundle, zero qualities, duplicate begins, more
+    than four in-edges per node -- the wide rows) through the small-window kernel: what it keeps equals the oracle, what it
+    sends back (ties beyond the id rule, far predecessors ...) comes out of poa_window_kernel2 the same."""
+    from test_gpu_fuzz import random_window
+    rng = np.random.default_rng(2000 + seed)
+    wins = [random_window(rng, 5 * int(rng.integers(0, 50)) + int(rng.integers(0, 3))) for _ in range(500)]      # styles 0-2: ACGT / AC / A
+    b = WindowBatch.from_windows(wins)
+    for trim in (True, False):
+        ref = oracle.consensus(b, *scores, trim, 0)
+        eng = Engine(*scores, trim)
+        assert_same(eng.consensus(b), ref, f"small fuzz seed {seed} {scores} trim={trim}")
+        st = eng.stats()
+        _no_bug(st)
+        assert st["n_small"] > 0.5 * b.n_windows, st
+    monkeypatch.setenv("RCN_FORCE_EXACT", "1")
+    ex = Engine(*scores, True)
+    assert_same(ex.consensus(b), oracle.consensus(b, *scores, True, 0), f"small fuzz seed {seed}, exact order")
+    _no_bug(ex.stats())

@@ -73,3 +73,27 @@ if has testsq; then   # quick subset: the suites touched this round
   timeout 1500 python -m pytest tests/test_gpu_small.py tests/test_gpu_pair_align.py tests/test_gpu_bench_contract.py tests/test_cli_e2e.py -m gpu -q -x --durations=8 > "$OUT/pytest_subset.log" 2>&1
   echo "pytest exit $?" >> "$OUT/pytest_subset.log"; tail -15 "$OUT/pytest_subset.log"
 fi
+# ---- the round's closing set: kernel stats + HBM counters of the default line and of cfg4, the other workloads ----
+if has final; then
+  BP="--steps 3 --warmup 1 --no-cpu --no-upload-leg --no-product"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python bench.py $BP > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+  find "$OUT/prof" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \; ; head -6 "$OUT/kernel_stats.csv" | cut -c1-200
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof4" -o trace -- python bench.py --config cfg4 $BP > "$OUT/prof_bench_cfg4.json" 2> "$OUT/prof4.err"
+  find "$OUT/prof4" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_cfg4.csv" \; ; head -5 "$OUT/kernel_stats_cfg4.csv" | cut -c1-200
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python bench.py $BP > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"; echo "pmc $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; tail -3 "$OUT/pmc_summary.txt"
+  mkdir -p "$OUT/c4"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/c4/pmc_$C" -o pmc -- python bench.py --config cfg4 $BP > "$OUT/c4/pmc_$C.json" 2> "$OUT/c4/pmc_$C.err"; echo "pmc cfg4 $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT/c4" > "$OUT/pmc_summary_cfg4.txt" 2>&1; tail -3 "$OUT/pmc_summary_cfg4.txt"
+  sqpasses cfg4 --config cfg4
+  sqpasses cfg2
+  timeout 900 python bench.py --config cfg4 --steps 10 --warmup 2 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4_full.err"; benchline cfg4 < "$OUT/bench_cfg4.json"
+  timeout 900 python bench.py --config w1000 --steps 5 --warmup 1 --no-product --no-upload-leg 2> "$OUT/bench_w1000.err" | tee "$OUT/bench_w1000.json" | benchline w1000
+  timeout 900 python bench.py --config cfg5x0.004 --steps 5 --warmup 1 --no-product --no-upload-leg 2> "$OUT/bench_cfg5.err" | tee "$OUT/bench_cfg5x0.004.json" | benchline cfg5x0.004
+  timeout 900 python bench.py --contig 4000000 --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg 2> "$OUT/bench_4mbp.err" | tee "$OUT/bench_4mbp.json" | benchline 4mbp
+  find "$OUT" -name "*kernel_trace.csv" -delete 2>/dev/null; find "$OUT" -name "*.db" -delete 2>/dev/null
+fi

@@ -24,8 +24,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for (kn, cn), (ids, total) in sorted(acc.items()):
             n = max(1, len(ids))
             print("%s | %s | dispatches %d | sum %.6g | per dispatch %.6g" % (kn, cn, n, total, total / n))
-            if "poa_window_kernel2" in kn:           # (the two instances of the kernel: poa_window_kernel2 and poa_window_kernel2_deep)
-                tot = per_kernel.setdefault("rcn::poa_window_kernel2*", {}).setdefault(cn, [0.0, 0])
+            if "poa_window_kernel" in kn:            # (the consensus kernels: poa_window_kernel2, its _deep instance, poa_window_kernel_small)
+                tot = per_kernel.setdefault("rcn::poa_window_kernel*", {}).setdefault(cn, [0.0, 0])
                 tot[0] += total; tot[1] += n
 # traffic.json: HBM bytes per launch of the consensus kernel.  Raw units are KB (rocprofv3 derived counters);
 # FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) prescribes for gfx950 wide reads, WRITE_SIZE is uncalibrated.
