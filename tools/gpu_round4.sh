@@ -97,3 +97,4 @@ if has final; then
   timeout 900 python bench.py --contig 4000000 --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg 2> "$OUT/bench_4mbp.err" | tee "$OUT/bench_4mbp.json" | benchline 4mbp
   find "$OUT" -name "*kernel_trace.csv" -delete 2>/dev/null; find "$OUT" -name "*.db" -delete 2>/dev/null
 fi
+if has sq8k; then sqpasses 4mbp --contig 4000000; fi
