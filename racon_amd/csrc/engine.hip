@@ -1146,7 +1146,9 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
     if (small) {
         e->pass_small = true;
         L.stream = e->sub_stream[c]; L.per_cu = L.c.per_cu;
-        L.slots = e->cfg.max_slots ? std::min(L.n_work, slots_left) : balanced_slots(L.n_work, slots_left);
+        // (every piece may fill the device: its work-groups are persistent over a queue, the ones that find no room at first
+        //  start as the earlier piece's retire -- a fixed share would idle once that piece is done)
+        L.slots = e->cfg.max_slots ? std::min(L.n_work, slots_left) : balanced_slots(L.n_work, static_cast<uint32_t>(e->n_cu) * L.c.per_cu);
     } else if (sp.on) {
         L.stream = c == 0 ? e->deep_stream : e->rest_stream;
         L.per_cu = c == 0 ? sp.deep_per_cu : sp.rest_per_cu;
@@ -1412,10 +1414,17 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     pp.cut[0] = 0; pp.cut[2] = nw;
     if (sp.on) pp.cut[1] = sp.n_deep;
     else {
-        const uint64_t q1 = nb / 24;
+        // (a batch for the small-window kernel: a third of the bases first -- its windows are alike and short-lived, what
+        //  counts is that the device has work while the host packs the rest: 130 MB take 6 ms)
+        Caps cs_;
+        const bool small_ = fast && small_caps(e, e->shapes.begin(), e->shapes.end(), cs_);
+        const uint64_t q1 = small_ ? nb / 3 : nb / 24;
         uint32_t k = 0;
         while (k < nw && win_base[k] < q1) ++k;
         pp.cut[1] = std::min(std::min(std::max(k, 1u), nw), std::max(1u, slots_total / 2));
+        // small windows, more of them than resident slots: the first piece is one whole round of the device (a window lasts
+        // ~5 ms whatever the piece: 3494 windows behind a first piece of 1506 were two rounds on half the slots)
+        if (small_ && nw > slots_total && !e->cfg.max_slots) pp.cut[1] = slots_total;
     }
     {   // reserve the scratch for the usual alphabet (A, C, G, T and one more symbol) before anything runs; a piece that
         // needs more grows the buffer below, behind a synchronisation.  (The symbol count of a window sizes its aligned
@@ -1446,15 +1455,18 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
             host_parallel(kb - ka, threads, [&](size_t kk) {
                 const uint32_t k = ka + static_cast<uint32_t>(kk), w = e->lpt[k], s0 = v.win_seq_off[w], n = v.win_seq_off[w + 1] - s0;
                 uint8_t* db = hs + o_bases + win_base[k]; uint8_t* dq = hs + o_quals + win_base[k];
+                uint8_t* const db0 = db;
                 uint64_t present[4] = {0, 0, 0, 0};
                 for (uint32_t i = 0; i < n; ++i) {
                     const uint64_t len = v.seq_off[s0 + i + 1] - v.seq_off[s0 + i];
                     if (!len) continue;
                     std::memcpy(db, v.seq[s0 + i], len);
-                    symbols_add(present, db, len);
                     if (v.qual[s0 + i]) std::memcpy(dq, v.qual[s0 + i], len); else std::memset(dq, '!', len);
                     db += len; dq += len;
                 }
+                // (one scan over the window's packed bytes: a short-read window is ~140 layers of ~90 bases, and a scan per
+                //  layer is below the vector path's 64 bytes half of the time)
+                symbols_add(present, db0, static_cast<uint64_t>(db - db0));
                 symbols_finish(present, e->shapes[w].nsym, s_flags[k]);
             });
             const uint64_t pa = win_base[ka], pz = win_base[kb];

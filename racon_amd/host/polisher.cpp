@@ -374,7 +374,7 @@ void Polisher::initialize() {
 // object and device: the kernel of one chunk fills the compute units that the tail of the other engine's chunk leaves
 // idle, while a host thread packs the next one.  Created with a first reservation for `-w` sized windows at ONT-like
 // depth; reserve_for_windows() corrects it once the windows exist.
-namespace { constexpr uint64_t kMaxChunkWindows = 8192, kMinChunkWindows = 2048, kMaxChunkBases = 512ull << 20; }
+namespace { constexpr uint64_t kMaxChunkWindows = 8192, kMinChunkWindows = 2048, kMaxChunkBases = 512ull << 20, kMinChunkBases = 64ull << 20; }
 
 void Polisher::create_engines() {
     const int32_t real_devices = HipEngine::DeviceCount();      // (0 without the library or a device: polish() reports that)
@@ -424,7 +424,10 @@ void Polisher::plan_chunks() {
     if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) { if (atoi(cw) > 0) target = static_cast<uint64_t>(atoi(cw)); }   // tests: many small chunks
     for (uint64_t a = 0; a < nw;) {
         uint64_t b = a, sum = 0;
-        while (b < nw && b - a < target && sum < kMaxChunkBases) sum += bases[rank_[b++]];
+        // (at least 64 MB of bases too -- what 2048 windows of 500 bases at 30x hold: short-read windows are a third of that,
+        //  and a chunk's fixed costs -- packing before its first launch, its launch tail -- do not shrink with them:
+        //  5000 windows of 150-base reads went as 2048 + 2048 + 904, the last chunk alone on the device for 6 of 23 ms)
+        while (b < nw && (b - a < target || sum < kMinChunkBases) && b - a < 4 * kMaxChunkWindows && sum < kMaxChunkBases) sum += bases[rank_[b++]];
         chunks_.emplace_back(a, b); a = b;
     }
 }

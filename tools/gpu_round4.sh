@@ -98,3 +98,16 @@ if has final; then
   find "$OUT" -name "*kernel_trace.csv" -delete 2>/dev/null; find "$OUT" -name "*.db" -delete 2>/dev/null
 fi
 if has sq8k; then sqpasses 4mbp --contig 4000000; fi
+if has timeline4; then
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(1_000_000, 60.0, 20260923, 32, short_reads=True))
+PY
+  F=/tmp/racon_amd_cache/files_1000000_60_20260923_short
+  for k in 1 2 3; do
+    RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 -w 200 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/timeline_cfg4_$k.err" | md5sum
+  done
+  grep -E "racon::|polish:|piece|collect|reserve|pass of" "$OUT/timeline_cfg4_3.err" | head -60
+fi
