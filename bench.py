@@ -255,7 +255,8 @@ def main():
         else:
             batch = config_windows(a.config)
             what = {"cfg4": "cfg4: synthetic 1 Mbp contig, 60x of 150 bp short reads (0.3% sub, 0.05% ins, 0.05% del, phred 30), -w 200, kNGS",
-                    "w1000": "w1000: synthetic 1 Mbp contig, 30x ONT-error reads, -w 1000"}.get(a.config, a.config)
+                    "w1000": "w1000: synthetic 1 Mbp contig, 30x ONT-error reads, -w 1000",
+                    "ngs_w500": "ngs_w500: synthetic 1 Mbp contig, 60x of 150 bp short reads, -w 500 (racon's default window), kNGS"}.get(a.config, a.config)
         contig = 0
     else:
         contig, seed, scaling, cfg_name = pick_workload(a.config, a.contig, rank, world)

@@ -341,8 +341,9 @@ bool small_caps(const rcn_engine* e, It first, It last, Caps& out) {
     c.fast = true; c.small = true;
     c.slot_bytes = rcn::small_slot_bytes(c.ncap);
     c.lds = rcn::small_layout(c.ncap).end;
-    // LDS is handed out in 1280-byte granules, 128 per CU; twelve one-wave work-groups (three per SIMD) are what the kernel's
-    // register budget admits (__launch_bounds__(64, 3): up to 168 VGPRs, nothing spilled)
+    // LDS is handed out in 1280-byte granules, 128 per CU (a 200-base window: 13 216 bytes = eleven granules: eleven per CU);
+    // twelve one-wave work-groups (three per SIMD) are what the kernel's register budget admits (__launch_bounds__(64, 3): up
+    // to 168 VGPRs, nothing spilled)
     const uint32_t granules = (c.lds + 1279u) / 1280u;
     c.per_cu = std::max(1u, std::min(12u, 128u / granules));
     if (e->knobs.small_per_cu > 0) c.per_cu = static_cast<uint32_t>(std::min(32, e->knobs.small_per_cu));

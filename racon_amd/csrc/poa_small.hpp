@@ -8,12 +8,12 @@
 // each a handful of hops through node / edge / order arrays that together are a few KB -- and three of its four waves idle
 // through the DP (profiles/r03/f_winprof_cfg4.txt, n_cfg4_residency.txt: bound by memory requests per CU).  Here:
 //
-//   * the graph lives in LDS for the life of the window, 16-bit ids: node symbol, aligned ring (at most three others: A, C,
-//     G, T), the incrementally maintained ring-contiguous topological order and its inverse, and per node the TAILS of its
+//   * the graph lives in LDS for the life of the window, 16-bit ids: node symbol, aligned ring (at most four others: A, C,
+//     G, T and N), the incrementally maintained ring-contiguous topological order and its inverse, and per node the TAILS of its
 //     in-edges in creation order (at most kSmIn; spoa's in-edge order is all the traceback's tie-break needs -- out-edge
 //     lists are not kept at all: "does edge tail -> head exist" is a look at head's in-record, "is it a sink" a scatter of
-//     marks from the in-records).  22 bytes per node + 11 per node of per-layer work area: a 200-base window takes 10 KB,
-//     sixteen windows share a CU;
+//     marks from the in-records).  31 bytes per node + 14 per node of per-layer work area: a 200-base window takes 13 KB,
+//     eleven windows share a CU;
 //   * edge weights and node coverage -- only read by the consensus at the very end -- stay in HBM and are only ever
 //     touched by fire-and-forget atomics (slot [node][in-edge number]);
 //   * the DP is the Z-domain packed-int16 row of poa_k2_dp.hpp (two cells per VGPR, DPP prefix max) over at most 256
@@ -23,7 +23,7 @@
 //     flight while the current one is walked;
 //   * one wave: no work-group barrier anywhere, a phase boundary is an LDS fence.
 //
-// Anything outside this shape -- a node with a fifth in-edge, a predecessor more than sixteen rows back, a ring beyond four
+// Anything outside this shape -- a node with a ninth in-edge, a predecessor more than sixteen rows back, a ring beyond five
 // symbols, a sink tie the id rule does not decide, a graph that outgrows the LDS -- flags the window (kFlagOverflow) and the
 // engine re-runs it with poa_window_kernel2: results are bit-identical either way, the flag only costs time.
 //
@@ -34,7 +34,7 @@
 namespace rcn {
 
 constexpr int kSmIn = 8;            // in-edge tails kept per node (move codes name a predecessor with three bits)
-constexpr int kSmRing = 3;          // aligned-ring members of a node besides itself
+constexpr int kSmRing = 4;          // aligned-ring members of a node besides itself (A, C, G, T and one more symbol: N)
 constexpr int kSmLen = 255;         // longest layer (256 columns: two packed VGPRs per lane)
 constexpr int kSmWin = 16;          // rows of the register window = farthest predecessor row
 constexpr int kSmMinCap = 256, kSmMaxCap = 1024;     // node capacities the LDS layout is made for
@@ -1034,7 +1034,6 @@ __global__ __launch_bounds__(64, 3) void poa_window_kernel_small(KParams P) {
         }
         int why = 0;
         if (L > ncap || L < 1) why = kSmCap;
-        if (!P.win_flags || !(P.win_flags[w] & 1)) why = kSmRingFull;      // a symbol besides A, C, G, T: rings of more than four
         int n = L;
         if (!why) {
             // ---- backbone -> graph (window.cpp:73-77); every weight / coverage word of the slot starts at its final-or-zero value ----

@@ -334,6 +334,9 @@ def config_windows(name: str, scale: float = 1.0) -> WindowBatch:
     if name == "cfg4":      # short reads: 150 bp at 60x, -w 200, kNGS
         return simulate_windows(int(1_000_000 * scale), 200, 60.0, 150, sub=0.003, ins=0.0005, dele=0.0005,
                                 seed=20260923, phred_mean=30.0, phred_sd=0.0, phred_lo=30, phred_hi=30)
+    if name == "ngs_w500":  # short reads on racon's default window: 150 bp at 60x, -w 500 (2000 windows of ~350 layers at scale 1)
+        return simulate_windows(int(1_000_000 * scale), 500, 60.0, 150, sub=0.003, ins=0.0005, dele=0.0005,
+                                seed=20260926, phred_mean=30.0, phred_sd=0.0, phred_lo=30, phred_hi=30)
     if name == "cfg5":      # fragment correction (-f): 100 000 reads x 10 kbp from a 33.3 Mbp genome, dual overlaps (2 M windows at scale 1)
         return simulate_fragment_windows(int(33_333_333 * scale), int(100_000 * scale), 10000, 500, seed=20260924)
     if name == "w1000":     # larger window (int32 score range)

@@ -95,23 +95,30 @@ def test_no_quality_other_symbols_and_corner_windows(Engine, oracle):
     e2 = Engine(3, -5, -4, True)
     assert_same(e2.consensus(b), oracle.consensus(b, 3, -5, -4, True, 2), "edge cases")
     _no_bug(e2.stats())
-    # a window with an N in one layer among ACGT windows
+    # a window with an N in one layer among ACGT windows (rings of up to five symbols stay in the kernel), and one whose
+    # column 50 sees seven symbols (the ring outgrows the kernel's: that window comes back flagged)
     wins = []
     rng = np.random.default_rng(5)
     for k in range(70):
-        bb = bytes(rng.choice(list(b"ACGT"), 120).astype(np.uint8))
+        bb = bytearray(rng.choice(list(b"ACGT"), 120).astype(np.uint8).tobytes())
+        bb[60] = ord("A")
+        bb = bytes(bb)
         lay = bb[10:110]
         seqs = [(bb, q(bb, 20), 0, 0)] + [(lay, q(lay, 25), 10, 109) for _ in range(4)] + [(bb, q(bb, 30), 0, 119)]
         if k == 13:
             withn = lay[:50] + b"N" + lay[51:]
             seqs[2] = (withn, q(withn, 25), 10, 109)
+        if k == 31:
+            for sym in b"CGTNRY":
+                alt = lay[:50] + bytes([sym]) + lay[51:]
+                seqs.append((alt, q(alt, 25), 10, 109))
         wins.append({"type": 0, "seqs": seqs})
     wb = WindowBatch.from_windows(wins)
     e3 = Engine(3, -5, -4, True)
-    assert_same(e3.consensus(wb), oracle.consensus(wb, 3, -5, -4, True, 2), "one window with an N")
+    assert_same(e3.consensus(wb), oracle.consensus(wb, 3, -5, -4, True, 2), "windows with N / with a seven-symbol column")
     st = e3.stats()
     _no_bug(st)
-    assert st["n_small_bailed"] >= 1 and st["small_bail_why"][3] >= 1, st
+    assert st["n_small_bailed"] == 1 and st["small_bail_why"][3] == 1 and st["n_small"] == wb.n_windows - 1, st
 
 
 def test_long_queue_and_slot_counts(Engine, oracle):

@@ -111,3 +111,8 @@ PY
   done
   grep -E "racon::|polish:|piece|collect|reserve|pass of" "$OUT/timeline_cfg4_3.err" | head -60
 fi
+if has ngs500; then
+  for e in "" "RCN_NO_SMALL=1" "RCN_SMALL_PER_CU=4" ; do
+    env $e timeout 900 python bench.py --config ngs_w500 --steps 3 --warmup 1 --no-cpu --no-product --no-upload-leg 2>/dev/null | benchline "ngs_w500 $e"
+  done | tee "$OUT/ngs_w500.txt"
+fi
