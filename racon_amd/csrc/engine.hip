@@ -165,7 +165,8 @@ void host_parallel(size_t n, unsigned threads, F fn) {
 // RCN_DEBUG (host timeline on stderr, no effect on results) is the one switch that needs no gate.
 struct Knobs {
     bool debug = false, no_ptab = false, force_exact = false, force_slow_tb = false, no_band = false, force_band_fail = false,
-         band_scores = false, no_code_wave = false, wide_only = false, no_stream = false, no_small = false, force_small = false, prof_layers = false;
+         band_scores = false, no_code_wave = false, wide_only = false, no_stream = false, no_small = false, force_small = false, prof_layers = false,
+         cigar_serial = false;
     int force_tie = 0, wg_per_cu = 0, split = -1, split_deep_per_cu = 0, split_rest_per_cu = 0, split_deep = 0, split_deep_wide = -1,
         split_cus = 0, hrows_div = 0, small_per_cu = 0;
     double heavy_pct = 1.0;
@@ -181,7 +182,7 @@ static Knobs read_knobs() {
     k.no_ptab = flag("RCN_NO_PTAB"); k.force_exact = flag("RCN_FORCE_EXACT"); k.force_slow_tb = flag("RCN_FORCE_SLOW_TB");
     k.no_band = flag("RCN_NO_BAND"); k.force_band_fail = flag("RCN_FORCE_BAND_FAIL"); k.band_scores = flag("RCN_BAND_SCORES");
     k.no_code_wave = flag("RCN_NO_CODE_WAVE"); k.wide_only = flag("RCN_WIDE_ONLY"); k.no_stream = flag("RCN_NO_STREAM");
-    k.no_small = flag("RCN_NO_SMALL"); k.force_small = flag("RCN_FORCE_SMALL"); k.prof_layers = flag("RCN_PROF_LAYERS");
+    k.cigar_serial = flag("RCN_CIGAR_SERIAL"); k.no_small = flag("RCN_NO_SMALL"); k.force_small = flag("RCN_FORCE_SMALL"); k.prof_layers = flag("RCN_PROF_LAYERS");
     k.force_tie = num("RCN_FORCE_TIE", 0); k.wg_per_cu = num("RCN_WG_PER_CU", 0); k.split = num("RCN_SPLIT", -1);
     k.split_deep_per_cu = num("RCN_SPLIT_DEEP_PER_CU", 0); k.split_rest_per_cu = num("RCN_SPLIT_REST_PER_CU", 0);
     k.split_deep = num("RCN_SPLIT_DEEP", 0); k.split_deep_wide = num("RCN_SPLIT_DEEP_WIDE", -1); k.split_cus = num("RCN_SPLIT_CUS", 0);

@@ -504,7 +504,7 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
         K.cigar_off = B[kBCigarOff].as<uint64_t>(); K.cigar = B[kBCigar].as<uint8_t>(); K.q_start = B[kBQStart].as<uint32_t>();
         K.t_begin = B[kBTBegin].as<uint32_t>(); K.t_end = B[kBTEnd].as<uint32_t>(); K.bp_off = P.bp_off;
         K.bp_t = B[kBBpT].as<uint32_t>(); K.bp_q = B[kBBpQ].as<uint32_t>(); K.n_overlaps = C->n_overlaps; K.W = W;
-        if (getenv("RCN_CIGAR_SERIAL")) {        // the per-thread restatement (kept: it is the reference's loop, operation by operation)
+        if (e->knobs.cigar_serial) {             // (test switch) the per-thread restatement (kept: it is the reference's loop, operation by operation)
             hipLaunchKernelGGL(k_cigar_breaking_points, dim3(static_cast<uint32_t>((C->n_overlaps + 255) / 256)), dim3(256), 0, st, K);
         } else {
             const uint64_t n_slots_all = n_points / 2;

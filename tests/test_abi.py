@@ -61,3 +61,33 @@ def test_library_holds_both_instances_of_the_consensus_kernel():
     blob = open(os.path.join(ROOT, "racon_amd", "csrc", "libracon_hip.so"), "rb").read()
     for name in (b"_ZN3rcn18poa_window_kernel2ENS_7KParamsE", b"_ZN3rcn23poa_window_kernel2_deepENS_7KParamsE", b"_ZN3rcn17poa_window_kernelENS_7KParamsE"):
         assert name in blob, name
+
+
+def test_library_holds_the_small_window_kernel():
+    """poa_small.hpp's kernel (one wave per window, graph in LDS) is a third translation unit of the same library."""
+    blob = open(os.path.join(ROOT, "racon_amd", "csrc", "libracon_hip.so"), "rb").read()
+    assert b"_ZN3rcn23poa_window_kernel_smallENS_7KParamsE" in blob
+
+
+def test_python_mirrors_have_the_c_structs_sizes(tmp_path):
+    """The ctypes mirrors of the ABI's structs (racon_amd/engine.py) against the C compiler's view of include/racon_hip.h."""
+    import subprocess
+    from racon_amd import engine
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "racon_hip.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(rcn_run_stats), '
+                   'sizeof(rcn_engine_config), sizeof(rcn_window_refs), sizeof(rcn_reserve_hint)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(engine.RcnRunStats), C.sizeof(engine.RcnEngineConfig), C.sizeof(engine.RcnWindowRefs), C.sizeof(engine.RcnReserveHint)]
+
+
+def test_engine_switches_are_read_once_at_creation():
+    """No getenv on the launch path: the engine's RCN_* switches are read by read_knobs() when an engine is created, behind
+    RCN_EXPERIMENT=1."""
+    src = open(os.path.join(ROOT, "racon_amd", "csrc", "engine.hip")).read()
+    body = src[src.index("static Knobs read_knobs()"):]
+    body = body[:body.index("\n}\n") + 3]
+    assert src.count("getenv") == body.count("getenv") and "RCN_EXPERIMENT" in body
+    for h in ("poa_small.hpp", "poa_kernel2.hpp", "poa_band.hpp", "pair_align.hpp", "window_build.hpp"):
+        assert "getenv" not in open(os.path.join(ROOT, "racon_amd", "csrc", h)).read(), h
