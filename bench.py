@@ -223,7 +223,7 @@ def main():
     ap.add_argument("--verify", action="store_true", help="also check every window against the oracle (untimed)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (code-path test with several ranks on ONE GPU)")
     ap.add_argument("--product-multi-contig", type=int, default=0, help="N > 1: contig bp of the product leg that ONE racon_hip process polishes on all N devices "
-                                                                         "(default: 6.25 Mbp per device, 50 Mbp = cfg3 at N = 8)")
+                                                                         "(default: 2 Mbp per device; 50000000 = cfg3 whole)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -278,7 +278,9 @@ def main():
             pfiles.append(("cfg3_share", product_files(a.product_contig, a.coverage, 20260922, workers)))
     pmulti = None
     if world > 1 and not a.no_product and a.window == 500 and not a.config and rank == 0:
-        pmulti = product_files(a.product_multi_contig or min(50_000_000, 6_250_000 * world), a.coverage, 20260922, workers)
+        # 2 Mbp (4000 windows) per device by default: 16 Mbp of files at N = 8 are written and polished twice within the
+        # minutes the default line may take (cfg3 whole -- 50 Mbp, 7 GB of text -- with --product-multi-contig 50000000)
+        pmulti = product_files(a.product_multi_contig or min(50_000_000, 2_000_000 * world), a.coverage, 20260922, workers)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.dist_backend == "nccl":
