@@ -200,7 +200,7 @@ __device__ __forceinline__ int sm_subgraph(const SmPtrs& g, int n, int begin, in
         if (!idok) own_t = 0ull;
         const unsigned long long own_b = idok ? (1ull << lane) : 0ull;
         unsigned long long bmask = own_b, btmask = own_t;
-        const int maxd = __ballot(mine && bsz >= 3) ? 4 : __ballot(mine && bsz >= 2) ? 2 : 1;
+        const int maxd = __ballot(mine && bsz >= 5) ? 8 : __ballot(mine && bsz >= 3) ? 4 : __ballot(mine && bsz >= 2) ? 2 : 1;      // (ring blocks of up to kSmRing + 1 = 5)
         for (int d = 1; d < maxd; ++d) {
             const unsigned long long mb = __shfl_down(own_b, d), mt = __shfl_down(own_t, d);
             if (d < bsz && lane + d < 64) { bmask |= mb; btmask |= mt; }

@@ -134,7 +134,7 @@ def test_long_queue_and_slot_counts(Engine, oracle):
     assert_same(few.consensus(b), ref, "five slots")
 
 
-@pytest.mark.parametrize("seed,scores", [(11, (3, -5, -4)), (12, (5, -4, -8)), (13, (1, -1, -1))])
+@pytest.mark.parametrize("seed,scores", [(11, (3, -5, -4)), (12, (5, -4, -8)), (13, (1, -1, -1)), (14, (2, -3, -2)), (15, (4, -6, -100)), (16, (3, -5, -4))])
 def test_fuzz_small_windows(Engine, oracle, monkeypatch, seed, scores):
     """The tie-break stress windows of test_gpu_fuzz.py in the alphabets the kernel keeps (A/C/G/T and subsets: low-complexity
     backbones, co-optimal alignments, sink ties, weight ties in the heaviest bundle, zero qualities, duplicate begins, more
@@ -142,7 +142,9 @@ def test_fuzz_small_windows(Engine, oracle, monkeypatch, seed, scores):
     sends back (ties beyond the id rule, far predecessors ...) comes out of poa_window_kernel2 the same."""
     from test_gpu_fuzz import random_window
     rng = np.random.default_rng(2000 + seed)
-    wins = [random_window(rng, 5 * int(rng.integers(0, 50)) + int(rng.integers(0, 3))) for _ in range(500)]      # styles 0-2: ACGT / AC / A
+    # styles 0-3: ACGT / AC / A / ACGTN (rings of up to five symbols stay in the kernel); one window in eight of style 4
+    # (eight symbols: its rings can outgrow the kernel's, and the window then comes back through the retry tier)
+    wins = [random_window(rng, 5 * int(rng.integers(0, 50)) + (4 if rng.random() < 0.125 else int(rng.integers(0, 4)))) for _ in range(500)]
     b = WindowBatch.from_windows(wins)
     for trim in (True, False):
         ref = oracle.consensus(b, *scores, trim, 0)
