@@ -732,13 +732,16 @@ inline int build_windows_from_pairs(rcn_engine* e, const rcn_read_set& R, const 
     int rc;
     if (R.n_seqs == 0 || R.n_targets == 0 || R.n_targets > R.n_seqs || !R.seq_off || !R.bases || !R.quals || !R.seq_has_qual) return RCN_E_ARG;
     if ((rc = upload_reads(e, R, e->stream))) return rc;
-    if ((rc = align_pairs(e, R, S, true))) return rc;
+    // an aligner that found no room (RCN_E_NOMEM / RCN_E_CAPACITY: the caller then aligns on the host and comes back through the
+    // CIGAR path) must not leave its pair tables and op bytes -- one byte per row + column of every overlap -- behind
+    auto drop_align = [&]() { for (DevBuf& d : e->d_align) d.release(); e->a_n_pairs = 0; e->a_ops_off.clear(); };
+    if ((rc = align_pairs(e, R, S, true))) { drop_align(); return rc; }
     e->d_align[kAScratch].release();            // the aligner's per-wave scratch (sized for the longest read) is done with
     std::vector<uint64_t> bp_off(S.n_pairs + 1, 0);
     std::vector<uint32_t> q_start(S.n_pairs);
     for (uint64_t o = 0; o < S.n_pairs; ++o) {
         const uint64_t tb = S.t_begin[o], te = S.t_end[o];
-        if (te <= tb) return RCN_E_ARG;
+        if (te <= tb) { drop_align(); return RCN_E_ARG; }
         const uint64_t inside = (te - 1) / W - tb / W;
         bp_off[o + 1] = bp_off[o] + 2 * (inside + 1);
         const uint64_t ql = R.seq_off[S.q_id[o] + 1] - R.seq_off[S.q_id[o]];

@@ -637,6 +637,7 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
                 const int32_t device = static_cast<int32_t>(sidx % static_cast<uint32_t>(n_devices));
                 auto engine = engines_[static_cast<size_t>(device)];
                 engine->set_fetch_range(wa, wb);                       // the strings of its own windows only
+                struct FetchAll { std::shared_ptr<HipEngine> e; ~FetchAll() { e->set_fetch_range(0, ~uint64_t(0)); } } fetch_all{engine};   // (also when a call below throws)
                 std::vector<std::string> c; std::vector<uint8_t> pl, ch;
                 bool aligned_on_device = false;
                 std::vector<uint8_t> host_cigar; std::vector<uint64_t> host_cigar_off; std::vector<uint32_t> host_q_start;
