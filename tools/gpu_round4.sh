@@ -111,6 +111,61 @@ PY
   done
   grep -E "racon::|polish:|piece|collect|reserve|pass of" "$OUT/timeline_cfg4_3.err" | head -60
 fi
+if has hwq; then
+  # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): two engines x five streams share them, and a
+  # copy stream that lands behind the other engine's running kernel waits for it.  polish() of the binary on one GPU's share
+  # of cfg3 (12 500 windows, three chunks on two engines) and on cfg2, per setting.
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(6_250_000, 30.0, 20260922, 32))
+print(bench.product_files(1_000_000, 30.0, 20260921, 32))
+PY
+  for F in /tmp/racon_amd_cache/files_6250000_30_20260922 /tmp/racon_amd_cache/files_1000000_30_20260921; do
+    for q in default 8 16 24; do
+      for k in 1 2 3 4; do
+        if [ $q = default ]; then env RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/hwq.err" | md5sum | cut -c1-8
+        else env GPU_MAX_HW_QUEUES=$q RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/hwq.err" | md5sum | cut -c1-8; fi
+        echo "$(basename $F) queues $q: $(grep 'generated consensus' $OUT/hwq.err)"
+      done
+    done
+  done | tee "$OUT/hwq.txt"
+fi
+if has chunks; then
+  # chunk size / engines per device of polish() on one GPU's share of cfg3 (12 500 windows) and on a 25 000-window job
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(6_250_000, 30.0, 20260922, 32))
+print(bench.product_files(12_500_000, 30.0, 20260922, 32))
+PY
+  for F in /tmp/racon_amd_cache/files_6250000_30_20260922 /tmp/racon_amd_cache/files_12500000_30_20260922; do
+    for e in "" "RACON_HIP_CHUNK_WINDOWS=3200" "RACON_HIP_CHUNK_WINDOWS=6300" "RACON_HIP_CHUNK_WINDOWS=8400" "RACON_HIP_CHUNK_WINDOWS=12600" "RACON_HIP_ENGINES_PER_DEVICE=3" "RACON_HIP_ENGINES_PER_DEVICE=1"; do
+      for k in 1 2 3; do
+        env $e RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/chunks.err" | md5sum | cut -c1-8
+        echo "$(basename $F) [$e]: $(grep 'generated consensus' $OUT/chunks.err) $(grep -c 'engine .* chunk' $OUT/chunks.err) chunks"
+      done
+    done
+  done | tee "$OUT/chunks.txt"
+fi
+if has ptrace; then
+  # kernel trace of polish() of the binary on one GPU's share of cfg3 (12 500 windows, three chunks on two engines): which
+  # consensus kernels overlap, and how long the device has none
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(6_250_000, 30.0, 20260922, 32))
+PY
+  F=/tmp/racon_amd_cache/files_6250000_30_20260922
+  racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2>/dev/null | md5sum
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/ptrace" -o ptrace -- env RACON_HIP_TIMING=1 "$GRAFT_REPO_ROOT/racon_amd/host/racon_hip" -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$GRAFT_REPO_ROOT/$OUT/ptrace.err" | md5sum)
+  grep -E "generated consensus|chunk" "$OUT/ptrace.err" | head
+  python tools/kernel_timeline.py "$OUT/ptrace" | tee "$OUT/product_kernel_timeline.txt"
+  find "$OUT/ptrace" -name "*kernel_trace.csv" -size +2M -delete
+fi
 if has ngs500; then
   for e in "" "RCN_NO_SMALL=1" "RCN_SMALL_PER_CU=4" ; do
     env $e timeout 900 python bench.py --config ngs_w500 --steps 3 --warmup 1 --no-cpu --no-product --no-upload-leg 2>/dev/null | benchline "ngs_w500 $e"
