@@ -17,8 +17,12 @@
 // serial carry chain.  Queries longer than 4096 rows take several passes (the carries of a pass's last word go through
 // a byte per column in HBM).  The query is held as bit planes of a dense symbol code (3 planes: up to 7 distinct query
 // symbols; 8 planes of the raw byte otherwise), Eq = "all planes agree with the column's symbol": no per-symbol table,
-// any byte alphabet.  One wave owns an overlap from start to end: the Hirschberg recursion is an explicit stack in LDS,
-// the two last-column vectors of a split live in the wave's HBM scratch, a leaf stores the vertical / horizontal delta
+// any byte alphabet.  A TEAM OF TWO WAVES (one work-group) owns an overlap from start to end: a launch that holds all its
+// overlaps at once ends with its largest one, and that overlap is a serial chain of passes -- but the two passes of a
+// split (left half forwards, right half backwards) do not depend on each other, nor do two leaves: wave 0 takes the one,
+// wave 1 the other, and the chain is half as long (profiles/r04: 3000 cfg2 overlaps 17.0 ms with one wave each).  The
+// Hirschberg recursion is an explicit stack in LDS that both waves read (uniform control flow, work-group barriers),
+// the two last-column vectors of a split live in the team's HBM scratch, a leaf stores the vertical / horizontal delta
 // words (Pv, Ph) of its cells (at most ~0.8 MiB + skew padding, the same bound edlib's own traceback state has) and the
 // walk tests one bit per move.  The path is written as one op byte per (row + column) position of the move's start
 // cell -- positions are unique along a monotone path, sub-problems own disjoint ranges, so pieces land in place in any
@@ -253,22 +257,28 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
 
 struct PairTask { int q0, m, t0, n, best; };
 
+// bytes of a team's scratch: two last-column vectors, two carry buffers and a leaf store per wave (host and kernel agree on this)
+__host__ __device__ __forceinline__ uint64_t pair_slot_bytes(uint64_t m_cap, uint64_t n_cap) {       // (m_cap, n_cap: multiples of 16)
+    return ((2 * 4 * (m_cap + 64) + 4 * (n_cap + 64) + 2 * pair_leaf_bytes(m_cap)) + 255) & ~uint64_t(255);
+}
+
 template <int NPL>
 __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairView& Q, const PairView& T, const uint8_t* codes, PairTask* stack,
                                               uint8_t* slot, uint8_t* ops) {
-    const int lane = threadIdx.x & 63;
-    // scratch of this wave
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    // scratch of this team: left[] / right[] are shared (wave 0 writes the one, wave 1 the other, both read both after the
+    // barrier), the carry buffers and the leaf store are per wave
     int32_t* left = reinterpret_cast<int32_t*>(slot);
     int32_t* right = left + (P.m_cap + 64);
-    uint8_t* hbuf0 = reinterpret_cast<uint8_t*>(right + (P.m_cap + 64));
+    uint8_t* hbuf0 = reinterpret_cast<uint8_t*>(right + (P.m_cap + 64)) + static_cast<uint64_t>(wv) * 2 * (P.n_cap + 64);
     uint8_t* hbuf1 = hbuf0 + (P.n_cap + 64);
-    ulonglong2* store = reinterpret_cast<ulonglong2*>(hbuf1 + (P.n_cap + 64));
+    ulonglong2* store = reinterpret_cast<ulonglong2*>(reinterpret_cast<uint8_t*>(right + (P.m_cap + 64)) + 4ull * (P.n_cap + 64) + static_cast<uint64_t>(wv) * P.leaf_bytes);
     int sp = 0, distance = -1;
-    if (lane == 0) stack[0] = PairTask{0, static_cast<int>(Q.n), 0, static_cast<int>(T.n), -1};
+    if (threadIdx.x == 0) stack[0] = PairTask{0, static_cast<int>(Q.n), 0, static_cast<int>(T.n), -1};
     sp = 1;
     while (sp > 0) {
         --sp;
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();                               // the stack as the last round left it; left[] / right[] are no longer read
         const PairTask tk = stack[sp];
         const int q0 = __builtin_amdgcn_readfirstlane(tk.q0), m = __builtin_amdgcn_readfirstlane(tk.m);
         const int t0 = __builtin_amdgcn_readfirstlane(tk.t0), n = __builtin_amdgcn_readfirstlane(tk.n);
@@ -277,16 +287,31 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         if (m == 0) { for (int k = lane; k < n; k += 64) ops[base + k] = 'D'; if (best < 0) distance = n; continue; }
         if (n == 0) { for (int k = lane; k < m; k += 64) ops[base + k] = 'I'; if (best < 0) distance = m; continue; }
         if (pair_is_leaf(m, n)) {
-            if (best < 0) {
-                // a leaf at the root: the distance is not known from a split; one extra forward pass provides it
-                distance = pair_columns<NPL>(Q, q0, m, false, T, t0, n, false, codes, hbuf0, hbuf1, left);
+            // the task below it on the stack is usually a leaf as well (the two children of the last split): wave 1 takes it
+            PairTask t2 = PairTask{0, 0, 0, 0, 0};
+            bool two = false;
+            if (best >= 0 && sp > 0) {
+                t2 = stack[sp - 1];
+                t2.q0 = __builtin_amdgcn_readfirstlane(t2.q0); t2.m = __builtin_amdgcn_readfirstlane(t2.m);
+                t2.t0 = __builtin_amdgcn_readfirstlane(t2.t0); t2.n = __builtin_amdgcn_readfirstlane(t2.n);
+                two = t2.m > 0 && t2.n > 0 && pair_is_leaf(t2.m, t2.n);
             }
-            pair_leaf<NPL>(Q, q0, m, T, t0, n, codes, hbuf0, hbuf1, store, ops);
+            if (two) --sp;
+            if (wv == 0) {
+                if (best < 0) {
+                    // a leaf at the root: the distance is not known from a split; one extra forward pass provides it
+                    distance = pair_columns<NPL>(Q, q0, m, false, T, t0, n, false, codes, hbuf0, hbuf1, left);
+                }
+                pair_leaf<NPL>(Q, q0, m, T, t0, n, codes, hbuf0, hbuf1, store, ops);
+            } else if (two) {
+                pair_leaf<NPL>(Q, t2.q0, t2.m, T, t2.t0, t2.n, codes, hbuf0, hbuf1, store, ops);
+            }
             continue;
         }
         const int lw = n / 2, rw = n - lw;
-        pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left);
-        pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right);
+        if (wv == 0) pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left);
+        else pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right);
+        __syncthreads();                               // (work-group fence + barrier: the other wave's vector is in HBM scratch)
         if (best < 0) {
             // the root: best = min over all rows of left + right (every path crosses the middle column somewhere)
             int mn = 0x7fffffff;
@@ -304,10 +329,10 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         }
         if (h < 0 && lw + right[m] == best) h = 0;
         if (h < 0 && left[m] + rw == best) h = m;
-        if (h < 0) { if (lane == 0) atomicAdd(P.err, 1u); break; }
+        if (h < 0) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
         const int ls = h > 0 ? left[h] : lw, rs = h < m ? right[m - h] : rw;
-        if (sp + 2 > kPairStack) { if (lane == 0) atomicAdd(P.err, 1u); break; }
-        if (lane == 0) {
+        if (sp + 2 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
+        if (threadIdx.x == 0) {
             stack[sp] = PairTask{q0 + h, m - h, t0 + lw, rw, rs};
             stack[sp + 1] = PairTask{q0, h, t0, lw, ls};
         }
@@ -316,18 +341,20 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
     return distance;
 }
 
-// One wave per overlap, persistent over the work queue.
-__global__ __launch_bounds__(64) void k_pair_align(PairParams P) {
+// One team (two waves) per overlap, persistent over the work queue.
+constexpr int kPairThreads = 128;
+__global__ __launch_bounds__(kPairThreads) void k_pair_align(PairParams P) {
     __shared__ uint8_t codes[256];
     __shared__ uint8_t present[256];
     __shared__ PairTask stack[kPairStack];
     __shared__ unsigned int s_work;
-    const int lane = threadIdx.x;
+    __shared__ int s_nsym;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t* slot = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
     for (;;) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) s_work = atomicAdd(P.next, 1u);
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (tid == 0) s_work = atomicAdd(P.next, 1u);
+        __syncthreads();
         const unsigned int wi = __builtin_amdgcn_readfirstlane(s_work);
         if (wi >= P.n_pairs) break;
         const uint32_t o = P.order[wi];
@@ -335,27 +362,27 @@ __global__ __launch_bounds__(64) void k_pair_align(PairParams P) {
         PairView T{P.bases + P.t_pos[o], false, static_cast<int64_t>(P.t_len[o])};
         uint8_t* ops = P.ops + P.ops_off[o];
         // dense codes of the query's symbols (in byte order); 7 = "not in the query" for target symbols
-        for (int k = lane; k < 256; k += 64) present[k] = 0;
-        __builtin_amdgcn_wave_barrier();
-        for (int64_t i = lane; i < Q.n; i += 64) present[pv_at(Q, i)] = 1;
-        __builtin_amdgcn_wave_barrier();
-        int nsym = 0;
-        {
+        for (int k = tid; k < 256; k += kPairThreads) present[k] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < Q.n; i += kPairThreads) present[pv_at(Q, i)] = 1;
+        __syncthreads();
+        if (wv == 0) {
             // four symbols per lane, exclusive count across the wave
             int cnt = 0;
             for (int k = 0; k < 4; ++k) cnt += present[4 * lane + k];
             int incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-            nsym = __shfl(incl, 63);
+            if (lane == 63) s_nsym = incl;
             int code = incl - cnt;
             for (int k = 0; k < 4; ++k) { const int c = 4 * lane + k; codes[c] = present[c] ? static_cast<uint8_t>(min(code, 7)) : 7; code += present[c]; }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        const int nsym = __builtin_amdgcn_readfirstlane(s_nsym);
         int d;
         if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, slot, ops);
         else d = pair_align_one<8>(P, Q, T, codes, stack, slot, ops);
-        if (lane == 0) P.dist[o] = d;
+        if (tid == 0) P.dist[o] = d;
     }
 }
 

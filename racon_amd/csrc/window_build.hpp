@@ -673,11 +673,9 @@ inline int align_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set&
         return static_cast<uint64_t>(q_len[a]) * t_len[a] > static_cast<uint64_t>(q_len[b]) * t_len[b]; });
     m_cap = (m_cap + 15) & ~uint64_t(15); n_cap = (n_cap + 15) & ~uint64_t(15);       // keeps the pieces of a slot 16-byte aligned
     const uint64_t ops_bytes = e->a_ops_off[n];
-    // per-wave scratch: two last-column vectors, two carry buffers, the leaf store
+    // per-team scratch (two waves): two last-column vectors, two carry buffers and a leaf store per wave
     const uint64_t leaf_bytes = rcn::pair_leaf_bytes(m_cap);
-    uint64_t slot_bytes = 2 * 4 * (m_cap + 64) + 2 * (n_cap + 64);
-    slot_bytes = ((slot_bytes + 15) & ~uint64_t(15)) + leaf_bytes;
-    slot_bytes = (slot_bytes + 255) & ~uint64_t(255);
+    const uint64_t slot_bytes = rcn::pair_slot_bytes(m_cap, n_cap);
     DevBuf* A = e->d_align;
     HIP_TRY(hipEventRecord(tc.a, st));
     int rc;
@@ -694,7 +692,7 @@ inline int align_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set&
     // (80 % of what is free now, within the caller's arena: see scratch_budget)
     const uint64_t free_now = static_cast<uint64_t>((fr + A[kAScratch].cap) * 0.8);
     const uint64_t budget = e->cfg.arena_bytes ? std::min<uint64_t>(e->cfg.arena_bytes, free_now) : free_now;
-    uint64_t slots = std::min<uint64_t>(std::max<uint64_t>(n, 1), static_cast<uint64_t>(e->n_cu) * 16);
+    uint64_t slots = std::min<uint64_t>(std::max<uint64_t>(n, 1), static_cast<uint64_t>(e->n_cu) * 8);      // teams of two waves, 117 VGPRs: four waves per SIMD are resident
     while (slots > 1 && slots * slot_bytes > budget) slots = (slots + 1) / 2;
     if (slots * slot_bytes > budget) return RCN_E_CAPACITY;
     if ((rc = A[kAScratch].reserve(slots * slot_bytes))) return rc;
@@ -709,7 +707,7 @@ inline int align_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set&
         P.scratch = A[kAScratch].as<uint8_t>(); P.slot_bytes = slot_bytes;
         P.m_cap = static_cast<uint32_t>(m_cap); P.n_cap = static_cast<uint32_t>(n_cap); P.leaf_bytes = leaf_bytes;
         HIP_TRY(hipEventRecord(tk.a, st));
-        hipLaunchKernelGGL(rcn::k_pair_align, dim3(static_cast<uint32_t>(slots)), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(rcn::k_pair_align, dim3(static_cast<uint32_t>(slots)), dim3(rcn::kPairThreads), 0, st, P);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(tk.b, st));
     }
