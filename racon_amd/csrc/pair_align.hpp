@@ -58,7 +58,9 @@ struct PairView {                    // a sequence read forwards, or backwards a
     int64_t n;
 };
 __device__ __forceinline__ uint32_t pair_comp(uint32_t c) {    // Sequence::create_reverse_complement (reference src/sequence.cpp:49-84)
-    return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+    uint32_t r = c;                                              // (selects, not a chain of branches)
+    r = c == 'A' ? 'T' : r; r = c == 'T' ? 'A' : r; r = c == 'C' ? 'G' : r; r = c == 'G' ? 'C' : r;
+    return r;
 }
 __device__ __forceinline__ uint32_t pv_at(const PairView& v, int64_t i) {
     return v.rc ? pair_comp(v.p[v.n - 1 - i]) : static_cast<uint32_t>(v.p[i]);
@@ -98,7 +100,34 @@ __device__ __forceinline__ int pair_shr1(int fill, int v) {      // lane l <- la
 //   columns likewise.  hin_buf / hout_buf: carries of the word above / for the word below (one byte per column:
 //   bit 0 = +1, bit 1 = -1); hin_buf == nullptr: the top boundary (+1 per column).  store != nullptr: leaf, (Pv, Ph)
 //   of the cell of lane l at step s goes to store[s * nwp + l].
+// One cell of the recurrence: this lane's word against the column symbol `tc`, horizontal carry `hin` (bit 0 = +1, bit 1 = -1) from
+// the word above.  Returns the carry for the word below; Ph0 = the horizontal plus-deltas of the word's rows (a leaf stores them).
 template <int NPL>
+__device__ __forceinline__ int pair_cell(PairLane<NPL>& L, int tc, int hin, unsigned long long& Ph0) {
+    // Eq: rows whose code agrees with the column's in every plane (32-bit halves: one sign-extended bit-field
+    // extract per plane makes the 0 / ~0 mask of both halves)
+    uint32_t dlo = 0u, dhi = 0u;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const uint32_t mk = static_cast<uint32_t>((tc << (31 - k)) >> 31);
+        dlo |= static_cast<uint32_t>(L.plane[k]) ^ mk; dhi |= static_cast<uint32_t>(L.plane[k] >> 32) ^ mk;
+    }
+    unsigned long long Eq = ~((static_cast<unsigned long long>(dhi) << 32) | dlo) & L.valid;
+    const unsigned long long hin_p = static_cast<unsigned long long>(hin & 1), hin_n = static_cast<unsigned long long>((hin >> 1) & 1);
+    const unsigned long long Xv = Eq | L.Mv;
+    Eq |= hin_n;
+    const unsigned long long Xh = (((Eq & L.Pv) + L.Pv) ^ L.Pv) | Eq;
+    unsigned long long Ph = L.Mv | ~(Xh | L.Pv);
+    unsigned long long Mh = L.Pv & Xh;
+    const int hout = static_cast<int>(Ph >> 63) | (static_cast<int>(Mh >> 63) << 1);
+    Ph0 = Ph;
+    Ph = (Ph << 1) | hin_p; Mh = (Mh << 1) | hin_n;
+    L.Pv = Mh | ~(Xv | Ph);
+    L.Mv = Ph & Xv;
+    return hout;
+}
+
+template <int NPL, bool STORE>
 __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
                                           int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
                                           ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out) {
@@ -108,62 +137,96 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
     for (int k = 0; k < NPL; ++k) L.plane[k] = 0ull;
     L.valid = 0ull; L.Pv = ~0ull; L.Mv = 0ull;
     if (lane < nwp) {
+        // this lane's 64 rows are 64 consecutive bytes of the stored read, up or down; sixteen loads in flight at a time
+        // (one load, one wait and a branchy complement per row was 64 memory round trips before the first step of a pass),
+        // the code -- complement included -- is one lookup in the pair's table
         const int64_t r0 = static_cast<int64_t>(w0 + lane) * 64;
-        for (int r = 0; r < 64; ++r) {
-            const int64_t row = r0 + r;
-            if (row >= m) break;
-            const uint32_t c = pv_at(Q, qflip ? q0 + m - 1 - row : q0 + row);
-            const uint32_t code = NPL == 8 ? c : codes[c];
+        const int nrow = static_cast<int>(min(static_cast<int64_t>(64), static_cast<int64_t>(m) - r0));
+        const int64_t l0 = qflip ? q0 + m - 1 - r0 : q0 + r0;                  // logical position of row r0; row r0 + r: l0 -/+ r
+        const int64_t i0 = Q.rc ? Q.n - 1 - l0 : l0;
+        const int64_t step = (qflip != Q.rc) ? -1 : 1;
+#pragma unroll 1
+        for (int rb = 0; rb < 64; rb += 16) {
+            uint32_t raw[16];
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) L.plane[k] |= static_cast<unsigned long long>((code >> k) & 1u) << r;
-            L.valid |= 1ull << r;
+            for (int u = 0; u < 16; ++u) raw[u] = Q.p[i0 + step * min(rb + u, nrow - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t code = codes[raw[u]];
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) L.plane[k] |= static_cast<unsigned long long>((code >> k) & 1u) << (rb + u);
+            }
         }
+        L.valid = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);                 // (rows past the end repeat the last one: masked here)
     }
+    // the target is stored forwards (PairView::rc is the query's): column `col` of this pass
+    auto tcol = [&](int col) -> uint32_t { return T.p[tflip ? t0 + n - 1 - col : t0 + col]; };
+    uint32_t traw = lane < n ? tcol(lane) : 0u;                                  // raw symbol / carry-in of the block's columns, fetched a block ahead
+    int hraw = (hin_buf && lane < n) ? hin_buf[lane] : 1;
     int tbuf = 0, hbuf = 0;          // columns s0 .. s0 + 63: symbol code / carry-in of the top word, one per lane
     int tc = 0, hc = 0;              // this lane's column symbol; carry pair of the lane above from the previous step
     const int steps = n + nwp - 1;
-    for (int s = 0; s < steps; ++s) {
-        if ((s & 63) == 0) {
-            const int col = s + lane;
-            int tv = 7, hv = 1;
-            if (col < n) {
-                const uint32_t c = pv_at(T, tflip ? t0 + n - 1 - col : t0 + col);
-                tv = NPL == 8 ? static_cast<int>(c) : static_cast<int>(codes[c]);
-                if (hin_buf) hv = hin_buf[col];
-            }
-            tbuf = tv; hbuf = hv;
+    const bool hb = hout_buf != nullptr;
+    for (int s0 = 0; s0 < steps; s0 += 64) {
+        {   // the 64 columns that enter at lane 0 during this block; the next block's are requested now and looked at then
+            const int col = s0 + lane;
+            traw = col < n ? tcol(col) : 0u;
+            hraw = (hin_buf && col < n) ? hin_buf[col] : 1;
+            tbuf = col < n ? static_cast<int>(codes[256 + traw]) : 7;
+            hbuf = hraw;
         }
-        // lane l takes over the column lane l - 1 had; lane 0 starts column s
-        const int t_new = __builtin_amdgcn_readlane(tbuf, s & 63), h_new = __builtin_amdgcn_readlane(hbuf, s & 63);
-        tc = pair_shr1(t_new, tc);
-        const int hin = pair_shr1(h_new, hc);
-        const int j = s - lane;
-        int hout = 0;
-        if (lane < nwp && j >= 0 && j < n) {
-            // Eq: rows whose code agrees with the column's in every plane (32-bit halves: one sign-extended bit-field
-            // extract per plane makes the 0 / ~0 mask of both halves)
-            uint32_t dlo = 0u, dhi = 0u;
+        if (s0 >= nwp - 1 && s0 + 63 < n) {
+            // steady state: at every step of the block every word of the pass has a column in [0, n) -- no range tests, no
+            // exec-mask regions (lanes past the pass's words compute on valid = 0; nobody reads them).  The carries out of the
+            // last word: every lane shifts its own two bits per step into a register, and at the end of the block the last
+            // word's 2 x 64 bits are handed out, one column per lane, and stored once.
+            unsigned long long hq[2];
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                const uint32_t mk = static_cast<uint32_t>((tc << (31 - k)) >> 31);
-                dlo |= static_cast<uint32_t>(L.plane[k]) ^ mk; dhi |= static_cast<uint32_t>(L.plane[k] >> 32) ^ mk;
+            for (int half = 0; half < 2; ++half) {
+                unsigned long long acc = 0ull;
+#pragma unroll 2
+                for (int kk = 0; kk < 32; ++kk) {
+                    const int k = 32 * half + kk;
+                    const int t_new = __builtin_amdgcn_readlane(tbuf, k), h_new = __builtin_amdgcn_readlane(hbuf, k);
+                    tc = pair_shr1(t_new, tc);
+                    const int hin = pair_shr1(h_new, hc);
+                    unsigned long long Ph0;
+                    const int hout = pair_cell<NPL>(L, tc, hin, Ph0);
+                    if (STORE) { if (lane < nwp) { ulonglong2 v; v.x = L.Pv; v.y = Ph0; store[static_cast<int64_t>(s0 + k) * nwp + lane] = v; } }
+                    acc = (acc << 2) | static_cast<unsigned long long>(static_cast<uint32_t>(hout));
+                    hc = hout;
+                }
+                hq[half] = acc;
             }
-            unsigned long long Eq = ~((static_cast<unsigned long long>(dhi) << 32) | dlo) & L.valid;
-            const unsigned long long hin_p = static_cast<unsigned long long>(hin & 1), hin_n = static_cast<unsigned long long>((hin >> 1) & 1);
-            const unsigned long long Xv = Eq | L.Mv;
-            Eq |= hin_n;
-            const unsigned long long Xh = (((Eq & L.Pv) + L.Pv) ^ L.Pv) | Eq;
-            unsigned long long Ph = L.Mv | ~(Xh | L.Pv);
-            unsigned long long Mh = L.Pv & Xh;
-            hout = static_cast<int>(Ph >> 63) | (static_cast<int>(Mh >> 63) << 1);
-            const unsigned long long Ph0 = Ph;
-            Ph = (Ph << 1) | hin_p; Mh = (Mh << 1) | hin_n;
-            L.Pv = Mh | ~(Xv | Ph);
-            L.Mv = Ph & Xv;
-            if (store) { ulonglong2 v; v.x = L.Pv; v.y = Ph0; store[static_cast<int64_t>(s) * nwp + lane] = v; }
-            if (hout_buf && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(hout);
+            if (hb) {
+                // the last word was at column s0 + k - (nwp - 1) at step k; step k = 32 half + kk sits at bits 2 (31 - kk) of its half
+                const int src = nwp - 1;
+                const uint32_t a0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[0]), src));
+                const uint32_t a1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[0] >> 32), src));
+                const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[1]), src));
+                const uint32_t b1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[1] >> 32), src));
+                const unsigned long long a = lane < 32 ? ((static_cast<unsigned long long>(a1) << 32) | a0) : ((static_cast<unsigned long long>(b1) << 32) | b0);
+                hout_buf[s0 + lane - (nwp - 1)] = static_cast<uint8_t>((a >> (2 * (31 - (lane & 31)))) & 3ull);
+            }
+            continue;
         }
-        hc = hout;
+        const int kend = min(64, steps - s0);
+        for (int k = 0; k < kend; ++k) {
+            const int s = s0 + k;
+            // lane l takes over the column lane l - 1 had; lane 0 starts column s
+            const int t_new = __builtin_amdgcn_readlane(tbuf, k), h_new = __builtin_amdgcn_readlane(hbuf, k);
+            tc = pair_shr1(t_new, tc);
+            const int hin = pair_shr1(h_new, hc);
+            const int j = s - lane;
+            int hout = 0;
+            if (lane < nwp && j >= 0 && j < n) {
+                unsigned long long Ph0;
+                hout = pair_cell<NPL>(L, tc, hin, Ph0);
+                if (STORE) { ulonglong2 v; v.x = L.Pv; v.y = Ph0; store[static_cast<int64_t>(s) * nwp + lane] = v; }
+                if (hb && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(hout);
+            }
+            hc = hout;
+        }
     }
     Pv_out = L.Pv; Mv_out = L.Mv;
 }
@@ -181,7 +244,7 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
         const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
         uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
         unsigned long long Pv, Mv;
-        pair_pass<NPL>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv);
+        pair_pass<NPL, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv);
         pair_wave_fence();                             // the carries of this pass are read (by other lanes) in the next one
         // scores of this pass's rows: running sum of the vertical deltas down the last column
         const int rows_here = lane < nwp ? min(64, m - (w0 + lane) * 64) : 0;
@@ -216,13 +279,18 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
             const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
             uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
             unsigned long long Pv, Mv;
-            pair_pass<NPL>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv);
+            pair_pass<NPL, true>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv);
             pair_wave_fence();
             off += static_cast<int64_t>(n + nwp - 1) * nwp;
         }
     }
     // every full pass has 64 words: pass p starts at p * (n + 63) * 64
     const int64_t pass_stride = static_cast<int64_t>(n + 63) * 64;
+    // The walk.  One move at a time it was ~70 instructions per move with one useful lane -- nearly half of all the kernel's
+    // instructions on 10 kb reads -- and nine moves in ten are diagonal: lane l of the cache already holds the cell l columns to
+    // the left, so every lane tests ITS cell of the current diagonal (bit b - t of its words), one ballot gives the length of the
+    // run of diagonal moves (neither "up" nor "left": the same rule, cell by cell), the run's op bytes are stored by its lanes
+    // at once, and only the cells that end a run are taken singly.  i, j and everything derived from them are wave-uniform.
     int i = m, j = n;                                 // current cell (rows 1..m, columns 1..n; 0 = boundary)
     int cw = -1, cj0 = -1;                            // cache: lane c holds cell (word cw, column cj0 - c)
     uint32_t pv_lo = 0, pv_hi = 0, ph_lo = 0, ph_hi = 0;
@@ -241,14 +309,22 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
             pv_lo = static_cast<uint32_t>(a); pv_hi = static_cast<uint32_t>(a >> 32);
             ph_lo = static_cast<uint32_t>(h); ph_hi = static_cast<uint32_t>(h >> 32);
         }
-        const int c = cj0 - j;
-        const uint32_t pvw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b < 32 ? pv_lo : pv_hi), c));
-        const uint32_t phw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b < 32 ? ph_lo : ph_hi), c));
-        const bool up = (pvw >> (b & 31)) & 1u, left = (phw >> (b & 31)) & 1u;
+        const int c = cj0 - j;                        // lane of the current cell
+        const int t = lane - c, bit = b - t;          // this lane's cell of the diagonal: (i - t, j - t), bit `bit` of word w
+        const bool ok = t >= 0 && bit >= 0 && j - t >= 1;
+        const uint32_t pw = (bit & 32) ? pv_hi : pv_lo, hw = (bit & 32) ? ph_hi : ph_lo;
+        const bool up = ok && ((pw >> (bit & 31)) & 1u) != 0u, left = ok && ((hw >> (bit & 31)) & 1u) != 0u;
+        const unsigned long long diag = __ballot(ok && !up && !left) >> c;
+        const int run = diag == ~0ull ? 64 : __builtin_ctzll(~diag);
+        if (run > 0) {
+            if (t >= 0 && t < run) ops[base + (i - 1 - t) + (j - 1 - t)] = 'M';
+            i -= run; j -= run;
+            continue;
+        }
+        const bool up_here = ((__ballot(up) >> c) & 1ull) != 0ull;
         uint8_t op; int64_t slot;
-        if (up) { op = 'I'; slot = base + (i - 1) + j; --i; }
-        else if (left) { op = 'D'; slot = base + i + (j - 1); --j; }
-        else { op = 'M'; slot = base + (i - 1) + (j - 1); --i; --j; }
+        if (up_here) { op = 'I'; slot = base + (i - 1) + j; --i; }
+        else { op = 'D'; slot = base + i + (j - 1); --j; }
         if (lane == 0) ops[slot] = op;
     }
     for (int k = lane; k < i; k += 64) ops[base + k] = 'I';          // column 0: D[k][0] = k, only "up" is possible
@@ -315,17 +391,23 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         if (best < 0) {
             // the root: best = min over all rows of left + right (every path crosses the middle column somewhere)
             int mn = 0x7fffffff;
+#pragma unroll 4
             for (int h = lane; h <= m; h += 64) mn = min(mn, left[h] + right[m - h]);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mn = min(mn, __shfl_xor(mn, d));
             best = mn; distance = mn;
         }
         int h = -1;
-        for (int h0 = 1; h0 < m && h < 0; h0 += 64) {
-            const int hh = h0 + lane;
-            const bool hit = hh < m && left[hh] + right[m - hh] == best;
-            const unsigned long long mask = __ballot(hit);
-            if (mask) h = h0 + __builtin_ctzll(mask);
+        for (int h0 = 1; h0 < m && h < 0; h0 += 256) {           // (four chunks of rows per trip: eight loads in flight, not two)
+            int sum[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int hh = h0 + 64 * u + lane; const int hc_ = min(hh, m); sum[u] = left[hc_] + right[m - hc_]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int hh = h0 + 64 * u + lane;
+                const unsigned long long mask = __ballot(hh < m && sum[u] == best);
+                if (mask && h < 0) h = h0 + 64 * u + __builtin_ctzll(mask);
+            }
         }
         if (h < 0 && lw + right[m] == best) h = 0;
         if (h < 0 && left[m] + rw == best) h = m;
@@ -343,9 +425,10 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
 
 // One team (two waves) per overlap, persistent over the work queue.
 constexpr int kPairThreads = 128;
-__global__ __launch_bounds__(kPairThreads) void k_pair_align(PairParams P) {
-    __shared__ uint8_t codes[256];
-    __shared__ uint8_t present[256];
+__global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
+    __shared__ uint8_t codes[512];          // [raw query byte] -> plane code of the (complemented) symbol; [256 + raw target byte] -> plane code
+    __shared__ uint8_t present[256];        // raw bytes of the stored query segment
+    __shared__ uint8_t lcode[256];          // logical symbol -> dense code
     __shared__ PairTask stack[kPairStack];
     __shared__ unsigned int s_work;
     __shared__ int s_nsym;
@@ -361,24 +444,37 @@ __global__ __launch_bounds__(kPairThreads) void k_pair_align(PairParams P) {
         PairView Q{P.bases + P.q_pos[o], P.q_rc[o] != 0, static_cast<int64_t>(P.q_len[o])};
         PairView T{P.bases + P.t_pos[o], false, static_cast<int64_t>(P.t_len[o])};
         uint8_t* ops = P.ops + P.ops_off[o];
-        // dense codes of the query's symbols (in byte order); 7 = "not in the query" for target symbols
+        // dense codes of the query's symbols (in byte order of the symbols as aligned, i.e. complemented for a reverse strand);
+        // 7 = "not in the query" for target symbols
         for (int k = tid; k < 256; k += kPairThreads) present[k] = 0;
         __syncthreads();
-        for (int64_t i = tid; i < Q.n; i += kPairThreads) present[pv_at(Q, i)] = 1;
+        for (int64_t i = tid; i < Q.n; i += 4 * kPairThreads) {
+            uint32_t r4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int64_t iu = i + u * kPairThreads; r4[u] = Q.p[iu < Q.n ? iu : i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) present[r4[u]] = 1;
+        }
         __syncthreads();
         if (wv == 0) {
             // four symbols per lane, exclusive count across the wave
-            int cnt = 0;
-            for (int k = 0; k < 4; ++k) cnt += present[4 * lane + k];
+            int cnt = 0, pr[4];
+            for (int k = 0; k < 4; ++k) { const uint32_t c = 4 * lane + k; pr[k] = present[Q.rc ? pair_comp(c) : c]; cnt += pr[k]; }
             int incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
             if (lane == 63) s_nsym = incl;
             int code = incl - cnt;
-            for (int k = 0; k < 4; ++k) { const int c = 4 * lane + k; codes[c] = present[c] ? static_cast<uint8_t>(min(code, 7)) : 7; code += present[c]; }
+            for (int k = 0; k < 4; ++k) { lcode[4 * lane + k] = pr[k] ? static_cast<uint8_t>(min(code, 7)) : 7; code += pr[k]; }
         }
         __syncthreads();
         const int nsym = __builtin_amdgcn_readfirstlane(s_nsym);
+        for (int k = tid; k < 256; k += kPairThreads) {
+            const uint32_t cq = Q.rc ? pair_comp(static_cast<uint32_t>(k)) : static_cast<uint32_t>(k);
+            codes[k] = nsym <= 7 ? lcode[cq] : static_cast<uint8_t>(cq);
+            codes[256 + k] = nsym <= 7 ? lcode[k] : static_cast<uint8_t>(k);
+        }
+        __syncthreads();
         int d;
         if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, slot, ops);
         else d = pair_align_one<8>(P, Q, T, codes, stack, slot, ops);

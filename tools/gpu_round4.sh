@@ -166,6 +166,35 @@ PY
   python tools/kernel_timeline.py "$OUT/ptrace" | tee "$OUT/product_kernel_timeline.txt"
   find "$OUT/ptrace" -name "*kernel_trace.csv" -size +2M -delete
 fi
+if has alignsq; then
+  # SQ counters of the pair aligner (k_pair_align) on the align bench: two passes
+  n=0
+  for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
+             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT"; do
+    n=$((n + 1))
+    timeout 600 rocprofv3 --pmc $SET --output-format csv -d "$OUT/asq_$n" -o pmc -- python tools/align_bench.py --reps 1 --host-sample 4 > "$OUT/asq_$n.json" 2> "$OUT/asq_$n.err"
+    echo "alignsq pass $n exit $?"
+  done
+  python - "$OUT" <<'PY' | tee "$OUT/align_sq_summary.txt"
+import csv, glob, os, sys
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(lambda: [set(), 0.0]))
+for f in glob.glob(os.path.join(sys.argv[1], "asq_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r["Kernel_Name"].split("(")[0]
+        if "k_pair_align" not in kn: continue
+        a = acc[kn][r["Counter_Name"]]; a[0].add(r["Dispatch_Id"]); a[1] += float(r["Counter_Value"] or 0)
+for kn, cs in acc.items():
+    per = {c: v[1] / max(1, len(v[0])) for c, v in cs.items()}
+    print(kn, {c: "%.4g" % v for c, v in sorted(per.items())})
+    if "SQ_BUSY_CYCLES" in per and "SQ_INSTS_VALU" in per:
+        # SQ_BUSY_CYCLES: quad-cycles summed over the 32 SEs x ...; report ratios that do not need its unit
+        ins = per["SQ_INSTS_VALU"] + per["SQ_INSTS_SALU"] + per.get("SQ_INSTS_LDS", 0) + per.get("SQ_INSTS_SMEM", 0) + per.get("SQ_INSTS_BRANCH", 0)
+        print("  wave-instructions %.4g (VALU %.3f)" % (ins, per["SQ_INSTS_VALU"] / ins), " per wave %.4g" % (ins / max(1, per.get("SQ_WAVES", 1))))
+    if "SQ_WAIT_ANY" in per and "SQ_WAVE_CYCLES" in per:
+        print("  wave time: waiting (s_waitcnt) %.3f, issuing %.3f" % (per["SQ_WAIT_ANY"] / per["SQ_WAVE_CYCLES"], per.get("SQ_ACTIVE_INST_ANY", 0) / per["SQ_WAVE_CYCLES"]))
+PY
+fi
 if has ngs500; then
   for e in "" "RCN_NO_SMALL=1" "RCN_SMALL_PER_CU=4" ; do
     env $e timeout 900 python bench.py --config ngs_w500 --steps 3 --warmup 1 --no-cpu --no-product --no-upload-leg 2>/dev/null | benchline "ngs_w500 $e"
