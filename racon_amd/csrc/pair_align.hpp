@@ -47,7 +47,8 @@ struct PairParams {
     int32_t* dist;                   // [n] edit distance
     uint8_t* scratch; uint64_t slot_bytes;
     uint32_t m_cap, n_cap;           // largest rows / columns of the batch (scratch layout)
-    uint64_t leaf_bytes;             // leaf store per slot
+    uint64_t leaf_bytes;             // leaf store per wave
+    uint32_t arena_ints;             // inherited column vectors of a team (pair_arena_ints)
     uint32_t* err;                   // [0] != 0: internal error (no optimal split found / stack overflow)
 };
 
@@ -130,7 +131,8 @@ __device__ __forceinline__ int pair_cell(PairLane<NPL>& L, int tc, int hin, unsi
 template <int NPL, bool STORE>
 __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
                                           int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
-                                          ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out) {
+                                          ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out,
+                                          int nsnap = 0, int sc0 = 0, int sc1 = 0, int sc2 = 0, ulonglong2* snapbuf = nullptr) {
     const int lane = threadIdx.x & 63;
     PairLane<NPL> L;
 #pragma unroll
@@ -175,7 +177,12 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
             tbuf = col < n ? static_cast<int>(codes[256 + traw]) : 7;
             hbuf = hraw;
         }
-        if (s0 >= nwp - 1 && s0 + 63 < n) {
+        // a column whose vector a later sub-problem inherits (pair_align_one): its words pass it during [c - 1, c - 1 + nwp - 1]
+        bool snap_here = false;
+        if (nsnap > 0) snap_here |= sc0 - 1 <= s0 + 63 && sc0 + nwp - 2 >= s0;
+        if (nsnap > 1) snap_here |= sc1 - 1 <= s0 + 63 && sc1 + nwp - 2 >= s0;
+        if (nsnap > 2) snap_here |= sc2 - 1 <= s0 + 63 && sc2 + nwp - 2 >= s0;
+        if (s0 >= nwp - 1 && s0 + 63 < n && !snap_here) {
             // steady state: at every step of the block every word of the pass has a column in [0, n) -- no range tests, no
             // exec-mask regions (lanes past the pass's words compute on valid = 0; nobody reads them).  The carries out of the
             // last word: every lane shifts its own two bits per step into a register, and at the end of the block the last
@@ -224,6 +231,12 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
                 hout = pair_cell<NPL>(L, tc, hin, Ph0);
                 if (STORE) { ulonglong2 v; v.x = L.Pv; v.y = Ph0; store[static_cast<int64_t>(s) * nwp + lane] = v; }
                 if (hb && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(hout);
+                if (snap_here) {
+                    ulonglong2 v; v.x = L.Pv; v.y = L.Mv;
+                    if (nsnap > 0 && j == sc0 - 1) snapbuf[lane] = v;
+                    if (nsnap > 1 && j == sc1 - 1) snapbuf[64 + lane] = v;
+                    if (nsnap > 2 && j == sc2 - 1) snapbuf[128 + lane] = v;
+                }
             }
             hc = hout;
         }
@@ -232,34 +245,55 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
 }
 
 // Last column of the sub-problem's matrix: out[i] = ED(rows[:i], all columns), i = 0 .. m.  Returns out[m].
+// nsnap > 0: the vectors of the columns sc0 > sc1 > sc2 (counted in the pass's direction) as well, into snap_out + k * snap_stride.
+constexpr int kPairSnap = 3;
 template <int NPL>
 __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
-                                            const uint8_t* codes, uint8_t* hbuf0, uint8_t* hbuf1, int32_t* out) {
+                                            const uint8_t* codes, uint8_t* hbuf0, uint8_t* hbuf1, int32_t* out,
+                                            int nsnap = 0, int sc0 = 0, int sc1 = 0, int sc2 = 0, int32_t* snap_out = nullptr, int snap_stride = 0,
+                                            ulonglong2* snapbuf = nullptr) {
     const int lane = threadIdx.x & 63;
     const int nb = (m + 63) / 64;
     int carry = n;                                   // score at the last row of the words done so far
-    if (lane == 0) out[0] = n;
+    int scarry[kPairSnap] = {sc0, sc1, sc2};
+    if (lane == 0) {
+        out[0] = n;
+        if (nsnap > 0) snap_out[0] = sc0;
+        if (nsnap > 1) snap_out[snap_stride] = sc1;
+        if (nsnap > 2) snap_out[2 * snap_stride] = sc2;
+    }
     for (int w0 = 0, pass = 0; w0 < nb; w0 += 64, ++pass) {
         const int nwp = min(64, nb - w0);
         const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
         uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
         unsigned long long Pv, Mv;
-        pair_pass<NPL, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv);
+        pair_pass<NPL, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv, nsnap, sc0, sc1, sc2, snapbuf);
         pair_wave_fence();                             // the carries of this pass are read (by other lanes) in the next one
-        // scores of this pass's rows: running sum of the vertical deltas down the last column
+        // scores of this pass's rows: running sum of the vertical deltas down the column
         const int rows_here = lane < nwp ? min(64, m - (w0 + lane) * 64) : 0;
         const unsigned long long vmask = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
-        int delta = __popcll(Pv & vmask) - __popcll(Mv & vmask);
-        int incl = delta;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-        int acc = carry + incl - delta;
         const int64_t r0 = static_cast<int64_t>(w0 + lane) * 64;
-        for (int r = 0; r < rows_here; ++r) {
-            acc += static_cast<int>((Pv >> r) & 1ull) - static_cast<int>((Mv >> r) & 1ull);
-            out[r0 + r + 1] = acc;
+        auto emit = [&](unsigned long long pv, unsigned long long mv, int& cy, int32_t* dst) {
+            int delta = __popcll(pv & vmask) - __popcll(mv & vmask);
+            int incl = delta;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            int acc = cy + incl - delta;
+            for (int r = 0; r < rows_here; ++r) {
+                acc += static_cast<int>((pv >> r) & 1ull) - static_cast<int>((mv >> r) & 1ull);
+                dst[r0 + r + 1] = acc;
+            }
+            cy += __shfl(incl, 63);
+        };
+        emit(Pv, Mv, carry, out);
+#pragma unroll
+        for (int k = 0; k < kPairSnap; ++k) {
+            if (k < nsnap) {
+                ulonglong2 v; v.x = ~0ull; v.y = 0ull;
+                if (lane < nwp) v = snapbuf[64 * k + lane];
+                emit(v.x, v.y, scarry[k], snap_out + static_cast<int64_t>(k) * snap_stride);
+            }
         }
-        carry += __shfl(incl, 63);
     }
     pair_wave_fence();                                 // out[] is read by other lanes than the ones that wrote it
     return carry;
@@ -331,31 +365,48 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
     for (int k = lane; k < j; k += 64) ops[base + k] = 'D';          // row 0
 }
 
-struct PairTask { int q0, m, t0, n, best; };
+// A sub-problem: rows [q0, q0 + m) x columns [t0, t0 + n), `best` = its distance (-1: the root).  lf / rt >= 0: its left / right
+// column vector is INHERITED -- it already stands in the team's arena at that offset (lf_more / rt_more further vectors of the
+// same pass follow at lf_stride / rt_stride: the next sub-problems down the same side).
+struct PairTask { int q0, m, t0, n, best, lf, lf_more, lf_stride, rt, rt_more, rt_stride; };
+// ints of a team's arena of inherited vectors: every split stores at most kPairSnap vectors of (rows + 1) ints per computed pass,
+// the rows of one level of the recursion add up to the overlap's rows, and a 10 kb overlap is ~10 levels deep; a split that
+// finds the arena full stores nothing and its sub-problems compute both their vectors
+__host__ __device__ __forceinline__ uint64_t pair_arena_ints(uint64_t m_cap) { return 40ull * (m_cap + 64); }
 
-// bytes of a team's scratch: two last-column vectors, two carry buffers and a leaf store per wave (host and kernel agree on this)
+// bytes of a team's scratch: two last-column vectors; two carry buffers, a leaf store and the snapshot words per wave; the arena
 __host__ __device__ __forceinline__ uint64_t pair_slot_bytes(uint64_t m_cap, uint64_t n_cap) {       // (m_cap, n_cap: multiples of 16)
-    return ((2 * 4 * (m_cap + 64) + 4 * (n_cap + 64) + 2 * pair_leaf_bytes(m_cap)) + 255) & ~uint64_t(255);
+    return ((2 * 4 * (m_cap + 64) + 4 * (n_cap + 64) + 2 * pair_leaf_bytes(m_cap) + 2 * kPairSnap * 64 * 16 + 4 * pair_arena_ints(m_cap)) + 255) & ~uint64_t(255);
 }
 
 template <int NPL>
 __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairView& Q, const PairView& T, const uint8_t* codes, PairTask* stack,
                                               uint8_t* slot, uint8_t* ops) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    // scratch of this team: left[] / right[] are shared (wave 0 writes the one, wave 1 the other, both read both after the
-    // barrier), the carry buffers and the leaf store are per wave
+    // scratch of this team: left[] / right[] and the arena are shared (one wave writes, both read after the barrier), the carry
+    // buffers, the leaf store and the snapshot words are per wave
     int32_t* left = reinterpret_cast<int32_t*>(slot);
     int32_t* right = left + (P.m_cap + 64);
-    uint8_t* hbuf0 = reinterpret_cast<uint8_t*>(right + (P.m_cap + 64)) + static_cast<uint64_t>(wv) * 2 * (P.n_cap + 64);
+    uint8_t* after = reinterpret_cast<uint8_t*>(right + (P.m_cap + 64));
+    uint8_t* hbuf0 = after + static_cast<uint64_t>(wv) * 2 * (P.n_cap + 64);
     uint8_t* hbuf1 = hbuf0 + (P.n_cap + 64);
-    ulonglong2* store = reinterpret_cast<ulonglong2*>(reinterpret_cast<uint8_t*>(right + (P.m_cap + 64)) + 4ull * (P.n_cap + 64) + static_cast<uint64_t>(wv) * P.leaf_bytes);
+    after += 4ull * (P.n_cap + 64);
+    ulonglong2* store = reinterpret_cast<ulonglong2*>(after + static_cast<uint64_t>(wv) * P.leaf_bytes);
+    after += 2 * P.leaf_bytes;
+    ulonglong2* snapbuf = reinterpret_cast<ulonglong2*>(after) + wv * (kPairSnap * 64);
+    after += 2 * kPairSnap * 64 * 16;
+    int32_t* arena = reinterpret_cast<int32_t*>(after);
+    int atop = 0;                                      // ints of the arena in use (the same number in both waves)
+    const int acap = static_cast<int>(P.arena_ints);
     int sp = 0, distance = -1;
-    if (threadIdx.x == 0) stack[0] = PairTask{0, static_cast<int>(Q.n), 0, static_cast<int>(T.n), -1};
+    if (threadIdx.x == 0) stack[0] = PairTask{0, static_cast<int>(Q.n), 0, static_cast<int>(T.n), -1, -1, 0, 0, -1, 0, 0};
     sp = 1;
     while (sp > 0) {
         --sp;
         __syncthreads();                               // the stack as the last round left it; left[] / right[] are no longer read
-        const PairTask tk = stack[sp];
+        PairTask tk = stack[sp];
+        tk.lf = __builtin_amdgcn_readfirstlane(tk.lf); tk.lf_more = __builtin_amdgcn_readfirstlane(tk.lf_more); tk.lf_stride = __builtin_amdgcn_readfirstlane(tk.lf_stride);
+        tk.rt = __builtin_amdgcn_readfirstlane(tk.rt); tk.rt_more = __builtin_amdgcn_readfirstlane(tk.rt_more); tk.rt_stride = __builtin_amdgcn_readfirstlane(tk.rt_stride);
         const int q0 = __builtin_amdgcn_readfirstlane(tk.q0), m = __builtin_amdgcn_readfirstlane(tk.m);
         const int t0 = __builtin_amdgcn_readfirstlane(tk.t0), n = __builtin_amdgcn_readfirstlane(tk.n);
         int best = __builtin_amdgcn_readfirstlane(tk.best);
@@ -364,7 +415,7 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         if (n == 0) { for (int k = lane; k < m; k += 64) ops[base + k] = 'I'; if (best < 0) distance = m; continue; }
         if (pair_is_leaf(m, n)) {
             // the task below it on the stack is usually a leaf as well (the two children of the last split): wave 1 takes it
-            PairTask t2 = PairTask{0, 0, 0, 0, 0};
+            PairTask t2 = PairTask{0, 0, 0, 0, 0, -1, 0, 0, -1, 0, 0};
             bool two = false;
             if (best >= 0 && sp > 0) {
                 t2 = stack[sp - 1];
@@ -384,15 +435,45 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
             }
             continue;
         }
+        // ---- a split ----
+        // left[h] = ED(rows[:h], left half of the columns), right[k] = ED(last k rows, right half), each one forward / backward
+        // pass over all the rows -- unless the vector is inherited: the left half of a LEFT child starts in the corner its parent's
+        // forward pass started in, so its left vector is a column of that pass (the child's middle column, rows 0 .. h: a prefix),
+        // and the right vector of a RIGHT child is a column of the parent's backward pass.  Every computed pass therefore also
+        // leaves the columns its next kPairSnap descendants down that side will ask for, and below the root a split costs one
+        // pass instead of two (edlib computes both every time; the values are the same numbers).
         const int lw = n / 2, rw = n - lw;
-        if (wv == 0) pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left);
-        else pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right);
-        __syncthreads();                               // (work-group fence + barrier: the other wave's vector is in HBM scratch)
+        const bool have_l = tk.lf >= 0, have_r = tk.rt >= 0;
+        int fc[kPairSnap] = {0, 0, 0}, bc[kPairSnap] = {0, 0, 0};
+        int nsf = 0, nsb = 0;
+        if (!have_l) {
+            int c = lw;
+#pragma unroll
+            for (int k = 0; k < kPairSnap; ++k) { c = c / 2; if (c >= 1 && nsf == k) { fc[k] = c; nsf = k + 1; } }
+        }
+        if (!have_r) {
+            int c = rw;
+#pragma unroll
+            for (int k = 0; k < kPairSnap; ++k) { const int cn = c - c / 2; if (cn >= 1 && cn < c && nsb == k) { bc[k] = cn; nsb = k + 1; } c = cn; }
+        }
+        if (atop + (nsf + nsb) * (m + 1) > acap) { nsf = 0; nsb = 0; }
+        const int fwd_off = atop, bwd_off = atop + nsf * (m + 1);
+        atop += (nsf + nsb) * (m + 1);
+        if (!have_l && !have_r) {
+            if (wv == 0) pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left, nsf, fc[0], fc[1], fc[2], arena + fwd_off, m + 1, snapbuf);
+            else pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right, nsb, bc[0], bc[1], bc[2], arena + bwd_off, m + 1, snapbuf);
+        } else if (wv == 0) {
+            if (!have_l) pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left, nsf, fc[0], fc[1], fc[2], arena + fwd_off, m + 1, snapbuf);
+            else pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right, nsb, bc[0], bc[1], bc[2], arena + bwd_off, m + 1, snapbuf);
+        }
+        __syncthreads();                               // (work-group fence + barrier: the other wave's vectors are in HBM scratch)
+        const int32_t* Lv = have_l ? arena + tk.lf : left;
+        const int32_t* Rv = have_r ? arena + tk.rt : right;
         if (best < 0) {
             // the root: best = min over all rows of left + right (every path crosses the middle column somewhere)
             int mn = 0x7fffffff;
 #pragma unroll 4
-            for (int h = lane; h <= m; h += 64) mn = min(mn, left[h] + right[m - h]);
+            for (int h = lane; h <= m; h += 64) mn = min(mn, Lv[h] + Rv[m - h]);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mn = min(mn, __shfl_xor(mn, d));
             best = mn; distance = mn;
@@ -401,7 +482,7 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         for (int h0 = 1; h0 < m && h < 0; h0 += 256) {           // (four chunks of rows per trip: eight loads in flight, not two)
             int sum[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int hh = h0 + 64 * u + lane; const int hc_ = min(hh, m); sum[u] = left[hc_] + right[m - hc_]; }
+            for (int u = 0; u < 4; ++u) { const int hh = h0 + 64 * u + lane; const int hc_ = min(hh, m); sum[u] = Lv[hc_] + Rv[m - hc_]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int hh = h0 + 64 * u + lane;
@@ -409,14 +490,20 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
                 if (mask && h < 0) h = h0 + 64 * u + __builtin_ctzll(mask);
             }
         }
-        if (h < 0 && lw + right[m] == best) h = 0;
-        if (h < 0 && left[m] + rw == best) h = m;
+        if (h < 0 && lw + Rv[m] == best) h = 0;
+        if (h < 0 && Lv[m] + rw == best) h = m;
         if (h < 0) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
-        const int ls = h > 0 ? left[h] : lw, rs = h < m ? right[m - h] : rw;
+        const int ls = h > 0 ? Lv[h] : lw, rs = h < m ? Rv[m - h] : rw;
         if (sp + 2 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
         if (threadIdx.x == 0) {
-            stack[sp] = PairTask{q0 + h, m - h, t0 + lw, rw, rs};
-            stack[sp + 1] = PairTask{q0, h, t0, lw, ls};
+            PairTask rc{q0 + h, m - h, t0 + lw, rw, rs, -1, 0, 0, -1, 0, 0};
+            if (have_r) { if (tk.rt_more > 0) { rc.rt = tk.rt + tk.rt_stride; rc.rt_more = tk.rt_more - 1; rc.rt_stride = tk.rt_stride; } }
+            else if (nsb > 0) { rc.rt = bwd_off; rc.rt_more = nsb - 1; rc.rt_stride = m + 1; }
+            PairTask lc{q0, h, t0, lw, ls, -1, 0, 0, -1, 0, 0};
+            if (have_l) { if (tk.lf_more > 0) { lc.lf = tk.lf + tk.lf_stride; lc.lf_more = tk.lf_more - 1; lc.lf_stride = tk.lf_stride; } }
+            else if (nsf > 0) { lc.lf = fwd_off; lc.lf_more = nsf - 1; lc.lf_stride = m + 1; }
+            stack[sp] = rc;
+            stack[sp + 1] = lc;
         }
         sp += 2;
     }

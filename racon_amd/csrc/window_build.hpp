@@ -706,6 +706,7 @@ inline int align_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set&
         P.ops = A[kAOps].as<uint8_t>(); P.ops_off = A[kAOpsOff].as<uint64_t>(); P.dist = A[kADist].as<int32_t>();
         P.scratch = A[kAScratch].as<uint8_t>(); P.slot_bytes = slot_bytes;
         P.m_cap = static_cast<uint32_t>(m_cap); P.n_cap = static_cast<uint32_t>(n_cap); P.leaf_bytes = leaf_bytes;
+        P.arena_ints = static_cast<uint32_t>(rcn::pair_arena_ints(m_cap));
         HIP_TRY(hipEventRecord(tk.a, st));
         hipLaunchKernelGGL(rcn::k_pair_align, dim3(static_cast<uint32_t>(slots)), dim3(rcn::kPairThreads), 0, st, P);
         HIP_TRY(hipGetLastError());
