@@ -379,9 +379,40 @@ __host__ __device__ __forceinline__ uint64_t pair_slot_bytes(uint64_t m_cap, uin
     return ((2 * 4 * (m_cap + 64) + 4 * (n_cap + 64) + 2 * pair_leaf_bytes(m_cap) + 2 * kPairSnap * 64 * 16 + 4 * pair_arena_ints(m_cap)) + 255) & ~uint64_t(255);
 }
 
+__device__ __forceinline__ PairTask pair_task_uniform(const PairTask& t) {
+    PairTask u;
+    u.q0 = __builtin_amdgcn_readfirstlane(t.q0); u.m = __builtin_amdgcn_readfirstlane(t.m); u.t0 = __builtin_amdgcn_readfirstlane(t.t0);
+    u.n = __builtin_amdgcn_readfirstlane(t.n); u.best = __builtin_amdgcn_readfirstlane(t.best);
+    u.lf = __builtin_amdgcn_readfirstlane(t.lf); u.lf_more = __builtin_amdgcn_readfirstlane(t.lf_more); u.lf_stride = __builtin_amdgcn_readfirstlane(t.lf_stride);
+    u.rt = __builtin_amdgcn_readfirstlane(t.rt); u.rt_more = __builtin_amdgcn_readfirstlane(t.rt_more); u.rt_stride = __builtin_amdgcn_readfirstlane(t.rt_stride);
+    return u;
+}
+__device__ __forceinline__ bool pair_task_splits(const PairTask& t) { return t.m > 0 && t.n > 0 && !pair_is_leaf(t.m, t.n); }
+
+// The columns a split's computed passes leave behind for the sub-problems below it (see pair_align_one), and their ints in the arena.
+struct PairSplitPlan { bool have_l, have_r; int nsf, nsb, fc[kPairSnap], bc[kPairSnap], need; };
+__device__ __forceinline__ PairSplitPlan pair_split_plan(const PairTask& t) {
+    PairSplitPlan p{t.lf >= 0, t.rt >= 0, 0, 0, {0, 0, 0}, {0, 0, 0}, 0};
+    const int lw = t.n / 2, rw = t.n - lw;
+    if (!p.have_l) {
+        int c = lw;
+#pragma unroll
+        for (int k = 0; k < kPairSnap; ++k) { c = c / 2; if (c >= 1 && p.nsf == k) { p.fc[k] = c; p.nsf = k + 1; } }
+    }
+    if (!p.have_r) {
+        int c = rw;
+#pragma unroll
+        for (int k = 0; k < kPairSnap; ++k) { const int cn = c - c / 2; if (cn >= 1 && cn < c && p.nsb == k) { p.bc[k] = cn; p.nsb = k + 1; } c = cn; }
+    }
+    p.need = (p.nsf + p.nsb) * (t.m + 1);
+    return p;
+}
+
+struct PairKids { PairTask k[2]; };
+
 template <int NPL>
 __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairView& Q, const PairView& T, const uint8_t* codes, PairTask* stack,
-                                              uint8_t* slot, uint8_t* ops) {
+                                              PairKids* kids, int* nkids, uint8_t* slot, uint8_t* ops) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     // scratch of this team: left[] / right[] and the arena are shared (one wave writes, both read after the barrier), the carry
     // buffers, the leaf store and the snapshot words are per wave
@@ -401,74 +432,22 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
     int sp = 0, distance = -1;
     if (threadIdx.x == 0) stack[0] = PairTask{0, static_cast<int>(Q.n), 0, static_cast<int>(T.n), -1, -1, 0, 0, -1, 0, 0};
     sp = 1;
-    while (sp > 0) {
-        --sp;
-        __syncthreads();                               // the stack as the last round left it; left[] / right[] are no longer read
-        PairTask tk = stack[sp];
-        tk.lf = __builtin_amdgcn_readfirstlane(tk.lf); tk.lf_more = __builtin_amdgcn_readfirstlane(tk.lf_more); tk.lf_stride = __builtin_amdgcn_readfirstlane(tk.lf_stride);
-        tk.rt = __builtin_amdgcn_readfirstlane(tk.rt); tk.rt_more = __builtin_amdgcn_readfirstlane(tk.rt_more); tk.rt_stride = __builtin_amdgcn_readfirstlane(tk.rt_stride);
-        const int q0 = __builtin_amdgcn_readfirstlane(tk.q0), m = __builtin_amdgcn_readfirstlane(tk.m);
-        const int t0 = __builtin_amdgcn_readfirstlane(tk.t0), n = __builtin_amdgcn_readfirstlane(tk.n);
-        int best = __builtin_amdgcn_readfirstlane(tk.best);
-        const int64_t base = static_cast<int64_t>(q0) + t0;
-        if (m == 0) { for (int k = lane; k < n; k += 64) ops[base + k] = 'D'; if (best < 0) distance = n; continue; }
-        if (n == 0) { for (int k = lane; k < m; k += 64) ops[base + k] = 'I'; if (best < 0) distance = m; continue; }
-        if (pair_is_leaf(m, n)) {
-            // the task below it on the stack is usually a leaf as well (the two children of the last split): wave 1 takes it
-            PairTask t2 = PairTask{0, 0, 0, 0, 0, -1, 0, 0, -1, 0, 0};
-            bool two = false;
-            if (best >= 0 && sp > 0) {
-                t2 = stack[sp - 1];
-                t2.q0 = __builtin_amdgcn_readfirstlane(t2.q0); t2.m = __builtin_amdgcn_readfirstlane(t2.m);
-                t2.t0 = __builtin_amdgcn_readfirstlane(t2.t0); t2.n = __builtin_amdgcn_readfirstlane(t2.n);
-                two = t2.m > 0 && t2.n > 0 && pair_is_leaf(t2.m, t2.n);
-            }
-            if (two) --sp;
-            if (wv == 0) {
-                if (best < 0) {
-                    // a leaf at the root: the distance is not known from a split; one extra forward pass provides it
-                    distance = pair_columns<NPL>(Q, q0, m, false, T, t0, n, false, codes, hbuf0, hbuf1, left);
-                }
-                pair_leaf<NPL>(Q, q0, m, T, t0, n, codes, hbuf0, hbuf1, store, ops);
-            } else if (two) {
-                pair_leaf<NPL>(Q, t2.q0, t2.m, T, t2.t0, t2.n, codes, hbuf0, hbuf1, store, ops);
-            }
-            continue;
-        }
-        // ---- a split ----
-        // left[h] = ED(rows[:h], left half of the columns), right[k] = ED(last k rows, right half), each one forward / backward
-        // pass over all the rows -- unless the vector is inherited: the left half of a LEFT child starts in the corner its parent's
-        // forward pass started in, so its left vector is a column of that pass (the child's middle column, rows 0 .. h: a prefix),
-        // and the right vector of a RIGHT child is a column of the parent's backward pass.  Every computed pass therefore also
-        // leaves the columns its next kPairSnap descendants down that side will ask for, and below the root a split costs one
-        // pass instead of two (edlib computes both every time; the values are the same numbers).
-        const int lw = n / 2, rw = n - lw;
-        const bool have_l = tk.lf >= 0, have_r = tk.rt >= 0;
-        int fc[kPairSnap] = {0, 0, 0}, bc[kPairSnap] = {0, 0, 0};
-        int nsf = 0, nsb = 0;
-        if (!have_l) {
-            int c = lw;
-#pragma unroll
-            for (int k = 0; k < kPairSnap; ++k) { c = c / 2; if (c >= 1 && nsf == k) { fc[k] = c; nsf = k + 1; } }
-        }
-        if (!have_r) {
-            int c = rw;
-#pragma unroll
-            for (int k = 0; k < kPairSnap; ++k) { const int cn = c - c / 2; if (cn >= 1 && cn < c && nsb == k) { bc[k] = cn; nsb = k + 1; } c = cn; }
-        }
-        if (atop + (nsf + nsb) * (m + 1) > acap) { nsf = 0; nsb = 0; }
-        const int fwd_off = atop, bwd_off = atop + nsf * (m + 1);
-        atop += (nsf + nsb) * (m + 1);
-        if (!have_l && !have_r) {
-            if (wv == 0) pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left, nsf, fc[0], fc[1], fc[2], arena + fwd_off, m + 1, snapbuf);
-            else pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right, nsb, bc[0], bc[1], bc[2], arena + bwd_off, m + 1, snapbuf);
-        } else if (wv == 0) {
-            if (!have_l) pair_columns<NPL>(Q, q0, m, false, T, t0, lw, false, codes, hbuf0, hbuf1, left, nsf, fc[0], fc[1], fc[2], arena + fwd_off, m + 1, snapbuf);
-            else pair_columns<NPL>(Q, q0, m, true, T, t0 + lw, rw, true, codes, hbuf0, hbuf1, right, nsb, bc[0], bc[1], bc[2], arena + bwd_off, m + 1, snapbuf);
-        }
-        __syncthreads();                               // (work-group fence + barrier: the other wave's vectors are in HBM scratch)
-        const int32_t* Lv = have_l ? arena + tk.lf : left;
-        const int32_t* Rv = have_r ? arena + tk.rt : right;
+
+    // ---- a split ----
+    // left[h] = ED(rows[:h], left half of the columns), right[k] = ED(last k rows, right half), each one forward / backward
+    // pass over all the rows -- unless the vector is inherited: the left half of a LEFT child starts in the corner its parent's
+    // forward pass started in, so its left vector is a column of that pass (the child's middle column, rows 0 .. h: a prefix),
+    // and the right vector of a RIGHT child is a column of the parent's backward pass.  Every computed pass therefore also
+    // leaves the columns its next kPairSnap descendants down that side will ask for, and below the root a split costs one
+    // pass instead of two (edlib computes both every time; the values are the same numbers).
+    auto run_pass = [&](const PairTask& t, const PairSplitPlan& pl, bool forward, int32_t* out, int off) {
+        const int lw = t.n / 2, rw = t.n - lw;
+        if (forward) pair_columns<NPL>(Q, t.q0, t.m, false, T, t.t0, lw, false, codes, hbuf0, hbuf1, out, pl.nsf, pl.fc[0], pl.fc[1], pl.fc[2], arena + off, t.m + 1, snapbuf);
+        else pair_columns<NPL>(Q, t.q0, t.m, true, T, t.t0 + lw, rw, true, codes, hbuf0, hbuf1, out, pl.nsb, pl.bc[0], pl.bc[1], pl.bc[2], arena + off + pl.nsf * (t.m + 1), t.m + 1, snapbuf);
+    };
+    // where the optimal path crosses the middle column (the smallest such row), and the two sub-problems; false: no such row
+    auto cut = [&](const PairTask& t, const PairSplitPlan& pl, int off, const int32_t* Lv, const int32_t* Rv, int& best, PairTask& lc, PairTask& rc) -> bool {
+        const int m = t.m, lw = t.n / 2, rw = t.n - lw;
         if (best < 0) {
             // the root: best = min over all rows of left + right (every path crosses the middle column somewhere)
             int mn = 0x7fffffff;
@@ -476,7 +455,7 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
             for (int h = lane; h <= m; h += 64) mn = min(mn, Lv[h] + Rv[m - h]);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mn = min(mn, __shfl_xor(mn, d));
-            best = mn; distance = mn;
+            best = mn;
         }
         int h = -1;
         for (int h0 = 1; h0 < m && h < 0; h0 += 256) {           // (four chunks of rows per trip: eight loads in flight, not two)
@@ -492,20 +471,88 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         }
         if (h < 0 && lw + Rv[m] == best) h = 0;
         if (h < 0 && Lv[m] + rw == best) h = m;
-        if (h < 0) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
+        if (h < 0) return false;
         const int ls = h > 0 ? Lv[h] : lw, rs = h < m ? Rv[m - h] : rw;
-        if (sp + 2 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
-        if (threadIdx.x == 0) {
-            PairTask rc{q0 + h, m - h, t0 + lw, rw, rs, -1, 0, 0, -1, 0, 0};
-            if (have_r) { if (tk.rt_more > 0) { rc.rt = tk.rt + tk.rt_stride; rc.rt_more = tk.rt_more - 1; rc.rt_stride = tk.rt_stride; } }
-            else if (nsb > 0) { rc.rt = bwd_off; rc.rt_more = nsb - 1; rc.rt_stride = m + 1; }
-            PairTask lc{q0, h, t0, lw, ls, -1, 0, 0, -1, 0, 0};
-            if (have_l) { if (tk.lf_more > 0) { lc.lf = tk.lf + tk.lf_stride; lc.lf_more = tk.lf_more - 1; lc.lf_stride = tk.lf_stride; } }
-            else if (nsf > 0) { lc.lf = fwd_off; lc.lf_more = nsf - 1; lc.lf_stride = m + 1; }
-            stack[sp] = rc;
-            stack[sp + 1] = lc;
+        rc = PairTask{t.q0 + h, m - h, t.t0 + lw, rw, rs, -1, 0, 0, -1, 0, 0};
+        if (pl.have_r) { if (t.rt_more > 0) { rc.rt = t.rt + t.rt_stride; rc.rt_more = t.rt_more - 1; rc.rt_stride = t.rt_stride; } }
+        else if (pl.nsb > 0) { rc.rt = off + pl.nsf * (m + 1); rc.rt_more = pl.nsb - 1; rc.rt_stride = m + 1; }
+        lc = PairTask{t.q0, h, t.t0, lw, ls, -1, 0, 0, -1, 0, 0};
+        if (pl.have_l) { if (t.lf_more > 0) { lc.lf = t.lf + t.lf_stride; lc.lf_more = t.lf_more - 1; lc.lf_stride = t.lf_stride; } }
+        else if (pl.nsf > 0) { lc.lf = off; lc.lf_more = pl.nsf - 1; lc.lf_stride = m + 1; }
+        return true;
+    };
+
+    while (sp > 0) {
+        __syncthreads();                               // the stack as the last round left it; left[] / right[] are no longer read
+        const PairTask A = pair_task_uniform(stack[sp - 1]);
+        const bool A_splits = pair_task_splits(A);
+        if (A_splits && A.lf < 0 && A.rt < 0) {
+            // ---- both vectors to compute (the root; a sub-problem whose ancestors' columns ran out): one pass per wave ----
+            --sp;
+            PairSplitPlan pl = pair_split_plan(A);
+            if (atop + pl.need > acap) { pl.nsf = 0; pl.nsb = 0; pl.need = 0; }
+            const int off = atop;
+            atop += pl.need;
+            run_pass(A, pl, wv == 0, wv == 0 ? left : right, off);
+            __syncthreads();                           // (work-group fence + barrier: the other wave's vector is in HBM scratch)
+            int best = A.best;
+            PairTask lc, rc;
+            const bool ok = cut(A, pl, off, left, right, best, lc, rc);
+            if (A.best < 0) distance = best;
+            if (!ok || sp + 2 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
+            if (threadIdx.x == 0) { stack[sp] = rc; stack[sp + 1] = lc; }
+            sp += 2;
+            continue;
         }
-        sp += 2;
+        // ---- a round of sub-problems that need one wave each: a leaf, an empty one, a split with an inherited vector ----
+        PairTask B = A;
+        bool two = false, B_splits = false;
+        if (sp >= 2) {
+            B = pair_task_uniform(stack[sp - 2]);
+            B_splits = pair_task_splits(B);
+            two = !(B_splits && B.lf < 0 && B.rt < 0);
+        }
+        sp -= two ? 2 : 1;
+        PairSplitPlan pa = pair_split_plan(A), pb = pair_split_plan(B);
+        if (!A_splits || atop + pa.need > acap) { pa.nsf = 0; pa.nsb = 0; pa.need = 0; }
+        const int offa = atop;
+        atop += pa.need;
+        if (!two || !B_splits || atop + pb.need > acap) { pb.nsf = 0; pb.nsb = 0; pb.need = 0; }
+        const int offb = atop;
+        atop += pb.need;
+        int nk = 0;
+        PairTask k0 = A, k1 = A;
+        if (wv == 0 || two) {
+            const PairTask& t = wv == 0 ? A : B;
+            const PairSplitPlan& pl = wv == 0 ? pa : pb;
+            const int off = wv == 0 ? offa : offb;
+            const bool splits = wv == 0 ? A_splits : B_splits;
+            const int64_t base = static_cast<int64_t>(t.q0) + t.t0;
+            if (t.m == 0) { for (int k = lane; k < t.n; k += 64) ops[base + k] = 'D'; if (t.best < 0) distance = t.n; }
+            else if (t.n == 0) { for (int k = lane; k < t.m; k += 64) ops[base + k] = 'I'; if (t.best < 0) distance = t.m; }
+            else if (!splits) {
+                // a leaf at the root: the distance is not known from a split; one extra forward pass provides it
+                if (t.best < 0) distance = pair_columns<NPL>(Q, t.q0, t.m, false, T, t.t0, t.n, false, codes, hbuf0, hbuf1, left);
+                pair_leaf<NPL>(Q, t.q0, t.m, T, t.t0, t.n, codes, hbuf0, hbuf1, store, ops);
+            } else {
+                int32_t* mine = wv == 0 ? left : right;          // the one vector this sub-problem computes
+                run_pass(t, pl, !pl.have_l, mine, off);
+                const int32_t* Lv = pl.have_l ? arena + t.lf : mine;
+                const int32_t* Rv = pl.have_r ? arena + t.rt : mine;
+                int best = t.best;
+                nk = cut(t, pl, off, Lv, Rv, best, k1, k0) ? 2 : -1;
+            }
+        }
+        if (lane == 0) { kids[wv].k[0] = k0; kids[wv].k[1] = k1; nkids[wv] = nk; }
+        __syncthreads();
+        const int n0 = __builtin_amdgcn_readfirstlane(nkids[0]), n1 = __builtin_amdgcn_readfirstlane(nkids[1]);
+        if (n0 < 0 || n1 < 0 || sp + n0 + n1 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
+        if (threadIdx.x == 0) {
+            int q = sp;
+            if (n1 == 2) { stack[q] = kids[1].k[0]; stack[q + 1] = kids[1].k[1]; q += 2; }
+            if (n0 == 2) { stack[q] = kids[0].k[0]; stack[q + 1] = kids[0].k[1]; }
+        }
+        sp += n0 + n1;
     }
     return distance;
 }
@@ -517,6 +564,8 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
     __shared__ uint8_t present[256];        // raw bytes of the stored query segment
     __shared__ uint8_t lcode[256];          // logical symbol -> dense code
     __shared__ PairTask stack[kPairStack];
+    __shared__ PairKids kids[2];
+    __shared__ int nkids[2];
     __shared__ unsigned int s_work;
     __shared__ int s_nsym;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,8 +612,8 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
         }
         __syncthreads();
         int d;
-        if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, slot, ops);
-        else d = pair_align_one<8>(P, Q, T, codes, stack, slot, ops);
+        if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, kids, nkids, slot, ops);
+        else d = pair_align_one<8>(P, Q, T, codes, stack, kids, nkids, slot, ops);
         if (tid == 0) P.dist[o] = d;
     }
 }
