@@ -568,6 +568,7 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
     __shared__ int nkids[2];
     __shared__ unsigned int s_work;
     __shared__ int s_nsym;
+    __shared__ int s_foreign;               // the target segment holds a symbol the query does not
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t* slot = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
     for (;;) {
@@ -605,6 +606,20 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
         }
         __syncthreads();
         const int nsym = __builtin_amdgcn_readfirstlane(s_nsym);
+        // four symbols or fewer and none in the target that the query lacks (plain ACGT reads): two bit planes instead of three
+        if (tid == 0) s_foreign = 0;
+        __syncthreads();
+        if (nsym <= 4) {
+            int foreign = 0;
+            for (int64_t i = tid; i < T.n; i += 4 * kPairThreads) {
+                uint32_t r4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int64_t iu = i + u * kPairThreads; r4[u] = T.p[iu < T.n ? iu : i]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) foreign |= lcode[r4[u]] == 7 ? 1 : 0;
+            }
+            if (foreign) s_foreign = 1;
+        }
         for (int k = tid; k < 256; k += kPairThreads) {
             const uint32_t cq = Q.rc ? pair_comp(static_cast<uint32_t>(k)) : static_cast<uint32_t>(k);
             codes[k] = nsym <= 7 ? lcode[cq] : static_cast<uint8_t>(cq);
@@ -612,7 +627,8 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
         }
         __syncthreads();
         int d;
-        if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, kids, nkids, slot, ops);
+        if (nsym <= 4 && __builtin_amdgcn_readfirstlane(s_foreign) == 0) d = pair_align_one<2>(P, Q, T, codes, stack, kids, nkids, slot, ops);
+        else if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, kids, nkids, slot, ops);
         else d = pair_align_one<8>(P, Q, T, codes, stack, kids, nkids, slot, ops);
         if (tid == 0) P.dist[o] = d;
     }

@@ -90,6 +90,35 @@ def test_hirschberg_sized_pairs(P, seed, n, rate, indels):
     assert st["cells"] == 2 * len(q) * len(t)
 
 
+def test_two_plane_pairs_and_symbols_only_the_target_has(P):
+    """Four query symbols or fewer and no target symbol outside them: two bit planes (k_pair_align); a target symbol the query
+    lacks (an N in the contig, a T where the read has none) must never match and sends the pair to three planes.  Both strands,
+    sizes with several levels of splits (inherited column vectors, two sub-problems at a time)."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(9250)
+    pairs, strands = [], []
+    for n in [700, 3100, 6400]:
+        t = random_seq(rng, n)                                            # ACGT
+        q = mutate(rng, t, 0.1)
+        pairs.append((q, t)); strands.append(0)
+        pairs.append((nw_oracle.reverse_complement(q), t)); strands.append(1)
+        tn = bytearray(t)
+        for k in rng.integers(0, n, n // 50):
+            tn[int(k)] = ord("N")                                         # only the target holds N
+        pairs.append((q, bytes(tn))); strands.append(0)
+        pairs.append((nw_oracle.reverse_complement(q), bytes(tn))); strands.append(1)
+    t3 = random_seq(rng, 2800, b"ACG")
+    pairs.append((mutate(rng, t3, 0.08, b"ACG"), random_seq(rng, 2700))); strands.append(0)          # three query symbols, T only in the target
+    pairs.append((mutate(rng, t3, 0.08, b"ACG"), t3)); strands.append(1)
+    t2 = random_seq(rng, 2600, b"AT")
+    pairs.append((nw_oracle.reverse_complement(mutate(rng, t2, 0.1, b"AT")), t2)); strands.append(1)   # two symbols that complement into each other
+    cig, dist, _ = _run(pairs, strands)
+    for k, ((q, t), c, d) in enumerate(zip(pairs, cig, dist)):
+        qs = nw_oracle.reverse_complement(q) if strands[k] else q
+        assert c == P.align_cigar(qs, t).encode(), (k, len(q), len(t))
+        assert d == P.edit_distance(qs, t)
+
+
 def test_degenerate_shapes_and_wide_alphabets(P):
     rng = np.random.default_rng(9300)
     iupac = b"ACGTNRYKMSWBDHV"
