@@ -248,7 +248,8 @@ def test_cfg5_share_through_the_binary():
     ~600 000 overlaps to align -- through `racon_hip -f` with everything on the device: the FASTA equals the engine's
     consensus on the device-built windows for every window, a 5 % sample of those windows (12 500) equals the oracle, no
     window needed the retry pass.  (The host-aligned modes 0 / 2 against mode 3 at 1 %: tools/cfg5_at_size.py,
-    profiles/r03/e_cfg5_at_size_x0.125.json.)"""
+    profiles/r03/e_cfg5_at_size_x0.125.json; mode 0 against mode 3 at the full share, --host-at-size, 200 s of host alignment:
+    profiles/r04/z_cfg5_at_size_x0.125_host_aligner.json.)"""
     import json
     import os
     import subprocess

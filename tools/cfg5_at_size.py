@@ -31,6 +31,7 @@ from racon_amd.synth import simulate_fragment_files                     # noqa: 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=float, default=0.125)
 ap.add_argument("--cross-scale", type=float, default=0.01)
+ap.add_argument("--host-at-size", action="store_true", help="also the binary with the HOST aligner on the full share (minutes of CPU): the two FASTA files must be identical")
 ap.add_argument("--sample", type=float, default=0.05)
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--dir", default=os.environ.get("RACON_AMD_CACHE", "/tmp/racon_amd_cache"))
@@ -124,6 +125,9 @@ out["oracle_sample"] = {"windows": len(pick), "differ": len(bad), "first": bad[:
 p.close()
 
 # ---- the three ways through the binary on a small share: same FASTA
+if a.host_at_size:
+    run0, _ = cli(big, "0")
+    out["host_aligner_at_size"] = {"run": run0, "identical_to_device_everything": run0["md5"] == run3["md5"]}
 if a.cross_scale > 0:
     small = files(a.cross_scale)
     runs = [cli(small, m)[0] for m in ("0", "2", "3")]
