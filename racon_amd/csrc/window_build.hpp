@@ -734,7 +734,11 @@ inline int build_windows_from_pairs(rcn_engine* e, const rcn_read_set& R, const 
     // an aligner that found no room (RCN_E_NOMEM / RCN_E_CAPACITY: the caller then aligns on the host and comes back through the
     // CIGAR path) must not leave its pair tables and op bytes -- one byte per row + column of every overlap -- behind
     auto drop_align = [&]() { for (DevBuf& d : e->d_align) d.release(); e->a_n_pairs = 0; e->a_ops_off.clear(); };
+    const auto t_al0 = std::chrono::steady_clock::now();
     if ((rc = align_pairs(e, R, S, true))) { drop_align(); return rc; }
+    if (e->knobs.debug) fprintf(stderr, "[racon_hip] pairs: %lu overlaps (%.3g matrix cells) aligned in %.1f ms (kernel %.1f ms = %.1f TCUPS, copies %.1f ms, %u teams)\n",
+                                static_cast<unsigned long>(S.n_pairs), static_cast<double>(e->astats.cells), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_al0).count(),
+                                e->astats.kernel_ms, static_cast<double>(e->astats.cells) / (1e9 * std::max(1e-6, static_cast<double>(e->astats.kernel_ms))), e->astats.h2d_ms, e->astats.slots);
     e->d_align[kAScratch].release();            // the aligner's per-wave scratch (sized for the longest read) is done with
     std::vector<uint64_t> bp_off(S.n_pairs + 1, 0);
     std::vector<uint32_t> q_start(S.n_pairs);
@@ -750,8 +754,10 @@ inline int build_windows_from_pairs(rcn_engine* e, const rcn_read_set& R, const 
     O.n_overlaps = S.n_pairs; O.q_id = S.q_id; O.t_id = S.t_id; O.strand = S.strand; O.bp_off = bp_off.data();
     OpsSource src{e->d_align[kAOps].as<uint8_t>(), e->d_align[kAOpsOff].as<uint64_t>(), q_start.data(), S.t_begin, S.t_end};
     const rcn_align_stats keep = e->astats;
+    const auto t_bw0 = std::chrono::steady_clock::now();
     rc = build_windows(e, R, O, W, qthr, window_type, nullptr, &src, true);
     e->astats = keep;
+    if (e->knobs.debug) fprintf(stderr, "[racon_hip] pairs: breaking points and windows in %.1f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_bw0).count());
     // the paths have been walked into breaking points: their op bytes (one per row + column of every overlap) must not
     // stay allocated through the consensus run (rcn_engine_alignment_cigars then reports RCN_E_STATE)
     for (int k : {kAOps, kAOpsOff, kAQPos, kATPos, kAQLen, kATLen, kAQRc, kAOrder}) e->d_align[k].release();

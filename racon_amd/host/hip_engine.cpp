@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 
 #include "fatal.hpp"
@@ -218,9 +219,15 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_pair_set& pairs, 
                           std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
     const Abi& a = abi();
     int rc = a.set_trim(handle_, trim ? 1 : 0);
+    const bool timing = getenv("RACON_HIP_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (rc == RCN_OK) rc = a.build_windows_from_pairs(handle_, &reads, &pairs, window_length, quality_threshold, window_type);
     if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
+    const auto t1 = std::chrono::steady_clock::now();
     fetch(rc, consensus, polished, chimeric);
+    if (timing) fprintf(stderr, "[racon::HipEngine::consensus] timing: %lu overlaps aligned and cut into windows on the device in %.1f ms, consensus and results in %.1f ms (kernel %.1f)\n",
+                        static_cast<unsigned long>(pairs.n_pairs), 1e3 * std::chrono::duration<double>(t1 - t0).count(),
+                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), last_kernel_ms_);
 }
 
 void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run) {
