@@ -200,3 +200,17 @@ if has ngs500; then
     env $e timeout 900 python bench.py --config ngs_w500 --steps 3 --warmup 1 --no-cpu --no-product --no-upload-leg 2>/dev/null | benchline "ngs_w500 $e"
   done | tee "$OUT/ngs_w500.txt"
 fi
+if has scratchlimit; then
+  # poa_window_kernel2 asks for 416 B of private segment per lane: above the runtime's single-allocation limit scratch is set up per
+  # dispatch.  The same lines with the limit raised (HSA_SCRATCH_SINGLE_LIMIT, bytes).
+  for e in "" "HSA_SCRATCH_SINGLE_LIMIT=4000000000"; do
+    for k in 1 2; do
+      env $e timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print('cfg2 [$e]', round(j['value']), r['step_kernel_ms'], r.get('launch_ms'))"
+    done
+    env $e timeout 600 python bench.py --contig 4000000 --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print('4mbp [$e]', round(j['value']), r['step_kernel_ms'], r.get('launch_ms'))"
+    env $e timeout 600 python bench.py --config cfg4 --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print('cfg4 [$e]', round(j['value']), r['step_kernel_ms'], r.get('launch_ms'))"
+  done | tee "$OUT/scratch_limit.txt"
+fi
