@@ -66,6 +66,9 @@ int  rcnh_polisher_polish(rcnh_polisher* p, int drop_unpolished_sequences, const
  * (reference src/polisher.cpp:493 -> :539-543, "[racon::Polisher::polish] generated consensus") -- the interval
  * "polished windows / second" is defined on.  Window count of the job alongside.               */
 double   rcnh_polisher_polish_seconds(rcnh_polisher* p);
+/* How the last rcnh_polisher_polish cut its job (host-built windows): chunks of the deepest-first work list and the engines
+ * that took at least one (reference: the ranges CUDAPolisher hands its per-device batches, src/cuda/cudapolisher.cpp:254-276). */
+int      rcnh_polisher_polish_plan(rcnh_polisher* p, uint32_t* chunks, uint32_t* engines_used);
 uint64_t rcnh_polisher_num_windows(rcnh_polisher* p);     /* valid between initialize and polish/assemble */
 void rcnh_polisher_destroy(rcnh_polisher* p);
 

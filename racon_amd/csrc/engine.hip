@@ -176,7 +176,17 @@ static Knobs read_knobs() {
     Knobs k;
     k.debug = getenv("RCN_DEBUG") != nullptr;
     const char* gate = getenv("RCN_EXPERIMENT");
-    if (!gate || atoi(gate) == 0) return k;
+    if (!gate || atoi(gate) == 0) {
+        // a script that exports RCN_* switches without the gate compares identical configurations: say so, once
+        static bool warned = false;
+        extern char** environ;
+        for (char** ev = environ; ev && *ev && !warned; ++ev)
+            if (!strncmp(*ev, "RCN_", 4) && strncmp(*ev, "RCN_DEBUG", 9) && strncmp(*ev, "RCN_EXPERIMENT", 14)) {
+                fprintf(stderr, "[racon_hip] warning: %.*s is set but ignored (experiment switches need RCN_EXPERIMENT=1)\n", static_cast<int>(strcspn(*ev, "=")), *ev);
+                warned = true;
+            }
+        return k;
+    }
     auto flag = [](const char* n) { return getenv(n) != nullptr; };
     auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
     k.no_ptab = flag("RCN_NO_PTAB"); k.force_exact = flag("RCN_FORCE_EXACT"); k.force_slow_tb = flag("RCN_FORCE_SLOW_TB");
@@ -212,6 +222,7 @@ struct rcn_engine {
     int caps_level = 0;                             // first_pass_caps: raised when a batch needed many retries
     bool small_off = false;                         // the small-window kernel sent too many windows back: not for this engine's next batches
     bool pass_small = false;                        // the first pass of the current batch ran (partly) on the small-window kernel
+    std::vector<uint8_t> item_small;                // ... and which work items did (collect: only those are re-run by poa_window_kernel2 first)
     bool stats_pending = false;                     // the last run's device counters have not been read yet (rcn_engine_stats)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
@@ -352,8 +363,8 @@ bool small_caps(const rcn_engine* e, It first, It last, Caps& out) {
     return true;
 }
 
-// What a pass may take for its slots: 80 % of what is free NOW (+ the scratch this engine already holds: free_mem is refreshed at
-// the start of every run), and never more than the caller's arena.  (An arena fixed when the engine was created -- the host
+// What a pass may take for its slots: 80 % of what is free NOW (free_mem is refreshed at the start of every run by begin_run / rcn_engine_reserve,
+// which fold the scratch this engine already holds into it -- nothing is added here), and never more than the caller's arena.  (An arena fixed when the engine was created -- the host
 // layer splits a device's free memory between its engines then -- says nothing about what reads, overlaps and other engines
 // have taken since: sized from it alone, a pass asked hipMalloc for memory that was no longer there.)
 uint64_t scratch_budget(const rcn_engine* e) {
@@ -943,17 +954,24 @@ static int collect(rcn_engine* e) {
     // Windows the first pass flagged are re-run on the GPU, never on the CPU: a window the small-window kernel sent back
     // (outside its shape: poa_small.hpp) goes to poa_window_kernel2 with first-pass capacities, what that one flags -- or
     // what it flagged in the first place -- to the int32 kernel with worst-case capacities.
-    std::vector<uint32_t> retry;
+    // (per work item: a batch can be cut into pieces of which only some ran the small-window kernel -- what
+    //  poa_window_kernel2 itself flagged goes straight to the int32 kernel, the same first-pass capacities again would overflow again)
+    std::vector<uint32_t> retry, retry_k2;
     for (uint32_t w = 0; w < nw; ++w) {
         if (flags[w] & rcn::kFlagError) { fprintf(stderr, "[racon_hip] internal error on window %u\n", w); return RCN_E_STATE; }
-        if (flags[w] & rcn::kFlagOverflow) retry.push_back(w);
+        if (!(flags[w] & rcn::kFlagOverflow)) continue;
+        if (e->pass_small && item_of[w] < e->item_small.size() && e->item_small[item_of[w]]) retry.push_back(w); else retry_k2.push_back(w);
     }
     std::vector<std::string> retry_cons;
     std::vector<uint32_t> retry_win;                 // windows whose bytes are in retry_cons, ascending
     {
         std::vector<std::pair<uint32_t, std::string>> redone;
-        const uint32_t n_first = static_cast<uint32_t>(retry.size());
-        for (int tier = e->pass_small ? 0 : 1; tier < 2 && !retry.empty(); ++tier) {
+        const uint32_t n_first_small = static_cast<uint32_t>(retry.size()), n_first_k2 = static_cast<uint32_t>(retry_k2.size());
+        uint32_t n_small_items = 0;
+        for (uint8_t s : e->item_small) n_small_items += s;
+        for (int tier = 0; tier < 2; ++tier) {
+            if (tier == 1) { retry.insert(retry.end(), retry_k2.begin(), retry_k2.end()); std::sort(retry.begin(), retry.end()); }
+            if (retry.empty()) continue;
             int32_t n2 = 0, l2 = 1, nsym = 2;
             const uint32_t nr = static_cast<uint32_t>(retry.size());
             std::vector<uint32_t> ids(nr);
@@ -1000,11 +1018,11 @@ static int collect(rcn_engine* e) {
         std::sort(redone.begin(), redone.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
         for (auto& r : redone) { retry_win.push_back(r.first); retry_cons.push_back(std::move(r.second)); }
         e->stats.n_retried = static_cast<uint32_t>(retry_win.size());
-        if (e->pass_small) {
-            // a batch whose windows keep leaving the small-window kernel (noisy reads on short windows: graphs that outgrow
-            // the LDS) pays for them twice: not for this engine's next batches
-            if (n_first * 8 > nw && nw >= 64) e->small_off = true;
-        } else if (n_first * 50 > nw && nw >= 50 && e->caps_level < 2) ++e->caps_level;
+        // a batch whose windows keep leaving the small-window kernel (noisy reads on short windows: graphs that outgrow
+        // the LDS) pays for them twice: not for this engine's next batches
+        if (n_first_small * 8 > n_small_items && n_small_items >= 64) e->small_off = true;
+        const uint32_t n_k2_items = nw - n_small_items;
+        if (n_first_k2 * 50 > n_k2_items && n_k2_items >= 50 && e->caps_level < 2) ++e->caps_level;
     }
 
     e->stats_pending = true;                      // the device counters of this run: fetched by rcn_engine_stats on demand
@@ -1085,6 +1103,7 @@ static int begin_run(rcn_engine* e) {
     if ((rc = e->h_out.reserve(result_layout(nw).off_cons + e->out_off[nw] + 16))) return rc;
     e->stats_pending = false;
     e->pass_small = false;
+    e->item_small.assign(nw, 0);
     HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, kCtrBytes, e->stream));
     {
         // windows in the top tail of the depth distribution can be given the 4-wave DP (RCN_HEAVY_PCT; off by default:
@@ -1147,6 +1166,7 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
     L.n_work = pp.cut[c + 1] - pp.cut[c]; L.work_base = pp.cut[c]; L.out_base = pp.cut[c]; L.ctr = c;
     if (small) {
         e->pass_small = true;
+        for (uint32_t k = pp.cut[c]; k < pp.cut[c + 1] && k < e->item_small.size(); ++k) e->item_small[k] = 1;
         L.stream = e->sub_stream[c]; L.per_cu = L.c.per_cu;
         // (every piece may fill the device: its work-groups are persistent over a queue, the ones that find no room at first
         //  start as the earlier piece's retire -- a fixed share would idle once that piece is done)
@@ -1213,6 +1233,7 @@ int rcn_engine_run(rcn_engine* e) {
         Caps cs;
         if (fast && small_caps(e, e->shapes.begin(), e->shapes.end(), cs)) {
             e->pass_small = true;
+            e->item_small.assign(nw, 1);
             if ((rc = run_pass(e, cs, ids, nw))) return rc;
             return collect(e);
         }

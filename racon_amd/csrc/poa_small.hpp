@@ -45,7 +45,7 @@ constexpr int kSmWideRows = 16;     // rows of that kind per alignment (more: th
 constexpr int kSmChain = 1 << 14;   // row descriptor: one predecessor, the row right above (the DP reads it from registers)
 
 // LDS layout (byte offsets from the work-group's dynamic LDS) for a graph of up to `ncap` nodes.
-//   persistent for the window: code, alcnt, ink [ncap] u8; rank, n2r [ncap] u16; intail [ncap][4] u16; ring [ncap][3] u16
+//   persistent for the window: code, alcnt, ink [ncap] u8; rank, n2r [ncap] u16; intail [ncap][kSmIn = 8] u16; ring [ncap][kSmRing = 4] u16
 //   per layer:   inc, mark [ncap] u8; rsub, nsub [ncap] u16; desc [ncap] u32; post [256] i16; misc: 32 words (rows of the tied
 //                sinks, wide-row counter, distances of the wide rows); lseq [2][256] u8: the bases of this layer and
 //                (prefetched) of the next one; lqual [256]: this layer's qualities
@@ -78,7 +78,7 @@ __device__ __forceinline__ void sm_fence() { asm volatile("s_waitcnt lgkmcnt(0)"
 // L2 of its XCD is where its atomics execute and where its sc1 loads read)
 __device__ __forceinline__ void sm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Why a window left the kernel (statistics, stats[25 + why]): 1 graph capacity, 2 fifth in-edge, 3 far predecessor, 4 ring,
+// Why a window left the kernel (statistics, stats[25 + why]): 1 graph capacity, 2 ninth in-edge (kSmIn = 8) or a seventeenth wide row, 3 far predecessor, 4 ring,
 // 5 int16 range, 6 layer too long, 7 sink tie, 8 consensus scratch, 9 internal inconsistency (a bug: tests assert it is zero)
 enum : int { kSmCap = 1, kSmInDeg = 2, kSmFar = 3, kSmRingFull = 4, kSmRange = 5, kSmLong = 6, kSmTie = 7, kSmStack = 8, kSmBug = 9 };
 
@@ -1155,6 +1155,7 @@ __global__ __launch_bounds__(64, 3) void poa_window_kernel_small(KParams P) {
             RCN_PHASE_S(6);
         }
         if (why) {
+            sm_drain();                                 // (a bail inside sm_add leaves weight / coverage atomics in flight: the next window zero-fills the same slot words with plain stores)
             // (rare: straight to the counter -- an array indexed by `why` would live in scratch memory)
             if (lane == 0) { *out_len = 0; *out_flags = kFlagOverflow; atomicAdd(&P.stats[25 + (why < 10 ? why : 9)], 1ull); }
         } else ++st_done;

@@ -121,6 +121,12 @@ int rcnh_polisher_polish(rcnh_polisher* p, int drop, const char** fasta, uint64_
 }
 
 double rcnh_polisher_polish_seconds(rcnh_polisher* p) { return p ? p->polisher->polish_seconds() : 0.0; }
+int rcnh_polisher_polish_plan(rcnh_polisher* p, uint32_t* chunks, uint32_t* engines_used) {
+    if (!p) return -1;
+    if (chunks) *chunks = p->polisher->polish_chunks();
+    if (engines_used) *engines_used = p->polisher->polish_engines_used();
+    return 0;
+}
 uint64_t rcnh_polisher_num_windows(rcnh_polisher* p) { return p ? p->polisher->num_windows() : 0; }
 
 void rcnh_polisher_destroy(rcnh_polisher* p) { delete p; }

@@ -1,9 +1,11 @@
 // main.cpp — `racon_hip`: racon's command line (reference src/main.cpp) in front of the
 // MI355X consensus engine.  Same positional arguments, same options and defaults,
 // same FASTA on stdout.  -c/--cudapoa-batches [n] keeps its spelling and now means
-// "HIP engines (batches in flight) per device"; -b and the cudaaligner options are
-// accepted for command-line compatibility and ignored (exact unbanded DP, host
-// pre-alignment).  The consensus stage always runs on the GPU.
+// "HIP engines (batches in flight) per device"; --cudaaligner-batches n > 0 moves the
+// overlap alignment to the device as it does in the reference (src/main.cpp:125-127 ->
+// src/polisher.cpp:137-147); -b and --cudaaligner-band-width are accepted and ignored
+// (the device DP is exact, there is no band to set).  The consensus stage always runs
+// on the GPU.
 #include <getopt.h>
 
 #include <cstdio>
@@ -64,8 +66,12 @@ void help() {
         "        -c, --cudapoa-batches <int>\n"
         "            default: 1\n"
         "            number of MI355X consensus engines per device\n"
-        "        -b, --cuda-banded-alignment / --cudaaligner-batches / --cudaaligner-band-width\n"
-        "            accepted and ignored (exact DP on the GPU, pre-alignment on the host)\n"
+        "        --cudaaligner-batches <int>\n"
+        "            default: 0\n"
+        "            > 0: overlaps without a CIGAR are aligned on the MI355X (exact, same\n"
+        "            paths as the host pre-alignment) and the windows are built there\n"
+        "        -b, --cuda-banded-alignment / --cudaaligner-band-width <int>\n"
+        "            accepted and ignored (the device DP is exact, unbanded)\n"
         "        --version\n"
         "            prints the version number\n"
         "        -h, --help\n"
@@ -83,7 +89,8 @@ int main(int argc, char** argv) {
         {"cudapoa-batches", optional_argument, 0, 'c'}, {"cuda-banded-alignment", no_argument, 0, 'b'},
         {"cudaaligner-batches", required_argument, 0, 10000}, {"cudaaligner-band-width", required_argument, 0, 10001},
         {0, 0, 0, 0}};
-    uint32_t window_length = 500, type = 0, num_threads = 1, hip_batches = 1;
+    uint32_t window_length = 500, type = 0, num_threads = 1, hip_batches = 1, hipaligner_batches = 0, hipaligner_band_width = 0;
+    bool hip_banded_alignment = false;
     double quality_threshold = 10.0, error_threshold = 0.3;
     bool trim = true, drop_unpolished_sequences = true;
     int8_t match = 3, mismatch = -5, gap = -4;
@@ -108,7 +115,9 @@ int main(int argc, char** argv) {
                 if (optarg == nullptr && argv[optind] != nullptr && argv[optind][0] != '-') hip_batches = atoi(argv[optind++]);
                 if (optarg != nullptr) hip_batches = atoi(optarg);
                 break;
-            case 'b': case 10000: case 10001: break;
+            case 'b': hip_banded_alignment = true; break;
+            case 10000: hipaligner_batches = atoi(optarg); break;
+            case 10001: hipaligner_band_width = atoi(optarg); break;
             default: return 1;
         }
     }
@@ -121,7 +130,7 @@ int main(int argc, char** argv) {
     }
     auto polisher = racon::createPolisher(input_paths[0], input_paths[1], input_paths[2],
         type == 0 ? racon::PolisherType::kC : racon::PolisherType::kF, window_length, quality_threshold, error_threshold,
-        trim, match, mismatch, gap, num_threads, hip_batches);
+        trim, match, mismatch, gap, num_threads, hip_batches, hip_banded_alignment, hipaligner_batches, hipaligner_band_width);
     polisher->initialize();
     std::vector<std::unique_ptr<racon::Sequence>> polished_sequences;
     polisher->polish(polished_sequences, drop_unpolished_sequences);

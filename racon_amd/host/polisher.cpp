@@ -87,7 +87,8 @@ std::unique_ptr<Polisher> createPolisher(const std::string& sequences_path, cons
     const std::string& target_path, PolisherType type, uint32_t window_length, double quality_threshold,
     double error_threshold, bool trim, int8_t match, int8_t mismatch, int8_t gap, uint32_t num_threads,
     uint32_t cudapoa_batches, bool cuda_banded_alignment, uint32_t cudaaligner_batches, uint32_t cudaaligner_band_width) {
-    (void)cuda_banded_alignment; (void)cudaaligner_batches; (void)cudaaligner_band_width;
+    // -b / --cudaaligner-band-width: the reference's banded approximations; the DP here is exact at any width
+    (void)cuda_banded_alignment; (void)cudaaligner_band_width;
     if (type != PolisherType::kC && type != PolisherType::kF) fatal("[racon::createPolisher] error: invalid polisher type!");
     if (window_length == 0) fatal("[racon::createPolisher] error: invalid window length!");
     const std::string seq_ext = "(valid extensions: .fasta, .fasta.gz, .fna, .fna.gz, .fa, .fa.gz, .fastq, .fastq.gz, .fq, .fq.gz)!";
@@ -100,8 +101,15 @@ std::unique_ptr<Polisher> createPolisher(const std::string& sequences_path, cons
               "(valid extensions: .mhap, .mhap.gz, .paf, .paf.gz, .sam, .sam.gz)!");
     if (!io::is_fasta_path(target_path) && !io::is_fastq_path(target_path))
         fatal("[racon::createPolisher] error: file " + target_path + " has unsupported format extension " + seq_ext);
-    return std::unique_ptr<Polisher>(new Polisher(sequences_path, overlaps_path, target_path, type, window_length,
+    std::unique_ptr<Polisher> polisher(new Polisher(sequences_path, overlaps_path, target_path, type, window_length,
         quality_threshold, error_threshold, trim, match, mismatch, gap, num_threads, cudapoa_batches));
+    // --cudaaligner-batches n > 0: overlap alignment on the device, as in the reference (src/main.cpp:125-127 ->
+    // src/polisher.cpp:137-147 -> CUDAPolisher::find_overlap_breaking_points, src/cuda/cudapolisher.cpp:74-214): overlaps
+    // without a CIGAR are aligned in HBM by the byte-exact pair aligner and the windows are cut there
+    // (rcn_engine_build_windows_from_pairs); a file whose overlaps carry CIGARs has nothing to align and takes the
+    // device's CIGAR walk.  Same FASTA either way (tests/test_cli_e2e.py).
+    if (cudaaligner_batches > 0) polisher->device_windows(true, false, true);
+    return polisher;
 }
 
 Polisher::Polisher(const std::string& sequences_path, const std::string& overlaps_path, const std::string& target_path,
@@ -421,13 +429,18 @@ void Polisher::plan_chunks() {
     // engines, 108 / 104 / 98 / 95 / 95 with three, 116 / 113 / 96 / 95 / 94 with four: fewer, larger chunks -- every chunk's launch
     // has a tail of its own -- and the number of engines beyond two does not matter
     uint64_t target = std::max(kMinChunkWindows, std::min(kMaxChunkWindows, (2 * nw + 3 * n_engines - 1) / (3 * n_engines)));
-    if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) { if (atoi(cw) > 0) target = static_cast<uint64_t>(atoi(cw)); }   // tests: many small chunks
+    // (at least 64 MB of bases too -- what 2048 windows of 500 bases at 30x hold: short-read windows are a third of that,
+    //  and a chunk's fixed costs -- packing before its first launch, its launch tail -- do not shrink with them:
+    //  5000 windows of 150-base reads went as 2048 + 2048 + 904, the last chunk alone on the device for 6 of 23 ms.
+    //  But never so much that an engine is left without a chunk: the floor is capped at an even share of the job.)
+    uint64_t total_bases = 0;
+    for (uint64_t i = 0; i < nw; ++i) total_bases += bases[i];
+    uint64_t floor_bases = std::min<uint64_t>(kMinChunkBases, total_bases / n_engines);
+    // RACON_HIP_CHUNK_WINDOWS=n (tests, sweeps): chunks of exactly n windows, no floor
+    if (const char* cw = getenv("RACON_HIP_CHUNK_WINDOWS")) { if (atoi(cw) > 0) { target = static_cast<uint64_t>(atoi(cw)); floor_bases = 0; } }
     for (uint64_t a = 0; a < nw;) {
         uint64_t b = a, sum = 0;
-        // (at least 64 MB of bases too -- what 2048 windows of 500 bases at 30x hold: short-read windows are a third of that,
-        //  and a chunk's fixed costs -- packing before its first launch, its launch tail -- do not shrink with them:
-        //  5000 windows of 150-base reads went as 2048 + 2048 + 904, the last chunk alone on the device for 6 of 23 ms)
-        while (b < nw && (b - a < target || sum < kMinChunkBases) && b - a < 4 * kMaxChunkWindows && sum < kMaxChunkBases) sum += bases[rank_[b++]];
+        while (b < nw && (b - a < target || sum < floor_bases) && b - a < 4 * kMaxChunkWindows && sum < kMaxChunkBases) sum += bases[rank_[b++]];
         chunks_.emplace_back(a, b); a = b;
     }
 }
@@ -723,6 +736,7 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
     const uint32_t n_workers = static_cast<uint32_t>(std::min<size_t>(n_engines, std::max<size_t>(1, chunks.size())));
     std::atomic<size_t> cursor{n_workers};          // engine k starts with chunk k (what reserve_for_windows sized it for)
     std::vector<std::exception_ptr> errors(n_engines);
+    std::vector<uint32_t> taken(n_engines, 0);      // chunks each engine took (rcnh_polisher_polish_plan: the tests assert the plan)
     auto worker = [&](uint32_t k) {
         FatalThrowsScope scope;
         try {
@@ -761,6 +775,7 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
                     }
                 }
                 if (!done) polish_range(chunks[ci].first, chunks[ci].second);
+                ++taken[k];
                 const double t_c = seconds_since(polish_begin);
                 if (timing) fprintf(stderr, "[racon::Polisher::polish] timing: engine %u chunk %zu (%lu windows): start %.1f ms, refs %.1f, engine done %.1f (kernel %.1f), stored %.1f\n",
                                     k, ci, static_cast<unsigned long>(chunks[ci].second - chunks[ci].first), 1e3 * t_a, 1e3 * t_b, 1e3 * t_c, engine->last_kernel_ms(), 1e3 * seconds_since(polish_begin));
@@ -776,6 +791,9 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         }
     }
     for (const auto& e : errors) if (e) fatal_from(e);
+    polish_chunks_ = static_cast<uint32_t>(chunks.size());
+    polish_engines_used_ = 0;
+    for (uint32_t n : taken) polish_engines_used_ += n > 0 ? 1 : 0;
     planned_refs_.clear();                          // (borrowed pointers into the windows assemble() is about to release)
 
     for (uint64_t i = 0; i < nw; ++i)

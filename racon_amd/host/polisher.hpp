@@ -145,6 +145,7 @@ protected:
     std::string engines_error_;     // what went wrong in the warm-up thread (reported by polish())
     int32_t n_devices_ = -1;
     double polish_seconds_ = 0;     // the Logger-bracketed interval of the last polish()
+    uint32_t polish_chunks_ = 0, polish_engines_used_ = 0;   // chunks / engines that took one in the last polish() (host-built windows)
     void create_engines();          // (warm-up thread, or polish() when the warm-up was switched off)
     void reserve_for_windows();     // end of initialize(): the arenas sized for the windows that were built
     // polish()'s work list: windows ranked deepest first, cut into chunks (planned once, by reserve_for_windows or polish)
@@ -154,6 +155,8 @@ protected:
     std::vector<WindowRefs> planned_refs_;                   // the pointer tables of the first chunks (built for the dry run, used by polish())
 public:
     double polish_seconds() const { return polish_seconds_; }
+    uint32_t polish_chunks() const { return polish_chunks_; }
+    uint32_t polish_engines_used() const { return polish_engines_used_; }
 };
 
 }  // namespace racon

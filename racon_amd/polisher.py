@@ -29,7 +29,8 @@ class RcnhParams(C.Structure):
 
 EXPORTS = ["rcnh_polisher_create", "rcnh_polisher_initialize", "rcnh_polisher_windows", "rcnh_polisher_assemble",
            "rcnh_polisher_polish", "rcnh_polisher_destroy", "rcnh_align_cigar", "rcnh_edit_distance", "rcnh_free",
-           "rcnh_last_error", "rcnh_polisher_polish_seconds", "rcnh_polisher_num_windows", "rcnh_polisher_pairs"]
+           "rcnh_last_error", "rcnh_polisher_polish_seconds", "rcnh_polisher_num_windows", "rcnh_polisher_pairs",
+           "rcnh_polisher_polish_plan"]
 
 _lib = None
 
@@ -57,6 +58,7 @@ def load_library():
     lib.rcnh_polisher_polish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.rcnh_polisher_polish_seconds.argtypes = [C.c_void_p]
     lib.rcnh_polisher_polish_seconds.restype = C.c_double
+    lib.rcnh_polisher_polish_plan.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.rcnh_polisher_num_windows.argtypes = [C.c_void_p]
     lib.rcnh_polisher_num_windows.restype = C.c_uint64
     lib.rcnh_polisher_destroy.argtypes = [C.c_void_p]
@@ -192,6 +194,12 @@ class Polisher:
     def polish_seconds(self) -> float:
         """The Logger-bracketed interval of the last polish() (reference src/polisher.cpp:493 -> :539-543)."""
         return float(self.lib.rcnh_polisher_polish_seconds(self.h))
+
+    def polish_plan(self):
+        """(chunks, engines that took at least one) of the last polish() on host-built windows."""
+        c, e = C.c_uint32(), C.c_uint32()
+        _check(self.lib.rcnh_polisher_polish_plan(self.h, C.byref(c), C.byref(e)))
+        return int(c.value), int(e.value)
 
     def num_windows(self) -> int:
         return int(self.lib.rcnh_polisher_num_windows(self.h))

@@ -119,9 +119,49 @@ def test_cli_on_three_logical_devices(P, oracle, data, ovl, mode):
     env = dict(os.environ, RACON_HIP_FAKE_DEVICES="3", RACON_HIP_CHUNK_WINDOWS="7")
     if mode != "0":
         env["RACON_HIP_DEVICE_WINDOWS"] = mode
-    out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
-    assert out == ref
+    env["RACON_HIP_TIMING"] = "1"
+    run = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.stdout == ref
+    if mode == "0":
+        # RACON_HIP_CHUNK_WINDOWS is an exact window count (no byte floor): many chunks, and more than one engine took some
+        import re
+        took = re.findall(rb"timing: engine (\d+) chunk (\d+) \((\d+) windows\)", run.stderr)
+        assert len(took) >= 3 and all(int(n) <= 7 for _, _, n in took), run.stderr[-2000:]
+        assert len({e for e, _, _ in took}) >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,ovl,aligner_on_device", [
+    (["--cudaaligner-batches", "1"], "paf", True),        # reference src/main.cpp:125-127 -> src/polisher.cpp:137-147
+    (["--cudaaligner-batches", "2"], "sam", False),       # CIGARs in the file: nothing to align, the device walks them
+    (["--cudaaligner-batches", "0"], "paf", False),       # 0 = the reference's default: host pre-alignment
+    (["-b"], "paf", False),                               # banded approximation: accepted, ignored (exact DP)
+    (["--cudaaligner-band-width", "128", "--cudaaligner-batches", "1"], "paf", True),
+    (["-c", "2", "--cudaaligner-batches", "1", "-b"], "paf", True),
+])
+def test_cli_reference_cuda_flags(P, oracle, data, flags, ovl, aligner_on_device):
+    """The reference's CUDA options keep the reference's meaning (src/main.cpp:117-131): `--cudaaligner-batches n > 0` moves
+    the overlap alignment to the device (the byte-exact pair aligner + window construction in HBM), `-c` is engines per
+    device, `-b` / `--cudaaligner-band-width` select approximations that do not exist here.  FASTA identical in every case."""
+    paths, _ = data
+    ref, _ = _oracle_fasta(P, oracle, paths, ovl)
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    env = {k: v for k, v in os.environ.items() if k != "RACON_HIP_DEVICE_WINDOWS"}
+    run = subprocess.run([exe, "-t", "4"] + flags + [paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.stdout == ref
+    assert (b"left the overlaps to the device aligner" in run.stderr) == aligner_on_device, run.stderr[-1500:]
+
+
+def test_cli_help_names_the_aligner_flag():
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    out = subprocess.run([exe, "--help"], check=True, stdout=subprocess.PIPE).stdout
+    assert b"--cudaaligner-batches <int>" in out and b"--cudaaligner-band-width" in out and b"-c, --cudapoa-batches" in out
+    # the flags parse (and the factory errors come after them, reference test/racon_test.cpp:60-84)
+    run = subprocess.run([exe, "--cudaaligner-batches", "1", "-b", "--cudaaligner-band-width", "64", "a.txt", "b.paf", "c.fasta"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode != 0 and b"unsupported format extension" in run.stderr
 
 
 @pytest.mark.gpu

@@ -147,6 +147,7 @@ def test_polish_interval_chunks_and_warmup(files, oracle, monkeypatch):
     p.close()
     p = make(); p.initialize()
     assert p.polish(True) == ref                                       # one chunk, engines from the warm-up thread
+    assert p.polish_plan() == (1, 1)
     t_warm = p.polish_seconds()
     assert 0.0 < t_warm < 5.0
     p.close()
@@ -154,6 +155,7 @@ def test_polish_interval_chunks_and_warmup(files, oracle, monkeypatch):
         monkeypatch.setenv("RACON_HIP_CHUNK_WINDOWS", chunk)
         p = make(); p.initialize()
         assert p.polish(True) == ref, chunk
+        assert p.polish_plan() == ((1400 + int(chunk) - 1) // int(chunk), 2), chunk      # RACON_HIP_CHUNK_WINDOWS is exact: no byte floor
         p.close()
     monkeypatch.delenv("RACON_HIP_CHUNK_WINDOWS")
     monkeypatch.setenv("RACON_HIP_NO_WARMUP", "1")                      # engines created inside polish() (the round-2 product)

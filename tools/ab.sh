@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of environment-switched kernel variants on one box: tools/ab.sh <tag> <reps> "<envA>" "<envB>" ...
 # Alternates the variants (launch times differ by a few % between processes), prints kernel ms / windows/s per run.
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 set -u
 TAG=$1; REPS=$2; shift 2
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"

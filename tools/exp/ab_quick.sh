@@ -1,5 +1,6 @@
 #!/bin/bash
 # bench A/B of the default launch against RCN_NO_CODE_WAVE=1, then all 2000 windows against the oracle
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 B="python bench.py --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg"
 run() { echo "== $1"; shift; env "$@" $B 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print('%.0f windows/s  step %.2f ms  launches %s  frac %.3f  redone %s code waves %s' % (j['value'], r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], r['frac'], r['band_redone'], r.get('code_wave_alignments')))"; }
 run "code waves off" RCN_NO_CODE_WAVE=1

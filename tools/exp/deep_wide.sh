@@ -1,6 +1,7 @@
 #!/bin/bash
 # Experiment: the deep launch of the split (64 deepest windows, one per CU) on the four-wave DP pipeline over full rows
 # (KParams::heavy_ns = 1 for that launch only) instead of the banded one-wave DP.
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 OUT=gpurun_out/${1:-deepwide}; mkdir -p $OUT
 B="python bench.py --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg"
 run() { echo "== $1"; shift; env "$@" $B 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print('%.0f windows/s  step %.2f ms  launches %s  frac %.3f  split %s' % (j['value'], r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], r['frac'], r['split_launch']))"; }

@@ -1,5 +1,6 @@
 #!/bin/bash
 # split launch: how many CUs (= windows, one per CU) the deep launch should get
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 B="python bench.py --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg"
 run() { echo "== $1"; shift; env "$@" $B 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print('%.0f windows/s  step %.2f ms  launches %s  frac %.3f' % (j['value'], r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], r['frac']))"; }
 run "no split" RCN_SPLIT=0

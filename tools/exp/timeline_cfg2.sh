@@ -1,5 +1,6 @@
 #!/bin/bash
 # host timeline of the product's polish() on cfg2-shaped files and on one GPU's share of cfg3 (third run of each)
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 python - <<'PY'
 import os, sys
 sys.path.insert(0, os.getcwd())

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 set -u
 OUT=gpurun_out/${1:-r02h}; mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -3,6 +3,7 @@
 # Usage (from the repo root on the GPU box):  bash tools/gpu_round.sh [tag] [what...]
 #   what: tests bench prof pmc build winprof   (default: tests bench prof pmc build)
 # Everything lands under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 set -u
 TAG=${1:-r01}; shift || true
 WHAT=${*:-tests bench prof pmc build}

@@ -2,6 +2,7 @@
 # Round-3 GPU visit (see tools/gpu_round.sh for the profile passes): parity tests, the bench line with the product legs
 # and the CPU sweep, the split-launch A/B, the host-core probe.
 # Usage: bash tools/gpu_round3.sh <tag> [what...]   what: tests bench split probe debug prof pmc big
+export RCN_EXPERIMENT=1   # engine.hip read_knobs: RCN_* switches are ignored without it
 set -u
 TAG=${1:-r03a}; shift || true
 WHAT=${*:-tests bench split probe debug}
