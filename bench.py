@@ -85,6 +85,52 @@ def cpu_limits():
     return out
 
 
+def physical_cores():
+    """Physical cores of the box (unique (package, core) pairs of /proc/cpuinfo), whatever the lease lets this process use."""
+    try:
+        cores, pkg = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pkg = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cores.add((pkg, line.split(":", 1)[1].strip()))
+        return len(cores) or None
+    except Exception:
+        return None
+
+
+def rccl_selftest(eng, batch, local_rank):
+    """N = 1: the RCCL (`nccl`) code path of the multi-GPU line on a ONE-rank process group -- init, the size all-reduce and slab
+    gather of racon_amd.distributed.polish_sharded (device tensors), the timing MAX reduction and the barrier -- so that the first
+    run on several GPUs is not the first execution of that code.  Untimed; the result goes into the line."""
+    import datetime
+    import socket
+    from racon_amd import distributed as rd
+    t0 = time.perf_counter()
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
+        sub = batch.select(range(min(256, batch.n_windows)))
+        plain = eng.consensus(sub)
+        forced = rd.polish_sharded(sub, eng.consensus, 0, 1, device=torch.device("cuda", local_rank), force_exchange=True)
+        t = torch.tensor([2.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        ok = forced.consensus == plain.consensus and bool((forced.polished == plain.polished).all()) and float(t.item()) == 2.5
+        backend = dist.get_backend()
+        dist.destroy_process_group()
+        return {"ok": bool(ok), "backend": backend, "world": 1, "windows": sub.n_windows, "seconds": round(time.perf_counter() - t0, 2),
+                "what": "one-rank RCCL group: polish_sharded(force_exchange) all-reduce + gather on device tensors, MAX reduction, barrier"}
+    except Exception as e:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        return {"ok": False, "error": repr(e)[:300]}
+
+
 def product_files(contig, coverage, seed, workers, short_reads=False):
     """The workload as racon input files in the scratch cache (generated in forked workers: call before HIP exists).
     `short_reads`: the cfg4 shape (150-base reads, 0.3 % substitutions, 0.05 % insertions / deletions, phred 30)."""
@@ -98,7 +144,7 @@ def product_files(contig, coverage, seed, workers, short_reads=False):
             simulate_window_files(d, contig, coverage, 10000, seed=seed, workers=workers)
         open(os.path.join(d, ".done"), "w").close()
     return {"targets": os.path.join(d, "targets.fasta"), "reads": os.path.join(d, "reads.fastq"), "sam": os.path.join(d, "overlaps.sam"),
-            "contig": contig, "files_s": round(time.perf_counter() - t0, 1)}
+            "paf": os.path.join(d, "overlaps.paf"), "contig": contig, "files_s": round(time.perf_counter() - t0, 1)}
 
 
 def product_polish(paths, window, scores, threads, expect=None, reps=2, batches=1):
@@ -130,19 +176,28 @@ def product_polish(paths, window, scores, threads, expect=None, reps=2, batches=
                     % (paths["contig"], threads, reps)}
 
 
-def product_cli(paths, window, scores, threads, expect=None, reps=2, batches=1):
+def product_cli(paths, window, scores, threads, expect=None, reps=2, batches=1, overlaps="sam", flags=(), env_add=None):
     """The same through the drop-in BINARY (racon_amd/host/racon_hip, the reference's command line): the interval is the
-    Logger's own line, "[racon::Polisher::polish] generated consensus <s> s" (reference src/polisher.cpp:539-543)."""
+    Logger's own line, "[racon::Polisher::polish] generated consensus <s> s" (reference src/polisher.cpp:539-543).
+    `overlaps`: which overlap file ("sam": CIGARs in the file; "paf": none, the overlaps are aligned first -- reference
+    src/overlap.cpp:205-224); `flags` / `env_add`: the device-side modes (--cudaaligner-batches 1 = alignment, CIGAR
+    walk and window construction in HBM; RACON_HIP_DEVICE_WINDOWS=2 = CIGAR walk and window construction in HBM)."""
+    import hashlib
     import re
     import subprocess
     m, x, g = scores
     exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
-    best, runs, same = None, [], None
+    best, runs, same, md5, best_wall = None, [], None, None, None
+    env = dict(os.environ)
+    env.pop("RACON_HIP_DEVICE_WINDOWS", None)
+    env.update(env_add or {})
     for _ in range(reps):
         t0 = time.perf_counter()
-        r = subprocess.run([exe, "-t", str(threads), "-w", str(window), "-m", str(m), "-x", str(x), "-g", str(g), "-c", str(batches),
-                            paths["reads"], paths["sam"], paths["targets"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r = subprocess.run([exe, "-t", str(threads), "-w", str(window), "-m", str(m), "-x", str(x), "-g", str(g), "-c", str(batches)] + list(flags) +
+                           [paths["reads"], paths[overlaps], paths["targets"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         wall = time.perf_counter() - t0
+        best_wall = wall if best_wall is None else min(best_wall, wall)
+        md5 = hashlib.md5(r.stdout).hexdigest()
         mt = re.search(r"\[racon::Polisher::polish\] generated consensus (\d+\.\d+) s", r.stderr.decode(errors="replace"))
         if r.returncode != 0 or not mt:
             return {"error": "racon_hip exit %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-200:])}
@@ -152,7 +207,8 @@ def product_cli(paths, window, scores, threads, expect=None, reps=2, batches=1):
         if expect is not None:
             same = b"".join(r.stdout.split(b"\n")[1::2]) == expect
     nw = sum((int(l) + window - 1) // window for l in [len(x) for x in open(paths["targets"], "rb").read().split(b"\n")[1::2]])
-    return {"windows": nw, "polish_s": best, "windows_per_s": nw / best, "runs": runs, "fasta_matches_kernel_leg": same}
+    return {"windows": nw, "polish_s": best, "windows_per_s": nw / best, "wall_s": round(best_wall, 3), "windows_per_s_whole_binary": nw / best_wall,
+            "runs": runs, "fasta_matches_kernel_leg": same, "fasta_md5": md5}
 
 
 def product_multi_device(paths, window, scores, threads, n_devices, fake=False):
@@ -222,6 +278,8 @@ def main():
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the untimed pack + upload + run leg (value_incl_upload): the rocprofv3 passes "
                                                                  "use it so that every traced launch of the kernel is one of the timed whole-batch launches")
     ap.add_argument("--no-product", action="store_true", help="skip the product leg (files -> Polisher::polish)")
+    ap.add_argument("--no-device-modes", action="store_true", help="product leg: skip the device-side construction / alignment modes (SURVEY 8(f))")
+    ap.add_argument("--no-rccl-selftest", action="store_true", help="N = 1: skip the one-rank RCCL exchange self-test (untimed)")
     ap.add_argument("--product-contig", type=int, default=6_250_000, help="second product job: contig bp (one GPU's share of cfg3)")
     ap.add_argument("--product-batches", type=int, default=1, help="-c of the product legs: batch objects (pairs of engines) per device")
     ap.add_argument("--verify", action="store_true", help="also check every window against the oracle (untimed)")
@@ -287,10 +345,14 @@ def main():
         pmulti = product_files(a.product_multi_contig or min(50_000_000, 2_000_000 * world), a.coverage, 20260922, workers)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (an explicit, long timeout: rank 0 runs two racon_hip jobs of the product leg while the other ranks sit at the last
+        #  barrier -- the default watchdog of the nccl backend, 10 min, must not be what ends a cfg3-sized product leg)
+        import datetime
+        tmo = datetime.timedelta(minutes=90)
         if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(a.dist_backend)
+            dist.init_process_group(a.dist_backend, timeout=tmo)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     if a.dist_backend != "nccl":
         local_rank %= torch.cuda.device_count()          # several test ranks on one GPU
@@ -426,6 +488,27 @@ def main():
                          "small_windows": st["n_small"], "small_bailed": st["n_small_bailed"], "small_bail_why": st["small_bail_why"],
                          "small_work": dict(zip(("alignments", "dp_rows", "subgraph_chunks", "traceback_boxes", "traceback_regathers", "subgraph_intervals"), st["small_work"]))},
         }
+        if world > 1:
+            # A 1 -> N curve drawn from `value` alone would mix workloads: N = 1 is cfg2 (2000 windows, resident all at once: the batch
+            # ends with its deepest window's chain), N > 1 is cfg3 / N per rank (12 500 ... 50 000 windows: the long-queue rate).  What the
+            # N-GPU number has to be read against is THE SAME JOB on one GPU (cfg3 whole: `bench.py --config cfg3`), printed here.
+            out["per_gpu_value"] = out["value"] / world
+            n1 = {"workload": "cfg3 whole (50 Mbp, 100 000 windows) on ONE GPU: `python bench.py --config cfg3`", "measured_in_this_run": False}
+            for f in ("profiles/r05/bench_cfg3_1gpu.json", "profiles/r03/h_bench_cfg3_1gpu.json"):
+                try:
+                    j1 = json.load(open(os.path.join(ROOT, f)))
+                    n1.update({"value": j1["value"], "ms_per_step": j1["ms_per_step"], "source": f})
+                    break
+                except Exception:
+                    continue
+            if scaling == "strong" and "value" in n1:
+                n1["speedup_over_same_job_on_one_gpu"] = out["value"] / n1["value"]
+                n1["efficiency_vs_same_job"] = out["value"] / n1["value"] / world
+            out["n1_same_job"] = n1
+            out["scaling_note"] = ("N > 1 polishes cfg3 (50 Mbp / N per rank); the driver's N = 1 line is cfg2 (1 Mbp). value(N) / value(1) therefore mixes "
+                                   "a batch-size effect into the curve: use n1_same_job for the one-GPU reference of THIS job")
+        elif not a.no_rccl_selftest and not a.no_upload_leg and a.dist_backend == "nccl":
+            out["rccl_selftest"] = rccl_selftest(eng, batch, local_rank)
         if do_product:
             # the product on the same workload (same seed -> the same windows, tests/test_synth_files.py)
             try:
@@ -437,6 +520,24 @@ def main():
                                                                  reps=1 if name == "cfg3" else 2, batches=a.product_batches)
                     out["product_polish"][name]["cli"] = product_cli(paths, pwindow, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
                                                                      reps=1 if name == "cfg3" else 2, batches=a.product_batches)
+                    if a.no_device_modes or name == "cfg3":
+                        continue
+                    # SURVEY 8(f) rows 1, 2, 4 on the interval they were built for (reference: CUDAPolisher::find_overlap_breaking_points
+                    # sits inside the same timed program, src/cuda/cudapolisher.cpp:74-214):
+                    #   device_cigars  SAM, RACON_HIP_DEVICE_WINDOWS=2: CIGAR walk + window construction in HBM (rcn_engine_build_windows_from_cigars)
+                    #   device_align   PAF, --cudaaligner-batches 1: pairwise alignment + CIGAR walk + construction in HBM (rcn_engine_build_windows_from_pairs)
+                    #   host_align     PAF, the default: the host's edlib-equivalent inside initialize(), then the host-built path
+                    # (PAF and SAM inputs differ in their alignments, hence in their windows: the PAF legs are compared with each other)
+                    ex = b"".join(res.consensus) if same_windows else None
+                    dm = {"device_cigars": product_cli(paths, pwindow, (m, x, g), th, expect=ex, reps=2, batches=a.product_batches, env_add={"RACON_HIP_DEVICE_WINDOWS": "2"})}
+                    dm["device_cigars"]["fasta_matches_host_built"] = dm["device_cigars"].get("fasta_md5") == out["product_polish"][name]["cli"].get("fasta_md5")
+                    if os.path.exists(paths.get("paf", "")):
+                        dm["device_align"] = product_cli(paths, pwindow, (m, x, g), th, reps=2, batches=a.product_batches, overlaps="paf", flags=("--cudaaligner-batches", "1"))
+                        dm["host_align"] = product_cli(paths, pwindow, (m, x, g), th, reps=1, batches=a.product_batches, overlaps="paf")
+                        dm["device_align"]["fasta_matches_host_aligner"] = dm["device_align"].get("fasta_md5") == dm["host_align"].get("fasta_md5")
+                        if dm["device_align"].get("wall_s") and dm["host_align"].get("wall_s"):
+                            dm["device_align"]["whole_binary_speedup_over_host_aligner"] = dm["host_align"]["wall_s"] / dm["device_align"]["wall_s"]
+                    out["product_polish"][name]["device_modes"] = dm
                 out["value_product_polish"] = out["product_polish"][pfiles[0][0]]["windows_per_s"]
                 if "cfg3_share" in out["product_polish"]:
                     out["value_product_polish_12k"] = out["product_polish"]["cfg3_share"]["windows_per_s"]
@@ -491,6 +592,20 @@ def main():
                                              % (cb.n_windows, cores, ncpu, lim.get("cgroup_cpus"), best_dt, n_s, min(ncpu, cores), n_s / dts),
                                    "thread_sweep_windows_per_s": sweep, "host": lim,
                                    "matches_gpu": bool(ok)}
+            # what "all host cores, same box" would be: the per-thread rate from the part of the sweep the lease can actually run
+            # (threads <= the cgroup quota), times the box's physical cores -- an extrapolation, said as such
+            quota = lim.get("cgroup_cpus") or ncpu
+            under = {int(t): v for t, v in sweep.items() if int(t) <= quota + 0.5} or {min(int(t) for t in sweep): sweep[str(min(int(t) for t in sweep))]}
+            t_q = max(under)
+            per_thread = under[t_q] / t_q
+            phys = physical_cores()
+            cb_ = out["cpu_baseline"]
+            cb_["per_thread_windows_per_s"] = per_thread
+            cb_["per_thread_from"] = "%d threads (<= the %.0f-CPU quota): %.0f windows/s" % (t_q, quota, under[t_q])
+            cb_["physical_cores"] = phys
+            cb_["extrapolated_all_cores"] = per_thread * phys if phys else None
+            cb_["note"] = ("value = measured on the CPUs this process may use (cgroup quota %s of %d logical CPUs); extrapolated_all_cores = "
+                           "per_thread_windows_per_s x physical_cores, what the whole box would give at perfect scaling (not measured)" % (lim.get("cgroup_cpus"), ncpu))
         # THE METRIC AS SURVEY.md 8(d) DEFINES IT, first class: windows/s on the polish() interval of the product (files ->
         # Polisher; in-process and through the binary), next to the resident-input kernel leg (`value`), each against the CPU
         # number of this line
@@ -504,6 +619,11 @@ def main():
                               "vs_cpu_baseline_cli": (out["value_product_polish_cli"] / cpu_v) if (cpu_v and out.get("value_product_polish_cli")) else None}
         if cpu_v:
             out["cpu_baseline"]["gpu_kernel_leg_over_cpu"] = out["value"] / cpu_v
+            allc = out["cpu_baseline"].get("extrapolated_all_cores")
+            if allc:
+                out["cpu_baseline"]["gpu_kernel_leg_over_cpu_all_cores_extrapolated"] = out["value"] / allc
+                if "product" in out:
+                    out["product"]["vs_cpu_baseline_all_cores_extrapolated"] = out["product"]["value"] / allc
         if a.verify:
             from oracle import oracle_lib
             ref = oracle_lib.consensus(batch, m, x, g, True, 0, simd=True)

@@ -18,7 +18,7 @@ from .batch import ConsensusResult, WindowBatch
 
 
 def polish_sharded(batch: WindowBatch, consensus_fn: Callable[[WindowBatch], ConsensusResult], rank: int, world: int,
-                   device: Optional[torch.device] = None) -> Optional[ConsensusResult]:
+                   device: Optional[torch.device] = None, force_exchange: bool = False) -> Optional[ConsensusResult]:
     """Every rank holds `batch` (or can build it); rank r polishes shard r with
     `consensus_fn` (the HIP engine in production) and rank 0 returns the
     assembled result in window order (the other ranks return None).
@@ -26,10 +26,13 @@ def polish_sharded(batch: WindowBatch, consensus_fn: Callable[[WindowBatch], Con
     The one exchange step: a 16-byte all-reduce (MAX) so that all ranks agree on the slab size, then ONE gather of
     equal padded slabs to rank 0 ({count, bytes, lengths, flags} as int64 + the consensus bytes) -- rank 0's links
     carry (world - 1) slabs, nobody else receives anything (reference analogue: results of every device's batches end
-    up in the one host process, src/cuda/cudapolisher.cpp:305-308)."""
+    up in the one host process, src/cuda/cudapolisher.cpp:305-308).
+
+    `force_exchange`: run the all-reduce and the gather even when world == 1 (a one-rank process group) -- the RCCL code
+    path on a one-GPU box: tests/test_gpu_fullsize.py::test_one_rank_rccl_exchange, bench.py's `rccl_selftest`."""
     sub, idx = batch.shard(rank, world)
     res = consensus_fn(sub)
-    if world == 1:
+    if world == 1 and not force_exchange:
         return res
     dev = device or torch.device("cpu")
     n = len(res.consensus)

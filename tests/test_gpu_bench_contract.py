@@ -38,6 +38,12 @@ def test_bench_single_rank_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "windows/s" and c["sample"]
     assert c["matches_gpu"] is True and max(c["thread_sweep_windows_per_s"].values()) == c["value"]
     assert c["host"]["sched_affinity"] >= 1 and "cgroup_cpus" in c["host"]          # what "all host cores" is on this box
+    # ... and what the whole box would be worth: per-thread rate from the part of the sweep the lease can run x physical cores
+    assert c["per_thread_windows_per_s"] > 0 and c["physical_cores"] >= 1
+    assert abs(c["extrapolated_all_cores"] - c["per_thread_windows_per_s"] * c["physical_cores"]) < 1e-6 * c["extrapolated_all_cores"]
+    assert abs(c["gpu_kernel_leg_over_cpu_all_cores_extrapolated"] - j["value"] / c["extrapolated_all_cores"]) < 1e-9 * j["value"]
+    # the RCCL code path of the multi-GPU line, exercised on a one-rank group (untimed)
+    assert j["rccl_selftest"]["ok"] is True and j["rccl_selftest"]["backend"] == "nccl", j["rccl_selftest"]
     # the upload-inclusive rate (pack + H2D + kernel + D2H per step) is reported next to `value`, never instead of it
     assert 0 < j["value_incl_upload"] <= j["value"] * 1.05 and j["ms_per_step_incl_upload"] > 0
 
@@ -55,6 +61,9 @@ def test_bench_two_ranks_on_one_gpu():
     pm = j["product_multi_device"]
     assert pm["devices"] == 2 and pm["fasta_identical"] is True and pm["all_devices"]["windows"] == 600, pm
     assert j["product"]["value"] == pm["all_devices"]["windows_per_s"]
+    # the curve cannot read as super-linear: per-GPU value and the one-GPU reference of the SAME job are in the line
+    assert abs(j["per_gpu_value"] - j["value"] / 2) < 1e-9 * j["value"] and "n1_same_job" in j and "scaling_note" in j
+    assert j["n1_same_job"]["measured_in_this_run"] is False and j["n1_same_job"].get("value", 0) > 0
 
 
 def test_gpus_flag_spawns_its_ranks_or_refuses():
@@ -95,3 +104,9 @@ def test_bench_product_legs_on_the_default_workload():
     assert j["product"]["value"] == j["value_product_polish"] and j["product"]["value_cli"] == p["cli"]["windows_per_s"]
     assert 0 < j["product"]["fraction_of_kernel_leg"] <= 1.05
     assert j["config"]["windows_per_gpu"] == 2000 and "cfg2" in j["config"]["workload"]
+    # SURVEY 8(f) rows on the interval they were built for: CIGAR walk + construction in HBM (SAM), alignment + walk + construction
+    # in HBM (PAF, --cudaaligner-batches 1) against the host aligner on the same PAF
+    dm = p["device_modes"]
+    assert dm["device_cigars"]["fasta_matches_kernel_leg"] is True and dm["device_cigars"]["fasta_matches_host_built"] is True
+    assert dm["device_align"]["fasta_matches_host_aligner"] is True and dm["device_align"]["windows"] == dm["host_align"]["windows"] == 2000
+    assert dm["device_align"]["wall_s"] < dm["host_align"]["wall_s"]

@@ -172,6 +172,49 @@ def test_two_ranks_two_gpus_rccl_gather():
     assert n == b.n_windows and digest == _digest(one.consensus)
 
 
+def _nccl_one_rank_worker(port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from racon_amd import distributed as rd
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(minutes=10))
+    b = simulate_windows(100_000, 500, 30.0, 10000, seed=20260922)
+    eng = HipEngine(3, -5, -4, True, device=0)
+    out = rd.polish_sharded(b, eng.consensus, 0, 1, device=torch.device("cuda", 0), force_exchange=True)
+    t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)            # bench.py's timing reduction
+    dist.barrier()
+    q.put((len(out.consensus), _digest(out.consensus), float(t.item()), dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_exchange():
+    """The RCCL (`nccl`) code path on the one-GPU box: a ONE-rank process group, and through it the exchange step of
+    racon_amd.distributed.polish_sharded (size all-reduce on a device tensor, slab gather to rank 0, decode) plus bench.py's
+    MAX reduction and barrier -- so that the first multi-GPU run is not the first execution of that code (the two-GPU twin
+    above can only skip here).  Reference: results of every device end up in one host process, src/cuda/cudapolisher.cpp:228-240."""
+    import socket
+    import torch.multiprocessing as mp
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(port, q))
+    p.start()
+    n, digest, red, backend = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0 and backend == "nccl" and red == 1.5
+    b = simulate_windows(100_000, 500, 30.0, 10000, seed=20260922)
+    one = HipEngine(3, -5, -4, True).consensus(b)
+    assert n == b.n_windows and digest == _digest(one.consensus)
+
+
 def _gloo_hip_worker(rank, world, port, q):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

@@ -56,6 +56,34 @@ def test_two_rank_gather_gloo():
     assert same and flags
 
 
+def _one_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    from racon_amd import distributed as rd
+    from oracle import oracle_lib
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    b = simulate_windows(8000, 500, 10, 3000, seed=5)
+    fn = lambda sub: oracle_lib.consensus(sub, 3, -5, -4, True, 2)
+    plain = rd.polish_sharded(b, fn, 0, 1)
+    forced = rd.polish_sharded(b, fn, 0, 1, force_exchange=True)         # all-reduce + gather + decode on a one-rank group
+    q.put((forced.consensus == plain.consensus, bool((forced.polished == plain.polished).all() and (forced.chimeric == plain.chimeric).all())))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_runs_the_exchange_step():
+    """force_exchange: the exchange step of polish_sharded on a ONE-rank process group gives back exactly what went in (the
+    RCCL twin of this test, tests/test_gpu_fullsize.py::test_one_rank_rccl_exchange, is how the nccl backend gets exercised
+    on a one-GPU box)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(port, q))
+    p.start()
+    same, flags = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0 and same and flags
+
+
 def test_cost_balanced_shards_at_cfg3_size():
     """100 000 windows (cfg3's window count), offsets only: shard bounds are monotone, cover the index space, and the cost
     proxy (layers x bases, the engine's own work-order proxy) of every shard is within 2 % of the mean although window
