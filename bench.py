@@ -530,11 +530,13 @@ def main():
                     # (PAF and SAM inputs differ in their alignments, hence in their windows: the PAF legs are compared with each other)
                     ex = b"".join(res.consensus) if same_windows else None
                     dm = {"device_cigars": product_cli(paths, pwindow, (m, x, g), th, expect=ex, reps=2, batches=a.product_batches, env_add={"RACON_HIP_DEVICE_WINDOWS": "2"})}
-                    dm["device_cigars"]["fasta_matches_host_built"] = dm["device_cigars"].get("fasta_md5") == out["product_polish"][name]["cli"].get("fasta_md5")
+                    if "error" not in dm["device_cigars"] and "error" not in out["product_polish"][name]["cli"]:
+                        dm["device_cigars"]["fasta_matches_host_built"] = dm["device_cigars"]["fasta_md5"] == out["product_polish"][name]["cli"]["fasta_md5"]
                     if os.path.exists(paths.get("paf", "")):
                         dm["device_align"] = product_cli(paths, pwindow, (m, x, g), th, reps=2, batches=a.product_batches, overlaps="paf", flags=("--cudaaligner-batches", "1"))
                         dm["host_align"] = product_cli(paths, pwindow, (m, x, g), th, reps=1, batches=a.product_batches, overlaps="paf")
-                        dm["device_align"]["fasta_matches_host_aligner"] = dm["device_align"].get("fasta_md5") == dm["host_align"].get("fasta_md5")
+                        if "error" not in dm["device_align"] and "error" not in dm["host_align"]:
+                            dm["device_align"]["fasta_matches_host_aligner"] = dm["device_align"]["fasta_md5"] == dm["host_align"]["fasta_md5"]
                         if dm["device_align"].get("wall_s") and dm["host_align"].get("wall_s"):
                             dm["device_align"]["whole_binary_speedup_over_host_aligner"] = dm["host_align"]["wall_s"] / dm["device_align"]["wall_s"]
                     out["product_polish"][name]["device_modes"] = dm
