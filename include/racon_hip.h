@@ -104,7 +104,7 @@ typedef struct rcn_run_stats {
                                   wave (windows with a CU and its LDS to themselves: the deep launch; poa_band.hpp)          */
     uint64_t n_small;          /* windows polished by the small-window kernel (one wave per window, graph in LDS: poa_small.hpp) */
     uint64_t n_small_bailed;   /* windows that kernel sent back (outside its shape) and poa_window_kernel2 polished instead       */
-    uint64_t small_bail_why[9];/* ... by reason: graph capacity, fifth in-edge, predecessor > 16 rows back, aligned ring (or a symbol
+    uint64_t small_bail_why[9];/* ... by reason: graph capacity, ninth in-edge, predecessor > 16 rows back, aligned ring (or a symbol
                                   besides A/C/G/T), int16 range, layer > 255 bases, sink tie beyond the id rule, consensus scratch,
                                   internal inconsistency (must be zero)                                                           */
     uint64_t small_work[6];    /* work of that kernel: alignments, DP rows, Subgraph sweep chunks, traceback boxes, boxes whose gather

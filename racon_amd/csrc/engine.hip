@@ -343,11 +343,18 @@ inline uint64_t first_pass_out_cap(const WinShape& s) {
 template <class It>
 bool small_caps(const rcn_engine* e, It first, It last, Caps& out) {
     if (first == last || e->knobs.no_small || e->knobs.wide_only || (e->small_off && !e->knobs.force_small) || e->cfg.gap >= 0) return false;
+    // A pass takes the kernel when (nearly) all of its windows have the shape: up to one window in eight may not (real reads
+    // on short windows: a few layers beyond 255 bases among thousands within) -- the kernel flags those at once (kSmCap /
+    // kSmLong, before it touches anything sized by the capacities below) and collect() hands them to poa_window_kernel2
+    // like every other window that leaves the kernel.  The capacities follow the windows that do have the shape.
     int32_t Lmax = 1;
-    for (It it = first; it != last; ++it) {
-        if (!small_shape(*it)) return false;
+    uint64_t shaped = 0, total = 0;
+    for (It it = first; it != last; ++it, ++total) {
+        if (!small_shape(*it)) continue;
+        ++shaped;
         Lmax = std::max(Lmax, it->L);
     }
+    if (shaped == 0 || (total - shaped) * 8 > total) return false;
     Caps c{};
     c.ncap = small_ncap(Lmax); c.ecap = 0; c.ring = rcn::kSmRing; c.lmax = rcn::kSmLen; c.hstride = 256; c.hrows = c.ncap + 1;
     c.fast = true; c.small = true;

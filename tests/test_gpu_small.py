@@ -157,3 +157,41 @@ def test_fuzz_small_windows(Engine, oracle, monkeypatch, seed, scores):
     ex = Engine(*scores, True)
     assert_same(ex.consensus(b), oracle.consensus(b, *scores, True, 0), f"small fuzz seed {seed}, exact order")
     _no_bug(ex.stats())
+
+
+@pytest.mark.parametrize("reads,ovl,scores", [("sample_reads.fastq.gz", "sample_overlaps.sam.gz", (3, -5, -4)),
+                                              ("sample_reads.fastq.gz", "sample_overlaps.paf.gz", (5, -4, -8)),
+                                              ("sample_reads.fasta.gz", "sample_overlaps.sam.gz", (1, -1, -1))])
+def test_real_noisy_reads_at_w200(Engine, oracle, reads, ovl, scores):
+    """REAL reads through the small-window kernel: the reference's own sample (test/data: ONT reads of a lambda phage assembly,
+    ~10-15 % error) cut at `-w 200` -- layers of up to ~255 bases, graphs that outgrow the LDS, fifth-to-ninth in-edges, far
+    predecessors: everything the synthetic short-read windows are too clean to produce (reference src/window.cpp:99-107 on the
+    reference's data).  The product (Polisher::polish on the MI355X) prints the FASTA of host layer + oracle; the engine alone
+    polishes the same windows with both kernels in play and no internal inconsistency."""
+    from helpers import REFDATA as DATA
+    from racon_amd import polisher as P
+    P.build()
+
+    def make():
+        p = P.Polisher(DATA + reads, DATA + ovl, DATA + "sample_layout.fasta.gz", "kC", 200, 10, 0.3, True, *scores, num_threads=8)
+        p.initialize()
+        return p
+    p = make()
+    b = p.windows()
+    assert b.n_windows > 200
+    lens = np.diff(b.seq_off.astype(np.int64))
+    assert 0 < int((lens > 255).sum()) * 8 < b.n_windows          # a few layers beyond the kernel's 255 bases: those windows are flagged at once
+    ref = oracle.consensus(b, *scores, True, 0)
+    ref_fasta = p.assemble(ref, True)
+    p.close()
+    eng = Engine(*scores, True)
+    got = eng.consensus(b)
+    st = eng.stats()
+    assert_same(got, ref, f"sample reads at -w 200, {ovl}, {scores}")
+    _no_bug(st)
+    # the small kernel took the pass (a minority of windows outside its shape does not keep the others from it); what it sent back
+    # -- graphs that outgrew the LDS, layers beyond 255 bases, far predecessors -- came back right through poa_window_kernel2
+    assert st["n_small"] > 0 and st["n_small_bailed"] > 0 and st["n_retried"] >= st["n_small_bailed"], st
+    p = make()
+    assert p.polish(True) == ref_fasta
+    p.close()

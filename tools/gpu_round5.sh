@@ -1,0 +1,125 @@
+#!/bin/bash
+# Round-5 GPU visits.  Usage: bash tools/gpu_round5.sh <tag> [what...]
+#   what: subset (this round's new / changed tests) tests (whole GPU suite) bench (default line) fuzz (tools/fuzz_sweep.py)
+#         cfg4 w1000 (bench lines of the other workloads) final (kernel stats + HBM / SQ counter passes + all lines)
+#         tiers (the three-tier split sweep) cfg4prod (short-read product, chunk plans) cfg5 (cfg5 whole on one GPU) cfg3bin (cfg3 whole through the binary)
+set -u
+TAG=${1:-r05a}; shift || true
+WHAT=${*:-subset bench}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export RCN_EXPERIMENT=1
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+(nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocm-smi --showproductname 2>/dev/null | head -12) > "$OUT/box.txt" 2>&1
+benchline() { python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
+print('%s: %.0f windows/s  step %.2f ms  launches %s  frac %.3f  gcups %.0f  small %s bailed %s why %s' % ('$1', j['value'], r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], r['frac'], r.get('gcups',0), r.get('small_windows'), r.get('small_bailed'), r.get('small_bail_why')))"; }
+QB="--steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg"
+
+if has subset; then
+  timeout 2400 python -m pytest tests/test_gpu_small.py tests/test_cli_e2e.py tests/test_gpu_bench_contract.py \
+      "tests/test_gpu_product_path.py::test_polish_interval_chunks_and_warmup" "tests/test_gpu_fullsize.py::test_one_rank_rccl_exchange" \
+      -m gpu -q -x --durations=10 > "$OUT/pytest_subset.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_subset.log"; tail -25 "$OUT/pytest_subset.log"
+fi
+if has tests; then
+  timeout 3000 python -m pytest tests -m gpu -q -x --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_gpu.log"; tail -30 "$OUT/pytest_gpu.log"
+fi
+if has bench; then
+  timeout 1500 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "bench exit $?"; cut -c1-3000 "$OUT/bench.json"; tail -5 "$OUT/bench.err"
+fi
+if has fuzz; then
+  timeout 1500 python tools/fuzz_sweep.py --seeds ${FUZZ_SEEDS:-120} --out "$OUT/fuzz_sweep.json" > "$OUT/fuzz_sweep.log" 2>&1
+  echo "fuzz exit $?"; tail -4 "$OUT/fuzz_sweep.log" | cut -c1-1500
+fi
+if has cfg4; then
+  for k in 1 2; do
+    timeout 900 python bench.py --config cfg4 $QB 2> "$OUT/bench_cfg4.err" | tee "$OUT/bench_cfg4_$k.json" | benchline "cfg4 run $k"
+  done
+fi
+if has w1000; then
+  timeout 900 python bench.py --config w1000 --steps 5 --warmup 1 --no-product --no-upload-leg --no-cpu 2> "$OUT/bench_w1000.err" | tee "$OUT/bench_w1000.json" | benchline w1000
+fi
+if has tiers; then
+  # the split launch's plan: deep tier (one work-group per CU, the _deep instance), middle tier (RCN_SPLIT_MID windows at RCN_SPLIT_MID_PER_CU
+  # per CU on RCN_SPLIT_MID_CUS CUs), rest -- cfg2, ms per step and per launch
+  run() { echo "== $1"; shift; env "$@" python bench.py $QB 2>/dev/null | benchline "$*"; }
+  {
+    run "default"
+    run "default again"
+    for spec in ${TIER_SPECS:-"64:4:16" "96:4:24" "128:4:32" "96:2:48" "64:2:32" "160:4:40" "128:6:24"}; do
+      IFS=: read n per cus <<< "$spec"
+      run "mid $n windows, $per per CU, $cus CUs" RCN_SPLIT_MID=$n RCN_SPLIT_MID_PER_CU=$per RCN_SPLIT_MID_CUS=$cus
+    done
+    run "default, third time"
+  } 2>&1 | tee "$OUT/tiers.txt"
+fi
+if has cfg4prod; then
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(1_000_000, 60.0, 20260923, 32, short_reads=True))
+PY
+  F=/tmp/racon_amd_cache/files_1000000_60_20260923_short
+  for e in "" "RACON_HIP_CHUNK_WINDOWS=5000" "RACON_HIP_CHUNK_WINDOWS=2500" "RACON_HIP_CHUNK_WINDOWS=1700" ${CFG4PROD_EXTRA:-}; do
+    for k in 1 2 3; do
+      env $e RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 -w 200 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/cfg4prod.err" | md5sum | cut -c1-8
+      echo "cfg4 files [$e]: $(grep 'generated consensus' $OUT/cfg4prod.err) $(grep -c 'engine .* chunk' $OUT/cfg4prod.err) chunks"
+    done
+  done | tee "$OUT/cfg4prod.txt"
+  RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 -w 200 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/timeline_cfg4.err" | md5sum
+  grep -E "racon::|polish:|piece|collect|reserve|pass of|timing" "$OUT/timeline_cfg4.err" | head -80 > "$OUT/timeline_cfg4_product.txt"
+fi
+# ---- issue / LDS counters (SURVEY 8(d) secondary ceilings): rocprofv3 --pmc passes of SQ counters, 8 per pass ----
+sqpasses() {   # $1 = label, rest = bench arguments
+  local label=$1; shift
+  local n=0
+  for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
+             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_I8 SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+    n=$((n + 1))
+    timeout 600 rocprofv3 --pmc $SET --output-format csv -d "$OUT/sq_${label}_$n" -o pmc -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu --no-product --no-upload-leg > "$OUT/sq_${label}_$n.json" 2> "$OUT/sq_${label}_$n.err"
+    echo "sq $label pass $n exit $?"; tail -2 "$OUT/sq_${label}_$n.err" | cut -c1-200
+  done
+  python tools/sq_summary.py "$OUT" "$label" > "$OUT/sq_${label}_summary.txt" 2>&1; cat "$OUT/sq_${label}_summary.txt"
+}
+if has final; then
+  BP="--steps 3 --warmup 1 --no-cpu --no-upload-leg --no-product"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python bench.py $BP > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+  find "$OUT/prof" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \; ; head -6 "$OUT/kernel_stats.csv" | cut -c1-200
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof4" -o trace -- python bench.py --config cfg4 $BP > "$OUT/prof_bench_cfg4.json" 2> "$OUT/prof4.err"
+  find "$OUT/prof4" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_cfg4.csv" \; ; head -5 "$OUT/kernel_stats_cfg4.csv" | cut -c1-200
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python bench.py $BP > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"; echo "pmc $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; tail -3 "$OUT/pmc_summary.txt"
+  mkdir -p "$OUT/c4"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/c4/pmc_$C" -o pmc -- python bench.py --config cfg4 $BP > "$OUT/c4/pmc_$C.json" 2> "$OUT/c4/pmc_$C.err"; echo "pmc cfg4 $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT/c4" > "$OUT/pmc_summary_cfg4.txt" 2>&1; tail -3 "$OUT/pmc_summary_cfg4.txt"
+  sqpasses cfg4 --config cfg4
+  sqpasses cfg2
+  timeout 900 python bench.py --config cfg4 --steps 10 --warmup 2 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4_full.err"; benchline cfg4 < "$OUT/bench_cfg4.json"
+  timeout 900 python bench.py --config w1000 --steps 5 --warmup 1 --no-product --no-upload-leg 2> "$OUT/bench_w1000.err" | tee "$OUT/bench_w1000.json" | benchline w1000
+  timeout 900 python bench.py --config cfg5x0.004 --steps 5 --warmup 1 --no-product --no-upload-leg 2> "$OUT/bench_cfg5.err" | tee "$OUT/bench_cfg5x0.004.json" | benchline cfg5x0.004
+  timeout 900 python bench.py --contig 4000000 --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg 2> "$OUT/bench_4mbp.err" | tee "$OUT/bench_4mbp.json" | benchline 4mbp
+fi
+if has sq2; then sqpasses cfg2; fi
+if has sq4; then sqpasses cfg4 --config cfg4; fi
+if has cfg5; then
+  timeout ${CFG5_TIMEOUT:-2400} python tools/cfg5_at_size.py ${CFG5_ARGS:---scale 1.0 --shards 8} > "$OUT/cfg5_at_size.json" 2> "$OUT/cfg5_at_size.err"
+  echo "cfg5 exit $?"; tail -3 "$OUT/cfg5_at_size.err" | cut -c1-400; cut -c1-2500 "$OUT/cfg5_at_size.json"
+fi
+if has cfg3bin; then
+  timeout 2400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu --no-upload-leg --product-contig 0 > "$OUT/bench_cfg3_1gpu.json" 2> "$OUT/bench_cfg3.err"
+  echo "cfg3 exit $?"; cut -c1-2500 "$OUT/bench_cfg3_1gpu.json"; tail -3 "$OUT/bench_cfg3.err"
+fi
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+find "$OUT" -name "*.db" -delete 2>/dev/null
+du -sh "$OUT" | tail -1
