@@ -473,7 +473,9 @@ def main():
                          "launches_per_step": len(per_launch_ms), "launch_ms": per_launch_ms,
                          "split_launch": None if not st["split_deep"] else
                              {"deep_windows": st["split_deep"], "deep_cus": st["split_cus"], "deep_work_groups_per_cu": st["split_deep_per_cu"],
-                              "note": "two concurrent launches on disjoint CU sets; bytes and interval are the step's"},
+                              "mid_windows": st["split_mid"], "mid_cus": st["split_mid_cus"], "mid_work_groups_per_cu": st["split_mid_per_cu"],
+                              "mid_launch_ms": st["launch_ms_mid"] if st["split_mid"] else None,
+                              "note": "two (three with a middle tier) concurrent launches on disjoint CU sets; bytes and interval are the step's"},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "gcups": st["dp_cells"] / step_s / 1e9,
                          # exact banded DP ("cells counts the cells actually evaluated and the full-matrix figure

@@ -109,6 +109,12 @@ typedef struct rcn_run_stats {
                                   internal inconsistency (must be zero)                                                           */
     uint64_t small_work[6];    /* work of that kernel: alignments, DP rows, Subgraph sweep chunks, traceback boxes, boxes whose gather
                                   pipeline had to start over (the walk left the diagonal), Subgraph masks that were a rank interval */
+    /* three-tier split launch: a middle tier between the deep launch and the rest (launch_ms[0] = deep, launch_ms[1] = rest) */
+    double   launch_ms_mid;    /* HIP-event duration of the middle tier's launch (0: no middle tier)                              */
+    uint32_t split_mid;        /* windows of the middle tier                                                                       */
+    uint32_t split_mid_cus;    /* CUs it ran on                                                                                    */
+    uint32_t split_mid_per_cu; /* its work-groups per CU                                                                           */
+    uint32_t reserved_;
 } rcn_run_stats;
 
 /* --- engine lifetime (replaces createCUDABatch, cudabatch.cpp:24-75) ------- */
@@ -168,6 +174,11 @@ int  rcn_engine_reserve(rcn_engine* e, const rcn_reserve_hint* hint);
 /* The same for ONE known batch: exactly what rcn_engine_polish_refs(w) will allocate (inputs, pinned staging, results,
  * the scratch of its launches as it will plan them), without packing, copying or running anything.                */
 int  rcn_engine_reserve_refs(rcn_engine* e, const rcn_window_refs* w);
+/* ... and for the batch that is RESIDENT (rcn_engine_upload / rcn_engine_build_windows*): exactly what rcn_engine_run will
+ * allocate -- the scratch of its launches as it will plan them, the pinned result block -- without running anything.  The
+ * host layer builds its windows in HBM inside Polisher::initialize (where the reference builds them: src/polisher.cpp:388-461)
+ * and calls this there, so that the interval around Polisher::polish holds the consensus only.                               */
+int  rcn_engine_reserve_run(rcn_engine* e);
 
 int  rcn_engine_result(rcn_engine* e, rcn_result* out);
 int  rcn_engine_stats(rcn_engine* e, rcn_run_stats* out);

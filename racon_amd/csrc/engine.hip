@@ -168,7 +168,7 @@ struct Knobs {
          band_scores = false, no_code_wave = false, wide_only = false, no_stream = false, no_small = false, force_small = false, prof_layers = false,
          cigar_serial = false;
     int force_tie = 0, wg_per_cu = 0, split = -1, split_deep_per_cu = 0, split_rest_per_cu = 0, split_deep = 0, split_deep_wide = -1,
-        split_cus = 0, hrows_div = 0, small_per_cu = 0;
+        split_cus = 0, hrows_div = 0, small_per_cu = 0, split_mid = 0, split_mid_per_cu = 0, split_mid_cus = 0;
     double heavy_pct = 1.0;
     unsigned long long fail_alloc_above = 0;
 };
@@ -197,6 +197,7 @@ static Knobs read_knobs() {
     k.split_deep_per_cu = num("RCN_SPLIT_DEEP_PER_CU", 0); k.split_rest_per_cu = num("RCN_SPLIT_REST_PER_CU", 0);
     k.split_deep = num("RCN_SPLIT_DEEP", 0); k.split_deep_wide = num("RCN_SPLIT_DEEP_WIDE", -1); k.split_cus = num("RCN_SPLIT_CUS", 0);
     k.hrows_div = num("RCN_HROWS_DIV", 0); k.small_per_cu = num("RCN_SMALL_PER_CU", 0);
+    k.split_mid = num("RCN_SPLIT_MID", 0); k.split_mid_per_cu = num("RCN_SPLIT_MID_PER_CU", 0); k.split_mid_cus = num("RCN_SPLIT_MID_CUS", 0);
     if (const char* v = getenv("RCN_HEAVY_PCT")) k.heavy_pct = atof(v);
     if (const char* v = getenv("RCN_FAIL_ALLOC_ABOVE")) k.fail_alloc_above = strtoull(v, nullptr, 10);
     return k;
@@ -217,15 +218,25 @@ struct rcn_engine {
     // work-groups per CU, all the others on `rest_stream` (the complement).  Null when the runtime refused the masks.
     hipStream_t deep_stream = nullptr, rest_stream = nullptr;
     int split_cus = 0;
+    // three tiers (RCN_SPLIT_MID*): the next-deepest windows at a few work-groups per CU on CUs of their own, the rest on what is left
+    hipStream_t mid_stream = nullptr, rest3_stream = nullptr;
+    int split_mid_cus = 0;
+    static constexpr int kMaxLaunches = 3;          // launches of one first pass (split launch: deep, [middle,] rest; streamed batch: its pieces)
     bool warmed = false;                            // rcn_engine_reserve ran its warm-up launch
     bool lds_optin = false;                         // a work-group may ask for more than 64 KB of LDS (fewer than three per CU)
     int caps_level = 0;                             // first_pass_caps: raised when a batch needed many retries
     bool small_off = false;                         // the small-window kernel sent too many windows back: not for this engine's next batches
     bool pass_small = false;                        // the first pass of the current batch ran (partly) on the small-window kernel
     std::vector<uint8_t> item_small;                // ... and which work items did (collect: only those are re-run by poa_window_kernel2 first)
+    // host preparation of the batch rcn_engine_reserve_refs made its dry run for (layer order, full-span flags; shapes / work order /
+    // output offsets stay in the fields above): the polish call for the SAME batch takes it over instead of sorting 700 000 layers again
+    bool pc_valid = false;
+    uint64_t pc_key[4] = {0, 0, 0, 0};
+    std::vector<uint32_t> pc_order;
+    std::vector<uint8_t> pc_full;
     bool stats_pending = false;                     // the last run's device counters have not been read yet (rcn_engine_stats)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t sub_ev[kSubLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
+    hipEvent_t sub_ev[kMaxLaunches][3] = {};        // per sub-launch: copy done, kernel begin, kernel end
     int n_cu = 256;
     uint64_t t_max = 0, t_sum = 0;      // bases of the deepest window / of all windows of the prepared batch (wg_per_cu)
     bool queued = false;                // RCN_REFS_QUEUED: the caller keeps several batches in flight (wg_per_cu: eight)
@@ -417,7 +428,7 @@ uint32_t lds_bytes_for(uint32_t per_cu) {
 // rest of the chip, persistent over their queue.  Same kernel, same results; the decision uses the cost proxy of
 // wg_per_cu.  RCN_SPLIT=0 switches it off, RCN_SPLIT=1 forces it (tests), RCN_SPLIT_DEEP / RCN_SPLIT_DEEP_PER_CU /
 // RCN_SPLIT_REST_PER_CU override the plan (experiments).
-struct SplitPlan { bool on = false; uint32_t n_deep = 0, deep_per_cu = 1, rest_per_cu = 8; };
+struct SplitPlan { bool on = false; uint32_t n_deep = 0, deep_per_cu = 1, rest_per_cu = 8, n_mid = 0, mid_per_cu = 4; };
 SplitPlan split_plan(const rcn_engine* e, uint32_t nw, bool fast) {
     SplitPlan sp;
     if (!fast || !e->deep_stream || !e->rest_stream || e->cfg.max_slots || e->knobs.split == 0) return sp;
@@ -433,6 +444,12 @@ SplitPlan split_plan(const rcn_engine* e, uint32_t nw, bool fast) {
     sp.n_deep = cus * sp.deep_per_cu;
     if (e->knobs.split_deep > 0) sp.n_deep = static_cast<uint32_t>(e->knobs.split_deep);
     sp.n_deep = std::min(sp.n_deep, nw - 1);
+    // middle tier (experiment switches; resident batches): the next n_mid windows at mid_per_cu work-groups per CU
+    if (e->mid_stream && e->knobs.split_mid > 0 && sp.n_deep + 1 < nw) {
+        sp.mid_per_cu = static_cast<uint32_t>(std::min(8, std::max(1, e->knobs.split_mid_per_cu > 0 ? e->knobs.split_mid_per_cu : 4)));
+        if (!e->lds_optin) sp.mid_per_cu = std::max(sp.mid_per_cu, 3u);
+        sp.n_mid = std::min(static_cast<uint32_t>(e->knobs.split_mid), nw - 1 - sp.n_deep);
+    }
     return sp;
 }
 
@@ -723,6 +740,17 @@ int rcn_engine_create(const rcn_engine_config* cfg, rcn_engine** out) {
             if (!e->rest_stream && e->deep_stream) { (void)hipStreamDestroy(e->deep_stream); e->deep_stream = nullptr; }
             (void)hipGetLastError();
             e->split_cus = e->deep_stream ? cus : 0;
+            // the middle tier's CUs follow the deep launch's in the mask; the third stream gets what both leave
+            const int mcus = (e->knobs.split_mid_cus / 8) * 8;
+            if (e->split_cus && mcus >= 8 && cus + mcus <= e->n_cu - 8) {
+                uint32_t mid[8] = {0}, rest3[8] = {0};
+                for (int b = cus; b < e->n_cu; ++b) (b < cus + mcus ? mid : rest3)[b >> 5] |= 1u << (b & 31);
+                if (hipExtStreamCreateWithCUMask(&e->mid_stream, words, mid) != hipSuccess) e->mid_stream = nullptr;
+                if (e->mid_stream && hipExtStreamCreateWithCUMask(&e->rest3_stream, words, rest3) != hipSuccess) e->rest3_stream = nullptr;
+                if (!e->rest3_stream && e->mid_stream) { (void)hipStreamDestroy(e->mid_stream); e->mid_stream = nullptr; }
+                (void)hipGetLastError();
+                e->split_mid_cus = e->mid_stream ? mcus : 0;
+            }
         }
         // fewer than eight work-groups per CU are enforced through the LDS request (lds_bytes_for): up to the whole LDS
         e->lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(rcn::poa_window_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -753,6 +781,8 @@ void rcn_engine_destroy(rcn_engine* e) {
     for (auto& st : e->sub_stream) if (st && st != e->stream) (void)hipStreamDestroy(st);
     if (e->deep_stream) (void)hipStreamDestroy(e->deep_stream);
     if (e->rest_stream) (void)hipStreamDestroy(e->rest_stream);
+    if (e->mid_stream) (void)hipStreamDestroy(e->mid_stream);
+    if (e->rest3_stream) (void)hipStreamDestroy(e->rest3_stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1161,7 +1191,7 @@ void materialize(const SrcView& v, HostBatch& h) {
 
 // The launches of a first pass: cut[c] .. cut[c + 1] are the work items of piece c (deepest first).  Fills the Launch
 // records (capacities from the pieces' own shapes, slots, scratch placement); false when the scratch does not fit.
-struct PassPlan { int n = 0; uint32_t cut[rcn_engine::kSubLaunches + 1] = {}; Launch L[rcn_engine::kSubLaunches]; uint64_t scratch = 0; bool split = false, copied = false; };
+struct PassPlan { int n = 0; uint32_t cut[rcn_engine::kMaxLaunches + 1] = {}; Launch L[rcn_engine::kMaxLaunches]; int tier[rcn_engine::kMaxLaunches] = {0, 2, 2};   /* split launch: 0 deep, 1 middle, 2 rest */ uint64_t scratch = 0; bool split = false, copied = false; };
 
 void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fast, uint32_t slots_left) {
     std::vector<WinShape> sh;
@@ -1179,10 +1209,13 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
         //  start as the earlier piece's retire -- a fixed share would idle once that piece is done)
         L.slots = e->cfg.max_slots ? std::min(L.n_work, slots_left) : balanced_slots(L.n_work, static_cast<uint32_t>(e->n_cu) * L.c.per_cu);
     } else if (sp.on) {
-        L.stream = c == 0 ? e->deep_stream : e->rest_stream;
-        L.per_cu = c == 0 ? sp.deep_per_cu : sp.rest_per_cu;
-        if (c == 0 && e->knobs.split_deep_wide >= 0) L.heavy_ns = e->knobs.split_deep_wide;
-        const uint32_t cus = c == 0 ? static_cast<uint32_t>(e->split_cus) : static_cast<uint32_t>(e->n_cu - e->split_cus);
+        const int tier = pp.tier[c];
+        const bool three = pp.n == 3;
+        L.stream = tier == 0 ? e->deep_stream : tier == 1 ? e->mid_stream : (three ? e->rest3_stream : e->rest_stream);
+        L.per_cu = tier == 0 ? sp.deep_per_cu : tier == 1 ? sp.mid_per_cu : sp.rest_per_cu;
+        if (tier == 0 && e->knobs.split_deep_wide >= 0) L.heavy_ns = e->knobs.split_deep_wide;
+        const uint32_t cus = tier == 0 ? static_cast<uint32_t>(e->split_cus) : tier == 1 ? static_cast<uint32_t>(e->split_mid_cus)
+                                       : static_cast<uint32_t>(e->n_cu - e->split_cus - (three ? e->split_mid_cus : 0));
         L.slots = std::min(L.n_work, cus * L.per_cu);
     } else {
         L.stream = e->sub_stream[c]; L.per_cu = 0;
@@ -1208,13 +1241,17 @@ int finish_pieces(rcn_engine* e, const PassPlan& pp, hipEvent_t ref) {
             fprintf(stderr, "[racon_hip] piece %d: work items [%u, %u) slots %u (%u per CU) ncap %d lmax %d | copy done %.2f ms, kernel %.2f .. %.2f ms\n",
                     c, pp.cut[c], pp.cut[c + 1], pp.L[c].slots, pp.L[c].per_cu, pp.L[c].c.ncap, pp.L[c].c.lmax, cp, a0, a1);
         }
-        e->stats.launch_ms[c] = a1 - a0;
+        if (pp.split && pp.n == 3) { if (pp.tier[c] == 1) e->stats.launch_ms_mid = a1 - a0; else e->stats.launch_ms[pp.tier[c] == 0 ? 0 : 1] = a1 - a0; }
+        else e->stats.launch_ms[c] = a1 - a0;
         e->stats.n_launches += 1;
     }
     e->stats.kernel_ms += span1 - span0;
     e->stats.split_deep = pp.split ? pp.L[0].n_work : 0;
     e->stats.split_cus = pp.split ? static_cast<uint32_t>(e->split_cus) : 0;
     e->stats.split_deep_per_cu = pp.split ? pp.L[0].per_cu : 0;
+    e->stats.split_mid = (pp.split && pp.n == 3) ? pp.L[1].n_work : 0;
+    e->stats.split_mid_cus = (pp.split && pp.n == 3) ? static_cast<uint32_t>(e->split_mid_cus) : 0;
+    e->stats.split_mid_per_cu = (pp.split && pp.n == 3) ? pp.L[1].per_cu : 0;
     return RCN_OK;
 }
 
@@ -1222,23 +1259,42 @@ int finish_pieces(rcn_engine* e, const PassPlan& pp, hipEvent_t ref) {
 
 extern "C" {
 
-int rcn_engine_run(rcn_engine* e) {
+}  // extern "C"
+namespace { __global__ void k_warm_out(uint32_t* p); }
+extern "C" {
+// The resident batch (rcn_engine_upload / rcn_engine_build_windows*) through the consensus kernels.  `dry`: everything the run
+// would allocate -- the scratch of its launches as it will plan them, the pinned result block -- and nothing else
+// (rcn_engine_reserve_run).
+static int run_resident(rcn_engine* e, bool dry) {
     if (!e) return RCN_E_ARG;
     if (!e->uploaded) return RCN_E_STATE;
     HIP_TRY(hipSetDevice(e->cfg.device));
     const uint32_t nw = e->n_windows;
     if (nw == 0) {
+        if (dry) return RCN_OK;
         e->stats = rcn_run_stats{};
         e->cons_off.assign(1, 0); e->polished.clear(); e->chimeric.clear(); e->cons.assign(1, 0); e->ran = true;
         return RCN_OK;
     }
     int rc;
     if ((rc = begin_run(e))) return rc;
+    auto warm_out = [&]() -> int {
+        // the kernel's first stores into the (new) pinned result block, as polish_view's dry run makes them
+        hipLaunchKernelGGL(k_warm_out, dim3(1), dim3(64), 0, e->stream, e->h_out.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return RCN_OK;
+    };
     const bool fast = !e->knobs.wide_only;
     const uint32_t* ids = e->lpt_layout ? nullptr : e->d_lpt_ids.as<uint32_t>();
     {
         Caps cs;
         if (fast && small_caps(e, e->shapes.begin(), e->shapes.end(), cs)) {
+            if (dry) {
+                const uint32_t slots = slots_for(e, cs, nw, scratch_budget(e));
+                if (slots && (rc = e->d_scratch.reserve(static_cast<uint64_t>(slots) * cs.slot_bytes))) return rc;
+                return warm_out();
+            }
             e->pass_small = true;
             e->item_small.assign(nw, 1);
             if ((rc = run_pass(e, cs, ids, nw))) return rc;
@@ -1248,12 +1304,15 @@ int rcn_engine_run(rcn_engine* e) {
     const SplitPlan sp = split_plan(e, nw, fast);
     if (sp.on) {
         // the split pair: deepest windows on their own CUs, everything else on the rest of the chip
-        PassPlan pp; pp.n = 2; pp.split = true; pp.cut[0] = 0; pp.cut[1] = sp.n_deep; pp.cut[2] = nw;
-        for (int c = 0; c < 2; ++c) { plan_piece(e, pp, c, sp, fast, 0); pp.L[c].d_ids = ids ? ids + pp.cut[c] : nullptr; }
+        PassPlan pp; pp.split = true; pp.cut[0] = 0; pp.cut[1] = sp.n_deep;
+        if (sp.n_mid > 0) { pp.n = 3; pp.cut[2] = sp.n_deep + sp.n_mid; pp.cut[3] = nw; pp.tier[0] = 0; pp.tier[1] = 1; pp.tier[2] = 2; }
+        else { pp.n = 2; pp.cut[2] = nw; pp.tier[0] = 0; pp.tier[1] = 2; }
+        for (int c = 0; c < pp.n; ++c) { plan_piece(e, pp, c, sp, fast, 0); pp.L[c].d_ids = ids ? ids + pp.cut[c] : nullptr; }
         if (pp.scratch <= scratch_budget(e)) {
             if ((rc = e->d_scratch.reserve(pp.scratch))) return rc;
+            if (dry) return warm_out();
             HIP_TRY(hipEventRecord(e->ev0, e->stream));             // the counters were zeroed on the main stream (begin_run)
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < pp.n; ++c) {
                 HIP_TRY(hipStreamWaitEvent(pp.L[c].stream, e->ev0, 0));
                 HIP_TRY(hipEventRecord(e->sub_ev[c][1], pp.L[c].stream));
                 if ((rc = launch_pass(e, pp.L[c]))) return rc;
@@ -1264,8 +1323,22 @@ int rcn_engine_run(rcn_engine* e) {
         }
     }
     const Caps c1 = first_pass_caps(e->shapes.begin(), e->shapes.end(), fast, e->caps_level, e->knobs.hrows_div);
+    if (dry) {
+        const uint32_t slots = slots_for(e, c1, nw, scratch_budget(e));
+        if (slots && (rc = e->d_scratch.reserve(static_cast<uint64_t>(slots) * c1.slot_bytes))) return rc;
+        return warm_out();
+    }
     if ((rc = run_pass(e, c1, ids, nw))) return rc;
     return collect(e);
+}
+
+int rcn_engine_run(rcn_engine* e) { return run_resident(e, false); }
+
+int rcn_engine_reserve_run(rcn_engine* e) {
+    if (!e) return RCN_E_ARG;
+    rcn_reserve_hint warm{};
+    const int rc = rcn_engine_reserve(e, &warm);                        // first use of the code object / streams / copy engines
+    return rc ? rc : run_resident(e, true);
 }
 
 }  // extern "C"
@@ -1318,6 +1391,7 @@ inline void symbols_finish(const uint64_t present[4], int32_t& nsym, uint8_t& ac
 // upload + run.
 // `dry`: everything polish_view(v) would allocate -- device inputs, pinned staging, result buffers, the scratch of its
 // launches (their slots and capacities planned from v's own shapes) -- and nothing else: rcn_engine_reserve_refs.
+inline bool dbg_prep(const rcn_engine* e) { return e->knobs.debug; }
 int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     const uint32_t nw = v.nw, ns = v.ns;
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -1339,8 +1413,27 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
     if (t.create()) return RCN_E_HIP;
     HIP_TRY(hipEventRecord(t.a, e->copy_stream));
     HostPrep hp;
-    int rc = prepare_host(e, hp, nw, ns, v.win_seq_off, v.seq_off, v.begin, v.end, nullptr, 0, false, /*scan=*/false);
-    if (rc) return rc;
+    int rc = RCN_OK;
+    {
+        // identity of the batch: sizes, total bases, and the sequence POINTERS at 64 sampled positions (a dry run and the call it was
+        // made for pass the same tables; one use, then the entry is gone)
+        uint64_t key[4] = {(static_cast<uint64_t>(nw) << 32) | ns, v.seq_off[ns], 1469598103934665603ull, reinterpret_cast<uintptr_t>(v.seq)};
+        for (uint32_t q = 0; q < 64 && ns; ++q) {
+            const uint32_t i = static_cast<uint32_t>((static_cast<uint64_t>(q) * (ns - 1)) / 63);
+            key[2] = (key[2] ^ reinterpret_cast<uintptr_t>(v.seq[i]) ^ (static_cast<uint64_t>(v.begin[i]) << 48) ^ (v.seq_off[i + 1] - v.seq_off[i])) * 1099511628211ull;
+        }
+        const bool hit = !dry && e->pc_valid && std::memcmp(key, e->pc_key, sizeof(key)) == 0 && e->pc_order.size() == ns && e->shapes.size() == nw && e->lpt.size() == nw;
+        e->pc_valid = false;
+        if (hit) {
+            hp.order.swap(e->pc_order); hp.full.swap(e->pc_full); hp.wflags.assign(nw, 0);
+            e->h_win_seq_off.assign(v.win_seq_off, v.win_seq_off + nw + 1);
+        } else {
+            rc = prepare_host(e, hp, nw, ns, v.win_seq_off, v.seq_off, v.begin, v.end, nullptr, 0, false, /*scan=*/false);
+            if (rc) return rc;
+            if (dry) { e->pc_order = hp.order; e->pc_full = hp.full; std::memcpy(e->pc_key, key, sizeof(key)); e->pc_valid = true; }
+        }
+        if (dbg_prep(e)) fprintf(stderr, "[racon_hip] polish: host preparation %s\n", hit ? "taken over from the dry run" : "computed");
+    }
     e->lpt_layout = true;
     e->stats = rcn_run_stats{};
     if (dbg) fprintf(stderr, "[racon_hip] polish: host preparation done at %.2f ms\n", since());
@@ -1376,9 +1469,14 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         est.cut[0] = 0; est.cut[2] = nw;
         if (sp.on) est.cut[1] = sp.n_deep;
         else {
+            // (the same cut as the call itself makes below: a different plan is a different arena, grown inside polish())
+            Caps cs_;
+            const bool small_ = fast && small_caps(e, e->shapes.begin(), e->shapes.end(), cs_);
+            const uint64_t q1 = small_ ? nb / 3 : nb / 24;
             uint64_t acc = 0; uint32_t k = 0;
-            while (k < nw && acc < nb / 24) { const uint32_t w = e->lpt[k], s0 = v.win_seq_off[w]; acc += v.seq_off[v.win_seq_off[w + 1]] - v.seq_off[s0]; ++k; }
+            while (k < nw && acc < q1) { const uint32_t w = e->lpt[k], s0 = v.win_seq_off[w]; acc += v.seq_off[v.win_seq_off[w + 1]] - v.seq_off[s0]; ++k; }
             est.cut[1] = std::min(std::min(std::max(k, 1u), nw), std::max(1u, slots_total / 2));
+            if (small_ && nw > slots_total && !e->cfg.max_slots) est.cut[1] = slots_total;
         }
         for (uint32_t w = 0; w < nw; ++w) e->shapes[w].nsym = 5;
         uint32_t left = slots_total;

@@ -36,7 +36,8 @@ class RcnRunStats(C.Structure):
                 ("band_redo_why", C.c_uint64 * 8), ("wg_per_cu", C.c_uint32), ("split_deep", C.c_uint32), ("split_cus", C.c_uint32),
                 ("split_deep_per_cu", C.c_uint32), ("launch_ms", C.c_double * 2), ("n_code_wave", C.c_uint64),
                 ("n_small", C.c_uint64), ("n_small_bailed", C.c_uint64), ("small_bail_why", C.c_uint64 * 9),
-                ("small_work", C.c_uint64 * 6)]
+                ("small_work", C.c_uint64 * 6), ("launch_ms_mid", C.c_double), ("split_mid", C.c_uint32), ("split_mid_cus", C.c_uint32),
+                ("split_mid_per_cu", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class RcnWindowDesc(C.Structure):
@@ -63,7 +64,7 @@ EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
            "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory",
            "rcn_engine_align_pairs", "rcn_engine_alignment_cigars", "rcn_engine_align_stats", "rcn_engine_build_windows_from_pairs",
-           "rcn_engine_polish_refs", "rcn_engine_reserve", "rcn_engine_reserve_refs"]
+           "rcn_engine_polish_refs", "rcn_engine_reserve", "rcn_engine_reserve_refs", "rcn_engine_reserve_run"]
 
 _lib = None
 
@@ -93,6 +94,7 @@ def load_library():
     lib.rcn_engine_polish_refs.argtypes = [C.c_void_p, C.POINTER(RcnWindowRefs)]
     lib.rcn_engine_reserve.argtypes = [C.c_void_p, C.POINTER(RcnReserveHint)]
     lib.rcn_engine_reserve_refs.argtypes = [C.c_void_p, C.POINTER(RcnWindowRefs)]
+    lib.rcn_engine_reserve_run.argtypes = [C.c_void_p]
     lib.rcn_device_free_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.rcn_engine_result.argtypes = [C.c_void_p, C.POINTER(RcnResult)]
     lib.rcn_engine_stats.argtypes = [C.c_void_p, C.POINTER(RcnRunStats)]

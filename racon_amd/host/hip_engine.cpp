@@ -26,6 +26,7 @@ struct Abi {
     decltype(&rcn_engine_polish_refs) polish_refs = nullptr;
     decltype(&rcn_engine_reserve) reserve = nullptr;
     decltype(&rcn_engine_reserve_refs) reserve_refs = nullptr;
+    decltype(&rcn_engine_reserve_run) reserve_run = nullptr;
     decltype(&rcn_device_free_memory) free_memory = nullptr;
     decltype(&rcn_engine_result) result = nullptr;
     decltype(&rcn_engine_stats) stats = nullptr;
@@ -66,7 +67,7 @@ const Abi& abi() {
 #define RCN_BIND(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); \
         if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
-        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(reserve_refs, "rcn_engine_reserve_refs") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
+        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(reserve_refs, "rcn_engine_reserve_refs") RCN_BIND(reserve_run, "rcn_engine_reserve_run") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
         RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
         RCN_BIND(build_windows_from_pairs, "rcn_engine_build_windows_from_pairs")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
@@ -194,40 +195,60 @@ void HipEngine::reserve(const WindowRefs& refs, bool queued) {
     if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::reserve] error: ") + abi().strerror_(rc) + "!");
 }
 
+// ---- windows built on the device: build (what Polisher::initialize does on the host, reference src/polisher.cpp:388-461) and
+//      run (Polisher::polish) are separate steps; consensus(...) is one after the other ----
+void HipEngine::built(int rc) {
+    last_rc_ = rc;
+    if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
+    if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::build] error: ") + abi().strerror_(rc) + "!");
+}
+
+void HipEngine::build(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold, uint8_t window_type) {
+    built(abi().build_windows(handle_, &reads, &overlaps, window_length, quality_threshold, window_type));
+}
+
+void HipEngine::build(const rcn_read_set& reads, const rcn_cigar_set& alignments, uint32_t window_length, double quality_threshold, uint8_t window_type) {
+    built(abi().build_windows_from_cigars(handle_, &reads, &alignments, window_length, quality_threshold, window_type));
+}
+
+void HipEngine::build(const rcn_read_set& reads, const rcn_pair_set& pairs, uint32_t window_length, double quality_threshold, uint8_t window_type) {
+    const bool timing = getenv("RACON_HIP_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    built(abi().build_windows_from_pairs(handle_, &reads, &pairs, window_length, quality_threshold, window_type));
+    if (timing) fprintf(stderr, "[racon::HipEngine::build] timing: %lu overlaps aligned and cut into windows on the device in %.1f ms\n",
+                        static_cast<unsigned long>(pairs.n_pairs), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+}
+
+void HipEngine::reserve_run() {
+    const int rc = abi().reserve_run(handle_);
+    last_rc_ = rc;
+    if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::reserve_run] error: ") + abi().strerror_(rc) + "!");
+}
+
+void HipEngine::run(bool trim, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
+    const int rc = abi().set_trim(handle_, trim ? 1 : 0);
+    fetch(rc, consensus, polished, chimeric, /*run=*/true);
+}
+
 void HipEngine::consensus(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold,
                           uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                           std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
-    const Abi& a = abi();
-    int rc = a.set_trim(handle_, trim ? 1 : 0);
-    if (rc == RCN_OK) rc = a.build_windows(handle_, &reads, &overlaps, window_length, quality_threshold, window_type);
-    if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
-    fetch(rc, consensus, polished, chimeric);
+    build(reads, overlaps, window_length, quality_threshold, window_type);
+    run(trim, consensus, polished, chimeric);
 }
 
 void HipEngine::consensus(const rcn_read_set& reads, const rcn_cigar_set& alignments, uint32_t window_length, double quality_threshold,
                           uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                           std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
-    const Abi& a = abi();
-    int rc = a.set_trim(handle_, trim ? 1 : 0);
-    if (rc == RCN_OK) rc = a.build_windows_from_cigars(handle_, &reads, &alignments, window_length, quality_threshold, window_type);
-    if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
-    fetch(rc, consensus, polished, chimeric);
+    build(reads, alignments, window_length, quality_threshold, window_type);
+    run(trim, consensus, polished, chimeric);
 }
 
 void HipEngine::consensus(const rcn_read_set& reads, const rcn_pair_set& pairs, uint32_t window_length, double quality_threshold,
                           uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                           std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {
-    const Abi& a = abi();
-    int rc = a.set_trim(handle_, trim ? 1 : 0);
-    const bool timing = getenv("RACON_HIP_TIMING") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    if (rc == RCN_OK) rc = a.build_windows_from_pairs(handle_, &reads, &pairs, window_length, quality_threshold, window_type);
-    if (rc == RCN_E_LAYER) fatal("[racon::Window::add_layer] error: layer begin and end positions are invalid!");
-    const auto t1 = std::chrono::steady_clock::now();
-    fetch(rc, consensus, polished, chimeric);
-    if (timing) fprintf(stderr, "[racon::HipEngine::consensus] timing: %lu overlaps aligned and cut into windows on the device in %.1f ms, consensus and results in %.1f ms (kernel %.1f)\n",
-                        static_cast<unsigned long>(pairs.n_pairs), 1e3 * std::chrono::duration<double>(t1 - t0).count(),
-                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), last_kernel_ms_);
+    build(reads, pairs, window_length, quality_threshold, window_type);
+    run(trim, consensus, polished, chimeric);
 }
 
 void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run) {
@@ -237,8 +258,10 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
     if (rc == RCN_OK) rc = a.result(handle_, &r);
     last_rc_ = rc;
     if (rc != RCN_OK) fatal(std::string("[racon::HipEngine::consensus] error: ") + a.strerror_(rc) + "!");
+    // (the device counters are a copy + a stream synchronisation away: only for the timing lines, not inside every polish())
+    static const bool want_stats = getenv("RACON_HIP_TIMING") != nullptr;
     rcn_run_stats st{};
-    if (a.stats(handle_, &st) == RCN_OK) last_kernel_ms_ = st.kernel_ms;
+    if (want_stats && a.stats(handle_, &st) == RCN_OK) last_kernel_ms_ = st.kernel_ms;
     consensus->resize(r.n_windows); polished->resize(r.n_windows); chimeric->resize(r.n_windows);
     for (uint32_t w = 0; w < r.n_windows; ++w) {
         if (w >= fetch_first_ && w < fetch_last_)

@@ -89,6 +89,14 @@ public:
     void consensus(const rcn_read_set& reads, const rcn_pair_set& pairs, uint32_t window_length, double quality_threshold,
                    uint8_t window_type, bool trim, std::vector<std::string>* consensus,
                    std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
+    // The two halves of those three: windows built in HBM and left resident (what Polisher::initialize does with host memory,
+    // reference src/polisher.cpp:388-461), reserve_run() = everything run() will allocate (rcn_engine_reserve_run), and run() =
+    // the consensus of the resident windows (Polisher::polish).  Fatal like consensus(); last_rc() says why.
+    void build(const rcn_read_set& reads, const rcn_overlap_set& overlaps, uint32_t window_length, double quality_threshold, uint8_t window_type);
+    void build(const rcn_read_set& reads, const rcn_cigar_set& alignments, uint32_t window_length, double quality_threshold, uint8_t window_type);
+    void build(const rcn_read_set& reads, const rcn_pair_set& pairs, uint32_t window_length, double quality_threshold, uint8_t window_type);
+    void reserve_run();
+    void run(bool trim, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric);
     double last_kernel_ms() const { return last_kernel_ms_; }
     int last_rc() const { return last_rc_; }      // return code of the ABI call behind the last consensus() (RCN_OK, RCN_E_*)
     // Only windows [first, last) of the next consensus() calls are copied into strings (the others come back empty):
@@ -98,6 +106,7 @@ public:
 private:
     HipEngine() = default;
     HipEngine(const HipEngine&) = delete;
+    void built(int rc);
     void fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run = true);
     rcn_engine* handle_ = nullptr;
     double last_kernel_ms_ = 0;

@@ -124,6 +124,7 @@ Polisher::Polisher(const std::string& sequences_path, const std::string& overlap
 Polisher::~Polisher() {
     if (device_warmup_.joinable()) device_warmup_.join();
     if (cleanup_.joinable()) cleanup_.join();
+    if (cleanup2_.joinable()) cleanup2_.join();
     logger_->total("[racon::Polisher::] total =");
 }
 
@@ -345,7 +346,9 @@ void Polisher::initialize() {
         for (auto& o : overlaps) { ++targets_coverages_[o->t_id()]; o.reset(); }
         // the reads now live in layout_ only (the targets stay: windows_ point into their backbones)
         for (uint64_t i = targets_size; i < sequences_.size(); ++i) sequences_[i]->release_data();
-        logger_->log("[racon::Polisher::initialize] transformed data into windows");
+        build_device_windows();
+        logger_->log(device_built_ ? "[racon::Polisher::initialize] transformed data into windows (on the device)"
+                                   : "[racon::Polisher::initialize] transformed data into windows");
         return;
     }
     for (auto& o : overlaps) {
@@ -486,6 +489,234 @@ void Polisher::find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>
     logger_->log(device_align_ ? "[racon::Polisher::initialize] left the overlaps to the device aligner" : "[racon::Polisher::initialize] aligned overlaps");
 }
 
+// ---------------------------------------------------------------- windows built on the device
+// End of initialize() with device-side construction: where the reference cuts its windows (src/polisher.cpp:388-461) -- and, on
+// its GPU path, aligns its overlaps (CUDAPolisher::find_overlap_breaking_points, called from initialize()) -- the engines do
+// the same in HBM and keep the windows resident; polish() is then the consensus alone.  Possible when every shard has an engine
+// of its own (shards <= devices); RACON_HIP_BUILD_IN_POLISH=1 keeps everything in polish() (the round-4 behaviour, experiments).
+void Polisher::build_device_windows() {
+    device_built_ = false;
+    device_cut_.clear();
+    if (getenv("RACON_HIP_BUILD_IN_POLISH")) return;
+    if (device_warmup_.joinable()) device_warmup_.join();
+    if (!engines_error_.empty() || engines_.empty() || windows_.empty()) return;        // polish() reports what is wrong
+    const int32_t n_devices = n_devices_ > 0 ? n_devices_ : HipEngine::DeviceCount();
+    uint32_t n_shards = static_cast<uint32_t>(std::max(1, n_devices));
+    if (const char* sh = getenv("RACON_HIP_DEVICE_SHARDS")) n_shards = std::max(1, atoi(sh));
+    if (n_devices <= 0 || n_shards > static_cast<uint32_t>(n_devices) || static_cast<size_t>(n_devices) > engines_.size()) return;
+    FatalThrowsScope scope;
+    try {
+        device_job(1, nullptr, nullptr, nullptr);
+        device_built_ = true;
+    } catch (const std::exception& e) {
+        // (no room at this moment, an input the device aligner cannot take: polish() builds shard by shard, with its fallbacks)
+        fprintf(stderr, "[racon::Polisher::initialize] warning: windows not built ahead of polish() (%s)\n", e.what());
+        device_cut_.clear();
+    }
+}
+
+// One engine per shard builds its windows in HBM from the reads and the overlaps' breaking points / CIGARs / segment pairs
+// (rcn_engine_build_windows*: reference src/polisher.cpp:388-461, src/overlap.cpp:176-292 on the device) and polishes them there.
+//   phase 1  build only: the end of initialize(), where the reference builds its windows (and, with --cudaaligner-batches, aligns
+//            its overlaps: CUDAPolisher::find_overlap_breaking_points is called from initialize()); the windows stay resident and
+//            the engine reserves what its run will need (rcn_engine_reserve_run)
+//   phase 2  run only: polish() of windows built by phase 1
+//   phase 0  both, shard after shard on its device's engine: polish() when the shards outnumber the engines that could keep them
+//            resident (RACON_HIP_DEVICE_SHARDS > devices: a job cut into pieces to fit one device), or when phase 1 found no room
+void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::vector<uint8_t>* pol_out, std::vector<uint8_t>* chim_out) {
+    const int32_t n_devices = n_devices_ > 0 ? n_devices_ : HipEngine::DeviceCount();
+    const uint64_t nw = windows_.size();
+    static std::vector<std::string> no_cons; static std::vector<uint8_t> no_flags;
+    std::vector<std::string>& cons = cons_out ? *cons_out : no_cons;
+    std::vector<uint8_t>& pol = pol_out ? *pol_out : no_flags;
+    std::vector<uint8_t>& chim = chim_out ? *chim_out : no_flags;
+    rcn_read_set r{}; rcn_overlap_set o{};
+    r.n_seqs = layout_.seq_off.size() - 1; r.n_targets = layout_.n_targets; r.seq_off = layout_.seq_off.data();
+    r.bases = layout_.bases.data(); r.quals = layout_.quals.data(); r.seq_has_qual = layout_.seq_has_qual.data();
+    o.n_overlaps = layout_.q_id.size(); o.q_id = layout_.q_id.data(); o.t_id = layout_.t_id.data(); o.strand = layout_.strand.data();
+    o.bp_off = layout_.bp_off.data(); o.bp_t = layout_.bp_t.data(); o.bp_q = layout_.bp_q.data();
+    // Shards: the window index space is cut into one contiguous range per device, balanced by the bases of the
+    // overlaps that fall into it (the reference's multi-device code hands window ranges to per-device batches the
+    // same way, src/cuda/cudapolisher.cpp:228-240).  A shard's engine gets every read (they are what overlaps
+    // point into) and the overlaps that touch its range -- an overlap across a boundary goes to both sides, the
+    // windows outside a shard's range come out as bare backbones there and are dropped.  RACON_HIP_DEVICE_SHARDS
+    // forces a shard count (tests: several shards on one device).
+    uint32_t n_shards = static_cast<uint32_t>(n_devices);
+    if (const char* sh = getenv("RACON_HIP_DEVICE_SHARDS")) n_shards = std::max(1, atoi(sh));
+    n_shards = static_cast<uint32_t>(std::min<uint64_t>(n_shards, std::max<uint64_t>(1, nw)));
+    std::vector<uint64_t> first_window(layout_.n_targets + 1, 0);
+    for (uint64_t t = 0; t < layout_.n_targets; ++t) {
+        const uint64_t len = layout_.seq_off[t + 1] - layout_.seq_off[t];
+        first_window[t + 1] = first_window[t] + (len + window_length_ - 1) / window_length_;
+    }
+    const uint64_t n_ovl = o.n_overlaps;
+    std::vector<uint64_t> w_lo, w_hi;                        // windows [w_lo, w_hi] an overlap touches
+    std::vector<double> win_cost;
+    const bool planned = phase == 2 && device_cut_.size() == static_cast<size_t>(n_shards) + 1;      // (phase 1 left its cut behind)
+    if (!planned) { w_lo.resize(n_ovl); w_hi.resize(n_ovl); win_cost.assign(nw + 1, 0.0); }
+    for (uint64_t k = 0; k < n_ovl && !planned; ++k) {
+        const uint64_t tb = layout_.t_begin[k], te = std::max<uint64_t>(layout_.t_end[k], tb + 1);
+        w_lo[k] = first_window[o.t_id[k]] + tb / window_length_;
+        w_hi[k] = std::min<uint64_t>(first_window[o.t_id[k]] + (te - 1) / window_length_, nw - 1);
+        for (uint64_t w = w_lo[k]; w <= w_hi[k]; ++w) win_cost[w] += 1.0;
+    }
+    std::vector<uint64_t> cut(n_shards + 1, nw);
+    cut[0] = 0;
+    if (planned) cut = device_cut_;
+    else {
+        double total = 0; for (uint64_t w = 0; w < nw; ++w) total += win_cost[w] + 0.05;
+        double acc = 0; uint32_t sidx = 1;
+        for (uint64_t w = 0; w < nw && sidx < n_shards; ++w) {
+            acc += win_cost[w] + 0.05;
+            if (acc >= total * sidx / n_shards) cut[sidx++] = w + 1;
+        }
+    }
+    if (phase == 1) device_cut_ = cut;
+    std::vector<std::string> shard_errors(n_shards);
+    auto run_shard = [&](uint32_t sidx) {
+        try {
+            const uint64_t wa = cut[sidx], wb = cut[sidx + 1];
+            if (wa >= wb) return;
+            if (phase == 2) {                                      // built by initialize(): the consensus of the resident windows
+                auto engine = engines_[static_cast<size_t>(sidx % static_cast<uint32_t>(n_devices))];
+                engine->set_fetch_range(wa, wb);
+                struct FetchAll { std::shared_ptr<HipEngine> e; ~FetchAll() { e->set_fetch_range(0, ~uint64_t(0)); } } fetch_all{engine};
+                std::vector<std::string> c; std::vector<uint8_t> pl, ch;
+                engine->run(trim_, &c, &pl, &ch);
+                if (c.size() != nw) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
+                for (uint64_t w = wa; w < wb; ++w) { cons[w].swap(c[w]); pol[w] = pl[w]; chim[w] = ch[w]; }
+                return;
+            }
+            std::vector<uint64_t> sel;
+            for (uint64_t k = 0; k < n_ovl; ++k) if (w_hi[k] >= wa && w_lo[k] < wb) sel.push_back(k);
+            const bool all = sel.size() == n_ovl;
+            // the selected overlaps' slices of the layout arrays
+            std::vector<uint32_t> q_id, t_id, bp_t, bp_q, q_start, t_begin, t_end, q_begin, q_end;
+            std::vector<uint8_t> strand, cigar;
+            std::vector<uint64_t> bp_off{0}, cigar_off{0};
+            if (!all) {
+                for (uint64_t k : sel) {
+                    q_id.push_back(o.q_id[k]); t_id.push_back(o.t_id[k]); strand.push_back(o.strand[k]);
+                    q_start.push_back(layout_.q_start[k]); t_begin.push_back(layout_.t_begin[k]); t_end.push_back(layout_.t_end[k]);
+                    q_begin.push_back(layout_.q_begin[k]); q_end.push_back(layout_.q_end[k]);
+                    bp_t.insert(bp_t.end(), layout_.bp_t.begin() + layout_.bp_off[k], layout_.bp_t.begin() + layout_.bp_off[k + 1]);
+                    bp_q.insert(bp_q.end(), layout_.bp_q.begin() + layout_.bp_off[k], layout_.bp_q.begin() + layout_.bp_off[k + 1]);
+                    bp_off.push_back(bp_t.size());
+                    cigar.insert(cigar.end(), layout_.cigar.begin() + layout_.cigar_off[k], layout_.cigar.begin() + layout_.cigar_off[k + 1]);
+                    cigar_off.push_back(cigar.size());
+                }
+            }
+            rcn_overlap_set so = o;
+            const uint32_t* p_q_start = layout_.q_start.data(); const uint32_t* p_t_begin = layout_.t_begin.data(); const uint32_t* p_t_end = layout_.t_end.data();
+            const uint32_t* p_q_begin = layout_.q_begin.data(); const uint32_t* p_q_end = layout_.q_end.data();
+            const uint64_t* p_cigar_off = layout_.cigar_off.data(); const uint8_t* p_cigar = layout_.cigar.data();
+            static const uint8_t kNoByte = 0; static const uint32_t kNoWord = 0;
+            if (!all) {
+                so.n_overlaps = sel.size(); so.q_id = q_id.empty() ? &kNoWord : q_id.data(); so.t_id = t_id.empty() ? &kNoWord : t_id.data();
+                so.strand = strand.empty() ? &kNoByte : strand.data(); so.bp_off = bp_off.data();
+                so.bp_t = bp_t.empty() ? &kNoWord : bp_t.data(); so.bp_q = bp_q.empty() ? &kNoWord : bp_q.data();
+                p_q_start = q_start.data(); p_t_begin = t_begin.data(); p_t_end = t_end.data(); p_q_begin = q_begin.data(); p_q_end = q_end.data();
+                p_cigar_off = cigar_off.data(); p_cigar = cigar.empty() ? &kNoByte : cigar.data();
+            }
+            // The reads this shard's overlaps point into, and nothing else: every shard needs every target (their
+            // windows outside the range come out as bare backbones), but of the reads only its own -- one eighth of
+            // cfg3's 1.5 G bases per device instead of all of them on each (the reference's multi-device path keeps the
+            // reads on the host and packs per batch, src/cuda/cudapolisher.cpp:254-276).
+            rcn_read_set sr = r;
+            std::vector<uint64_t> r_seq_off; std::vector<uint8_t> r_bases, r_quals, r_hq;
+            if (!all && r.n_seqs > r.n_targets) {
+                constexpr uint32_t kUnused = 0xffffffffu;
+                std::vector<uint32_t> remap(r.n_seqs, kUnused), old_of;
+                for (uint64_t t = 0; t < r.n_targets; ++t) { remap[t] = static_cast<uint32_t>(t); old_of.push_back(static_cast<uint32_t>(t)); }
+                for (uint32_t& q : q_id) {
+                    if (remap[q] == kUnused) { remap[q] = static_cast<uint32_t>(old_of.size()); old_of.push_back(q); }
+                    q = remap[q];
+                }
+                uint64_t total = 0;
+                for (uint32_t old : old_of) total += r.seq_off[old + 1] - r.seq_off[old];
+                r_seq_off.assign(1, 0); r_seq_off.reserve(old_of.size() + 1);
+                r_bases.resize(total + 1); r_quals.resize(total + 1); r_hq.reserve(old_of.size());
+                for (uint32_t old : old_of) {
+                    const uint64_t a = r.seq_off[old], len = r.seq_off[old + 1] - a, d = r_seq_off.back();
+                    std::copy(r.bases + a, r.bases + a + len, r_bases.begin() + d);
+                    std::copy(r.quals + a, r.quals + a + len, r_quals.begin() + d);
+                    r_hq.push_back(r.seq_has_qual[old]);
+                    r_seq_off.push_back(d + len);
+                }
+                sr.n_seqs = old_of.size(); sr.seq_off = r_seq_off.data(); sr.bases = r_bases.data(); sr.quals = r_quals.data(); sr.seq_has_qual = r_hq.data();
+            }
+            // (the shards of one device run one after the other on its lane thread: they share the device's first engine)
+            const int32_t device = static_cast<int32_t>(sidx % static_cast<uint32_t>(n_devices));
+            auto engine = engines_[static_cast<size_t>(device)];
+            engine->set_fetch_range(wa, wb);                       // the strings of its own windows only
+            struct FetchAll { std::shared_ptr<HipEngine> e; ~FetchAll() { e->set_fetch_range(0, ~uint64_t(0)); } } fetch_all{engine};   // (also when a call below throws)
+            std::vector<std::string> c; std::vector<uint8_t> pl, ch;
+            auto take = [&]() {
+                if (c.size() != nw) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
+                for (uint64_t w = wa; w < wb; ++w) { cons[w].swap(c[w]); pol[w] = pl[w]; chim[w] = ch[w]; }
+            };
+            bool aligned_on_device = false;
+            std::vector<uint8_t> host_cigar; std::vector<uint64_t> host_cigar_off; std::vector<uint32_t> host_q_start;
+            if (device_align_) {
+                rcn_pair_set ps{};
+                ps.n_pairs = so.n_overlaps; ps.q_id = so.q_id; ps.t_id = so.t_id; ps.strand = so.strand;
+                ps.q_begin = p_q_begin; ps.q_end = p_q_end; ps.t_begin = p_t_begin; ps.t_end = p_t_end;
+                try {
+                    if (getenv("RACON_HIP_FORCE_ALIGN_FALLBACK")) throw FatalError("forced");      // (tests)
+                    engine->build(sr, ps, window_length_, quality_threshold_, layout_.window_type);
+                    aligned_on_device = true;
+                } catch (const FatalError&) {
+                    // The device aligner holds one op byte per row + column of every overlap and a per-wave scratch sized
+                    // for the longest read: an input it has no room for (RCN_E_CAPACITY / RCN_E_NOMEM; also a read beyond
+                    // its 3 Mbp limit) is aligned HERE instead, by the host's edlib-equivalent (reference
+                    // src/overlap.cpp:205-224) -- same paths, hence the same windows -- and goes on through the CIGAR path.
+                    if (!getenv("RACON_HIP_FORCE_ALIGN_FALLBACK") && engine->last_rc() != RCN_E_CAPACITY && engine->last_rc() != RCN_E_NOMEM) throw;
+                    static const struct Comp { char t[256]; Comp() { for (int i = 0; i < 256; ++i) t[i] = static_cast<char>(i); t['A'] = 'T'; t['T'] = 'A'; t['C'] = 'G'; t['G'] = 'C'; } } comp;
+                    const uint64_t n = so.n_overlaps;
+                    std::vector<std::string> cg(n);
+                    host_q_start.resize(n);
+                    parallel_for(n, num_threads_, [&](uint64_t k) {
+                        const uint64_t qa = sr.seq_off[so.q_id[k]], ql = sr.seq_off[so.q_id[k] + 1] - qa, ta = sr.seq_off[so.t_id[k]];
+                        std::string q(reinterpret_cast<const char*>(sr.bases + qa + p_q_begin[k]), p_q_end[k] - p_q_begin[k]);
+                        if (so.strand[k]) { std::reverse(q.begin(), q.end()); for (char& ch_ : q) ch_ = comp.t[static_cast<unsigned char>(ch_)]; }
+                        cg[k] = nwpath::align_cigar(q.data(), static_cast<uint32_t>(q.size()), reinterpret_cast<const char*>(sr.bases + ta + p_t_begin[k]), p_t_end[k] - p_t_begin[k]);
+                        host_q_start[k] = so.strand[k] ? static_cast<uint32_t>(ql - p_q_end[k]) : p_q_begin[k];       // reference src/overlap.cpp:241-242
+                    });
+                    host_cigar_off.assign(1, 0);
+                    for (const auto& s_ : cg) { host_cigar.insert(host_cigar.end(), s_.begin(), s_.end()); host_cigar_off.push_back(host_cigar.size()); }
+                }
+            }
+            if (device_align_ && !aligned_on_device) {
+                rcn_cigar_set a{};
+                static const uint8_t kNoCigar = 0;
+                a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
+                a.q_start = host_q_start.empty() ? &kNoWord : host_q_start.data(); a.t_begin = p_t_begin; a.t_end = p_t_end;
+                a.cigar_off = host_cigar_off.data(); a.cigar = host_cigar.empty() ? &kNoCigar : host_cigar.data();
+                engine->build(sr, a, window_length_, quality_threshold_, layout_.window_type);
+            } else if (device_align_) {
+            } else if (device_cigars_) {
+                rcn_cigar_set a{};
+                a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
+                a.q_start = p_q_start; a.t_begin = p_t_begin; a.t_end = p_t_end; a.cigar_off = p_cigar_off; a.cigar = p_cigar;
+                engine->build(sr, a, window_length_, quality_threshold_, layout_.window_type);
+            } else {
+                engine->build(sr, so, window_length_, quality_threshold_, layout_.window_type);
+            }
+            if (phase == 1) { engine->reserve_run(); return; }    // the windows stay resident for polish()
+            engine->run(trim_, &c, &pl, &ch);
+            take();
+        } catch (const std::exception& ex) { shard_errors[sidx] = ex.what(); }
+    };
+    {
+        // one thread per device; the shards of one device run one after the other on it
+        std::vector<std::thread> pool;
+        const uint32_t lanes = std::min<uint32_t>(n_shards, static_cast<uint32_t>(n_devices));
+        for (uint32_t l = 0; l < lanes; ++l) pool.emplace_back([&, l]() { FatalThrowsScope scope; for (uint32_t sidx = l; sidx < n_shards; sidx += lanes) run_shard(sidx); });
+        for (auto& th : pool) th.join();
+    }
+    for (const auto& e : shard_errors) if (!e.empty()) fatal(e);
+}
+
 // ---------------------------------------------------------------- polish
 void Polisher::pack_windows(PackedBatch* out) const {
     out->clear();
@@ -516,12 +747,14 @@ void Polisher::assemble(const std::function<const std::string&(uint64_t)>& conse
     // (src/polisher.cpp:532,545-546).  For one GPU's share of cfg3 that is ~400 MB in ~40 000 heap blocks -- 30 ms of
     // free() in a 110 ms polish() -- and nobody waits for it: a helper thread does it while the caller goes on with the
     // polished sequences (joined by the destructor / the next call).
-    rank_.clear(); chunks_.clear(); planned_refs_.clear();       // (planned for the windows that are released here)
     if (cleanup_.joinable()) cleanup_.join();
     auto* old_windows = new std::vector<std::shared_ptr<Window>>(std::move(windows_));
     auto* old_sequences = new std::vector<std::unique_ptr<Sequence>>(std::move(sequences_));
-    windows_.clear(); sequences_.clear();
-    cleanup_ = std::thread([old_windows, old_sequences] { delete old_windows; delete old_sequences; });
+    // (the work list and the pointer tables planned for these windows go the same way: a short-read job's tables are tens of MB)
+    auto* old_refs = new std::vector<WindowRefs>(std::move(planned_refs_));
+    auto* old_rank = new std::vector<uint32_t>(std::move(rank_));
+    windows_.clear(); sequences_.clear(); planned_refs_.clear(); rank_.clear(); chunks_.clear();
+    cleanup_ = std::thread([old_windows, old_sequences, old_refs, old_rank] { delete old_windows; delete old_sequences; delete old_refs; delete old_rank; });
 }
 
 void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {
@@ -544,175 +777,9 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
     std::vector<std::string> cons(nw);
     std::vector<uint8_t> pol(nw, 0), chim(nw, 0);
     if (device_windows_) {
-        // one engine builds every window in HBM from the resident reads and breaking points and polishes them there
-        rcn_read_set r{}; rcn_overlap_set o{};
-        r.n_seqs = layout_.seq_off.size() - 1; r.n_targets = layout_.n_targets; r.seq_off = layout_.seq_off.data();
-        r.bases = layout_.bases.data(); r.quals = layout_.quals.data(); r.seq_has_qual = layout_.seq_has_qual.data();
-        o.n_overlaps = layout_.q_id.size(); o.q_id = layout_.q_id.data(); o.t_id = layout_.t_id.data(); o.strand = layout_.strand.data();
-        o.bp_off = layout_.bp_off.data(); o.bp_t = layout_.bp_t.data(); o.bp_q = layout_.bp_q.data();
-        // Shards: the window index space is cut into one contiguous range per device, balanced by the bases of the
-        // overlaps that fall into it (the reference's multi-device code hands window ranges to per-device batches the
-        // same way, src/cuda/cudapolisher.cpp:228-240).  A shard's engine gets every read (they are what overlaps
-        // point into) and the overlaps that touch its range -- an overlap across a boundary goes to both sides, the
-        // windows outside a shard's range come out as bare backbones there and are dropped.  RACON_HIP_DEVICE_SHARDS
-        // forces a shard count (tests: several shards on one device).
-        uint32_t n_shards = static_cast<uint32_t>(n_devices);
-        if (const char* sh = getenv("RACON_HIP_DEVICE_SHARDS")) n_shards = std::max(1, atoi(sh));
-        n_shards = static_cast<uint32_t>(std::min<uint64_t>(n_shards, std::max<uint64_t>(1, nw)));
-        std::vector<uint64_t> first_window(layout_.n_targets + 1, 0);
-        for (uint64_t t = 0; t < layout_.n_targets; ++t) {
-            const uint64_t len = layout_.seq_off[t + 1] - layout_.seq_off[t];
-            first_window[t + 1] = first_window[t] + (len + window_length_ - 1) / window_length_;
-        }
-        const uint64_t n_ovl = o.n_overlaps;
-        std::vector<uint64_t> w_lo(n_ovl), w_hi(n_ovl);          // windows [w_lo, w_hi] an overlap touches
-        std::vector<double> win_cost(nw + 1, 0.0);
-        for (uint64_t k = 0; k < n_ovl; ++k) {
-            const uint64_t tb = layout_.t_begin[k], te = std::max<uint64_t>(layout_.t_end[k], tb + 1);
-            w_lo[k] = first_window[o.t_id[k]] + tb / window_length_;
-            w_hi[k] = std::min<uint64_t>(first_window[o.t_id[k]] + (te - 1) / window_length_, nw - 1);
-            for (uint64_t w = w_lo[k]; w <= w_hi[k]; ++w) win_cost[w] += 1.0;
-        }
-        std::vector<uint64_t> cut(n_shards + 1, nw);
-        cut[0] = 0;
-        {
-            double total = 0; for (uint64_t w = 0; w < nw; ++w) total += win_cost[w] + 0.05;
-            double acc = 0; uint32_t sidx = 1;
-            for (uint64_t w = 0; w < nw && sidx < n_shards; ++w) {
-                acc += win_cost[w] + 0.05;
-                if (acc >= total * sidx / n_shards) cut[sidx++] = w + 1;
-            }
-        }
-        std::vector<std::string> shard_errors(n_shards);
-        auto run_shard = [&](uint32_t sidx) {
-            try {
-                const uint64_t wa = cut[sidx], wb = cut[sidx + 1];
-                if (wa >= wb) return;
-                std::vector<uint64_t> sel;
-                for (uint64_t k = 0; k < n_ovl; ++k) if (w_hi[k] >= wa && w_lo[k] < wb) sel.push_back(k);
-                const bool all = sel.size() == n_ovl;
-                // the selected overlaps' slices of the layout arrays
-                std::vector<uint32_t> q_id, t_id, bp_t, bp_q, q_start, t_begin, t_end, q_begin, q_end;
-                std::vector<uint8_t> strand, cigar;
-                std::vector<uint64_t> bp_off{0}, cigar_off{0};
-                if (!all) {
-                    for (uint64_t k : sel) {
-                        q_id.push_back(o.q_id[k]); t_id.push_back(o.t_id[k]); strand.push_back(o.strand[k]);
-                        q_start.push_back(layout_.q_start[k]); t_begin.push_back(layout_.t_begin[k]); t_end.push_back(layout_.t_end[k]);
-                        q_begin.push_back(layout_.q_begin[k]); q_end.push_back(layout_.q_end[k]);
-                        bp_t.insert(bp_t.end(), layout_.bp_t.begin() + layout_.bp_off[k], layout_.bp_t.begin() + layout_.bp_off[k + 1]);
-                        bp_q.insert(bp_q.end(), layout_.bp_q.begin() + layout_.bp_off[k], layout_.bp_q.begin() + layout_.bp_off[k + 1]);
-                        bp_off.push_back(bp_t.size());
-                        cigar.insert(cigar.end(), layout_.cigar.begin() + layout_.cigar_off[k], layout_.cigar.begin() + layout_.cigar_off[k + 1]);
-                        cigar_off.push_back(cigar.size());
-                    }
-                }
-                rcn_overlap_set so = o;
-                const uint32_t* p_q_start = layout_.q_start.data(); const uint32_t* p_t_begin = layout_.t_begin.data(); const uint32_t* p_t_end = layout_.t_end.data();
-                const uint32_t* p_q_begin = layout_.q_begin.data(); const uint32_t* p_q_end = layout_.q_end.data();
-                const uint64_t* p_cigar_off = layout_.cigar_off.data(); const uint8_t* p_cigar = layout_.cigar.data();
-                static const uint8_t kNoByte = 0; static const uint32_t kNoWord = 0;
-                if (!all) {
-                    so.n_overlaps = sel.size(); so.q_id = q_id.empty() ? &kNoWord : q_id.data(); so.t_id = t_id.empty() ? &kNoWord : t_id.data();
-                    so.strand = strand.empty() ? &kNoByte : strand.data(); so.bp_off = bp_off.data();
-                    so.bp_t = bp_t.empty() ? &kNoWord : bp_t.data(); so.bp_q = bp_q.empty() ? &kNoWord : bp_q.data();
-                    p_q_start = q_start.data(); p_t_begin = t_begin.data(); p_t_end = t_end.data(); p_q_begin = q_begin.data(); p_q_end = q_end.data();
-                    p_cigar_off = cigar_off.data(); p_cigar = cigar.empty() ? &kNoByte : cigar.data();
-                }
-                // The reads this shard's overlaps point into, and nothing else: every shard needs every target (their
-                // windows outside the range come out as bare backbones), but of the reads only its own -- one eighth of
-                // cfg3's 1.5 G bases per device instead of all of them on each (the reference's multi-device path keeps the
-                // reads on the host and packs per batch, src/cuda/cudapolisher.cpp:254-276).
-                rcn_read_set sr = r;
-                std::vector<uint64_t> r_seq_off; std::vector<uint8_t> r_bases, r_quals, r_hq;
-                if (!all && r.n_seqs > r.n_targets) {
-                    constexpr uint32_t kUnused = 0xffffffffu;
-                    std::vector<uint32_t> remap(r.n_seqs, kUnused), old_of;
-                    for (uint64_t t = 0; t < r.n_targets; ++t) { remap[t] = static_cast<uint32_t>(t); old_of.push_back(static_cast<uint32_t>(t)); }
-                    for (uint32_t& q : q_id) {
-                        if (remap[q] == kUnused) { remap[q] = static_cast<uint32_t>(old_of.size()); old_of.push_back(q); }
-                        q = remap[q];
-                    }
-                    uint64_t total = 0;
-                    for (uint32_t old : old_of) total += r.seq_off[old + 1] - r.seq_off[old];
-                    r_seq_off.assign(1, 0); r_seq_off.reserve(old_of.size() + 1);
-                    r_bases.resize(total + 1); r_quals.resize(total + 1); r_hq.reserve(old_of.size());
-                    for (uint32_t old : old_of) {
-                        const uint64_t a = r.seq_off[old], len = r.seq_off[old + 1] - a, d = r_seq_off.back();
-                        std::copy(r.bases + a, r.bases + a + len, r_bases.begin() + d);
-                        std::copy(r.quals + a, r.quals + a + len, r_quals.begin() + d);
-                        r_hq.push_back(r.seq_has_qual[old]);
-                        r_seq_off.push_back(d + len);
-                    }
-                    sr.n_seqs = old_of.size(); sr.seq_off = r_seq_off.data(); sr.bases = r_bases.data(); sr.quals = r_quals.data(); sr.seq_has_qual = r_hq.data();
-                }
-                // (the shards of one device run one after the other on its lane thread: they share the device's first engine)
-                const int32_t device = static_cast<int32_t>(sidx % static_cast<uint32_t>(n_devices));
-                auto engine = engines_[static_cast<size_t>(device)];
-                engine->set_fetch_range(wa, wb);                       // the strings of its own windows only
-                struct FetchAll { std::shared_ptr<HipEngine> e; ~FetchAll() { e->set_fetch_range(0, ~uint64_t(0)); } } fetch_all{engine};   // (also when a call below throws)
-                std::vector<std::string> c; std::vector<uint8_t> pl, ch;
-                bool aligned_on_device = false;
-                std::vector<uint8_t> host_cigar; std::vector<uint64_t> host_cigar_off; std::vector<uint32_t> host_q_start;
-                if (device_align_) {
-                    rcn_pair_set ps{};
-                    ps.n_pairs = so.n_overlaps; ps.q_id = so.q_id; ps.t_id = so.t_id; ps.strand = so.strand;
-                    ps.q_begin = p_q_begin; ps.q_end = p_q_end; ps.t_begin = p_t_begin; ps.t_end = p_t_end;
-                    try {
-                        if (getenv("RACON_HIP_FORCE_ALIGN_FALLBACK")) throw FatalError("forced");      // (tests)
-                        engine->consensus(sr, ps, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
-                        aligned_on_device = true;
-                    } catch (const FatalError&) {
-                        // The device aligner holds one op byte per row + column of every overlap and a per-wave scratch sized
-                        // for the longest read: an input it has no room for (RCN_E_CAPACITY / RCN_E_NOMEM; also a read beyond
-                        // its 3 Mbp limit) is aligned HERE instead, by the host's edlib-equivalent (reference
-                        // src/overlap.cpp:205-224) -- same paths, hence the same windows -- and goes on through the CIGAR path.
-                        if (!getenv("RACON_HIP_FORCE_ALIGN_FALLBACK") && engine->last_rc() != RCN_E_CAPACITY && engine->last_rc() != RCN_E_NOMEM) throw;
-                        static const struct Comp { char t[256]; Comp() { for (int i = 0; i < 256; ++i) t[i] = static_cast<char>(i); t['A'] = 'T'; t['T'] = 'A'; t['C'] = 'G'; t['G'] = 'C'; } } comp;
-                        const uint64_t n = so.n_overlaps;
-                        std::vector<std::string> cg(n);
-                        host_q_start.resize(n);
-                        parallel_for(n, num_threads_, [&](uint64_t k) {
-                            const uint64_t qa = sr.seq_off[so.q_id[k]], ql = sr.seq_off[so.q_id[k] + 1] - qa, ta = sr.seq_off[so.t_id[k]];
-                            std::string q(reinterpret_cast<const char*>(sr.bases + qa + p_q_begin[k]), p_q_end[k] - p_q_begin[k]);
-                            if (so.strand[k]) { std::reverse(q.begin(), q.end()); for (char& ch_ : q) ch_ = comp.t[static_cast<unsigned char>(ch_)]; }
-                            cg[k] = nwpath::align_cigar(q.data(), static_cast<uint32_t>(q.size()), reinterpret_cast<const char*>(sr.bases + ta + p_t_begin[k]), p_t_end[k] - p_t_begin[k]);
-                            host_q_start[k] = so.strand[k] ? static_cast<uint32_t>(ql - p_q_end[k]) : p_q_begin[k];       // reference src/overlap.cpp:241-242
-                        });
-                        host_cigar_off.assign(1, 0);
-                        for (const auto& s_ : cg) { host_cigar.insert(host_cigar.end(), s_.begin(), s_.end()); host_cigar_off.push_back(host_cigar.size()); }
-                    }
-                }
-                if (device_align_ && !aligned_on_device) {
-                    rcn_cigar_set a{};
-                    static const uint8_t kNoCigar = 0;
-                    a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
-                    a.q_start = host_q_start.empty() ? &kNoWord : host_q_start.data(); a.t_begin = p_t_begin; a.t_end = p_t_end;
-                    a.cigar_off = host_cigar_off.data(); a.cigar = host_cigar.empty() ? &kNoCigar : host_cigar.data();
-                    engine->consensus(sr, a, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
-                } else if (device_align_) {
-                } else if (device_cigars_) {
-                    rcn_cigar_set a{};
-                    a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
-                    a.q_start = p_q_start; a.t_begin = p_t_begin; a.t_end = p_t_end; a.cigar_off = p_cigar_off; a.cigar = p_cigar;
-                    engine->consensus(sr, a, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
-                } else {
-                    engine->consensus(sr, so, window_length_, quality_threshold_, layout_.window_type, trim_, &c, &pl, &ch);
-                }
-                engine->set_fetch_range(0, ~uint64_t(0));
-                if (c.size() != nw) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
-                for (uint64_t w = wa; w < wb; ++w) { cons[w].swap(c[w]); pol[w] = pl[w]; chim[w] = ch[w]; }
-            } catch (const std::exception& ex) { shard_errors[sidx] = ex.what(); }
-        };
-        {
-            // one thread per device; the shards of one device run one after the other on it
-            std::vector<std::thread> pool;
-            const uint32_t lanes = std::min<uint32_t>(n_shards, static_cast<uint32_t>(n_devices));
-            for (uint32_t l = 0; l < lanes; ++l) pool.emplace_back([&, l]() { FatalThrowsScope scope; for (uint32_t sidx = l; sidx < n_shards; sidx += lanes) run_shard(sidx); });
-            for (auto& th : pool) th.join();
-        }
-        for (const auto& e : shard_errors) if (!e.empty()) fatal(e);
-        if (cons.size() != nw) fatal("[racon::Polisher::polish] error: window count mismatch between host and device!");
+        // windows built in HBM (device_job): by initialize() already where every shard has an engine of its own -- polish() is then
+        // the consensus of resident windows --, otherwise built and polished here, shard after shard
+        device_job(device_built_ ? 2 : 0, &cons, &pol, &chim);
         for (uint64_t i = 0; i < nw; ++i)
             if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
                                  static_cast<unsigned long>(windows_[i]->id()), windows_[i]->rank());
@@ -791,16 +858,22 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         }
     }
     for (const auto& e : errors) if (e) fatal_from(e);
+    if (timing) fprintf(stderr, "[racon::Polisher::polish] timing: engines done at %.2f ms\n", 1e3 * seconds_since(polish_begin));
     polish_chunks_ = static_cast<uint32_t>(chunks.size());
     polish_engines_used_ = 0;
     for (uint32_t n : taken) polish_engines_used_ += n > 0 ? 1 : 0;
-    planned_refs_.clear();                          // (borrowed pointers into the windows assemble() is about to release)
-
     for (uint64_t i = 0; i < nw; ++i)
         if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
                              static_cast<unsigned long>(windows_[i]->id()), windows_[i]->rank());
     assemble([&](uint64_t i) -> const std::string& { return cons[i]; }, [&](uint64_t i) { return pol[i] != 0; },
              dst, drop_unpolished_sequences);
+    if (timing) fprintf(stderr, "[racon::Polisher::polish] timing: assembled at %.2f ms\n", 1e3 * seconds_since(polish_begin));
+    {
+        // (2000 ... 100 000 result strings: freed next to the windows, not inside the interval)
+        auto* old_cons = new std::vector<std::string>(std::move(cons));
+        if (cleanup2_.joinable()) cleanup2_.join();
+        cleanup2_ = std::thread([old_cons] { delete old_cons; });
+    }
     logger_->log("[racon::Polisher::polish] generated consensus");
 }
 

@@ -137,6 +137,7 @@ protected:
     // files are parsed (0.2 s that polish() would otherwise spend before its first launch); joined by polish() / the destructor.
     std::thread device_warmup_;
     std::thread cleanup_;           // frees the windows and sequences polish() is done with (see assemble())
+    std::thread cleanup2_;          // ... and the per-window result strings
     // The engines polish() drives: `2 * hip_batches_` per device, created ONCE by the warm-up thread together with their
     // arenas, pinned staging and the first use of the code object (HipEngine::reserve; the reference creates its
     // alignment engines in the constructor and Preallocs them, src/polisher.cpp:176-183), so that the interval the
@@ -147,6 +148,11 @@ protected:
     double polish_seconds_ = 0;     // the Logger-bracketed interval of the last polish()
     uint32_t polish_chunks_ = 0, polish_engines_used_ = 0;   // chunks / engines that took one in the last polish() (host-built windows)
     void create_engines();          // (warm-up thread, or polish() when the warm-up was switched off)
+    // windows built on the device (device_windows_): phase 1 at the end of initialize(), phase 2 in polish(); phase 0 = both in polish()
+    void build_device_windows();
+    void device_job(int phase, std::vector<std::string>* cons, std::vector<uint8_t>* pol, std::vector<uint8_t>* chim);
+    bool device_built_ = false;             // initialize() left the windows resident on the engines
+    std::vector<uint64_t> device_cut_;      // ... cut into these window ranges, one per shard
     void reserve_for_windows();     // end of initialize(): the arenas sized for the windows that were built
     // polish()'s work list: windows ranked deepest first, cut into chunks (planned once, by reserve_for_windows or polish)
     std::vector<uint32_t> rank_;

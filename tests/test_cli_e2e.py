@@ -87,9 +87,16 @@ def test_cli_with_device_side_windows_matches_oracle(P, oracle, data, ovl, mode)
     exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
     # mode 2: the CIGAR walk (breaking points, reference src/overlap.cpp:226-292) runs on the device as well
     env = dict(os.environ, RACON_HIP_DEVICE_WINDOWS=mode)
-    out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
-    assert out == ref
+    run = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.stdout == ref
+    # the windows are built where the reference builds them -- at the end of initialize() -- and stay resident: polish() is the
+    # consensus alone; RACON_HIP_BUILD_IN_POLISH=1 (construction inside polish(), shard after shard) prints the same FASTA
+    assert b"transformed data into windows (on the device)" in run.stderr
+    env["RACON_HIP_BUILD_IN_POLISH"] = "1"
+    late = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert late.stdout == ref and b"(on the device)" not in late.stderr
 
 
 @pytest.mark.gpu

@@ -15,9 +15,14 @@ has() { [[ " $WHAT " == *" $1 "* ]]; }
 benchline() { python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
-print('%s: %.0f windows/s  step %.2f ms  launches %s  frac %.3f  gcups %.0f  small %s bailed %s why %s' % ('$1', j['value'], r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], r['frac'], r.get('gcups',0), r.get('small_windows'), r.get('small_bailed'), r.get('small_bail_why')))"; }
+sl=r.get('split_launch') or {}
+print('%s: %.0f windows/s  step %.2f ms  launches %s mid %s  frac %.3f  gcups %.0f  small %s bailed %s why %s' % ('$1', j['value'], r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], sl.get('mid_launch_ms'), r['frac'], r.get('gcups',0), r.get('small_windows'), r.get('small_bailed'), r.get('small_bail_why')))"; }
 QB="--steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg"
 
+if has subset2; then
+  timeout 2400 python -m pytest tests/test_gpu_small.py tests/test_cli_e2e.py tests/test_gpu_product_path.py tests/test_gpu_window_build.py -m gpu -q --durations=10 > "$OUT/pytest_subset2.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_subset2.log"; tail -25 "$OUT/pytest_subset2.log"
+fi
 if has subset; then
   timeout 2400 python -m pytest tests/test_gpu_small.py tests/test_cli_e2e.py tests/test_gpu_bench_contract.py \
       "tests/test_gpu_product_path.py::test_polish_interval_chunks_and_warmup" "tests/test_gpu_fullsize.py::test_one_rank_rccl_exchange" \
@@ -57,6 +62,29 @@ if has tiers; then
     done
     run "default, third time"
   } 2>&1 | tee "$OUT/tiers.txt"
+fi
+if has repro; then
+  timeout 900 python tools/exp/fuzz_repro.py ${REPRO_ARGS:-5088 115 1,-1,-1 1} > "$OUT/fuzz_repro.txt" 2>&1
+  echo "repro exit $?"; cut -c1-400 "$OUT/fuzz_repro.txt" | head -150
+fi
+if has timeline2; then
+  # polish() of the binary on cfg2-shaped files, by mode: host-built windows (0), CIGAR walk + construction in HBM (2, SAM),
+  # alignment + walk + construction in HBM (--cudaaligner-batches 1, PAF) -- host timeline of the last of three runs each
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(1_000_000, 30.0, 20260921, 32))
+PY
+  F=/tmp/racon_amd_cache/files_1000000_30_20260921
+  for spec in "mode0:sam:" "mode2:sam:RACON_HIP_DEVICE_WINDOWS=2" "mode3:paf:RACON_HIP_DEVICE_WINDOWS=3" "mode2late:sam:RACON_HIP_DEVICE_WINDOWS=2 RACON_HIP_BUILD_IN_POLISH=1"; do
+    IFS=: read name ovl envs <<< "$spec"
+    for k in 1 2 3; do
+      env $envs RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.$ovl $F/targets.fasta 2> "$OUT/timeline_cfg2_$name.err" | md5sum | cut -c1-8
+      echo "cfg2 $name: $(grep 'generated consensus' $OUT/timeline_cfg2_$name.err) | $(grep 'total =' $OUT/timeline_cfg2_$name.err)"
+    done
+    grep -E "racon::|polish:|piece|collect|reserve|pass of|timing|pairs:" "$OUT/timeline_cfg2_$name.err" | cut -c1-300 > "$OUT/timeline_cfg2_$name.txt"
+  done 2>&1 | tee "$OUT/timeline2.txt"
 fi
 if has cfg4prod; then
   python - <<'PY'
