@@ -152,6 +152,9 @@ def product_polish(paths, window, scores, threads, expect=None, reps=2, batches=
     from racon_amd.polisher import Polisher
     m, x, g = scores
     best, runs, nw, same = None, [], 0, None
+    # (the library keeps host-built windows by default -- its callers may ask for windows() --; the product, `racon_hip`, builds them in
+    #  HBM at the end of initialize() whenever they fit: the same here)
+    os.environ.setdefault("RACON_HIP_DEVICE_WINDOWS", "auto")
     for _ in range(reps):
         p = Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", window, 10.0, 0.3, True, m, x, g, threads, batches)
         t1 = time.perf_counter()
@@ -526,14 +529,17 @@ def main():
                         continue
                     # SURVEY 8(f) rows 1, 2, 4 on the interval they were built for (reference: CUDAPolisher::find_overlap_breaking_points
                     # sits inside the same timed program, src/cuda/cudapolisher.cpp:74-214):
-                    #   device_cigars  SAM, RACON_HIP_DEVICE_WINDOWS=2: CIGAR walk + window construction in HBM (rcn_engine_build_windows_from_cigars)
+                    #   (cli, above)   SAM, the binary's default: CIGAR walk + window construction in HBM at the end of initialize() (rcn_engine_build_windows_from_cigars)
+                    #   host_built     SAM, RACON_HIP_DEVICE_WINDOWS=0: Window::add_layer on the host, chunks packed and streamed inside polish()
                     #   device_align   PAF, --cudaaligner-batches 1: pairwise alignment + CIGAR walk + construction in HBM (rcn_engine_build_windows_from_pairs)
                     #   host_align     PAF, the default: the host's edlib-equivalent inside initialize(), then the host-built path
                     # (PAF and SAM inputs differ in their alignments, hence in their windows: the PAF legs are compared with each other)
                     ex = b"".join(res.consensus) if same_windows else None
-                    dm = {"device_cigars": product_cli(paths, pwindow, (m, x, g), th, expect=ex, reps=2, batches=a.product_batches, env_add={"RACON_HIP_DEVICE_WINDOWS": "2"})}
-                    if "error" not in dm["device_cigars"] and "error" not in out["product_polish"][name]["cli"]:
-                        dm["device_cigars"]["fasta_matches_host_built"] = dm["device_cigars"]["fasta_md5"] == out["product_polish"][name]["cli"]["fasta_md5"]
+                    # (the binary's default is `auto`: construction in HBM when it fits -- the "cli" leg above; here the host-built path,
+                    #  windows packed per chunk inside polish(), RACON_HIP_DEVICE_WINDOWS=0)
+                    dm = {"host_built": product_cli(paths, pwindow, (m, x, g), th, expect=ex, reps=2, batches=a.product_batches, env_add={"RACON_HIP_DEVICE_WINDOWS": "0"})}
+                    if "error" not in dm["host_built"] and "error" not in out["product_polish"][name]["cli"]:
+                        dm["host_built"]["fasta_matches_device_built"] = dm["host_built"]["fasta_md5"] == out["product_polish"][name]["cli"]["fasta_md5"]
                     if os.path.exists(paths.get("paf", "")):
                         dm["device_align"] = product_cli(paths, pwindow, (m, x, g), th, reps=2, batches=a.product_batches, overlaps="paf", flags=("--cudaaligner-batches", "1"))
                         dm["host_align"] = product_cli(paths, pwindow, (m, x, g), th, reps=1, batches=a.product_batches, overlaps="paf")

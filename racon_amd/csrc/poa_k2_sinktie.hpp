@@ -14,6 +14,8 @@ namespace rcn {
 //      nobody's closure: it is appended exactly when the start loop reaches its own id.  Hence the key
 //      (p, id) for sinks whose ring holds a backbone node, (inf, id) for lone non-backbone sinks, and
 //      (inf, smallest id of the ring, position behind it) for rings of non-backbone nodes without out-edges.
+//      Rings, out-edges and starts are those of the graph being aligned: for a Subgraph alignment only what `inc` marks.
+//      Restated on the CPU and compared with the DFS at every tie of the CPU test sets: tests/emul/emul_main.cpp (rc -8).
 //  (2) the tied sinks include rings of non-backbone nodes: mark the backbone closure (= Subgraph(0, L-1), the
 //      parallel sweep) as done and run the exact DFS only over the few nodes outside it.
 //  (3) otherwise the full exact DFS.
@@ -34,12 +36,20 @@ __device__ __noinline__ void phase_sink_tie_rule() {
         for (int k = 0; k < c.tied; ++k) {
             const int v = rank[(k == 0 ? c.best_row : o->tie_rows[k]) - 1];
             const int na = g.al_cnt[v];
-            int rm = v;
-            for (int a = 0; a < na; ++a) rm = min(rm, g.al_nodes[v * g.ring + a]);
+            // the ring AS THE (SUB)GRAPH HAS IT: spoa's DFS over a subgraph neither starts at nor visits the nodes outside it, so a
+            // ring member outside -- a backbone node b_p left of `begin` whose aligned alternatives were pulled in through
+            // their own successors -- appends nothing and orders nothing.  (Taken over all members the key was (p, id) of a
+            // start that never happens: one window in 666 600 of tools/fuzz_sweep.py, seed 5088, found this.)
+            int rm = v, na_in = 0;
+            for (int a = 0; a < na; ++a) {
+                const int u = g.al_nodes[v * g.ring + a];
+                if (sub && !g.inc[u]) continue;
+                ++na_in; rm = min(rm, u);
+            }
             long long key;
             if (rm < c.bblen) key = (static_cast<long long>(rm) << 32) | static_cast<unsigned int>(v);
             else if (v >= (1 << 25)) { classified = false; break; }
-            else if (na == 0) key = (0x7ffffffell << 32) | (static_cast<unsigned int>(v) << 6);
+            else if (na_in == 0) key = (0x7ffffffell << 32) | (static_cast<unsigned int>(v) << 6);
             else {
                 // a ring of non-backbone nodes none of which has an out-edge (alternative last bases past the backbone's
                 // end: every later layer that stops short of them ties there): nothing is appended because of them and

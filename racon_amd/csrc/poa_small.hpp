@@ -542,11 +542,16 @@ __device__ __forceinline__ int sm_sink_tie(const SmPtrs& g, int tied, int best_r
         for (int k = 0; k < tied && classified; ++k) {
             const int v = rk[(k == 0 ? best_row : g.misc[k]) - 1];
             const int na = g.alcnt[v];
-            int rm = v;
-            for (int a = 0; a < na; ++a) rm = min(rm, static_cast<int>(g.ring[v * kSmRing + a]));
+            // (the ring as the (sub)graph has it: members outside a Subgraph start nothing and order nothing, see phase_sink_tie_rule)
+            int rm = v, na_in = 0;
+            for (int a = 0; a < na; ++a) {
+                const int u = static_cast<int>(g.ring[v * kSmRing + a]);
+                if (partial && !g.inc[u]) continue;
+                ++na_in; rm = min(rm, u);
+            }
             long long key;
             if (rm < L) key = (static_cast<long long>(rm) << 32) | static_cast<unsigned int>(v);
-            else if (na == 0) key = (0x7ffffffell << 32) | (static_cast<unsigned int>(v) << 6);
+            else if (na_in == 0) key = (0x7ffffffell << 32) | (static_cast<unsigned int>(v) << 6);
             else {
                 // a ring of non-backbone nodes none of which has a successor in the (sub)graph: the DFS start loop finds it at
                 // its smallest id m and appends m, then m's aligned list in list order

@@ -139,6 +139,13 @@ int32_t HipEngine::DeviceCount() {
     return a.lib ? a.device_count() : 0;
 }
 
+uint64_t HipEngine::UsedMemory(int32_t device) {
+    const Abi& a = abi();
+    uint64_t fr = 0, tot = 0;
+    if (!a.lib || a.free_memory(device, &fr, &tot) != RCN_OK) return 0;
+    return tot - fr;
+}
+
 uint64_t HipEngine::FreeMemory(int32_t device) {
     const Abi& a = abi();
     uint64_t fr = 0, tot = 0;

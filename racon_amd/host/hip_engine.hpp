@@ -60,6 +60,7 @@ public:
     // several engines on one device must split it, see FreeMemory).
     static std::shared_ptr<HipEngine> Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap, uint64_t arena_bytes = 0);
     static uint64_t FreeMemory(int32_t device);   // free HBM in bytes (0 on error)
+    static uint64_t UsedMemory(int32_t device);   // HBM in use on the device, by anyone (0 on error)
     static int32_t DeviceCount();      // 0 when the library cannot be loaded or no device is visible
     ~HipEngine();
 

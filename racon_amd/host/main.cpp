@@ -131,6 +131,8 @@ int main(int argc, char** argv) {
     auto polisher = racon::createPolisher(input_paths[0], input_paths[1], input_paths[2],
         type == 0 ? racon::PolisherType::kC : racon::PolisherType::kF, window_length, quality_threshold, error_threshold,
         trim, match, mismatch, gap, num_threads, hip_batches, hip_banded_alignment, hipaligner_batches, hipaligner_band_width);
+    // windows are built in HBM at the end of initialize() when everything fits the device(s) (RACON_HIP_DEVICE_WINDOWS=0: on the host)
+    polisher->set_default_device_mode("auto");
     polisher->initialize();
     std::vector<std::unique_ptr<racon::Sequence>> polished_sequences;
     polisher->polish(polished_sequences, drop_unpolished_sequences);

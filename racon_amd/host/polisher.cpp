@@ -282,7 +282,29 @@ void Polisher::initialize() {
 
     parallel_for(sequences_.size(), num_threads_, [&](uint64_t j) { sequences_[j]->transmute(has_name[j], has_data[j], has_reverse_data[j]); });
 
-    if (const char* dv = getenv("RACON_HIP_DEVICE_WINDOWS")) { if (dv[0] >= '1' && dv[0] <= '3') device_windows(true, dv[0] == '2', dv[0] == '3'); }
+    {
+        // Where the windows are built.  RACON_HIP_DEVICE_WINDOWS = 0 (host: Window::add_layer, packed per chunk inside polish()),
+        // 1 / 2 / 3 (in HBM: from host breaking points / + the CIGAR walk / + the pairwise alignment), or auto -- what the
+        // `racon_hip` binary defaults to (set_default_device_mode): in HBM with the CIGAR walk whenever reads, windows and scratch
+        // fit the devices with room to spare, on the host (chunks streamed through the engines, any size) otherwise.
+        const char* dv_env = getenv("RACON_HIP_DEVICE_WINDOWS");
+        const std::string dv = dv_env ? dv_env : default_device_mode_;
+        if (!dv.empty() && dv[0] >= '1' && dv[0] <= '3') device_windows(true, dv[0] == '2', dv[0] == '3');
+        else if (dv == "auto" && !keep_layout_) {
+            uint64_t read_bases = 0, layer_bases = 0;
+            for (const auto& s_ : sequences_) read_bases += s_->data().size();
+            for (const auto& o : overlaps) layer_bases += o->q_end() - o->q_begin();
+            for (uint64_t i = 0; i < targets_size; ++i) layer_bases += sequences_[i]->data().size();
+            const int32_t devices = HipEngine::DeviceCount();
+            // per device: every read (bases + qualities), its share of the packed windows (x 2 for the sort / gather buffers next to
+            // them), CIGAR text, and a scratch arena; against HALF of what is free on device 0
+            const double need = 2.0 * read_bases + 4.0 * layer_bases / std::max(1, devices) + 24e9;
+            const double have = devices > 0 ? 0.5 * static_cast<double>(HipEngine::FreeMemory(0)) : 0.0;
+            if (devices > 0 && need < have) device_windows(true, true, device_align_);
+            else if (device_windows_ && need >= have)
+                fprintf(stderr, "[racon::Polisher::initialize] warning: the device-side construction needs about %.0f GB per device\n", need / 1e9);
+        }
+    }
     if (device_align_) {
         // all or nothing per overlap file: SAM records carry CIGARs (nothing to align), PAF / MHAP records do not
         bool any_cigar = false;
@@ -572,11 +594,14 @@ void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::ve
         }
     }
     if (phase == 1) device_cut_ = cut;
+    const auto job_begin = std::chrono::steady_clock::now();
+    std::mutex peak_mutex; uint64_t peak_used = 0;
     std::vector<std::string> shard_errors(n_shards);
     auto run_shard = [&](uint32_t sidx) {
         try {
             const uint64_t wa = cut[sidx], wb = cut[sidx + 1];
             if (wa >= wb) return;
+            const double t_shard = seconds_since(job_begin);
             if (phase == 2) {                                      // built by initialize(): the consensus of the resident windows
                 auto engine = engines_[static_cast<size_t>(sidx % static_cast<uint32_t>(n_devices))];
                 engine->set_fetch_range(wa, wb);
@@ -702,9 +727,25 @@ void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::ve
             } else {
                 engine->build(sr, so, window_length_, quality_threshold_, layout_.window_type);
             }
-            if (phase == 1) { engine->reserve_run(); return; }    // the windows stay resident for polish()
+            const bool timing = getenv("RACON_HIP_TIMING") != nullptr;
+            const double t_built = seconds_since(job_begin);
+            if (phase == 1) {                                      // the windows stay resident for polish()
+                engine->reserve_run();
+                if (timing) fprintf(stderr, "[racon::Polisher::initialize] timing: shard %u (windows %lu..%lu, %lu overlaps) built on device %d in %.1f ms, run reserved after %.1f ms, %.2f GB of HBM in use\n",
+                                    sidx, static_cast<unsigned long>(wa), static_cast<unsigned long>(wb), static_cast<unsigned long>(so.n_overlaps), device,
+                                    1e3 * (t_built - t_shard), 1e3 * (seconds_since(job_begin) - t_shard), HipEngine::UsedMemory(device % std::max(1, HipEngine::DeviceCount())) / 1e9);
+                return;
+            }
+            const uint64_t used_built = timing ? HipEngine::UsedMemory(device % std::max(1, HipEngine::DeviceCount())) : 0;
             engine->run(trim_, &c, &pl, &ch);
             take();
+            if (timing) {
+                const uint64_t used = std::max(used_built, HipEngine::UsedMemory(device % std::max(1, HipEngine::DeviceCount())));
+                fprintf(stderr, "[racon::Polisher::polish] timing: shard %u (windows %lu..%lu, %lu overlaps) on device %d: built in %.1f ms, consensus + results in %.1f ms (kernel %.1f), %.2f GB of HBM in use\n",
+                        sidx, static_cast<unsigned long>(wa), static_cast<unsigned long>(wb), static_cast<unsigned long>(so.n_overlaps), device,
+                        1e3 * (t_built - t_shard), 1e3 * (seconds_since(job_begin) - t_built), engine->last_kernel_ms(), used / 1e9);
+                std::lock_guard<std::mutex> lock(peak_mutex); peak_used = std::max(peak_used, used);
+            }
         } catch (const std::exception& ex) { shard_errors[sidx] = ex.what(); }
     };
     {
@@ -715,6 +756,7 @@ void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::ve
         for (auto& th : pool) th.join();
     }
     for (const auto& e : shard_errors) if (!e.empty()) fatal(e);
+    if (peak_used) fprintf(stderr, "[racon::Polisher::polish] timing: %u shard(s), peak HBM in use %.2f GB\n", n_shards, peak_used / 1e9);
 }
 
 // ---------------------------------------------------------------- polish

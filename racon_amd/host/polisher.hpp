@@ -83,6 +83,9 @@ public:
         uint8_t window_type = 0;
     };
     void keep_layout(bool on) { keep_layout_ = on; }
+    // what initialize() does when RACON_HIP_DEVICE_WINDOWS is not set: "0" (the library's default: the caller may ask for windows())
+    // or "auto" (the racon_hip binary)
+    void set_default_device_mode(const std::string& mode) { default_device_mode_ = mode; }
     // Windows built on the device: initialize() then skips the serial add_layer loop (windows_ keep only their backbones,
     // which polish() needs for the stitching) and records the layout instead.  Also switched on by RACON_HIP_DEVICE_WINDOWS=1.
     // cigars: the CIGAR walk (Overlap::find_breaking_points, reference src/overlap.cpp:226-292) runs on the device too
@@ -128,6 +131,7 @@ protected:
     uint32_t window_length_;
     std::vector<std::shared_ptr<Window>> windows_;
     bool keep_layout_ = false;
+    std::string default_device_mode_ = "0";
     bool device_cigars_ = false;
     bool device_align_ = false;     // overlaps without a CIGAR are aligned on the device (set back by initialize() when the file has CIGARs)
     bool device_windows_ = false;   // polish(): windows built in HBM (rcn_engine_build_windows) instead of packed from windows_

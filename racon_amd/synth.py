@@ -293,7 +293,7 @@ def simulate_fragment_files(out_dir: str, genome_len: int, n_reads: int, read_le
             if strand:
                 seq, qual = seq.translate(_COMP)[::-1], qual[::-1]
             fr.write(b"@f%d\n" % i + seq + b"\n+\n" + qual + b"\n")
-            reads.append((ts, te, qlen, qstart, strand))
+            reads.append((ts, te, qlen, qstart.astype(np.int32), strand))      # (100 000 reads at full scale: 4 GB of these, not 8)
     n_ovl = 0
     with open(paths["paf"], "wb") as fp:
         lo = 0

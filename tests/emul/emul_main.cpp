@@ -13,7 +13,8 @@
 
 using namespace rcn;
 
-static int g_ties = 0, g_aligns = 0;
+static int g_ties = 0, g_aligns = 0, g_tie_rule = 0, g_tie_rule_open = 0;
+static std::vector<int> g_tie_rows;       // rows of the tied best sinks of the last alignment, in row order
 static long long g_sweeps = 0, g_sweep_chunks = 0, g_sweep_runs = 0;   // Subgraph sweeps compared with the DFS, their 64-rank chunks, chain runs taken
 static long long g_hist[8] = {0};   // pred distance: 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, >64
 static long long g_rows = 0, g_row0 = 0;
@@ -55,8 +56,8 @@ static void host_dp(Win& g, const int32_t* rank, const Arr<int32_t>& nr, int V, 
         g_cur_maxin = std::max(g_cur_maxin, nin);
         for (int j = 1; j <= len; ++j) row[j] = std::max(row[j], row[j - 1] + gp);
         if (d.meta & 256) {
-            if (!have || best < row[len]) { have = true; best = row[len]; best_row = r + 1; tied = 1; }
-            else if (best == row[len]) ++tied;
+            if (!have || best < row[len]) { have = true; best = row[len]; best_row = r + 1; tied = 1; g_tie_rows.assign(1, r + 1); }
+            else if (best == row[len]) { ++tied; g_tie_rows.push_back(r + 1); }
         }
     }
 }
@@ -333,6 +334,65 @@ extern "C" int rcn_emul_consensus(const rcn_batch* b, int m, int x, int gp, int 
                 for (int r = 0; r < nx; ++r) {
                     int v = g.rank_x[r]; int row = (*nr)[v] + 1;
                     if ((g.desc[row - 1].meta & 256) && g.H[(int64_t)row * g.hstride + sl(i)] == best) { best_row = row; break; }
+                }
+                // the kernel's level-1 rule (racon_amd/csrc/poa_k2_sinktie.hpp: phase_sink_tie_rule), restated on the same arrays: where it
+                // decides, its pick must be the DFS's
+                if (tied <= 8) {
+                    const bool sub = !full;
+                    bool classified = true;
+                    long long bestkey = 0x7fffffffffffffffll; int pick = -1;
+                    for (int k = 0; k < tied; ++k) {
+                        const int v = rk[g_tie_rows[k] - 1];
+                        const int na = g.al_cnt[v];
+                        int rm = v, na_in = 0;
+                        for (int a = 0; a < na; ++a) {
+                            const int u = g.al_nodes[v * g.ring + a];
+                            if (sub && !g.inc[u]) continue;
+                            ++na_in; rm = std::min(rm, u);
+                        }
+                        long long key;
+                        if (rm < (int)L) key = ((long long)rm << 32) | (unsigned int)v;
+                        else if (na_in == 0) key = (0x7ffffffell << 32) | ((unsigned int)v << 6);
+                        else {
+                            bool closed = true;
+                            for (int a = -1; a < na && closed; ++a) {
+                                const int u = a < 0 ? v : g.al_nodes[v * g.ring + a];
+                                if (sub && !g.inc[u]) continue;
+                                for (int e = g.out_head[u]; e >= 0 && closed; e = g.e_nout[e]) if (!sub || g.inc[g.e_head[e]]) closed = false;
+                            }
+                            if (!closed) { classified = false; break; }
+                            int pos = 0;
+                            if (v != rm) {
+                                if (sub && !g.inc[rm]) { classified = false; break; }
+                                const int nm = g.al_cnt[rm];
+                                pos = -1;
+                                for (int a = 0, q = 0; a < nm; ++a) {
+                                    const int u = g.al_nodes[rm * g.ring + a];
+                                    if (sub && !g.inc[u]) continue;
+                                    ++q;
+                                    if (u == v) { pos = q; break; }
+                                }
+                                if (pos < 0 || pos >= 64) { classified = false; break; }
+                            }
+                            key = (0x7ffffffell << 32) | ((unsigned int)rm << 6) | (unsigned int)pos;
+                        }
+                        if (key < bestkey) { bestkey = key; pick = v; }
+                    }
+                    if (classified) {
+                        ++g_tie_rule;
+                        if ((*nr)[pick] + 1 != best_row) {
+                            fprintf(stderr, "emul: the sink-tie rule picks node %d (row %d), spoa's DFS order row %d (node %d); window %u layer %u, %d tied, sub %d, L %d, nodes %d\n",
+                                    pick, (*nr)[pick] + 1, best_row, rk[best_row - 1], w, j, tied, (int)sub, (int)L, g.n_nodes);
+                            for (int k = 0; k < tied; ++k) {
+                                const int v = rk[g_tie_rows[k] - 1];
+                                fprintf(stderr, "   tied row %d node %d code %c ring:", g_tie_rows[k], v, g.code[v]);
+                                for (int a = 0; a < g.al_cnt[v]; ++a) fprintf(stderr, " %d%s", (int)g.al_nodes[v * g.ring + a], (sub && !g.inc[g.al_nodes[v * g.ring + a]]) ? "(out)" : "");
+                                fprintf(stderr, "\n");
+                            }
+                            fprintf(stderr, "   DFS order:"); for (int r = 0; r < nx; ++r) fprintf(stderr, " %d", g.rank_x[r]); fprintf(stderr, "\n");
+                            if (!getenv("RCN_EMUL_TIE_RULE_WARN")) return -8;
+                        }
+                    } else ++g_tie_rule_open;
                 }
             }
             int plen = nw_traceback(g, rk, *nr, !full, sp(i), sl(i), best_row, m, x, gp);

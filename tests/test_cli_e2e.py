@@ -54,12 +54,19 @@ def test_pipeline_polishes(P, oracle, data):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ovl", ["sam", "paf"])
 def test_cli_matches_oracle(P, oracle, data, ovl):
+    """The binary as a user runs it (windows built in HBM at the end of initialize(): its default when the job fits the device) and
+    with RACON_HIP_DEVICE_WINDOWS=0 (Window::add_layer on the host, chunks packed inside polish()): the FASTA of host layer + oracle."""
     paths, _ = data
     ref, _ = _oracle_fasta(P, oracle, paths, ovl)
     exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
-    out = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
-    assert out == ref
+    env = {k: v for k, v in os.environ.items() if k != "RACON_HIP_DEVICE_WINDOWS"}
+    run = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.stdout == ref and b"transformed data into windows (on the device)" in run.stderr
+    env["RACON_HIP_DEVICE_WINDOWS"] = "0"
+    host = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert host.stdout == ref and b"(on the device)" not in host.stderr
 
 
 @pytest.mark.gpu
@@ -123,9 +130,7 @@ def test_cli_on_three_logical_devices(P, oracle, data, ovl, mode):
     paths, _ = data
     ref, _ = _oracle_fasta(P, oracle, paths, ovl)
     exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
-    env = dict(os.environ, RACON_HIP_FAKE_DEVICES="3", RACON_HIP_CHUNK_WINDOWS="7")
-    if mode != "0":
-        env["RACON_HIP_DEVICE_WINDOWS"] = mode
+    env = dict(os.environ, RACON_HIP_FAKE_DEVICES="3", RACON_HIP_CHUNK_WINDOWS="7", RACON_HIP_DEVICE_WINDOWS=mode)
     env["RACON_HIP_TIMING"] = "1"
     run = subprocess.run([exe, "-t", "4", paths["reads"], paths[ovl], paths["targets"]], check=True, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -182,7 +187,8 @@ def test_cli_survives_a_device_short_of_memory(tmp_path):
     exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
     cmd = [exe, "-t", "8", paths["reads"], paths["sam"], paths["targets"]]
     free = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    env = dict(os.environ, RCN_EXPERIMENT="1", RCN_FAIL_ALLOC_ABOVE=str(1 << 30))
+    # (the host-built path: chunks streamed through the engines, what a job too large for the device-side construction takes)
+    env = dict(os.environ, RCN_EXPERIMENT="1", RCN_FAIL_ALLOC_ABOVE=str(1 << 30), RACON_HIP_DEVICE_WINDOWS="0")
     tight = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert tight.stdout == free.stdout and tight.stdout.count(b">") == 1
     assert b"polishing them in halves" in tight.stderr and b"polishing them in halves" not in free.stderr

@@ -69,3 +69,22 @@ def test_emul_serial_add_keeps_in_edge_records(emul, oracle, monkeypatch):
     ref = oracle.consensus(b, *sc, True, 4)
     got, pol = run_emul(emul, b, *sc)
     assert got == ref.consensus
+
+
+def test_emul_sink_tie_rule_on_fuzz_windows(emul, oracle):
+    """The kernels' sink-tie rule (racon_amd/csrc/poa_k2_sinktie.hpp: phase_sink_tie_rule, the same rule in poa_small.hpp), restated in
+    the emulator on the same arrays and compared with spoa's DFS order at EVERY tie (rc -8 on a difference), on the low-complexity fuzz
+    windows where ties are the rule -- among them the window (tools/fuzz_sweep.py seed 5088, window 115, scores 1/-1/-1) on which the
+    rule took a ring member OUTSIDE the Subgraph for the ring's backbone node: one window in 666 600 on the GPU, found by the sweep."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from racon_amd.batch import WindowBatch
+    from test_gpu_fuzz import random_window
+    for seed, pick in ((5088, [115]), (5088, range(100, 260)), (7001, range(0, 160))):
+        rng = np.random.default_rng(seed)
+        wins = [random_window(rng, 5 * int(rng.integers(0, 50)) + (4 if rng.random() < 0.125 else int(rng.integers(0, 4)))) for _ in range(500)]
+        b = WindowBatch.from_windows([wins[k] for k in pick])
+        for sc in ((1, -1, -1), (3, -5, -4)):
+            ref = oracle.consensus(b, *sc, True, 4)
+            got, pol = run_emul(emul, b, *sc)
+            assert got == ref.consensus, (seed, sc)

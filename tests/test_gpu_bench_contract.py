@@ -107,6 +107,6 @@ def test_bench_product_legs_on_the_default_workload():
     # SURVEY 8(f) rows on the interval they were built for: CIGAR walk + construction in HBM (SAM), alignment + walk + construction
     # in HBM (PAF, --cudaaligner-batches 1) against the host aligner on the same PAF
     dm = p["device_modes"]
-    assert dm["device_cigars"]["fasta_matches_kernel_leg"] is True and dm["device_cigars"]["fasta_matches_host_built"] is True
+    assert dm["host_built"]["fasta_matches_kernel_leg"] is True and dm["host_built"]["fasta_matches_device_built"] is True
     assert dm["device_align"]["fasta_matches_host_aligner"] is True and dm["device_align"]["windows"] == dm["host_align"]["windows"] == 2000
     assert dm["device_align"]["wall_s"] < dm["host_align"]["wall_s"]

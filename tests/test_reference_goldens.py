@@ -158,16 +158,24 @@ def test_fragment_goldens_oracle(P, oracle, reads, ovl, ty, drop, gold, lines):
 
 
 # ---- the same pipelines end-to-end on the MI355X: createPolisher -> initialize -> polish with the HIP engine ----
+# `where`: "0" = windows built on the host and streamed through the engines inside polish() (the library's default), "auto" = built in
+# HBM at the end of initialize() and left resident (what the racon_hip binary does whenever the job fits the device)
 @pytest.mark.gpu
+@pytest.mark.parametrize("where", ["0", "auto"])
 @pytest.mark.parametrize("reads,ovl,w,sc,gold,line", CONTIG + CLI_DEFAULT)
-def test_contig_goldens_hip(P, reference_contig, reads, ovl, w, sc, gold, line):
+def test_contig_goldens_hip(P, reference_contig, monkeypatch, reads, ovl, w, sc, gold, line, where):
+    monkeypatch.setenv("RACON_HIP_DEVICE_WINDOWS", where)
     seq = _contig_case(P, "hip", reads, ovl, w, sc)
     _check_contig(P, reference_contig, seq, reads, ovl, w, sc, gold, line)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("where", ["0", "auto"])
 @pytest.mark.parametrize("reads,ovl,ty,drop,gold,lines", FRAGMENT)
-def test_fragment_goldens_hip(P, reads, ovl, ty, drop, gold, lines):
+def test_fragment_goldens_hip(P, monkeypatch, reads, ovl, ty, drop, gold, lines, where):
     pin = KF_WINDOWS_MD5 if (ty, reads, ovl) == ("kF", "sample_reads.fastq.gz", "sample_ava_overlaps.paf.gz") else None
+    if where == "auto":
+        pin = None                  # (p.windows() needs host-built windows: the pin of the window consensi is the "0" run's)
+    monkeypatch.setenv("RACON_HIP_DEVICE_WINDOWS", where)
     fa = _fragment_case(P, "hip", reads, ovl, ty, drop, pin)
     assert (len(fa), sum(len(s) for _, s in fa)) == gold, f"racon_test.cpp:{lines}"
