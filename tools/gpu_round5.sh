@@ -86,6 +86,11 @@ PY
     grep -E "racon::|polish:|piece|collect|reserve|pass of|timing|pairs:" "$OUT/timeline_cfg2_$name.err" | cut -c1-300 > "$OUT/timeline_cfg2_$name.txt"
   done 2>&1 | tee "$OUT/timeline2.txt"
 fi
+if has splitcus; then
+  # CUs (= windows, one per CU) of the deep launch, once more on this round's kernels
+  run() { echo "== $1"; shift; env "$@" python bench.py $QB 2>/dev/null | benchline "$*"; }
+  { for c in 16 24 32 64; do run "deep launch on $c CUs" RCN_SPLIT_CUS=$c; done; run "deep launch on 32 CUs, 48 windows in it (two rounds for 16 CUs)" RCN_SPLIT_CUS=32 RCN_SPLIT_DEEP=48; } 2>&1 | tee "$OUT/splitcus.txt"
+fi
 if has cfg4prod; then
   python - <<'PY'
 import os, sys
@@ -94,7 +99,7 @@ import bench
 print(bench.product_files(1_000_000, 60.0, 20260923, 32, short_reads=True))
 PY
   F=/tmp/racon_amd_cache/files_1000000_60_20260923_short
-  for e in "" "RACON_HIP_CHUNK_WINDOWS=5000" "RACON_HIP_CHUNK_WINDOWS=2500" "RACON_HIP_CHUNK_WINDOWS=1700" ${CFG4PROD_EXTRA:-}; do
+  for e in "" "RACON_HIP_DEVICE_WINDOWS=0" "RACON_HIP_DEVICE_WINDOWS=0 RACON_HIP_CHUNK_WINDOWS=5000" ${CFG4PROD_EXTRA:-}; do
     for k in 1 2 3; do
       env $e RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 -w 200 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/cfg4prod.err" | md5sum | cut -c1-8
       echo "cfg4 files [$e]: $(grep 'generated consensus' $OUT/cfg4prod.err) $(grep -c 'engine .* chunk' $OUT/cfg4prod.err) chunks"
