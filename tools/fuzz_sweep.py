@@ -98,7 +98,11 @@ def main():
     ap.add_argument("--windows", type=int, default=500)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default="")
+    ap.add_argument("--no-small", action="store_true", help="RCN_NO_SMALL=1: every window through poa_window_kernel2 (and its retry tier) instead")
     a = ap.parse_args()
+    if a.no_small:
+        os.environ["RCN_NO_SMALL"] = "1"
+        os.environ.pop("RCN_FORCE_SMALL", None)
 
     from racon_amd.batch import WindowBatch
     from racon_amd.engine import HipEngine
@@ -152,6 +156,7 @@ def main():
     tot["ok_no_internal_inconsistency"] = tot["small_bail_why"][8] == 0
     tot["what"] = ("%d seeds x (%d random + 5 directed windows) x %d score sets x trim on/off, + RCN_FORCE_EXACT once per seed: HIP engine (small-window kernel "
                    "+ its retry tiers) vs oracle/poa_oracle.cpp, every window" % (a.seeds, a.windows, len(SCORES)))
+    tot["kernel"] = "poa_window_kernel2 (RCN_NO_SMALL=1)" if a.no_small else "poa_window_kernel_small + retry tiers"
     tot["ok"] = tot["mismatching_windows"] == 0 and tot["small_bail_why"][8] == 0
     line = json.dumps(tot)
     print(line)

@@ -41,6 +41,10 @@ if has fuzz; then
   timeout 1500 python tools/fuzz_sweep.py --seeds ${FUZZ_SEEDS:-120} --out "$OUT/fuzz_sweep.json" > "$OUT/fuzz_sweep.log" 2>&1
   echo "fuzz exit $?"; tail -4 "$OUT/fuzz_sweep.log" | cut -c1-1500
 fi
+if has fuzzk2; then
+  timeout 1500 python tools/fuzz_sweep.py --no-small --first-seed 9000 --seeds ${FUZZ_K2_SEEDS:-60} --out "$OUT/fuzz_sweep_kernel2.json" > "$OUT/fuzz_sweep_kernel2.log" 2>&1
+  echo "fuzz (kernel2) exit $?"; tail -2 "$OUT/fuzz_sweep_kernel2.log" | cut -c1-1200
+fi
 if has cfg4; then
   for k in 1 2; do
     timeout 900 python bench.py --config cfg4 $QB 2> "$OUT/bench_cfg4.err" | tee "$OUT/bench_cfg4_$k.json" | benchline "cfg4 run $k"
