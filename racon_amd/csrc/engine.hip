@@ -1279,6 +1279,9 @@ static int run_resident(rcn_engine* e, bool dry) {
     int rc;
     if ((rc = begin_run(e))) return rc;
     auto warm_out = [&]() -> int {
+        // the arena's first touch (what AlignmentEngine::Prealloc does to its matrices, reference src/polisher.cpp:180-182): the
+        // launches of the run then find its pages mapped and their translations fresh
+        if (e->d_scratch.p && e->d_scratch.cap) HIP_TRY(hipMemsetAsync(e->d_scratch.p, 0, e->d_scratch.cap, e->stream));
         // the kernel's first stores into the (new) pinned result block, as polish_view's dry run makes them
         hipLaunchKernelGGL(k_warm_out, dim3(1), dim3(64), 0, e->stream, e->h_out.as<uint32_t>());
         HIP_TRY(hipGetLastError());
@@ -1495,7 +1498,8 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
             HIP_TRY(hipMemcpyAsync(e->d_bases.p, hs + o_bases, part, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipMemcpyAsync(e->d_quals.p, hs + o_quals, part, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipStreamSynchronize(cs));
-            // ... and the kernel's first stores into the pinned result block
+            // ... the arena's first touch, and the kernel's first stores into the pinned result block
+            if (e->d_scratch.p && e->d_scratch.cap) HIP_TRY(hipMemsetAsync(e->d_scratch.p, 0, e->d_scratch.cap, e->stream));
             hipLaunchKernelGGL(k_warm_out, dim3(1), dim3(64), 0, e->stream, e->h_out.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(e->stream));

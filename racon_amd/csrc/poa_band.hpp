@@ -62,7 +62,10 @@ __host__ __device__ constexpr int dp2_ring_rows_band(int np, bool tab) {
 constexpr int kHelpRows = 256;                                   // rows of the large ring (NP = 2: 512 bytes each)
 constexpr int kHelpRingBytes = kHelpRows * 64 * 2 * 4;
 constexpr int kHelpLdsBytes = kHelpRingBytes + 64 * 4 + 16;      // + progress words (one per lane of wave 0) + {rows done by waves 1-3, failure flag}
-constexpr int kHelpSpin = 1 << 18;                               // polls (s_sleep 1 each) before a wait gives up
+#ifndef RCN_HELP_SLEEP
+#define RCN_HELP_SLEEP 1                                           // s_sleep argument between two polls of a code wave (experiment builds: -DRCN_HELP_SLEEP=n)
+#endif
+constexpr int kHelpSpin = 1 << 18;                               // polls (s_sleep RCN_HELP_SLEEP each) before a wait gives up
 __device__ __forceinline__ uint32_t* help_ring() { return reinterpret_cast<uint32_t*>(lds_words2() + (kLdsBytes + kCtxBytes) / 4); }
 __device__ __forceinline__ uint32_t* help_prog() { return help_ring() + kHelpRingBytes / 4; }        // [64] rows finished by wave 0, x 0x00010001; 0xffffffff = gave up
 __device__ __forceinline__ uint32_t* help_done() { return help_prog() + 64; }                        // [0..2] rows waves 1-3 are through with, [3] one of them gave up
@@ -689,7 +692,7 @@ __device__ __noinline__ void dp2_band_codes(const int hw) {        // hw = 0, 1,
             have = static_cast<int>(v & 0xffffu);
             if (have >= i) break;
             if (++spins > kHelpSpin) { gone = true; lds_store(help_done() + 3, 1u); return; }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(RCN_HELP_SLEEP);
         }
 #ifdef RCN_PROF_WIN
         if (t == 0) { atomicAdd(&g_whelp[2], 1ull); atomicAdd(&g_whelp[3], static_cast<unsigned long long>(spins)); }

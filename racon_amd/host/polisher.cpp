@@ -770,6 +770,12 @@ void Polisher::assemble(const std::function<const std::string&(uint64_t)>& conse
     std::string polished_data;
     uint32_t num_polished_windows = 0;
     for (uint64_t i = 0; i < windows_.size(); ++i) {
+        if (windows_[i]->rank() == 0) {
+            // (one allocation per target, moved into the Sequence: a megabase grown by doubling and then copied is its pages touched twice)
+            uint64_t total = 0;
+            for (uint64_t k = i; k < windows_.size() && (k == i || windows_[k]->rank() != 0); ++k) total += consensus(k).size();
+            polished_data.reserve(total);
+        }
         num_polished_windows += polished(i) ? 1 : 0;
         polished_data += consensus(i);
         if (i == windows_.size() - 1 || windows_[i + 1]->rank() == 0) {       // last window of this target
@@ -779,10 +785,10 @@ void Polisher::assemble(const std::function<const std::string&(uint64_t)>& conse
                 tags += " LN:i:" + std::to_string(polished_data.size());
                 tags += " RC:i:" + std::to_string(targets_coverages_[windows_[i]->id()]);
                 tags += " XC:f:" + std::to_string(polished_ratio);
-                dst.emplace_back(createSequence(sequences_[windows_[i]->id()]->name() + tags, polished_data));
+                dst.emplace_back(createSequence(sequences_[windows_[i]->id()]->name() + tags, std::move(polished_data)));
             }
             num_polished_windows = 0;
-            polished_data.clear();
+            polished_data = std::string();
         }
     }
     // The reference frees every window and every sequence here, inside the interval its Logger brackets

@@ -7,6 +7,9 @@ namespace racon {
 std::unique_ptr<Sequence> createSequence(const std::string& name, const std::string& data) {
     return std::unique_ptr<Sequence>(new Sequence(name, data));
 }
+std::unique_ptr<Sequence> createSequence(const std::string& name, std::string&& data) {
+    return std::unique_ptr<Sequence>(new Sequence(name, std::move(data)));
+}
 
 Sequence::Sequence(const char* name, uint32_t name_length, const char* data, uint32_t data_length)
         : name_(name, name_length), data_(data, data_length) {
@@ -22,6 +25,7 @@ Sequence::Sequence(const char* name, uint32_t name_length, const char* data, uin
 }
 
 Sequence::Sequence(const std::string& name, const std::string& data) : name_(name), data_(data) {}
+Sequence::Sequence(const std::string& name, std::string&& data) : name_(name), data_(std::move(data)) {}
 
 void Sequence::create_reverse_complement() {
     if (!reverse_complement_.empty()) return;

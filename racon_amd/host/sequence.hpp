@@ -10,6 +10,7 @@ namespace racon {
 
 class Sequence;
 std::unique_ptr<Sequence> createSequence(const std::string& name, const std::string& data);
+std::unique_ptr<Sequence> createSequence(const std::string& name, std::string&& data);     // (takes the buffer over)
 
 class Sequence {
 public:
@@ -19,6 +20,7 @@ public:
     Sequence(const char* name, uint32_t name_length, const char* data, uint32_t data_length,
              const char* quality, uint32_t quality_length);
     Sequence(const std::string& name, const std::string& data);
+    Sequence(const std::string& name, std::string&& data);
     Sequence(const Sequence&) = delete;
     Sequence& operator=(const Sequence&) = delete;
 

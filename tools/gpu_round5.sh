@@ -90,6 +90,13 @@ PY
     grep -E "racon::|polish:|piece|collect|reserve|pass of|timing|pairs:" "$OUT/timeline_cfg2_$name.err" | cut -c1-300 > "$OUT/timeline_cfg2_$name.txt"
   done 2>&1 | tee "$OUT/timeline2.txt"
 fi
+if has sleep; then
+  # code waves polling less often (libracon_hip_exp.so: -DRCN_HELP_SLEEP=8), A/B/A/B on one box
+  for k in 1 2; do
+    python bench.py $QB 2>/dev/null | benchline "as shipped ($k)"
+    RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_exp.so python bench.py $QB 2>/dev/null | benchline "experiment build ($k)"
+  done 2>&1 | tee "$OUT/exp_build.txt"
+fi
 if has splitcus; then
   # CUs (= windows, one per CU) of the deep launch, once more on this round's kernels
   run() { echo "== $1"; shift; env "$@" python bench.py $QB 2>/dev/null | benchline "$*"; }
