@@ -157,8 +157,8 @@ fi
 if has sq2; then sqpasses cfg2; fi
 if has sq4; then sqpasses cfg4 --config cfg4; fi
 if has cfg5; then
-  timeout ${CFG5_TIMEOUT:-2400} python tools/cfg5_at_size.py ${CFG5_ARGS:---scale 1.0 --shards 8} > "$OUT/cfg5_at_size.json" 2> "$OUT/cfg5_at_size.err"
-  echo "cfg5 exit $?"; tail -3 "$OUT/cfg5_at_size.err" | cut -c1-400; cut -c1-2500 "$OUT/cfg5_at_size.json"
+  timeout ${CFG5_TIMEOUT:-2400} python tools/cfg5_whole.py ${CFG5_ARGS:---scale 1.0 --shards 8} > "$OUT/cfg5_whole.json" 2> "$OUT/cfg5_whole.err"
+  echo "cfg5 exit $?"; tail -3 "$OUT/cfg5_whole.err" | cut -c1-400; cut -c1-3500 "$OUT/cfg5_whole.json"
 fi
 if has cfg3bin; then
   timeout 2400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu --no-upload-leg --product-contig 0 > "$OUT/bench_cfg3_1gpu.json" 2> "$OUT/bench_cfg3.err"
