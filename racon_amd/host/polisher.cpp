@@ -291,14 +291,14 @@ void Polisher::initialize() {
         const std::string dv = dv_env ? dv_env : default_device_mode_;
         if (!dv.empty() && dv[0] >= '1' && dv[0] <= '3') device_windows(true, dv[0] == '2', dv[0] == '3');
         else if (dv == "auto" && !keep_layout_) {
-            uint64_t read_bases = 0, layer_bases = 0;
-            for (const auto& s_ : sequences_) read_bases += s_->data().size();
-            for (const auto& o : overlaps) layer_bases += o->q_end() - o->q_begin();
+            uint64_t read_bases = 0, layer_bases = 0, cigar_bytes = 0;
+            for (const auto& s_ : sequences_) read_bases += std::max(s_->data().size(), s_->reverse_complement().size());
+            for (const auto& o : overlaps) { layer_bases += o->q_end() - o->q_begin(); cigar_bytes += o->cigar().size(); }
             for (uint64_t i = 0; i < targets_size; ++i) layer_bases += sequences_[i]->data().size();
             const int32_t devices = HipEngine::DeviceCount();
             // per device: every read (bases + qualities), its share of the packed windows (x 2 for the sort / gather buffers next to
             // them), CIGAR text, and a scratch arena; against HALF of what is free on device 0
-            const double need = 2.0 * read_bases + 4.0 * layer_bases / std::max(1, devices) + 24e9;
+            const double need = 2.0 * read_bases + (4.0 * layer_bases + 1.0 * cigar_bytes) / std::max(1, devices) + 24e9;
             const double have = devices > 0 ? 0.5 * static_cast<double>(HipEngine::FreeMemory(0)) : 0.0;
             if (devices > 0 && need < have) device_windows(true, true, device_align_);
             else if (device_windows_ && need >= have)
