@@ -312,15 +312,20 @@ __global__ __launch_bounds__(256) void k_cigar_breaking_points_wave(CigarWavePar
     __syncthreads();
     const uint64_t o = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (o >= C.n_overlaps) return;
-    const uint64_t W = C.W;
-    const uint64_t t_begin = C.t_begin[o], t_end = C.t_end[o];
-    const uint64_t slot0 = C.bp_off[o] / 2, n_slots = (C.bp_off[o + 1] - C.bp_off[o]) / 2;
-    const uint64_t wb = t_begin / W;                                  // window number of slot 0
-    auto end_of = [&](uint64_t k) -> uint64_t { return k + 1 < n_slots ? (wb + 1 + k) * W - 1 : t_end - 1; };
+    // Positions are 32-bit, as in the reference (`uint32_t q_ptr, t_ptr`, src/overlap.cpp:239-242: a CIGAR whose numbers overflow them
+    // wraps there exactly as here); only the slot and text offsets are 64-bit.  (Round 5: the walk's position arithmetic was 64-bit
+    // throughout -- two 16-bit-half scans per sum, 64-bit compares and multiplies per run: most of the kernel's ~500 instructions per
+    // 64-byte step.)
+    const uint32_t W = static_cast<uint32_t>(C.W);
+    const uint32_t t_begin = C.t_begin[o], t_end = C.t_end[o];
+    const uint64_t slot0 = C.bp_off[o] / 2;
+    const uint32_t n_slots = static_cast<uint32_t>((C.bp_off[o + 1] - C.bp_off[o]) / 2);
+    const uint32_t wb = t_begin / W;                                  // window number of slot 0
+    auto end_of = [&](uint32_t k) -> uint32_t { return k + 1 < n_slots ? (wb + 1 + k) * W - 1 : t_end - 1; };
     const uint64_t a = C.cigar_off[o], z = C.cigar_off[o + 1];
-    uint64_t t_run = t_begin, q_run = C.q_start[o];                    // next target / query position to be consumed
+    uint32_t t_run = t_begin, q_run = C.q_start[o];                    // next target / query position to be consumed
     uint32_t carry = 0;                                               // value of the digits pending from the previous step
-    long long kdone = -1;                                             // last window a match run of the previous steps reached
+    int kdone = -1;                                                   // last window a match run of the previous steps reached
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t c_next = a + lane < z ? C.cigar[a + lane] : '0';           // (the next step's text is in flight while this one is worked on)
     for (uint64_t p0 = a; p0 < z; p0 += 64) {
@@ -351,54 +356,48 @@ __global__ __launch_bounds__(256) void k_cigar_breaking_points_wave(CigarWavePar
         const bool isM = !is_digit && (c == 'M' || c == '=' || c == 'X');
         const uint32_t dt = (isM || (!is_digit && (c == 'D' || c == 'N'))) ? n : 0u;
         const uint32_t dq = (isM || (!is_digit && c == 'I')) ? n : 0u;
-        // inclusive 64-bit sums from 16-bit halves (64 x 65535 fits a dword)
-        const unsigned long long st = wave_incl_add(dt & 0xffffu) + (static_cast<unsigned long long>(wave_incl_add(dt >> 16)) << 16);
-        const unsigned long long sq = wave_incl_add(dq & 0xffffu) + (static_cast<unsigned long long>(wave_incl_add(dq >> 16)) << 16);
-        const uint64_t ts = t_run + (st - dt), qs = q_run + (sq - dq);
+        const uint32_t st = wave_incl_add(dt), sq = wave_incl_add(dq);      // (mod 2^32, like the reference's pointers)
+        const uint32_t ts = t_run + (st - dt), qs = q_run + (sq - dq);
         // This lane's match run covers the windows kf .. kl of the overlap.  Positions only grow along the walk, so a
         // window's first match column comes from the FIRST run that reaches it and its last one from the LAST: a run
         // writes "first" only for the windows no earlier run (of this step, or of the steps before: kdone) reached,
         // and "last" only for those the next run of this step does not reach as well -- plain stores, later steps
         // overwrite "last" (the slots belong to this overlap alone; one atomic pair per run and window was 34 M
         // 64-bit atomics for 24 000 overlaps, and their rate at the L2 was the kernel's time).
-        const uint64_t te = ts + n;                                   // match columns ts .. te - 1
-        long long kf = 0, kl = -1;
-        if (isM && n > 0) {
-            // (window numbers by 32-bit division where the positions allow it: a 64-bit division is ~100 instructions)
-            uint64_t wf, wl;
-            if ((te >> 32) == 0) { wf = static_cast<uint32_t>(ts) / static_cast<uint32_t>(W); wl = static_cast<uint32_t>(te - 1) / static_cast<uint32_t>(W); }
-            else { wf = ts / W; wl = (te - 1) / W; }
-            if (wf - wb < n_slots && !(wf - wb == n_slots - 1 && ts >= t_end)) {
-                kf = static_cast<long long>(wf - wb);
-                kl = static_cast<long long>(wl - wb);
-                if (kl > static_cast<long long>(n_slots) - 1) kl = static_cast<long long>(n_slots) - 1;
+        const uint32_t te = ts + n;                                   // match columns ts .. te - 1
+        int kf = 0, kl = -1;
+        if (isM && n > 0 && te > ts) {                                // (te <= ts: the positions wrapped -- nothing sane to record)
+            const uint32_t wf = ts / W, wl = (te - 1) / W;
+            if (wf >= wb && wf - wb < n_slots && !(wf - wb == n_slots - 1 && ts >= t_end)) {
+                kf = static_cast<int>(wf - wb);
+                kl = static_cast<int>(min(wl - wb, n_slots - 1));
             }
         }
         const unsigned long long runs = __ballot(kl >= kf);
         const unsigned long long rb = runs & below, ra = lane < 63 ? (runs >> (lane + 1)) : 0ull;
-        const long long kl_prev = __shfl(kl, rb ? 63 - __builtin_clzll(rb) : 0), kf_next = __shfl(kf, ra ? lane + 1 + __builtin_ctzll(ra) : 0);
+        const int kl_prev = __shfl(kl, rb ? 63 - __builtin_clzll(rb) : 0), kf_next = __shfl(kf, ra ? lane + 1 + __builtin_ctzll(ra) : 0);
         if (kl >= kf) {
-            const long long reached = rb ? kl_prev : kdone;           // windows up to here have their first match column
-            const long long lf = kf > reached + 1 ? kf : reached + 1; // "first": windows lf .. kl
-            const long long ll = (ra && kf_next - 1 < kl) ? kf_next - 1 : kl;     // "last": windows kf .. ll
-            for (long long k = kf; k <= kl; ++k) {
-                const uint64_t wstart = k == 0 ? t_begin : (wb + k) * W, wend = end_of(static_cast<uint64_t>(k));
-                const uint64_t f = ts > wstart ? ts : wstart, l = te < wend + 1 ? te : wend + 1;
+            const int reached = rb ? kl_prev : kdone;                 // windows up to here have their first match column
+            const int lf = kf > reached + 1 ? kf : reached + 1;       // "first": windows lf .. kl
+            const int ll = (ra && kf_next - 1 < kl) ? kf_next - 1 : kl;     // "last": windows kf .. ll
+            for (int k = kf; k <= kl; ++k) {
+                const uint32_t wstart = k == 0 ? t_begin : (wb + static_cast<uint32_t>(k)) * W, wend = end_of(static_cast<uint32_t>(k));
+                const uint32_t f = ts > wstart ? ts : wstart, l = te < wend + 1 ? te : wend + 1;
                 if (f < l) {
-                    if (k >= lf) P.first_key[slot0 + k] = (f << 32) | (qs + (f - ts));
-                    if (k <= ll) P.last_key[slot0 + k] = (l << 32) | (qs + (l - ts));
+                    if (k >= lf) P.first_key[slot0 + k] = (static_cast<unsigned long long>(f) << 32) | (qs + (f - ts));
+                    if (k <= ll) P.last_key[slot0 + k] = (static_cast<unsigned long long>(l) << 32) | (qs + (l - ts));
                 }
             }
         }
         if (runs) kdone = __shfl(kl, 63 - __builtin_clzll(runs));
-        t_run += __shfl(st, 63); q_run += __shfl(sq, 63);
+        t_run += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(st), 63)); q_run += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(sq), 63));
     }
     __threadfence();
     // a window whose end the walk has passed is closed: its pair (if a match column was seen) is what the reference pushed
-    for (uint64_t k = lane; k < n_slots; k += 64) {
+    for (uint32_t k = lane; k < n_slots; k += 64) {
         const unsigned long long f = P.first_key[slot0 + k], l = P.last_key[slot0 + k];
         if (l != 0 && f != ~0ull && end_of(k) + 1 <= t_run) {
-            const uint64_t out = C.bp_off[o] + 2 * k;
+            const uint64_t out = C.bp_off[o] + 2ull * k;
             C.bp_t[out] = static_cast<uint32_t>(f >> 32); C.bp_q[out] = static_cast<uint32_t>(f);
             C.bp_t[out + 1] = static_cast<uint32_t>(l >> 32); C.bp_q[out + 1] = static_cast<uint32_t>(l);
         }

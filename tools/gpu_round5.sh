@@ -97,6 +97,11 @@ if has sleep; then
     RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_exp.so python bench.py $QB 2>/dev/null | benchline "experiment build ($k)"
   done 2>&1 | tee "$OUT/exp_build.txt"
 fi
+if has build; then
+  # window construction in HBM, with the CIGAR walk (32-bit positions since round 5): kernel times on cfg2's shape and on 8 Mbp; its tests
+  timeout 900 python -m pytest tests/test_gpu_window_build.py -m gpu -q > "$OUT/pytest_window_build.log" 2>&1; tail -3 "$OUT/pytest_window_build.log"
+  for c in 1000000 8000000; do timeout 600 python tools/build_bench.py --contig $c 2>/dev/null | tail -1 | tee "$OUT/build_bench_$c.json" | cut -c1-700; done
+fi
 if has splitcus; then
   # CUs (= windows, one per CU) of the deep launch, once more on this round's kernels
   run() { echo "== $1"; shift; env "$@" python bench.py $QB 2>/dev/null | benchline "$*"; }
