@@ -47,8 +47,15 @@ struct DevBuf {
     int reserve(size_t bytes) {
         if (bytes <= cap && p) return RCN_OK;
         { const uint64_t lim = g_fail_alloc_above.load(std::memory_order_relaxed); if (lim && bytes > lim) return RCN_E_NOMEM; }
+        // A buffer that GROWS gets an eighth more than asked for: a sequence of like-sized jobs on one engine (the window-range
+        // shards of a job cut to fit one device: cfg5 whole, eight of them) differs by fractions of a percent, and every
+        // regrowth of a multi-GB buffer is a hipFree + hipMalloc that waits for the driver's page clearing (0.6-2.4 s,
+        // tools/probe/malloc_time.hip).  The first allocation is exact.
+        const bool regrow = p != nullptr;
         if (p) { if (hipFree(p) != hipSuccess) return RCN_E_HIP; p = nullptr; cap = 0; }
         size_t want = std::max<size_t>(bytes, 256);
+        if (regrow && bytes >= (64u << 20) && hipMalloc(&p, want + want / 8) == hipSuccess) { cap = want + want / 8; return RCN_OK; }
+        (void)hipGetLastError();
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return RCN_E_NOMEM; }
         cap = want; return RCN_OK;
     }
