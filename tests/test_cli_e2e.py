@@ -166,6 +166,21 @@ def test_cli_reference_cuda_flags(P, oracle, data, flags, ovl, aligner_on_device
     assert (b"left the overlaps to the device aligner" in run.stderr) == aligner_on_device, run.stderr[-1500:]
 
 
+def test_cli_fails_loudly_without_a_device(data):
+    """No MI355X (or no libracon_hip.so): the product does not fall back to anything -- `racon_hip` parses its input, then exits non-zero
+    with the reason, and prints no FASTA.  (Runs where there is no GPU: the CPU test tier; skipped on a GPU box.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    paths, _ = data
+    exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
+    for env_add in ({}, {"RACON_HIP_DEVICE_WINDOWS": "0"}, {"RACON_HIP_DEVICE_WINDOWS": "2"}):
+        run = subprocess.run([exe, "-t", "2", paths["reads"], paths["sam"], paths["targets"]], env=dict(os.environ, **env_add),
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert run.returncode != 0 and run.stdout == b"", env_add
+        assert b"no MI355X device / libracon_hip.so available (the consensus stage has no CPU fallback)" in run.stderr, run.stderr[-500:]
+
+
 def test_cli_help_names_the_aligner_flag():
     exe = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
     out = subprocess.run([exe, "--help"], check=True, stdout=subprocess.PIPE).stdout
