@@ -90,6 +90,16 @@ PY
     grep -E "racon::|polish:|piece|collect|reserve|pass of|timing|pairs:" "$OUT/timeline_cfg2_$name.err" | cut -c1-300 > "$OUT/timeline_cfg2_$name.txt"
   done 2>&1 | tee "$OUT/timeline2.txt"
 fi
+if has variants; then
+  # compiler-scheduling variants of the consensus kernels (built by hand into libracon_hip_exp*.so: -mllvm -amdgpu-sched-strategy=max-ilp on
+  # engine_deep.hip alone / on engine.hip and engine_deep.hip), A/B on one box: cfg2, and 8000 windows for the long-queue rate
+  for k in 1 2; do
+    python bench.py $QB 2>/dev/null | benchline "as shipped ($k)"
+    for v in exp exp2; do [ -f racon_amd/csrc/libracon_hip_$v.so ] && RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_$v.so python bench.py $QB 2>/dev/null | benchline "libracon_hip_$v.so ($k)"; done
+  done 2>&1 | tee "$OUT/variants.txt"
+  python bench.py --contig 4000000 $QB 2>/dev/null | benchline "4 Mbp as shipped" | tee -a "$OUT/variants.txt"
+  RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_exp2.so python bench.py --contig 4000000 $QB 2>/dev/null | benchline "4 Mbp libracon_hip_exp2.so" | tee -a "$OUT/variants.txt"
+fi
 if has sleep; then
   # code waves polling less often (libracon_hip_exp.so: -DRCN_HELP_SLEEP=8), A/B/A/B on one box
   for k in 1 2; do
