@@ -416,12 +416,51 @@ struct OpsSource {
     const uint32_t* q_start; const uint32_t* t_begin; const uint32_t* t_end;
 };
 
+// A large array out of PAGEABLE host memory (the caller's reads, qualities, CIGAR text): hipMemcpyAsync stages such a copy through the
+// runtime's own bounce buffers at 1.5-3 GB/s (cfg3 whole: 4.5 GB, most of the 3.2 s "transformed data into windows (on the device)"
+// took in round 5's first measurement).  Here host threads copy 32 MB chunks into two pinned slots and the DMA engine takes each
+// slot as soon as it is full: the link rate, bounded by the host's memcpy.  Small arrays go the plain way.
+inline int upload_staged(DevBuf& d, const void* src, size_t bytes, hipStream_t st) {
+    int rc = d.reserve(bytes);
+    if (rc) return rc;
+    if (!bytes) return RCN_OK;
+    constexpr size_t kChunk = 32u << 20;
+    if (bytes < kChunk / 2) { HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, st)); return RCN_OK; }
+    // (one staging pair per device: the engines of one device take turns -- uploads of this size are rare and long --, the devices of a
+    //  multi-GPU job upload side by side)
+    static std::mutex mus[64];
+    static HostBuf slot_bufs[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::mutex& mu = mus[dev & 63];
+    HostBuf& slots = slot_bufs[dev & 63];
+    std::lock_guard<std::mutex> lock(mu);
+    if ((rc = slots.reserve(2 * kChunk))) { HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, st)); return RCN_OK; }
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (auto& x : ev) HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    const unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    const uint8_t* s8 = static_cast<const uint8_t*>(src);
+    int rc_out = RCN_OK;
+    size_t k = 0;
+    for (size_t off = 0; off < bytes; off += kChunk, ++k) {
+        const size_t n = std::min(kChunk, bytes - off);
+        uint8_t* slot = slots.as<uint8_t>() + (k & 1) * kChunk;
+        if (k >= 2 && hipEventSynchronize(ev[k & 1]) != hipSuccess) { rc_out = RCN_E_HIP; break; }
+        const size_t parts = (n + (4u << 20) - 1) / (4u << 20);
+        host_parallel(parts, threads, [&](size_t q) { const size_t a = q * (4u << 20), z = std::min(n, a + (4u << 20)); std::memcpy(slot + a, s8 + off + a, z - a); });
+        if (hipMemcpyAsync(static_cast<uint8_t*>(d.p) + off, slot, n, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k & 1], st) != hipSuccess) { rc_out = RCN_E_HIP; break; }
+    }
+    for (int q = 0; q < 2; ++q) if (k > static_cast<size_t>(q)) (void)hipEventSynchronize(ev[q]);          // the slots are free again when this returns
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    return rc_out;
+}
+
 inline int upload_reads(rcn_engine* e, const rcn_read_set& R, hipStream_t st) {
     DevBuf* B = e->d_build;
     const uint64_t read_bytes = R.seq_off[R.n_seqs];
     int rc;
-    if ((rc = upload_vec(B[kBReadOff], R.seq_off, 8 * (R.n_seqs + 1), st)) || (rc = upload_vec(B[kBReadBases], R.bases, read_bytes, st)) ||
-        (rc = upload_vec(B[kBReadQuals], R.quals, read_bytes, st)) || (rc = upload_vec(B[kBReadHasQual], R.seq_has_qual, R.n_seqs, st))) return rc;
+    if ((rc = upload_vec(B[kBReadOff], R.seq_off, 8 * (R.n_seqs + 1), st)) || (rc = upload_staged(B[kBReadBases], R.bases, read_bytes, st)) ||
+        (rc = upload_staged(B[kBReadQuals], R.quals, read_bytes, st)) || (rc = upload_vec(B[kBReadHasQual], R.seq_has_qual, R.n_seqs, st))) return rc;
     return RCN_OK;
 }
 
@@ -471,7 +510,7 @@ inline int build_windows(rcn_engine* e, const rcn_read_set& R, const rcn_overlap
     } else {
         const uint64_t cig_bytes = C->n_overlaps ? C->cigar_off[C->n_overlaps] : 0;
         if ((rc = B[kBBpT].reserve(4 * n_points + 16)) || (rc = B[kBBpQ].reserve(4 * n_points + 16)) ||
-            (rc = upload_vec(B[kBCigarOff], C->cigar_off, 8 * (C->n_overlaps + 1), st)) || (rc = B[kBCigar].reserve(cig_bytes + 16)) || (rc = upload_vec(B[kBCigar], C->cigar, cig_bytes, st)) ||
+            (rc = upload_vec(B[kBCigarOff], C->cigar_off, 8 * (C->n_overlaps + 1), st)) || (rc = B[kBCigar].reserve(cig_bytes + 16)) || (rc = upload_staged(B[kBCigar], C->cigar, cig_bytes, st)) ||
             (rc = upload_vec(B[kBQStart], C->q_start, 4 * C->n_overlaps, st)) || (rc = upload_vec(B[kBTBegin], C->t_begin, 4 * C->n_overlaps, st)) ||
             (rc = upload_vec(B[kBTEnd], C->t_end, 4 * C->n_overlaps, st))) { drop_events(); return rc; }
         HIP_TRY(hipMemsetAsync(B[kBBpT].p, 0, 4 * n_points + 16, st));

@@ -90,6 +90,31 @@ PY
     grep -E "racon::|polish:|piece|collect|reserve|pass of|timing|pairs:" "$OUT/timeline_cfg2_$name.err" | cut -c1-300 > "$OUT/timeline_cfg2_$name.txt"
   done 2>&1 | tee "$OUT/timeline2.txt"
 fi
+if has inittime; then
+  # initialize() with device-side construction: where its time goes at 12 500 and 50 000 windows (uploads out of pageable memory staged through pinned slots)
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(6_250_000, 30.0, 20260922, 32))
+print(bench.product_files(25_000_000, 30.0, 20260922, 32))
+PY
+  for F in /tmp/racon_amd_cache/files_6250000_30_20260922 /tmp/racon_amd_cache/files_25000000_30_20260922; do
+    for e in "" "RACON_HIP_DEVICE_WINDOWS=0"; do
+      for k in 1 2; do
+        env $e RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/inittime.err" | md5sum | cut -c1-8
+        echo "$(basename $F) [$e]: $(grep -E 'transformed data|generated consensus|total =|built on device' $OUT/inittime.err | sed 's/.racon::Polisher:://' | tr '\n' '|' | cut -c1-600)"
+      done
+    done
+  done 2>&1 | tee "$OUT/inittime.txt"
+fi
+if has variants2; then
+  # more scheduling variants of engine_deep.hip (libracon_hip_v<k>.so, built by hand: see profiles/r05/i_deep_tu_variants.txt), A/B on one box
+  for k in 1 2; do
+    python bench.py $QB 2>/dev/null | benchline "as shipped ($k)"
+    for v in ${VARIANTS:-v1 v3 v5}; do [ -f racon_amd/csrc/libracon_hip_$v.so ] && RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_$v.so python bench.py $QB 2>/dev/null | benchline "libracon_hip_$v.so ($k)"; done
+  done 2>&1 | tee "$OUT/variants2.txt"
+fi
 if has variants; then
   # compiler-scheduling variants of the consensus kernels (built by hand into libracon_hip_exp*.so: -mllvm -amdgpu-sched-strategy=max-ilp on
   # engine_deep.hip alone / on engine.hip and engine_deep.hip), A/B on one box: cfg2, and 8000 windows for the long-queue rate
