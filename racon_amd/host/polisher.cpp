@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdio>
 #include <exception>
+#include <cstring>
 #include <mutex>
 #include <iostream>
 #include <thread>
@@ -318,23 +319,48 @@ void Polisher::initialize() {
         layout_ = Layout();
         layout_.n_targets = targets_size;
         layout_.window_type = window_type == WindowType::kTGS ? 1 : 0;
-        for (const auto& sq : sequences_) {
-            // forward strand of every sequence (transmute() may have kept only the reverse complement: complementing
-            // again gives it back, the table of Sequence::create_reverse_complement is an involution)
-            std::string fwd = sq->data(), fq = sq->quality();
-            if (fwd.empty() && !sq->reverse_complement().empty()) {
-                auto tmp = createSequence("", sq->reverse_complement());
-                tmp->create_reverse_complement();
-                fwd = tmp->reverse_complement();
-                fq.assign(sq->reverse_quality().rbegin(), sq->reverse_quality().rend());
-            }
-            const bool hq = !fq.empty();
-            layout_.bases.insert(layout_.bases.end(), fwd.begin(), fwd.end());
-            if (hq) layout_.quals.insert(layout_.quals.end(), fq.begin(), fq.end());
-            else layout_.quals.insert(layout_.quals.end(), fwd.size(), static_cast<uint8_t>('!'));
-            layout_.seq_has_qual.push_back(hq ? 1 : 0);
-            layout_.seq_off.push_back(layout_.bases.size());
+        // The forward strand of every sequence, flat (transmute() may have kept only the reverse complement: complementing again
+        // gives it back, the table of Sequence::create_reverse_complement is an involution).  Offsets first, then the bytes by all
+        // host threads into buffers sized once: grown by insert() on one thread this was most of the second that "transformed data
+        // into windows (on the device)" took at 50 000 windows -- the device's own share of it is 80 ms.
+        const uint64_t n_seq = sequences_.size();
+        layout_.seq_off.assign(n_seq + 1, 0);
+        layout_.seq_has_qual.assign(n_seq, 0);
+        for (uint64_t i = 0; i < n_seq; ++i) {
+            const auto& sq = sequences_[i];
+            const bool rev_only = sq->data().empty() && !sq->reverse_complement().empty();
+            layout_.seq_off[i + 1] = layout_.seq_off[i] + (rev_only ? sq->reverse_complement().size() : sq->data().size());
+            layout_.seq_has_qual[i] = (rev_only ? !sq->reverse_quality().empty() : !sq->quality().empty()) ? 1 : 0;
         }
+        layout_.bases.resize(layout_.seq_off[n_seq]);
+        layout_.quals.resize(layout_.seq_off[n_seq]);
+        parallel_for(n_seq, num_threads_, [&](uint64_t i) {
+            static const struct Comp { uint8_t t[256]; Comp() { for (int k = 0; k < 256; ++k) t[k] = static_cast<uint8_t>(k); t['A'] = 'T'; t['T'] = 'A'; t['C'] = 'G'; t['G'] = 'C'; } } comp;
+            const auto& sq = sequences_[i];
+            uint8_t* db = layout_.bases.data() + layout_.seq_off[i];
+            uint8_t* dq = layout_.quals.data() + layout_.seq_off[i];
+            const uint64_t n = layout_.seq_off[i + 1] - layout_.seq_off[i];
+            if (sq->data().empty() && !sq->reverse_complement().empty()) {
+                const std::string& rc = sq->reverse_complement();
+                for (uint64_t k = 0; k < n; ++k) db[k] = comp.t[static_cast<uint8_t>(rc[n - 1 - k])];
+                const std::string& rq = sq->reverse_quality();
+                if (!rq.empty()) for (uint64_t k = 0; k < n; ++k) dq[k] = static_cast<uint8_t>(rq[n - 1 - k]);
+                else std::memset(dq, '!', n);
+            } else {
+                std::memcpy(db, sq->data().data(), n);
+                if (!sq->quality().empty()) std::memcpy(dq, sq->quality().data(), n); else std::memset(dq, '!', n);
+            }
+        });
+        const uint64_t n_ovl_all = overlaps.size();
+        layout_.cigar_off.assign(n_ovl_all + 1, 0);
+        for (uint64_t k = 0; k < n_ovl_all; ++k) layout_.cigar_off[k + 1] = layout_.cigar_off[k] + overlaps[k]->cigar().size();
+        layout_.cigar.resize(layout_.cigar_off[n_ovl_all]);
+        parallel_for(n_ovl_all, num_threads_, [&](uint64_t k) {
+            const std::string& cg = overlaps[k]->cigar();
+            if (!cg.empty()) std::memcpy(layout_.cigar.data() + layout_.cigar_off[k], cg.data(), cg.size());
+        });
+        for (auto* v : {&layout_.q_id, &layout_.t_id, &layout_.q_start, &layout_.t_begin, &layout_.t_end, &layout_.q_begin, &layout_.q_end}) v->reserve(n_ovl_all);
+        layout_.strand.reserve(n_ovl_all); layout_.bp_off.reserve(n_ovl_all + 1);
         for (const auto& o : overlaps) {
             layout_.q_id.push_back(static_cast<uint32_t>(o->q_id()));
             layout_.t_id.push_back(static_cast<uint32_t>(o->t_id()));
@@ -343,8 +369,6 @@ void Polisher::initialize() {
             layout_.bp_off.push_back(layout_.bp_t.size());
             layout_.q_start.push_back(o->q_start_on_strand()); layout_.t_begin.push_back(o->t_begin()); layout_.t_end.push_back(o->t_end());
             layout_.q_begin.push_back(o->q_begin()); layout_.q_end.push_back(o->q_end());
-            layout_.cigar.insert(layout_.cigar.end(), o->cigar().begin(), o->cigar().end());
-            layout_.cigar_off.push_back(layout_.cigar.size());
         }
     }
 

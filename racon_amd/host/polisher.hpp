@@ -64,9 +64,18 @@ public:
     // What the two loops at the end of initialize() consume, flattened (include/racon_hip.h: rcn_read_set /
     // rcn_overlap_set): every sequence on its forward strand and every kept overlap with its breaking points.
     // Recorded by initialize() when keep_layout(true) was called before it; the input of rcn_engine_build_windows.
+    // (bytes that are about to be overwritten need no zero fill first: resize() of these leaves them uninitialised)
+    template <class T> struct NoInit : std::allocator<T> {
+        template <class U> struct rebind { using other = NoInit<U>; };
+        template <class U, class... A> void construct(U* p, A&&... a) {
+            if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U; else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+        }
+    };
+    using ByteBuf = std::vector<uint8_t, NoInit<uint8_t>>;
     struct Layout {
         std::vector<uint64_t> seq_off{0};
-        std::vector<uint8_t> bases, quals, seq_has_qual;
+        ByteBuf bases, quals;
+        std::vector<uint8_t> seq_has_qual;
         uint64_t n_targets = 0;
         std::vector<uint32_t> q_id, t_id;
         std::vector<uint8_t> strand;
@@ -75,7 +84,7 @@ public:
         // the alignments the breaking points came from (rcn_cigar_set): CIGAR text, first query position on the
         // overlap's strand, target extent
         std::vector<uint64_t> cigar_off{0};
-        std::vector<uint8_t> cigar;
+        ByteBuf cigar;
         std::vector<uint32_t> q_start, t_begin, t_end;
         // the aligned query segment on the forward read (rcn_pair_set): what the device aligner needs of an overlap
         // that came without a CIGAR
