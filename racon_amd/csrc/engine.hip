@@ -365,9 +365,15 @@ bool small_caps(const rcn_engine* e, It first, It last, Caps& out) {
     // on short windows: a few layers beyond 255 bases among thousands within) -- the kernel flags those at once (kSmCap /
     // kSmLong, before it touches anything sized by the capacities below) and collect() hands them to poa_window_kernel2
     // like every other window that leaves the kernel.  The capacities follow the windows that do have the shape.
+    // Only windows that will be POLISHED count (three or more sequences = two or more layers = sum_l > lmax; the others are copied
+    // through by either kernel, window.cpp:68-71): a window-range shard of a device-built job holds every OTHER range's windows as
+    // bare backbones, and counting those as "has the shape" handed a batch of 250 000 ten-kilobase-read windows among 1.75 M bare
+    // backbones to this kernel -- which flagged every real window and left them all to the retry tier (cfg5 whole, round 5).
     int32_t Lmax = 1;
     uint64_t shaped = 0, total = 0;
-    for (It it = first; it != last; ++it, ++total) {
+    for (It it = first; it != last; ++it) {
+        if (it->sum_l <= it->lmax) { if (small_shape(*it)) Lmax = std::max(Lmax, it->L); continue; }
+        ++total;
         if (!small_shape(*it)) continue;
         ++shaped;
         Lmax = std::max(Lmax, it->L);
@@ -1050,12 +1056,25 @@ static int collect(rcn_engine* e) {
                 redone.emplace_back(w, std::string(len2[k], '\0'));
                 out_len[w] = len2[k]; flags[w] = fl2[k];
             }
-            for (size_t k = 0, j = first_new; k < nr; ++k) {
-                if (fl2[k] & rcn::kFlagOverflow) continue;
-                if (len2[k]) HIP_TRY(hipMemcpyAsync(&redone[j].second[0], e->d_out_cons.as<uint8_t>() + off2[k], len2[k], hipMemcpyDeviceToHost, e->stream));
-                ++j;
+            if (nr <= 64) {
+                for (size_t k = 0, j = first_new; k < nr; ++k) {
+                    if (fl2[k] & rcn::kFlagOverflow) continue;
+                    if (len2[k]) HIP_TRY(hipMemcpyAsync(&redone[j].second[0], e->d_out_cons.as<uint8_t>() + off2[k], len2[k], hipMemcpyDeviceToHost, e->stream));
+                    ++j;
+                }
+                HIP_TRY(hipStreamSynchronize(e->stream));
+            } else {
+                // many windows (a pass that the small-window kernel gave back wholesale): one copy of the block, not one per window
+                // (250 000 of them were 4.5 s)
+                std::vector<uint8_t> block(off2[nr] + 16);
+                HIP_TRY(hipMemcpyAsync(block.data(), e->d_out_cons.p, off2[nr], hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                for (size_t k = 0, j = first_new; k < nr; ++k) {
+                    if (fl2[k] & rcn::kFlagOverflow) continue;
+                    if (len2[k]) std::memcpy(&redone[j].second[0], block.data() + off2[k], len2[k]);
+                    ++j;
+                }
             }
-            HIP_TRY(hipStreamSynchronize(e->stream));
             if (tier == 0) e->stats.n_small_bailed = nr;
             retry.swap(again);
         }

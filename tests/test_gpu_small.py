@@ -196,3 +196,25 @@ def test_real_noisy_reads_at_w200(Engine, oracle, reads, ovl, scores):
     p = make()
     assert p.polish(True) == ref_fasta
     p.close()
+
+
+def test_bare_backbones_do_not_vote_for_the_small_kernel(Engine, oracle):
+    """A window-range shard of a device-built job holds the other ranges' windows as bare backbones (fewer than three sequences: copied
+    through, reference src/window.cpp:68-71).  Those have no shape to speak of: counted as "small", 1.75 M of them handed a batch of
+    250 000 long-read windows to the small-window kernel, which flagged every real window (cfg5 whole in eight shards, round 5).  Only
+    windows that will be polished count -- and a mostly-bare batch of SHORT-read windows still takes the kernel."""
+    ont = simulate_windows(15_000, 500, 20.0, 3000, seed=61)                       # 30 windows with 500-base layers: outside the shape
+    bare = [{"type": 1, "seqs": [(bytes([65 + (k % 3)]) * 500, None, 0, 0)]} for k in range(400)]
+    wins = bare[:200] + [ont.window(k) for k in range(ont.n_windows)] + bare[200:]
+    b = WindowBatch.from_windows(wins)
+    ref = oracle.consensus(b, 3, -5, -4, True, 0)
+    eng = Engine(3, -5, -4, True)
+    assert_same(eng.consensus(b), ref, "bare backbones around long-read windows")
+    st = eng.stats()
+    assert st["n_small"] == 0 and st["n_small_bailed"] == 0, st                  # poa_window_kernel2 took the pass, nothing went through the retry tier
+    short = simulate_windows(6_000, 200, 40.0, 150, seed=62, **SHORT)
+    wins = bare[:300] + [short.window(k) for k in range(short.n_windows)]
+    b2 = WindowBatch.from_windows(wins)
+    e2 = Engine(3, -5, -4, True)
+    assert_same(e2.consensus(b2), oracle.consensus(b2, 3, -5, -4, True, 0), "bare backbones around short-read windows")
+    assert e2.stats()["n_small"] >= short.n_windows - e2.stats()["n_small_bailed"] > 0

@@ -90,6 +90,20 @@ PY
     grep -E "racon::|polish:|piece|collect|reserve|pass of|timing|pairs:" "$OUT/timeline_cfg2_$name.err" | cut -c1-300 > "$OUT/timeline_cfg2_$name.txt"
   done 2>&1 | tee "$OUT/timeline2.txt"
 fi
+if has shardtime; then
+  # where a shard's time goes when a job is cut into more window ranges than devices (cfg5 at a quarter of its size, three sequential shards)
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+from racon_amd.synth import simulate_fragment_files
+SC = float(os.environ.get("SHARD_SCALE", "0.25")); d = "/tmp/racon_amd_cache/cfg5_%g" % SC
+if not os.path.exists(d + "/.done"):
+    p = simulate_fragment_files(d, int(33_333_333 * SC), int(100_000 * SC), seed=20260924); open(d + "/.done", "w").write(str(p["n_overlaps"]))
+PY
+  F=/tmp/racon_amd_cache/cfg5_${SHARD_SCALE:-0.25}
+  RACON_HIP_DEVICE_SHARDS=${SHARD_N:-3} RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -f -t 32 --cudaaligner-batches 1 $F/reads.fastq $F/overlaps.paf $F/reads.fastq 2> "$OUT/shardtime.err" | md5sum
+  grep -E "racon::|polish:|piece|collect|reserve|pass of|timing|pairs:|racon_hip" "$OUT/shardtime.err" | cut -c1-260 > "$OUT/shardtime.txt"; tail -60 "$OUT/shardtime.txt"
+fi
 if has inittime; then
   # initialize() with device-side construction: where its time goes at 12 500 and 50 000 windows (uploads out of pageable memory staged through pinned slots)
   python - <<'PY'
