@@ -41,6 +41,14 @@ if has fuzz; then
   timeout 1500 python tools/fuzz_sweep.py --seeds ${FUZZ_SEEDS:-120} --out "$OUT/fuzz_sweep.json" > "$OUT/fuzz_sweep.log" 2>&1
   echo "fuzz exit $?"; tail -4 "$OUT/fuzz_sweep.log" | cut -c1-1500
 fi
+if has fuzz2; then
+  # a second, disjoint set of seeds on the closing tree
+  timeout 1500 python tools/fuzz_sweep.py --first-seed 20000 --seeds ${FUZZ2_SEEDS:-200} --out "$OUT/fuzz_sweep_second_set.json" > "$OUT/fuzz_sweep_second_set.log" 2>&1
+  echo "fuzz2 exit $?"; tail -1 "$OUT/fuzz_sweep_second_set.log" | cut -c1-900
+  timeout 900 python tools/fuzz_sweep.py --no-small --first-seed 30000 --seeds ${FUZZ2_K2_SEEDS:-80} --out "$OUT/fuzz_sweep_kernel2_second_set.json" > "$OUT/fuzz_sweep_kernel2_second_set.log" 2>&1
+  echo "fuzz2 (kernel2) exit $?"; tail -1 "$OUT/fuzz_sweep_kernel2_second_set.log" | cut -c1-700
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+fi
 if has fuzzk2; then
   timeout 1500 python tools/fuzz_sweep.py --no-small --first-seed 9000 --seeds ${FUZZ_K2_SEEDS:-60} --out "$OUT/fuzz_sweep_kernel2.json" > "$OUT/fuzz_sweep_kernel2.log" 2>&1
   echo "fuzz (kernel2) exit $?"; tail -2 "$OUT/fuzz_sweep_kernel2.log" | cut -c1-1200
