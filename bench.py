@@ -641,6 +641,19 @@ def main():
             out["verified_flags"] = bool((ref.polished == res.polished).all() and (ref.chimeric == res.chimeric).all())
         print(json.dumps(out), flush=True)
     if world > 1:
+        # The other ranks wait for rank 0's product leg on the HOST (a key in the process group's store), not inside a collective: an
+        # NCCL barrier entered early is a kernel that spins on every other GPU until rank 0 arrives -- on exactly the devices the
+        # product leg's one racon_hip process is polishing on (and a launch that wants whole compute units to itself could wait for
+        # that kernel for ever).
+        try:
+            import datetime
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("racon_bench_rank0_done", "1")
+            else:
+                store.wait(["racon_bench_rank0_done"], datetime.timedelta(minutes=90))
+        except Exception:
+            pass
         dist.barrier()
         dist.destroy_process_group()
 
