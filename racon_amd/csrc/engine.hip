@@ -1090,13 +1090,13 @@ static int collect(rcn_engine* e) {
 
     e->stats_pending = true;                      // the device counters of this run: fetched by rcn_engine_stats on demand
 #ifdef RCN_PROF_ROWS
-    { static unsigned long long rp[256][16]; HIP_TRY(hipMemcpyFromSymbol(rp, HIP_SYMBOL(rcn::g_rowprof), sizeof(rp)));
-      unsigned long long clk[8] = {0}, cnt[8] = {0}, allc = 0, alln = 0;
-      for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) { clk[k] += rp[b][k]; cnt[k] += rp[b][8 + k]; }
-      for (int k = 0; k < 8; ++k) { allc += clk[k]; alln += cnt[k]; }
-      static const char* names[8] = {"chain", "fast, 1 pred", "fast, 2 preds", "fast, 3-4 preds", "medium", "general", "window moves", "sink"};
+    { static unsigned long long rp[256][20]; HIP_TRY(hipMemcpyFromSymbol(rp, HIP_SYMBOL(rcn::g_rowprof), sizeof(rp)));
+      unsigned long long clk[9] = {0}, cnt[9] = {0}, allc = 0, alln = 0;
+      for (int b = 0; b < 256; ++b) for (int k = 0; k < 9; ++k) { clk[k] += rp[b][k]; cnt[k] += rp[b][10 + k]; }
+      for (int k = 0; k < 9; ++k) { allc += clk[k]; alln += cnt[k]; }
+      static const char* names[9] = {"chain", "fast, 1 pred", "fast, 2 preds", "fast, 3-4 preds", "medium", "general", "window moves", "sink", "rows in octets"};
       fprintf(stderr, "[racon_hip] banded DP rows since the library was loaded (clocks include the probe itself):\n");
-      for (int k = 0; k < 8; ++k) if (cnt[k]) fprintf(stderr, "  %-16s rows %5.1f %%  clocks %5.1f %%  %7.0f clocks/row\n", names[k], 100.0 * cnt[k] / std::max(1ull, alln),
+      for (int k = 0; k < 9; ++k) if (cnt[k]) fprintf(stderr, "  %-16s rows %5.1f %%  clocks %5.1f %%  %7.0f clocks/row\n", names[k], 100.0 * cnt[k] / std::max(1ull, alln),
                                                          100.0 * clk[k] / std::max(1ull, allc), (double)clk[k] / cnt[k]);
       fprintf(stderr, "  all              rows %llu  %7.0f clocks/row\n", alln, (double)allc / std::max(1ull, alln)); }
 #endif

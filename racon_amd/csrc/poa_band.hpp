@@ -33,7 +33,8 @@
 namespace rcn {
 
 constexpr int kBandG = 32;            // window offsets are multiples of this many columns
-constexpr int kBandSeq = 1536;        // LDS copy of the layer's bases (window shifts re-read their columns from it)
+constexpr int kBandSeq = 1088;        // LDS copy of the layer's bases (window shifts re-read their columns from it) + the cold window state
+constexpr int kBandRing = 32;         // rows of the LDS ring of the banded DP (a power of two and a multiple of the octet: see dp2_rows_band_body)
 
 // NP of the banded DP for a layer of `len` bases (0 = not banded).  The alive zone is about len / 3 wide
 // (profiles/r02/band_study.txt), so a window serves layers up to ~2.5 x its width.
@@ -42,9 +43,10 @@ __host__ __device__ __forceinline__ int band_np(int len) {
     if (W > 256 && W <= 640) return 2;
     return 0;
 }
-__host__ __device__ constexpr int dp2_ring_rows_band(int np, bool tab) {
-    return (kLdsBytes - 64 - kBandSeq - (tab ? 4 * 4 * 64 * np : 0)) / (4 * 64 * np) - 1;
+__host__ __device__ constexpr int dp2_band_slots(int np, bool tab) {       // row slots the work area has room for
+    return (kLdsBytes - 64 - kBandSeq - (tab ? 4 * 4 * 64 * np : 0)) / (4 * 64 * np);
 }
+__host__ __device__ constexpr int dp2_ring_rows_band(int np, bool tab) { return np == 2 ? kBandRing : dp2_band_slots(np, tab) - 1; }
 
 // ---- the code wave (HELP) ----
 // A window that has a CU to itself (the deep launch of engine.hip's split: one work-group per CU, enforced by asking for
@@ -127,8 +129,8 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 
 #ifdef RCN_PROF_ROWS
 // profiling build: clocks and counts of the banded DP's rows by class (0 chain, 1 / 2 / 3 = fast rows with one / two /
-// three or four predecessors, 4 medium, 5 general, 6 rows where the window moved, 7 sink rows), spread over 256 copies
-__device__ unsigned long long g_rowprof[256][16];
+// three or four predecessors, 4 medium, 5 general, 6 rows where the window moved, 7 sink rows, 8 rows inside octets), spread over 256 copies
+__device__ unsigned long long g_rowprof[256][20];
 #endif
 // ---- the banded one-wave DP (wave 0 of the work-group) ----
 // CODE: instead of the row of scores the wave stores, per cell, what the traceback would find out from the scores (one
@@ -160,9 +162,9 @@ __device__ __forceinline__ void dp2_rows_band_body() {
     constexpr int kTab = TAB ? 4 * 4 * NTH * NP : 0;
     constexpr int KT = (kLdsBytes - 64 - kBandSeq - kTab) / (4 * NTH * NP);
     // HELP: the ring is the large one behind the context (phase_desc2 classifies rows for the small one: conservative)
-    constexpr int K = HELP ? kHelpRows : KT - 1;
-    static_assert(KT - 1 == dp2_ring_rows_band(NP, TAB), "phase_desc2 classifies rows with the same ring depth");
-    static_assert(KT - 1 >= 8 && KT - 1 <= 63, "ring depth");
+    constexpr int K = HELP ? kHelpRows : kBandRing;
+    static_assert(NP == 2 && kBandRing == dp2_ring_rows_band(NP, TAB) && KT == dp2_band_slots(NP, TAB), "phase_desc2 classifies rows with the same ring depth");
+    static_assert(KT >= kBandRing && (K & (K - 1)) == 0 && K % 8 == 0, "ring: a power of two of rows, inside the work area");
     uint32_t* ring0 = reinterpret_cast<uint32_t*>(Block4::work());         // [KT][NTH][NP]
     uint32_t* ring = HELP ? help_ring() : ring0;
     uint32_t* ptab = ring0 + KT * NTH * NP;                                   // [4][NTH][NP] (TAB)
@@ -251,7 +253,7 @@ __device__ __forceinline__ void dp2_rows_band_body() {
 
     int best = 0, best_row = 0, have_best = 0, tied = 0;
     unsigned int pred_rows = 0;             // predecessor rows combined (statistics: the algorithmic bytes of this alignment)
-    int slot = 1 % K;
+    int slot = 0;                               // ring slot of row i: (i - 1) & (K - 1) -- the eight rows of an octet never wrap
     RCN_G uint32_t* hrow = H + hs2;             // wave-uniform: row i of the matrix at the window's first column
     // CODE: one byte per cell, absolute columns, row stride hs BYTES (same base as the score matrix it replaces)
     RCN_G uint8_t* cbase = reinterpret_cast<RCN_G uint8_t*>(g.H.ptr());
@@ -261,6 +263,7 @@ __device__ __forceinline__ void dp2_rows_band_body() {
     asm volatile("" : "+v"(coff));
     RCN_G int32_t* sinkz = g.path_node.ptr();   // CODE: end score (column len) of the sink rows, for phase_sink_tie_full
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
+    unsigned int fast8 = 0u;                    // octets of the current descriptor block that consist of ordinary chain / fast rows
 
     // the window moves to new_off before row i is computed
     auto shift_to = [&](int i_in, int new_off) {
@@ -353,6 +356,30 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                 for (int sh = 32; sh >= 1; sh >>= 1) npl += __shfl_xor(npl, sh);
                 pred_rows += static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(npl));
             }
+            {
+                // chain / fast rows, this wave's copy of the descriptor word: predecessor DISTANCES (bits 16-31, four bits each) become
+                // the predecessors' places in the register window -- row j lives in win[(j & (R - 1)) * NP ...] -- so that a row
+                // reads a predecessor with the index it pulls out of the word (three scalar instructions less per predecessor).
+                // HELP: a row with one predecessor names it twice: the octet rows below combine two predecessors without asking.
+                const int il = rbase + lane + 1, npl_ = (d.meta >> 9) & 7;
+                unsigned int f = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int de = static_cast<int>((static_cast<unsigned int>(d.meta) >> (16 + 4 * e)) & 15u);
+                    const unsigned int fe = static_cast<unsigned int>(((il - de) & (R - 1)) * NP);
+                    f |= (e < npl_ ? fe : 0u) << (4 * e);
+                }
+                if (HELP) f |= npl_ == 1 ? (f & 15u) << 4 : 0u;
+                const int tm = static_cast<int>((static_cast<unsigned int>(d.meta) & 0xffffu) | (f << 16));
+                d.meta = (d.meta & (1 << 13)) ? tm : d.meta;
+            }
+            // rows 8 g + 1 ... 8 g + 8 of this block are all ordinary chain / fast rows (bit 13 set, bit 12 clear): bit g
+            fast8 = 0u;
+            {
+                const unsigned long long fm = __ballot(rbase + lane < V && (d.meta & ((1 << 13) | (1 << 12))) == (1 << 13));
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) fast8 |= ((fm >> (8 * g8)) & 0xffull) == 0xffull ? (1u << g8) : 0u;
+            }
             dl_p0 = d.p[0]; dl_p1 = d.p[1]; dl_p2 = d.p[2]; dl_p3 = d.p[3]; dl_p4 = d.p[4]; dl_p5 = d.p[5]; dl_er = d.erest; dl_meta = d.meta; dl_off = ro;
             asm volatile("; row descriptors retired" : "+v"(dl_p0), "+v"(dl_p1), "+v"(dl_p2), "+v"(dl_p3), "+v"(dl_p4), "+v"(dl_p5), "+v"(dl_er), "+v"(dl_meta), "+v"(dl_off));
         }
@@ -374,6 +401,60 @@ __device__ __forceinline__ void dp2_rows_band_body() {
 #pragma unroll 1
         for (int i = rbase + 1; i <= rend; ++i) {
             const int k = (i - 1) & 63;
+#ifndef RCN_NO_OCTETS
+            if ((k & 7) == 0 && ((fast8 >> (k >> 3)) & 1u)) {
+                // ---- an OCTET: eight ordinary chain / fast rows in one trip, straight-line, with STATIC register-window places.
+                // A lone wave pays for every instruction it issues and ~70 clocks for a taken branch; the row-at-a-time loop
+                // spends 4 instructions and a taken branch on its back-edge, 5 on the indexed window write, 3 on the class test,
+                // 3 on the ring slot and 2 on row pointers -- per row.  Here row 8 g + 1 + o writes its result straight into
+                // win[((o + 1) & (R - 1)) * NP ...], the ring row at a constant offset from the octet's first, and the rest once
+                // per octet (84 % of the rows of cfg2 run through here).  Same arithmetic, same order: poa_band_row_octet.inc.
+                static_assert(R == 8 && NP == 2, "octet = one turn of the register window");
+#ifdef RCN_PROF_ROWS
+                const long long oct_t0 = clock64();
+#endif
+#pragma unroll
+                for (int q = 0; q < NP; ++q) win[q] = prev[q];                      // row i - 1 = 8 g: place 0
+                uint32_t* const roct = ring + (slot * NTH + t) * NP;
+#define RCN_OCT_ROW 0
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#define RCN_OCT_ROW 1
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#define RCN_OCT_ROW 2
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#define RCN_OCT_ROW 3
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#define RCN_OCT_ROW 4
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#define RCN_OCT_ROW 5
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#define RCN_OCT_ROW 6
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#define RCN_OCT_ROW 7
+#include "poa_band_row_octet.inc"
+#undef RCN_OCT_ROW
+#pragma unroll
+                for (int q = 0; q < NP; ++q) prev[q] = win[q];                      // row 8 g + 8: place 0 again
+#ifdef RCN_PROF_ROWS
+                if (CODE && lane == 0) {
+                    atomicAdd(&g_rowprof[blockIdx.x & 255][8], static_cast<unsigned long long>(clock64() - oct_t0));
+                    atomicAdd(&g_rowprof[blockIdx.x & 255][10 + 8], 8ull);
+                }
+#endif
+                slot = (slot + 8) & (K - 1);
+                hrow += 8 * hs2;
+                if (CODE && HELP) coff += 8u * static_cast<uint32_t>(hs);
+                i += 7;
+                continue;
+            }
+#endif
             const int meta = meta_next;
             // the row just finished enters the register window here, at ONE place: the copies of the row tail below then
             // only hand over `prev` (with the window written in each of them the compiler copies all sixteen registers
@@ -554,13 +635,13 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                 const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
                 const int npf = (meta >> 9) & 7;
                 {
-                    const int wi = ((i - static_cast<int>(dd & 15)) & (R - 1)) * NP;
+                    const int wi = static_cast<int>(dd & 15);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) M[q] = win[wi + q];
                 }
                 if (__builtin_expect(npf > 1, 0)) {      // (38 % of the rows; kept off the fall-through path of the other 60 %)
                     {
-                        const int wi = ((i - static_cast<int>((dd >> 4) & 15)) & (R - 1)) * NP;
+                        const int wi = static_cast<int>((dd >> 4) & 15);
                         uint32_t zq[NP];
                         __builtin_amdgcn_sched_barrier(0);   // (both indexed reads in one register-index mode region)
 #pragma unroll
@@ -572,7 +653,7 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                     }
 #pragma unroll 1
                     for (int e = 2; e < npf; ++e) {
-                        const int wi = ((i - static_cast<int>((dd >> (4 * e)) & 15)) & (R - 1)) * NP;
+                        const int wi = static_cast<int>((dd >> (4 * e)) & 15);
                         uint32_t zq[NP];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -718,11 +799,14 @@ __device__ __noinline__ void dp2_band_codes(const int hw) {        // hw = 0, 1,
             const int meta = __builtin_amdgcn_readlane(dl_meta, k);
             if (!(meta & (1 << 13))) continue;                          // wave 0 keeps the codes of this row
             if (have < i) { wait_for(i); if (gone) break; }
+#ifdef RCN_EXP_CODEWAVE_NOP
+            continue;                                                   // (timing experiment: what wave 0 does when nobody holds it back; results are wrong)
+#endif
             const int wi = __builtin_amdgcn_readlane(dl_off, k);
             if (wi != woff) { woff = wi; set_columns(woff); }
             const unsigned int dd = static_cast<unsigned int>(meta) >> 16;
             const int npf = (meta >> 9) & 7;
-            const int slot = i & (K - 1);
+            const int slot = (i - 1) & (K - 1);
             uint32_t acc[NP], M[NP], Aq[NP];
             {
                 const uint32_t* src = ring + (slot * NTH + t) * NP;

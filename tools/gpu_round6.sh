@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round-6 GPU visits.  Usage: bash tools/gpu_round6.sh <tag> [what...]
+#   what: probe (tools/probe/row_chain.hip) parity (the parity tests that exercise the banded DP) tests (whole GPU suite)
+#         ab (cfg2 / 4 Mbp / w1000 bench lines, shipped library against libracon_hip_v_*.so variants) bench (default line)
+#         fuzz (tools/fuzz_sweep.py) final (kernel stats + counter passes + all lines)
+set -u
+TAG=${1:-r06a}; shift || true
+WHAT=${*:-probe parity ab}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export RCN_EXPERIMENT=1
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+(nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocm-smi --showproductname 2>/dev/null | head -12) > "$OUT/box.txt" 2>&1
+benchline() { python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
+print('%s: %.0f windows/s  step %.2f ms  launches %s  frac %.3f  gcups %.0f  small %s bailed %s' % ('$1', j.get('value_kernel_leg', j['value']), r['step_kernel_ms'], ['%.2f' % v for v in r['launch_ms']], r['frac'], r.get('gcups',0), r.get('small_windows'), r.get('small_bailed')))"; }
+QB="--steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg"
+
+if has probe; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/row_chain tools/probe/row_chain.hip && /tmp/row_chain | tee "$OUT/row_chain_probe.txt"
+fi
+if has parity; then
+  timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_band.py tests/test_gpu_fuzz.py "tests/test_gpu_fullsize.py" \
+      -m gpu -q -x --durations=10 > "$OUT/pytest_parity.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_parity.log"; tail -25 "$OUT/pytest_parity.log"
+fi
+if has tests; then
+  timeout 3000 python -m pytest tests -m gpu -q -x --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_gpu.log"; tail -30 "$OUT/pytest_gpu.log"
+fi
+if has ab; then
+  for k in 1 2; do
+    python bench.py $QB 2>/dev/null | benchline "cfg2 as shipped ($k)"
+    for v in ${VARIANTS:-nooct}; do [ -f racon_amd/csrc/libracon_hip_v_$v.so ] && RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_v_$v.so python bench.py $QB 2>/dev/null | benchline "cfg2 libracon_hip_v_$v.so ($k)"; done
+  done 2>&1 | tee "$OUT/ab.txt"
+  python bench.py --contig 4000000 $QB 2>/dev/null | benchline "4 Mbp as shipped" | tee -a "$OUT/ab.txt"
+  for v in ${VARIANTS:-nooct}; do [ -f racon_amd/csrc/libracon_hip_v_$v.so ] && RACON_HIP_LIB=$PWD/racon_amd/csrc/libracon_hip_v_$v.so python bench.py --contig 4000000 $QB 2>/dev/null | benchline "4 Mbp libracon_hip_v_$v.so" | tee -a "$OUT/ab.txt"; done
+  python bench.py --config w1000 $QB 2>/dev/null | benchline "w1000 as shipped" | tee -a "$OUT/ab.txt"
+  python bench.py --config cfg4 $QB 2>/dev/null | benchline "cfg4 as shipped" | tee -a "$OUT/ab.txt"
+fi
+if has bench; then
+  timeout 1500 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "bench exit $?"; cut -c1-3000 "$OUT/bench.json"; tail -5 "$OUT/bench.err"
+fi
+if has fuzz; then
+  timeout 1500 python tools/fuzz_sweep.py --seeds ${FUZZ_SEEDS:-120} --out "$OUT/fuzz_sweep.json" > "$OUT/fuzz_sweep.log" 2>&1
+  echo "fuzz exit $?"; tail -4 "$OUT/fuzz_sweep.log" | cut -c1-1500
+  timeout 1500 python tools/fuzz_sweep.py --no-small --first-seed 9000 --seeds ${FUZZ_K2_SEEDS:-60} --out "$OUT/fuzz_sweep_kernel2.json" > "$OUT/fuzz_sweep_kernel2.log" 2>&1
+  echo "fuzz (kernel2) exit $?"; tail -2 "$OUT/fuzz_sweep_kernel2.log" | cut -c1-1200
+fi

@@ -5,6 +5,12 @@
 //   B  "lazy carry": the row's pre-scan values are formed from the previous row's PRE-scan values and the previous carry
 //      (max(a, z) + c = max(a + c, z + c)); only tail -> scan -> carry is on the row-to-row path
 //   C  A without the scan (its other dependent operations only);  D  the scan alone
+//   H  (round 6) the row as TWO HALF-ROW STREAMS in one wave: register 0 = columns [0, 128) two per lane, register 1 = columns
+//      [128, 256) -- two independent six-step scans per row, coupled by one carried value (v_readlane of lane 63's running
+//      maximum) and one diagonal cell; H1 = both halves of row i in one trip, H2 = skewed ((row i, half A) next to
+//      (row i - 1, half B): nothing of one stream waits for the other), H3 = H2 + register window + LDS + scalar bookkeeping
+//      (to be read against "A + all three")
+//   U  "A + all three" with EIGHT rows per trip and static register-window places (what the octets of poa_band.hpp do)
 // Build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/row_chain tools/probe/row_chain.hip && /tmp/row_chain
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -71,6 +77,118 @@ __device__ __forceinline__ void rows_wls(int n, uint32_t seed, uint32_t& m0, uin
         if (!L) P0 ^= 0x00010000u;
     }
 }
+// ---- half-row streams ----
+// lane l: h0 = columns 2 l, 2 l + 1 (half A), h1 = columns 128 + 2 l, 129 + 2 l (half B)
+template <bool SKEW, bool EXTRA>
+__device__ __forceinline__ void rows_half(int n, uint32_t seed, uint32_t& m0, uint32_t& m1, int& zshA) {
+    const int t = threadIdx.x;
+    uint32_t P0 = 0x00070007u ^ (t & 1 ? 0x8u : 0u), P1 = 0x0007ffffu;
+    const uint32_t GG = 0xfffcfffcu;
+    uint32_t mpvA = 0x83000000u;
+    int zshB = static_cast<int>(0x80000000u);
+    int cA = -32000, cA_prev = -32000;           // half A's row maximum (carry into half B), of this row / of the row before
+    uint32_t a63 = 0x83008300u;                  // half A's lane 63 of the predecessor row (diagonal into half B's first cell)
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 win;
+    for (int k = 0; k < 16; ++k) win[k] = seed + k;
+    extern __shared__ uint32_t lds[];
+    uint32_t* ring = lds; uint32_t* ptab = lds + 27 * 128;
+    if (EXTRA) for (int k = t; k < 28 * 128; k += 64) lds[k] = k * seed;
+    int slot = 1, meta_next = static_cast<int>(seed);
+    int dl_meta = (t * 7919 + seed) & 0x0fff00ff;
+    uint32_t Pn0 = P0, Pn1 = P1;
+#pragma unroll 1
+    for (int i = 1; i <= n; ++i) {
+        const int meta = meta_next;
+        if (EXTRA) {
+            __builtin_amdgcn_sched_barrier(0);
+            win[((i - 1) & 7) * 2] = m0; win[((i - 1) & 7) * 2 + 1] = m1;
+            __builtin_amdgcn_sched_barrier(0);
+            meta_next = __builtin_amdgcn_readlane(dl_meta, i & 63);
+            if (__builtin_expect((meta & (1 << 12)) != 0, 0)) { m0 ^= 1u; asm volatile("; rare a" : "+v"(m0)); }
+            if (__builtin_expect((meta & (1 << 13)) != 0, 0)) { m1 ^= 1u; asm volatile("; rare b" : "+v"(m1)); }
+            if (__builtin_expect((meta & (0xf << 9)) != 0, 0)) { m1 ^= 2u; asm volatile("; rare c" : "+v"(m1)); }
+            const int wi = ((i - 1) & 7) * 2;
+            m0 = win[wi]; m1 = win[wi + 1];
+            P0 = Pn0; P1 = Pn1;
+        }
+        // stream A: row i, columns [0, 128)
+        const uint32_t mprevA = mpvA = __builtin_amdgcn_update_dpp(mpvA, m0, 0x138, 0xf, 0xf, false);
+        const uint32_t D0 = __builtin_amdgcn_alignbit(m0, mprevA, 16);
+        uint32_t a0 = pk_chain_pair(pk_max(pk_add(D0, P0), pk_add(m0, GG)));
+        int s0 = static_cast<int>(a0) >> 16;
+        // stream B: row i (H1) or row i - 1 (H2: m1 is a row behind, its inputs from stream A are a row old) -- same instructions
+        const uint32_t rot = __builtin_amdgcn_update_dpp(a63, m1, 0x138, 0xf, 0xf, false);      // lane 0 keeps half A's last cell
+        const uint32_t D1 = __builtin_amdgcn_alignbit(m1, rot, 16);
+        uint32_t a1 = pk_chain_pair(pk_max(pk_add(D1, P1), pk_add(m1, GG)));
+        int s1 = static_cast<int>(a1) >> 16;
+        if (EXTRA) { const uint32_t* src = ptab + ((meta_next >> 1) & 3) * 128 + t * 2; Pn0 = src[0]; Pn1 = src[1]; }
+        constexpr int I = static_cast<int>(0x80000000u);
+        s0 = max(s0, dpp_or<0x111, 0xf>(I, s0)); s1 = max(s1, dpp_or<0x111, 0xf>(I, s1));
+        s0 = max(s0, dpp_or<0x112, 0xf>(I, s0)); s1 = max(s1, dpp_or<0x112, 0xf>(I, s1));
+        s0 = max(s0, dpp_or<0x114, 0xf>(I, s0)); s1 = max(s1, dpp_or<0x114, 0xf>(I, s1));
+        s0 = max(s0, dpp_or<0x118, 0xf>(I, s0)); s1 = max(s1, dpp_or<0x118, 0xf>(I, s1));
+        s0 = max(s0, dpp_or<0x142, 0xa>(I, s0)); s1 = max(s1, dpp_or<0x142, 0xa>(I, s1));
+        s0 = max(s0, dpp_or<0x143, 0xc>(I, s0)); s1 = max(s1, dpp_or<0x143, 0xc>(I, s1));
+        zshA = dpp_or<0x138, 0xf>(zshA, s0);
+        zshB = dpp_or<0x138, 0xf>(zshB, s1);
+        cA_prev = cA;
+        cA = __builtin_amdgcn_readlane(s0, 63);
+        const int zexA = max(zshA, -32000);
+        const int zexB = max(max(zshB, SKEW ? cA_prev : cA), -32000);
+        const uint32_t n0 = pk_max_blo(a0, static_cast<uint32_t>(zexA)), n1 = pk_max_blo(a1, static_cast<uint32_t>(zexB));
+        // the diagonal into half B's first cell of the NEXT row B works on: half A's lane 63 of its predecessor row
+        a63 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(SKEW ? m0 : n0), 63));
+        m0 = n0; m1 = n1;
+        if (EXTRA) { uint32_t* dst = ring + (slot * 64 + t) * 2; dst[0] = m0; dst[1] = m1; slot = (slot + 1 == 27) ? 0 : slot + 1; }
+        else P0 ^= 0x00010000u;
+    }
+}
+// ---- eight rows per trip, static register-window places ----
+__device__ __forceinline__ void rows_oct(int n, uint32_t seed, uint32_t& m0, uint32_t& m1, int& zsh) {
+    const int t = threadIdx.x;
+    uint32_t P0, P1; const uint32_t GG = 0xfffcfffcu;
+    uint32_t mpv = 0x83000000u;
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 win;
+    for (int k = 0; k < 16; ++k) win[k] = seed + k;
+    extern __shared__ uint32_t lds[];
+    uint32_t* ring = lds; uint32_t* ptab = lds + 27 * 128;
+    for (int k = t; k < 28 * 128; k += 64) lds[k] = k * seed;
+    int slot = 0, meta_next = static_cast<int>(seed);
+    int dl_meta = (t * 7919 + seed) & 0x0fff00ff;
+    uint32_t Pn0 = 0x00070007u, Pn1 = 0x0007ffffu;
+    win[0] = m0; win[1] = m1;
+#pragma unroll 1
+    for (int i = 1; i <= n; i += 8) {
+        uint32_t* const roct = ring + (slot * 64 + t) * 2;
+#define OCT_ROW(o) { \
+            const int meta = meta_next; \
+            meta_next = __builtin_amdgcn_readlane(dl_meta, (i + (o)) & 63); \
+            const int wi = (meta >> 16) & 14; \
+            __builtin_amdgcn_sched_barrier(0); \
+            m0 = win[wi]; m1 = win[wi + 1]; \
+            __builtin_amdgcn_sched_barrier(0); \
+            if (__builtin_expect((meta & (0xf << 9)) != 0, 0)) { m1 ^= 2u; asm volatile("; rare c" : "+v"(m1)); } \
+            P0 = Pn0; P1 = Pn1; \
+            const uint32_t mprev = mpv = __builtin_amdgcn_update_dpp(mpv, m1, 0x138, 0xf, 0xf, false); \
+            const uint32_t D0 = __builtin_amdgcn_alignbit(m0, mprev, 16), D1 = __builtin_amdgcn_alignbit(m1, m0, 16); \
+            uint32_t a0 = pk_max(pk_add(D0, P0), pk_add(m0, GG)), a1 = pk_max(pk_add(D1, P1), pk_add(m1, GG)); \
+            a0 = pk_chain_pair(a0); a1 = pk_chain_pair(a1); \
+            a1 = pk_max_bhi(a1, a0); \
+            int sc = static_cast<int>(a1) >> 16; \
+            { const uint32_t* src = ptab + ((meta_next >> 1) & 3) * 128 + t * 2; Pn0 = src[0]; Pn1 = src[1]; } \
+            sc = scan6(sc); \
+            zsh = dpp_or<0x138, 0xf>(zsh, sc); \
+            const int zex = max(zsh, -32000); \
+            m0 = pk_max_blo(a0, static_cast<uint32_t>(zex)); m1 = pk_max_blo(a1, static_cast<uint32_t>(zex)); \
+            roct[(o) * 128] = m0; roct[(o) * 128 + 1] = m1; \
+            win[(((o) + 1) & 7) * 2] = m0; win[(((o) + 1) & 7) * 2 + 1] = m1; }
+        OCT_ROW(0) OCT_ROW(1) OCT_ROW(2) OCT_ROW(3) OCT_ROW(4) OCT_ROW(5) OCT_ROW(6) OCT_ROW(7)
+#undef OCT_ROW
+        slot = (slot + 8) & 15;
+    }
+}
 __global__ void probe(unsigned long long* out, uint32_t* sink, int n, int mode, uint32_t seed) {
     const int t = threadIdx.x;
     uint32_t m0 = seed * (t + 1), m1 = seed * (t + 7);
@@ -127,6 +245,13 @@ __global__ void probe(unsigned long long* out, uint32_t* sink, int n, int mode, 
             m0 = pk_max_blo(a0, static_cast<uint32_t>(zex)); m1 = pk_max_blo(a1, static_cast<uint32_t>(zex));
             P0 ^= 0x00010000u;
         }
+    } else if (mode >= 10) {
+        switch (mode) {
+            case 10: rows_half<false, false>(n, seed, m0, m1, zsh); break;
+            case 11: rows_half<true, false>(n, seed, m0, m1, zsh); break;
+            case 12: rows_half<true, true>(n, seed, m0, m1, zsh); break;
+            default: rows_oct(n, seed, m0, m1, zsh); break;
+        }
     } else if (mode >= 4) {
         // A plus pieces of the real row: 5 = the register window (indexed write of the finished row, indexed read of the
         // predecessor), 6 = the LDS traffic (profile table read for the next row, ring write), 7 = the scalar bookkeeping
@@ -152,8 +277,9 @@ int main() {
     unsigned long long* d; uint32_t* s;
     if (hipMalloc(&d, 64 * 16 * 8) != hipSuccess || hipMalloc(&s, 64 * 64 * 4) != hipSuccess) return 1;
     const int n = 200000;
-    const char* names[10] = {"A chain row as it is", "B lazy carry", "C row without the scan", "D scan + carry alone", "A again (other loop form)", "A + register window", "A + LDS table read, ring write", "A + scalar bookkeeping", "A + window + LDS", "A + all three"};
-    for (int mode = 0; mode < 10; ++mode) {
+    const char* names[14] = {"A chain row as it is", "B lazy carry", "C row without the scan", "D scan + carry alone", "A again (other loop form)", "A + register window", "A + LDS table read, ring write", "A + scalar bookkeeping", "A + window + LDS", "A + all three",
+        "H1 half-row streams, one row per trip", "H2 half-row streams, skewed", "H3 = H2 + all three", "U  A + all three, 8 rows per trip"};
+    for (int mode = 0; mode < 14; ++mode) {
         hipLaunchKernelGGL(probe, dim3(1), dim3(64), 20480, 0, d, s, n, mode, 0x10001u);
         if (hipDeviceSynchronize() != hipSuccess) return 2;
         unsigned long long h[16];
