@@ -12,7 +12,13 @@ configs[2] (cfg3): the 50 Mbp / 100 000-window job split evenly over the ranks
 are independent: there is no data-path collective, only the timing barrier /
 all-reduce.
 
-Next to `value` (inputs resident) the line carries
+WHICH NUMBER IS WHICH (round 6).  On the default workload (cfg2 at N = 1) `value` is THE CONTRACT METRIC of SURVEY.md 8(d): polished
+windows/s on the product's Polisher::polish() interval (value_product_polish, in-process).  `value_kernel_leg` is the timed loop of
+this file -- K steps over inputs resident in HBM, windows x K / (K x ms_per_step) -- and it is what `ms_per_step`, `steps` and
+`roofline` describe.  Wherever the product leg does not run (N > 1, --no-product, other workloads) `value` is the kernel leg;
+`value_is` says which.
+
+Next to them the line carries
   value_incl_upload     the same windows through pack-to-pinned + H2D + kernel + D2H on a warm engine;
   value_product_polish  THE PRODUCT: the same workload written as racon input files (FASTQ + SAM + FASTA), read by
                         racon_amd/host's Polisher (include/racon_host.h), and the interval the reference's Logger
@@ -147,33 +153,44 @@ def product_files(contig, coverage, seed, workers, short_reads=False):
             "paf": os.path.join(d, "overlaps.paf"), "contig": contig, "files_s": round(time.perf_counter() - t0, 1)}
 
 
-def product_polish(paths, window, scores, threads, expect=None, reps=2, batches=1):
-    """files -> racon_amd.host Polisher -> initialize() -> polish(); returns the Logger-bracketed polish() interval."""
+def product_polish(paths, window, scores, threads, expect=None, reps=2, batches=1, mode="auto"):
+    """files -> racon_amd.host Polisher -> initialize() -> polish(); returns the Logger-bracketed polish() interval.
+    `mode`: RACON_HIP_DEVICE_WINDOWS for this leg -- "auto" is what the binary does (windows built in HBM at the end of
+    initialize() when the job fits: polish() is the consensus alone), "0" the host-built path (windows packed and uploaded
+    chunk by chunk INSIDE polish(), as the reference's GPU path does it, src/cuda/cudapolisher.cpp:254-276)."""
     from racon_amd.polisher import Polisher
     m, x, g = scores
     best, runs, nw, same = None, [], 0, None
     # (the library keeps host-built windows by default -- its callers may ask for windows() --; the product, `racon_hip`, builds them in
     #  HBM at the end of initialize() whenever they fit: the same here)
-    os.environ.setdefault("RACON_HIP_DEVICE_WINDOWS", "auto")
-    for _ in range(reps):
-        p = Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", window, 10.0, 0.3, True, m, x, g, threads, batches)
-        t1 = time.perf_counter()
-        p.initialize()
-        t_init = time.perf_counter() - t1
-        nw = p.num_windows()
-        fasta = p.polish(True)
-        sec = p.polish_seconds()
-        p.close()
-        runs.append({"initialize_s": round(t_init, 3), "polish_s": round(sec, 5)})
-        best = sec if best is None else min(best, sec)
-        if expect is not None:
-            same = b"".join(fasta.split(b"\n")[1::2]) == expect
+    # (set for this leg only and restored: later legs and the subprocesses they start must not inherit it)
+    saved = os.environ.get("RACON_HIP_DEVICE_WINDOWS")
+    os.environ["RACON_HIP_DEVICE_WINDOWS"] = mode
+    try:
+        for _ in range(reps):
+            p = Polisher(paths["reads"], paths["sam"], paths["targets"], "kC", window, 10.0, 0.3, True, m, x, g, threads, batches)
+            t1 = time.perf_counter()
+            p.initialize()
+            t_init = time.perf_counter() - t1
+            nw = p.num_windows()
+            fasta = p.polish(True)
+            sec = p.polish_seconds()
+            p.close()
+            runs.append({"initialize_s": round(t_init, 3), "polish_s": round(sec, 5)})
+            best = sec if best is None else min(best, sec)
+            if expect is not None:
+                same = b"".join(fasta.split(b"\n")[1::2]) == expect
+    finally:
+        if saved is None:
+            os.environ.pop("RACON_HIP_DEVICE_WINDOWS", None)
+        else:
+            os.environ["RACON_HIP_DEVICE_WINDOWS"] = saved
     # (next to the polish() interval: the same rate with initialize() in it -- the reference's GPU path allocates its batches inside
     #  polish(), src/cuda/cudapolisher.cpp:212-242; here engines, arenas and pinned staging are set up behind the file parsing in
     #  initialize(), like the CPU path's Prealloc in the constructor, src/polisher.cpp:176-183)
     incl_init = min(r["initialize_s"] + r["polish_s"] for r in runs)
     return {"windows": nw, "polish_s": best, "windows_per_s": nw / best, "windows_per_s_incl_initialize": nw / incl_init, "runs": runs, "files_s": paths["files_s"],
-            "fasta_matches_kernel_leg": same,
+            "fasta_matches_kernel_leg": same, "device_windows_mode": mode,
             "what": "racon_amd/host Polisher on %d bp of cfg-shaped files (FASTQ + SAM + FASTA), -t %d: the interval of reference "
                     "src/polisher.cpp:493 -> :539-543 (rcnh_polisher_polish_seconds); best of %d createPolisher + initialize + polish rounds"
                     % (paths["contig"], threads, reps)}
@@ -523,6 +540,11 @@ def main():
                     same_windows = name in ("cfg2", "cfg3")             # (the packed batch of this run holds the same windows)
                     out["product_polish"][name] = product_polish(paths, pwindow, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
                                                                  reps=1 if name == "cfg3" else 2, batches=a.product_batches)
+                    if name != "cfg3":
+                        # like for like with the reference's GPU path, which packs and copies its windows inside polish(): host-built windows
+                        hb = product_polish(paths, pwindow, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None, reps=2,
+                                            batches=a.product_batches, mode="0")
+                        out["product_polish"][name]["host_built_in_process"] = {k: hb[k] for k in ("polish_s", "windows_per_s", "windows_per_s_incl_initialize", "runs", "fasta_matches_kernel_leg")}
                     out["product_polish"][name]["cli"] = product_cli(paths, pwindow, (m, x, g), th, expect=b"".join(res.consensus) if same_windows else None,
                                                                      reps=1 if name == "cfg3" else 2, batches=a.product_batches)
                     if a.no_device_modes or name == "cfg3":
@@ -620,18 +642,33 @@ def main():
         # Polisher; in-process and through the binary), next to the resident-input kernel leg (`value`), each against the CPU
         # number of this line
         cpu_v = out.get("cpu_baseline", {}).get("value")
+        kernel_leg = out["value"]
+        out["value_kernel_leg"] = kernel_leg
+        out["value_is"] = "kernel leg: the timed loop of this line (inputs resident in HBM), windows x steps / (steps x ms_per_step)"
         if out.get("value_product_polish"):
+            first = out.get("product_polish", {}).get(pfiles[0][0], {}) if pfiles else {}
             out["product"] = {"definition": "polished windows/s on the Polisher::polish() interval (reference src/polisher.cpp:493 -> :539-543)",
                               "value": out["value_product_polish"], "value_cli": out.get("value_product_polish_cli"), "unit": "windows/s",
                               "workload": pfiles[0][0] if pfiles else ("%d devices, one process" % world),
-                              "fraction_of_kernel_leg": out["value_product_polish"] / out["value"] if world == 1 else None,
+                              "fraction_of_kernel_leg": out["value_product_polish"] / kernel_leg if world == 1 else None,
+                              # the same interval when the windows are packed and uploaded INSIDE it (the reference's GPU path does that:
+                              # src/cuda/cudapolisher.cpp:254-276), and with initialize() counted in
+                              "value_host_built": (first.get("host_built_in_process") or {}).get("windows_per_s"),
+                              "value_incl_initialize": first.get("windows_per_s_incl_initialize"),
                               "vs_cpu_baseline": (out["value_product_polish"] / cpu_v) if cpu_v else None,
                               "vs_cpu_baseline_cli": (out["value_product_polish_cli"] / cpu_v) if (cpu_v and out.get("value_product_polish_cli")) else None}
+            if world == 1 and not a.config and contig == 1_000_000:
+                # THE HEADLINE IS THE CONTRACT METRIC: windows/s on the product's polish() interval, in-process, on the
+                # configuration the metric is quoted on.  The kernel leg stays in the line as value_kernel_leg; `ms_per_step`, `roofline` and
+                # `steps` describe the timed kernel loop (value_kernel_leg = windows x steps / (steps x ms_per_step)).
+                out["value"] = out["value_product_polish"]
+                out["value_is"] = ("product: polished windows/s on the Polisher::polish() interval (in-process, files -> racon_amd/host Polisher, windows built in HBM "
+                                   "at the end of initialize()); value_kernel_leg = the timed loop of this line (ms_per_step, roofline)")
         if cpu_v:
-            out["cpu_baseline"]["gpu_kernel_leg_over_cpu"] = out["value"] / cpu_v
+            out["cpu_baseline"]["gpu_kernel_leg_over_cpu"] = kernel_leg / cpu_v
             allc = out["cpu_baseline"].get("extrapolated_all_cores")
             if allc:
-                out["cpu_baseline"]["gpu_kernel_leg_over_cpu_all_cores_extrapolated"] = out["value"] / allc
+                out["cpu_baseline"]["gpu_kernel_leg_over_cpu_all_cores_extrapolated"] = kernel_leg / allc
                 if "product" in out:
                     out["product"]["vs_cpu_baseline_all_cores_extrapolated"] = out["product"]["value"] / allc
         if a.verify:
