@@ -182,6 +182,25 @@ int  rcn_engine_reserve_run(rcn_engine* e);
 
 int  rcn_engine_result(rcn_engine* e, rcn_result* out);
 int  rcn_engine_stats(rcn_engine* e, rcn_run_stats* out);
+/* --- self-check (no counterpart in the reference: its CPU path has no shortcuts to check) ---------------------------------
+ * The consensus kernels take proved shortcuts where spoa does plain work: an exact 256-column band with a certificate, one-byte
+ * move codes instead of the score matrix, a rule instead of spoa's DFS order at tied sinks and in the consensus, a rank-interval
+ * Subgraph, a one-wave kernel for small windows.  rcn_engine_verify re-polishes a deterministic sample of the windows of the LAST
+ * run ON THE GPU with every one of them switched off -- full rows, score-matrix traceback, spoa's DFS order wherever an order is
+ * asked for, poa_window_kernel2 (and the int32 kernel for what outgrows it) -- and compares consensus bytes and flags with what
+ * the run returned.  No oracle, no CPU: the device inputs of the run are still resident.  `fraction` in (0, 1]: the share of the
+ * windows sampled (by a hash of the window index: the same windows every time), at least one.  Returns RCN_OK when the check RAN;
+ * the caller looks at n_differ (the host layer treats > 0 as fatal and names first_window).  Product switch of the host layer:
+ * RACON_HIP_VERIFY=<fraction>. */
+typedef struct rcn_verify_report {
+    uint32_t n_checked;        /* windows re-polished                                                             */
+    uint32_t n_differ;         /* ... whose bytes or flags differ from the run's                                  */
+    uint32_t first_window;     /* the first of them (index within the run's batch), 0xffffffff = none             */
+    uint32_t n_int32;          /* sampled windows the exact pass of poa_window_kernel2 handed on to the int32 kernel */
+    double   ms;               /* wall time of the check                                                          */
+} rcn_verify_report;
+int  rcn_engine_verify(rcn_engine* e, double fraction, rcn_verify_report* out);
+
 /* Changes the trim flag (Window::generate_consensus takes it per call, reference
  * src/window.hpp:47-48); takes effect at the next rcn_engine_run.                 */
 int  rcn_engine_set_trim(rcn_engine* e, int trim);

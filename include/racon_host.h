@@ -70,6 +70,21 @@ double   rcnh_polisher_polish_seconds(rcnh_polisher* p);
  * that took at least one (reference: the ranges CUDAPolisher hands its per-device batches, src/cuda/cudapolisher.cpp:254-276). */
 int      rcnh_polisher_polish_plan(rcnh_polisher* p, uint32_t* chunks, uint32_t* engines_used);
 uint64_t rcnh_polisher_num_windows(rcnh_polisher* p);     /* valid between initialize and polish/assemble */
+/* The device-built path's PLAN for a job cut into n_shards window ranges (racon_amd/host/device_job.cpp; the reference hands window
+ * ranges to per-device batches, src/cuda/cudapolisher.cpp:228-240) -- pure host code, no device needed; rcnh_polisher_keep_layout +
+ * initialize first.  cut[n + 1]: shard s owns windows [cut[s], cut[s + 1]); target_lo / target_hi[n]: the targets those windows lie in;
+ * n_overlaps[n]: overlaps of each shard (one across a boundary counts on both sides).  Arrays of the caller (n = the return value <=
+ * n_shards must fit: size them for n_shards), any may be NULL.  Returns the number of shards planned, < 0 on error. */
+int  rcnh_polisher_device_plan(rcnh_polisher* p, uint32_t n_shards, uint64_t* cut, uint64_t* target_lo, uint64_t* target_hi, uint64_t* n_overlaps);
+/* ... and ONE shard's input as its engine gets it (rcn_engine_build_windows*): the shard's targets first, then the reads its overlaps
+ * point into, re-numbered; its overlaps' breaking points / alignments / segment pairs.  The engine numbers its windows from the
+ * shard's first target: local window l is the job's window window_base + l.  Pointers stay valid until the next call / destroy. */
+typedef struct rcnh_shard_dims {
+    uint64_t window_first, window_last;   /* the shard's windows [first, last) in the job's numbering */
+    uint64_t window_base, n_windows_local;
+} rcnh_shard_dims;
+int  rcnh_polisher_shard_input(rcnh_polisher* p, uint32_t n_shards, uint32_t shard, rcnh_shard_dims* dims, rcn_read_set* reads,
+                               rcn_overlap_set* overlaps, rcn_cigar_set* alignments, rcn_pair_set* pairs);
 void rcnh_polisher_destroy(rcnh_polisher* p);
 
 /* Pairwise global alignment used for overlaps without CIGAR (reference src/overlap.cpp:205-224).

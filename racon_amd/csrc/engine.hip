@@ -174,6 +174,7 @@ struct Knobs {
     bool debug = false, no_ptab = false, force_exact = false, force_slow_tb = false, no_band = false, force_band_fail = false,
          band_scores = false, no_code_wave = false, wide_only = false, no_stream = false, no_small = false, force_small = false, prof_layers = false,
          cigar_serial = false;
+    int plant_fault = 0;                            // RCN_PLANT_FAULT (tests of the self-check): 1 = the sink-tie rule picks the LAST key instead of the first
     int force_tie = 0, wg_per_cu = 0, split = -1, split_deep_per_cu = 0, split_rest_per_cu = 0, split_deep = 0, split_deep_wide = -1,
         split_cus = 0, hrows_div = 0, small_per_cu = 0, split_mid = 0, split_mid_per_cu = 0, split_mid_cus = 0;
     double heavy_pct = 1.0;
@@ -200,6 +201,7 @@ static Knobs read_knobs() {
     k.no_band = flag("RCN_NO_BAND"); k.force_band_fail = flag("RCN_FORCE_BAND_FAIL"); k.band_scores = flag("RCN_BAND_SCORES");
     k.no_code_wave = flag("RCN_NO_CODE_WAVE"); k.wide_only = flag("RCN_WIDE_ONLY"); k.no_stream = flag("RCN_NO_STREAM");
     k.cigar_serial = flag("RCN_CIGAR_SERIAL"); k.no_small = flag("RCN_NO_SMALL"); k.force_small = flag("RCN_FORCE_SMALL"); k.prof_layers = flag("RCN_PROF_LAYERS");
+    k.plant_fault = num("RCN_PLANT_FAULT", 0);
     k.force_tie = num("RCN_FORCE_TIE", 0); k.wg_per_cu = num("RCN_WG_PER_CU", 0); k.split = num("RCN_SPLIT", -1);
     k.split_deep_per_cu = num("RCN_SPLIT_DEEP_PER_CU", 0); k.split_rest_per_cu = num("RCN_SPLIT_REST_PER_CU", 0);
     k.split_deep = num("RCN_SPLIT_DEEP", 0); k.split_deep_wide = num("RCN_SPLIT_DEEP_WIDE", -1); k.split_cus = num("RCN_SPLIT_CUS", 0);
@@ -512,7 +514,7 @@ int launch_pass(rcn_engine* e, const Launch& L) {
     P.m = e->cfg.match; P.x = e->cfg.mismatch; P.g = e->cfg.gap; P.trim = e->cfg.trim;
     P.heavy_ns = L.heavy_ns >= 0 ? L.heavy_ns : e->heavy_ns; P.force_exact = K.force_exact ? 1 : 0;
     P.force_tie = K.force_tie;
-    P.force_slow_tb = K.force_slow_tb ? 1 : 0;
+    P.force_slow_tb = (K.force_slow_tb ? 1 : 0) | (K.plant_fault == 1 ? 2 : 0);       // (bit 1: the planted wrong tie rule, poa_k2_sinktie.hpp)
     // the band's exactness certificate (poa_band.hpp: a cell is alive when H' + m (len - j) >= T) assumes that a remaining
     // base adds at most m: any -m/-x/-g is legal on the command line (reference src/main.cpp:51-53,91-99), so score sets
     // with x > m or g > m take full rows
@@ -1813,6 +1815,89 @@ int rcn_engine_stats(rcn_engine* e, rcn_run_stats* out) {
         e->stats_pending = false;
     }
     *out = e->stats;
+    return RCN_OK;
+}
+
+// Self-check: a deterministic sample of the last run's windows again, every shortcut off, compared with what the run returned
+// (include/racon_hip.h).  The pattern of collect()'s retry tiers: a pass over a list of device windows into the retry buffers.
+int rcn_engine_verify(rcn_engine* e, double fraction, rcn_verify_report* out) {
+    if (!e || !out || !(fraction > 0.0)) return RCN_E_ARG;
+    if (!e->ran || e->n_windows == 0 || e->shapes.size() != e->n_windows || e->lpt.size() != e->n_windows) return RCN_E_STATE;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t nw = e->n_windows;
+    *out = rcn_verify_report{}; out->first_window = 0xffffffffu;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    // the run's own counters first: the passes below add to the device counters and to the launch statistics
+    { rcn_run_stats tmp; int rc0 = rcn_engine_stats(e, &tmp); if (rc0) return rc0; }
+    const rcn_run_stats saved_stats = e->stats;
+    const Knobs saved_knobs = e->knobs;
+    struct Restore { rcn_engine* e; const rcn_run_stats& st; const Knobs& k; ~Restore() { e->stats = st; e->knobs = k; e->stats_pending = false; } } restore{e, saved_stats, saved_knobs};
+    Knobs& K = e->knobs;
+    K.no_band = true; K.force_band_fail = false; K.band_scores = false;      // full rows, int16 scores in HBM
+    K.force_slow_tb = true;                                                   // traceback over the score matrix, cell by cell
+    K.force_tie = 3; K.force_exact = true;                                    // spoa's DFS order at tied sinks and in the consensus
+    K.no_small = true; K.force_small = false; K.no_code_wave = true; K.plant_fault = 0;
+    // the sample: by a hash of the window index (the same windows whoever asks), windows of fewer than three sequences
+    // are copied through by every path (window.cpp:68-71) and prove nothing
+    std::vector<uint32_t> sample;
+    {
+        const uint64_t thr = fraction >= 1.0 ? (1ull << 32) : static_cast<uint64_t>(fraction * 4294967296.0);
+        uint32_t fallback = 0xffffffffu;
+        for (uint32_t w = 0; w < nw; ++w) {
+            if (e->h_win_seq_off[w + 1] - e->h_win_seq_off[w] < 3) continue;
+            if (fallback == 0xffffffffu) fallback = w;
+            uint32_t h = w * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            if (h < thr) sample.push_back(w);
+        }
+        if (sample.empty() && fallback != 0xffffffffu) sample.push_back(fallback);
+    }
+    if (sample.empty()) return RCN_OK;
+    std::vector<uint32_t> item_of;
+    if (e->lpt_layout) { item_of.resize(nw); for (uint32_t wi = 0; wi < nw; ++wi) item_of[e->lpt[wi]] = wi; }
+    int rc;
+    std::vector<uint32_t> todo = sample;
+    for (int tier = 0; tier < 2 && !todo.empty(); ++tier) {
+        const uint32_t nr = static_cast<uint32_t>(todo.size());
+        int32_t n2 = 0, l2 = 1, nsym = 2;
+        std::vector<uint32_t> ids(nr);
+        std::vector<uint64_t> off2(nr + 1, 0);
+        std::vector<WinShape> sh(nr);
+        for (size_t k = 0; k < nr; ++k) {
+            const uint32_t w = todo[k];
+            const auto& sw = e->shapes[w];
+            sh[k] = sw;
+            n2 = std::max<int32_t>(n2, sw.L + sw.sum_l + 8); l2 = std::max(l2, sw.lmax); nsym = std::max(nsym, sw.nsym);
+            ids[k] = e->lpt_layout ? item_of[w] : w;
+            off2[k + 1] = off2[k] + ((static_cast<uint64_t>(sw.L) + sw.sum_l + 8 + 15) & ~uint64_t(15));
+        }
+        const Caps c2 = tier == 0 ? first_pass_caps(sh.begin(), sh.end(), true, std::max(e->caps_level, 1), e->knobs.hrows_div)
+                                  : make_caps(n2, n2 + 8, std::max(1, nsym - 1), l2, false);
+        if ((rc = e->d_out_cons.reserve(off2[nr] + 16)) || (rc = e->d_out_len.reserve(4ull * nr)) || (rc = e->d_out_flags.reserve(nr))) return rc;
+        if ((rc = upload_vec(e->d_retry_off, off2.data(), 8ull * (nr + 1), e->stream))) return rc;
+        if ((rc = upload_vec(e->d_win_ids, ids.data(), 4ull * nr, e->stream))) return rc;
+        if ((rc = run_pass(e, c2, e->d_win_ids.as<uint32_t>(), nr, /*host_out=*/false))) return rc;
+        std::vector<uint32_t> len2(nr);
+        std::vector<uint8_t> fl2(nr), block(off2[nr] + 16);
+        HIP_TRY(hipMemcpyAsync(len2.data(), e->d_out_len.p, 4ull * nr, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(fl2.data(), e->d_out_flags.p, nr, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(block.data(), e->d_out_cons.p, off2[nr], hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        std::vector<uint32_t> again;
+        for (size_t k = 0; k < nr; ++k) {
+            const uint32_t w = todo[k];
+            if (fl2[k] & rcn::kFlagError) { fprintf(stderr, "[racon_hip] internal error on window %u (self-check)\n", w); return RCN_E_STATE; }
+            if (fl2[k] & rcn::kFlagOverflow) { if (tier == 1) return RCN_E_CAPACITY; again.push_back(w); continue; }
+            out->n_checked += 1;
+            const uint64_t a = e->cons_off[w], len = e->cons_off[w + 1] - a;
+            const bool same = len == len2[k] && (len == 0 || std::memcmp(e->cons.data() + a, block.data() + off2[k], len) == 0) &&
+                              e->polished[w] == ((fl2[k] & rcn::kFlagPolished) ? 1 : 0) && e->chimeric[w] == ((fl2[k] & rcn::kFlagChimeric) ? 1 : 0);
+            if (!same) { out->n_differ += 1; out->first_window = std::min(out->first_window, w); }
+        }
+        if (tier == 0) out->n_int32 = static_cast<uint32_t>(again.size());
+        todo.swap(again);
+    }
+    out->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (saved_knobs.debug) fprintf(stderr, "[racon_hip] self-check: %u of %u windows re-polished on the exact paths in %.1f ms, %u differ\n", out->n_checked, nw, out->ms, out->n_differ);
     return RCN_OK;
 }
 

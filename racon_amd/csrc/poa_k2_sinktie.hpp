@@ -79,7 +79,8 @@ __device__ __noinline__ void phase_sink_tie_rule() {
                 }
                 key = (0x7ffffffell << 32) | (static_cast<unsigned int>(rm) << 6) | static_cast<unsigned int>(pos);
             }
-            if (key < bestkey) { bestkey = key; pick = v; }
+            // (c.tie_pad[2] bit 1: RCN_PLANT_FAULT=1, the planted wrong rule for the tests of rcn_engine_verify -- the LAST key wins)
+            if ((c.tie_pad[2] & 2) ? (pick < 0 || key > bestkey) : key < bestkey) { bestkey = key; pick = v; }
         }
         if (classified) { o->best_row = nr[pick] + 1; status = 0; }
         else if (g.n_nodes <= kSubMaxNodes) status = 1;

@@ -99,7 +99,7 @@ __device__ __noinline__ void phase_traceback3() {
             // box = kBoxRows x kBoxCols cells below/left of the current cell, one per lane: (i - a, j - b)
             const int a = lane / kBoxCols, b = lane % kBoxCols;
             for (;;) {
-                if (c.tie_pad[2]) break;                 // test switch (KParams::force_slow_tb): no box walk at all
+                if (c.tie_pad[2] & 1) break;             // test switch (KParams::force_slow_tb bit 0): no box walk at all
                 if (i == 0 && j == 0) break;
 #ifdef RCN_PROF_DP
                 ++nbox__;

@@ -64,7 +64,7 @@ EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
            "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory",
            "rcn_engine_align_pairs", "rcn_engine_alignment_cigars", "rcn_engine_align_stats", "rcn_engine_build_windows_from_pairs",
-           "rcn_engine_polish_refs", "rcn_engine_reserve", "rcn_engine_reserve_refs", "rcn_engine_reserve_run"]
+           "rcn_engine_polish_refs", "rcn_engine_reserve", "rcn_engine_reserve_refs", "rcn_engine_reserve_run", "rcn_engine_verify"]
 
 _lib = None
 
@@ -166,6 +166,16 @@ class HipEngine:
         r = RcnResult()
         _check(self.lib.rcn_engine_result(self.h, C.byref(r)), "rcn_engine_result")
         return ConsensusResult.from_c(r)
+
+    def verify(self, fraction: float = 1.0) -> dict:
+        """rcn_engine_verify: a deterministic sample of the last run's windows again on the GPU with every shortcut rule off
+        (full rows, score-matrix traceback, spoa's DFS order), compared with what the run returned."""
+        class Rep(C.Structure):
+            _fields_ = [("n_checked", C.c_uint32), ("n_differ", C.c_uint32), ("first_window", C.c_uint32), ("n_int32", C.c_uint32), ("ms", C.c_double)]
+        r = Rep()
+        self.lib.rcn_engine_verify.argtypes = [C.c_void_p, C.c_double, C.POINTER(Rep)]
+        _check(self.lib.rcn_engine_verify(self.h, float(fraction), C.byref(r)), "rcn_engine_verify")
+        return {k: getattr(r, k) for k, _ in Rep._fields_}
 
     def stats(self) -> dict:
         s = RcnRunStats()

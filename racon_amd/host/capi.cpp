@@ -1,6 +1,7 @@
 // capi.cpp — C ABI of the host layer (include/racon_host.h).
 #include "../../include/racon_host.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -15,6 +16,8 @@ struct rcnh_polisher {
     std::unique_ptr<racon::Polisher> polisher;
     racon::PackedBatch batch;
     std::string fasta;
+    racon::Polisher::DevicePlan plan;           // rcnh_polisher_device_plan / _shard_input
+    racon::Polisher::ShardInput shard;
 };
 
 namespace {
@@ -42,7 +45,7 @@ int rcnh_polisher_create(const char* sequences_path, const char* overlaps_path, 
         auto p = racon::createPolisher(sequences_path, overlaps_path, target_path,
             static_cast<racon::PolisherType>(q->type), q->window_length, q->quality_threshold, q->error_threshold,
             q->trim != 0, q->match, q->mismatch, q->gap, q->num_threads, q->hip_batches);
-        *out = new rcnh_polisher{std::move(p), {}, {}};
+        *out = new rcnh_polisher{std::move(p), {}, {}, {}, {}};
     });
 }
 
@@ -128,6 +131,46 @@ int rcnh_polisher_polish_plan(rcnh_polisher* p, uint32_t* chunks, uint32_t* engi
     return 0;
 }
 uint64_t rcnh_polisher_num_windows(rcnh_polisher* p) { return p ? p->polisher->num_windows() : 0; }
+
+int rcnh_polisher_device_plan(rcnh_polisher* p, uint32_t n_shards, uint64_t* cut, uint64_t* target_lo, uint64_t* target_hi, uint64_t* n_overlaps) {
+    if (!p || n_shards == 0) { g_error = "invalid argument"; return -1; }
+    if (p->polisher->layout().seq_off.size() < 2) { g_error = "no layout recorded (rcnh_polisher_keep_layout before initialize)"; return -1; }
+    const int rc = guarded([&] { p->plan = p->polisher->plan_device_job(n_shards); });
+    if (rc) return rc;
+    const uint32_t n = p->plan.n_shards;
+    for (uint32_t s = 0; s < n; ++s) {
+        if (cut) cut[s] = p->plan.cut[s];
+        if (target_lo) target_lo[s] = p->plan.target_lo[s];
+        if (target_hi) target_hi[s] = p->plan.target_hi[s];
+        if (n_overlaps) n_overlaps[s] = p->plan.bucket_off[s + 1] - p->plan.bucket_off[s];
+    }
+    if (cut) cut[n] = p->plan.cut[n];
+    return static_cast<int>(n);
+}
+
+int rcnh_polisher_shard_input(rcnh_polisher* p, uint32_t n_shards, uint32_t shard, rcnh_shard_dims* dims, rcn_read_set* reads,
+                              rcn_overlap_set* overlaps, rcn_cigar_set* a, rcn_pair_set* pr) {
+    if (!p || n_shards == 0) { g_error = "invalid argument"; return -1; }
+    if (p->polisher->layout().seq_off.size() < 2) { g_error = "no layout recorded (rcnh_polisher_keep_layout before initialize)"; return -1; }
+    return guarded([&] {
+        if (p->plan.n_shards == 0 || p->plan.n_shards != std::min<uint64_t>(n_shards, std::max<uint64_t>(1, p->plan.first_window.empty() ? 1 : p->plan.first_window.back())))
+            p->plan = p->polisher->plan_device_job(n_shards);
+        if (shard >= p->plan.n_shards) throw std::runtime_error("shard index out of range");
+        p->polisher->make_shard_input(p->plan, shard, &p->shard);
+        const auto& in = p->shard;
+        if (dims) { dims->window_first = in.wa; dims->window_last = in.wb; dims->window_base = in.window_base; dims->n_windows_local = in.n_local; }
+        if (reads) *reads = in.reads;
+        if (overlaps) *overlaps = in.overlaps;
+        if (a) {
+            a->n_overlaps = in.overlaps.n_overlaps; a->q_id = in.overlaps.q_id; a->t_id = in.overlaps.t_id; a->strand = in.overlaps.strand;
+            a->q_start = in.p_q_start; a->t_begin = in.p_t_begin; a->t_end = in.p_t_end; a->cigar_off = in.p_cigar_off; a->cigar = in.p_cigar;
+        }
+        if (pr) {
+            pr->n_pairs = in.overlaps.n_overlaps; pr->q_id = in.overlaps.q_id; pr->t_id = in.overlaps.t_id; pr->strand = in.overlaps.strand;
+            pr->q_begin = in.p_q_begin; pr->q_end = in.p_q_end; pr->t_begin = in.p_t_begin; pr->t_end = in.p_t_end;
+        }
+    });
+}
 
 void rcnh_polisher_destroy(rcnh_polisher* p) { delete p; }
 

@@ -30,6 +30,7 @@ struct Abi {
     decltype(&rcn_device_free_memory) free_memory = nullptr;
     decltype(&rcn_engine_result) result = nullptr;
     decltype(&rcn_engine_stats) stats = nullptr;
+    decltype(&rcn_engine_verify) verify = nullptr;
     decltype(&rcn_engine_set_trim) set_trim = nullptr;
     decltype(&rcn_engine_build_windows) build_windows = nullptr;
     decltype(&rcn_engine_build_windows_from_cigars) build_windows_from_cigars = nullptr;
@@ -67,7 +68,7 @@ const Abi& abi() {
 #define RCN_BIND(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); \
         if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
-        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(reserve_refs, "rcn_engine_reserve_refs") RCN_BIND(reserve_run, "rcn_engine_reserve_run") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats")
+        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(reserve_refs, "rcn_engine_reserve_refs") RCN_BIND(reserve_run, "rcn_engine_reserve_run") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats") RCN_BIND(verify, "rcn_engine_verify")
         RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
         RCN_BIND(build_windows_from_pairs, "rcn_engine_build_windows_from_pairs")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
@@ -269,6 +270,23 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
     static const bool want_stats = getenv("RACON_HIP_TIMING") != nullptr;
     rcn_run_stats st{};
     if (want_stats && a.stats(handle_, &st) == RCN_OK) last_kernel_ms_ = st.kernel_ms;
+    // RACON_HIP_VERIFY=<fraction> (product option, off by default): that share of every batch's windows is polished a second time
+    // on the GPU with every shortcut rule of the kernels switched off (rcn_engine_verify) -- a window that comes out differently is
+    // a bug in a rule, and fatal
+    static const double verify_fraction = [] { const char* v = getenv("RACON_HIP_VERIFY"); const double f = v ? atof(v) : 0.0; return f > 1.0 ? 1.0 : f; }();
+    if (verify_fraction > 0.0 && r.n_windows > 0) {
+        rcn_verify_report rep{};
+        const int vrc = a.verify(handle_, verify_fraction, &rep);
+        if (vrc != RCN_OK) fatal(std::string("[racon::HipEngine::consensus] error: the self-check could not run: ") + a.strerror_(vrc) + "!");
+        verified_windows_ += rep.n_checked;
+        if (rep.n_differ) {
+            const uint64_t gw = verify_ids_ ? verify_ids_(rep.first_window) : rep.first_window;
+            fatal("[racon::HipEngine::consensus] error: self-check failed: " + std::to_string(rep.n_differ) + " of " + std::to_string(rep.n_checked) +
+                  " re-polished windows differ from the exact paths, first: window " + std::to_string(gw) + (verify_ids_ ? "" : " of its batch") + "!");
+        }
+        static const bool say = getenv("RACON_HIP_TIMING") != nullptr;
+        if (say) fprintf(stderr, "[racon_hip] self-check: %u windows re-polished on the exact paths in %.1f ms (%u through the int32 kernel), none differs\n", rep.n_checked, rep.ms, rep.n_int32);
+    }
     consensus->resize(r.n_windows); polished->resize(r.n_windows); chimeric->resize(r.n_windows);
     for (uint32_t w = 0; w < r.n_windows; ++w) {
         if (w >= fetch_first_ && w < fetch_last_)

@@ -13,6 +13,7 @@
 // src/cuda/cudabatch.cpp:80-122, plus positions_.second / type, which it drops).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -103,6 +104,10 @@ public:
     // Only windows [first, last) of the next consensus() calls are copied into strings (the others come back empty):
     // a shard of a device-built job owns a range of the windows its engine returns.  (0, ~0) = all.
     void set_fetch_range(uint64_t first, uint64_t last) { fetch_first_ = first; fetch_last_ = last; }
+    // RACON_HIP_VERIFY (rcn_engine_verify, run behind every batch when set): the Polisher's ids of the next batch's windows, so that a
+    // failed self-check names the window as the Polisher numbers it (empty: the index within the batch); windows checked so far
+    void set_verify_ids(std::function<uint64_t(uint32_t)> ids) { verify_ids_ = std::move(ids); }
+    uint64_t verified_windows() const { return verified_windows_; }
 
 private:
     HipEngine() = default;
@@ -113,6 +118,8 @@ private:
     double last_kernel_ms_ = 0;
     int last_rc_ = 0;
     uint64_t fetch_first_ = 0, fetch_last_ = ~uint64_t(0);
+    std::function<uint64_t(uint32_t)> verify_ids_;
+    uint64_t verified_windows_ = 0;
 };
 
 }  // namespace racon

@@ -12,6 +12,7 @@
 
 #include "fatal.hpp"
 #include "hip_engine.hpp"
+#include "host_util.hpp"
 #include "nw_path.hpp"
 #include "overlap.hpp"
 #include "parsers.hpp"
@@ -34,38 +35,6 @@ void fatal_from(const std::exception_ptr& error) {
     catch (const std::exception& e) { fatal(e.what()); }
     catch (...) { fatal("[racon::] error: unknown exception in a worker thread!"); }
 }
-
-namespace {
-double seconds_since(const std::chrono::time_point<std::chrono::steady_clock>& t) {
-    return std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t).count();
-}
-
-// fn(i) for i in [0, n) on `threads` host threads (dynamic distribution)
-template <class F>
-void parallel_for(uint64_t n, uint32_t threads, F fn) {
-    threads = std::max<uint32_t>(1, std::min<uint64_t>(threads, n));
-    if (threads == 1) { for (uint64_t i = 0; i < n; ++i) fn(i); return; }
-    // an exception inside a worker (fatal() in library mode, nw_path's runtime_error, bad_alloc) must not escape its thread
-    // (std::terminate): the first one is kept and rethrown on the caller's thread after the join
-    std::atomic<uint64_t> next{0};
-    std::exception_ptr first_error;
-    std::mutex error_mutex;
-    std::vector<std::thread> pool;
-    for (uint32_t t = 0; t < threads; ++t)
-        pool.emplace_back([&] {
-            FatalThrowsScope scope;
-            try {
-                for (uint64_t i; (i = next.fetch_add(1)) < n;) fn(i);
-            } catch (...) {
-                std::lock_guard<std::mutex> lock(error_mutex);
-                if (!first_error) first_error = std::current_exception();
-                next.store(n);                                     // the other workers stop at their next item
-            }
-        });
-    for (auto& t : pool) t.join();
-    if (first_error) fatal_from(first_error);
-}
-}  // namespace
 
 void Logger::log() {
     const auto now = std::chrono::steady_clock::now();
@@ -296,11 +265,18 @@ void Polisher::initialize() {
             for (const auto& s_ : sequences_) read_bases += std::max(s_->data().size(), s_->reverse_complement().size());
             for (const auto& o : overlaps) { layer_bases += o->q_end() - o->q_begin(); cigar_bytes += o->cigar().size(); }
             for (uint64_t i = 0; i < targets_size; ++i) layer_bases += sequences_[i]->data().size();
+            // (the warm-up thread is allocating on the devices: what is free is only known once it is done)
+            if (device_warmup_.joinable()) device_warmup_.join();
             const int32_t devices = HipEngine::DeviceCount();
+            // overlaps without a CIGAR get theirs from the aligner (host or device) after this decision: about one op character per
+            // two or three bases of a noisy read -- bounded by half the layer bases
+            if (cigar_bytes == 0) cigar_bytes = layer_bases / 2;
             // per device: every read (bases + qualities), its share of the packed windows (x 2 for the sort / gather buffers next to
-            // them), CIGAR text, and a scratch arena; against HALF of what is free on device 0
+            // them), CIGAR text, and a scratch arena; against HALF of what is free on the device with the least
             const double need = 2.0 * read_bases + (4.0 * layer_bases + 1.0 * cigar_bytes) / std::max(1, devices) + 24e9;
-            const double have = devices > 0 ? 0.5 * static_cast<double>(HipEngine::FreeMemory(0)) : 0.0;
+            uint64_t least_free = ~uint64_t(0);
+            for (int32_t d = 0; d < devices; ++d) least_free = std::min(least_free, HipEngine::FreeMemory(d));
+            const double have = devices > 0 ? 0.5 * static_cast<double>(least_free) : 0.0;
             if (devices > 0 && need < have) device_windows(true, true, device_align_);
             else if (device_windows_ && need >= have)
                 fprintf(stderr, "[racon::Polisher::initialize] warning: the device-side construction needs about %.0f GB per device\n", need / 1e9);
@@ -542,245 +518,27 @@ void Polisher::find_overlap_breaking_points(std::vector<std::unique_ptr<Overlap>
 // of its own (shards <= devices); RACON_HIP_BUILD_IN_POLISH=1 keeps everything in polish() (the round-4 behaviour, experiments).
 void Polisher::build_device_windows() {
     device_built_ = false;
-    device_cut_.clear();
+    device_plan_ = DevicePlan();
     if (getenv("RACON_HIP_BUILD_IN_POLISH")) return;
     if (device_warmup_.joinable()) device_warmup_.join();
     if (!engines_error_.empty() || engines_.empty() || windows_.empty()) return;        // polish() reports what is wrong
     const int32_t n_devices = n_devices_ > 0 ? n_devices_ : HipEngine::DeviceCount();
-    uint32_t n_shards = static_cast<uint32_t>(std::max(1, n_devices));
-    if (const char* sh = getenv("RACON_HIP_DEVICE_SHARDS")) n_shards = std::max(1, atoi(sh));
+    const uint32_t n_shards = device_shards();
     if (n_devices <= 0 || n_shards > static_cast<uint32_t>(n_devices) || static_cast<size_t>(n_devices) > engines_.size()) return;
     FatalThrowsScope scope;
     try {
         device_job(1, nullptr, nullptr, nullptr);
         device_built_ = true;
     } catch (const std::exception& e) {
-        // (no room at this moment, an input the device aligner cannot take: polish() builds shard by shard, with its fallbacks)
+        // No room at this moment, or an input the device aligner cannot take: polish() builds shard by shard, with its fallbacks --
+        // and, when it was memory, in MORE and smaller shards than devices, one after the other (the host never ran add_layer for
+        // this job and the reads are gone: cutting the job finer is the way down, not the host-built path)
         fprintf(stderr, "[racon::Polisher::initialize] warning: windows not built ahead of polish() (%s)\n", e.what());
-        device_cut_.clear();
+        device_plan_ = DevicePlan();
+        bool memory = false;
+        for (const auto& eng : engines_) memory = memory || eng->last_rc() == RCN_E_NOMEM || eng->last_rc() == RCN_E_CAPACITY;
+        if (memory) device_min_shards_ = std::max<uint32_t>(2 * n_shards, 2);
     }
-}
-
-// One engine per shard builds its windows in HBM from the reads and the overlaps' breaking points / CIGARs / segment pairs
-// (rcn_engine_build_windows*: reference src/polisher.cpp:388-461, src/overlap.cpp:176-292 on the device) and polishes them there.
-//   phase 1  build only: the end of initialize(), where the reference builds its windows (and, with --cudaaligner-batches, aligns
-//            its overlaps: CUDAPolisher::find_overlap_breaking_points is called from initialize()); the windows stay resident and
-//            the engine reserves what its run will need (rcn_engine_reserve_run)
-//   phase 2  run only: polish() of windows built by phase 1
-//   phase 0  both, shard after shard on its device's engine: polish() when the shards outnumber the engines that could keep them
-//            resident (RACON_HIP_DEVICE_SHARDS > devices: a job cut into pieces to fit one device), or when phase 1 found no room
-void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::vector<uint8_t>* pol_out, std::vector<uint8_t>* chim_out) {
-    const int32_t n_devices = n_devices_ > 0 ? n_devices_ : HipEngine::DeviceCount();
-    const uint64_t nw = windows_.size();
-    static std::vector<std::string> no_cons; static std::vector<uint8_t> no_flags;
-    std::vector<std::string>& cons = cons_out ? *cons_out : no_cons;
-    std::vector<uint8_t>& pol = pol_out ? *pol_out : no_flags;
-    std::vector<uint8_t>& chim = chim_out ? *chim_out : no_flags;
-    rcn_read_set r{}; rcn_overlap_set o{};
-    r.n_seqs = layout_.seq_off.size() - 1; r.n_targets = layout_.n_targets; r.seq_off = layout_.seq_off.data();
-    r.bases = layout_.bases.data(); r.quals = layout_.quals.data(); r.seq_has_qual = layout_.seq_has_qual.data();
-    o.n_overlaps = layout_.q_id.size(); o.q_id = layout_.q_id.data(); o.t_id = layout_.t_id.data(); o.strand = layout_.strand.data();
-    o.bp_off = layout_.bp_off.data(); o.bp_t = layout_.bp_t.data(); o.bp_q = layout_.bp_q.data();
-    // Shards: the window index space is cut into one contiguous range per device, balanced by the bases of the
-    // overlaps that fall into it (the reference's multi-device code hands window ranges to per-device batches the
-    // same way, src/cuda/cudapolisher.cpp:228-240).  A shard's engine gets every read (they are what overlaps
-    // point into) and the overlaps that touch its range -- an overlap across a boundary goes to both sides, the
-    // windows outside a shard's range come out as bare backbones there and are dropped.  RACON_HIP_DEVICE_SHARDS
-    // forces a shard count (tests: several shards on one device).
-    uint32_t n_shards = static_cast<uint32_t>(n_devices);
-    if (const char* sh = getenv("RACON_HIP_DEVICE_SHARDS")) n_shards = std::max(1, atoi(sh));
-    n_shards = static_cast<uint32_t>(std::min<uint64_t>(n_shards, std::max<uint64_t>(1, nw)));
-    std::vector<uint64_t> first_window(layout_.n_targets + 1, 0);
-    for (uint64_t t = 0; t < layout_.n_targets; ++t) {
-        const uint64_t len = layout_.seq_off[t + 1] - layout_.seq_off[t];
-        first_window[t + 1] = first_window[t] + (len + window_length_ - 1) / window_length_;
-    }
-    const uint64_t n_ovl = o.n_overlaps;
-    std::vector<uint64_t> w_lo, w_hi;                        // windows [w_lo, w_hi] an overlap touches
-    std::vector<double> win_cost;
-    const bool planned = phase == 2 && device_cut_.size() == static_cast<size_t>(n_shards) + 1;      // (phase 1 left its cut behind)
-    if (!planned) { w_lo.resize(n_ovl); w_hi.resize(n_ovl); win_cost.assign(nw + 1, 0.0); }
-    for (uint64_t k = 0; k < n_ovl && !planned; ++k) {
-        const uint64_t tb = layout_.t_begin[k], te = std::max<uint64_t>(layout_.t_end[k], tb + 1);
-        w_lo[k] = first_window[o.t_id[k]] + tb / window_length_;
-        w_hi[k] = std::min<uint64_t>(first_window[o.t_id[k]] + (te - 1) / window_length_, nw - 1);
-        for (uint64_t w = w_lo[k]; w <= w_hi[k]; ++w) win_cost[w] += 1.0;
-    }
-    std::vector<uint64_t> cut(n_shards + 1, nw);
-    cut[0] = 0;
-    if (planned) cut = device_cut_;
-    else {
-        double total = 0; for (uint64_t w = 0; w < nw; ++w) total += win_cost[w] + 0.05;
-        double acc = 0; uint32_t sidx = 1;
-        for (uint64_t w = 0; w < nw && sidx < n_shards; ++w) {
-            acc += win_cost[w] + 0.05;
-            if (acc >= total * sidx / n_shards) cut[sidx++] = w + 1;
-        }
-    }
-    if (phase == 1) device_cut_ = cut;
-    const auto job_begin = std::chrono::steady_clock::now();
-    std::mutex peak_mutex; uint64_t peak_used = 0;
-    std::vector<std::string> shard_errors(n_shards);
-    auto run_shard = [&](uint32_t sidx) {
-        try {
-            const uint64_t wa = cut[sidx], wb = cut[sidx + 1];
-            if (wa >= wb) return;
-            const double t_shard = seconds_since(job_begin);
-            if (phase == 2) {                                      // built by initialize(): the consensus of the resident windows
-                auto engine = engines_[static_cast<size_t>(sidx % static_cast<uint32_t>(n_devices))];
-                engine->set_fetch_range(wa, wb);
-                struct FetchAll { std::shared_ptr<HipEngine> e; ~FetchAll() { e->set_fetch_range(0, ~uint64_t(0)); } } fetch_all{engine};
-                std::vector<std::string> c; std::vector<uint8_t> pl, ch;
-                engine->run(trim_, &c, &pl, &ch);
-                if (c.size() != nw) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
-                for (uint64_t w = wa; w < wb; ++w) { cons[w].swap(c[w]); pol[w] = pl[w]; chim[w] = ch[w]; }
-                return;
-            }
-            std::vector<uint64_t> sel;
-            for (uint64_t k = 0; k < n_ovl; ++k) if (w_hi[k] >= wa && w_lo[k] < wb) sel.push_back(k);
-            const bool all = sel.size() == n_ovl;
-            // the selected overlaps' slices of the layout arrays
-            std::vector<uint32_t> q_id, t_id, bp_t, bp_q, q_start, t_begin, t_end, q_begin, q_end;
-            std::vector<uint8_t> strand, cigar;
-            std::vector<uint64_t> bp_off{0}, cigar_off{0};
-            if (!all) {
-                for (uint64_t k : sel) {
-                    q_id.push_back(o.q_id[k]); t_id.push_back(o.t_id[k]); strand.push_back(o.strand[k]);
-                    q_start.push_back(layout_.q_start[k]); t_begin.push_back(layout_.t_begin[k]); t_end.push_back(layout_.t_end[k]);
-                    q_begin.push_back(layout_.q_begin[k]); q_end.push_back(layout_.q_end[k]);
-                    bp_t.insert(bp_t.end(), layout_.bp_t.begin() + layout_.bp_off[k], layout_.bp_t.begin() + layout_.bp_off[k + 1]);
-                    bp_q.insert(bp_q.end(), layout_.bp_q.begin() + layout_.bp_off[k], layout_.bp_q.begin() + layout_.bp_off[k + 1]);
-                    bp_off.push_back(bp_t.size());
-                    cigar.insert(cigar.end(), layout_.cigar.begin() + layout_.cigar_off[k], layout_.cigar.begin() + layout_.cigar_off[k + 1]);
-                    cigar_off.push_back(cigar.size());
-                }
-            }
-            rcn_overlap_set so = o;
-            const uint32_t* p_q_start = layout_.q_start.data(); const uint32_t* p_t_begin = layout_.t_begin.data(); const uint32_t* p_t_end = layout_.t_end.data();
-            const uint32_t* p_q_begin = layout_.q_begin.data(); const uint32_t* p_q_end = layout_.q_end.data();
-            const uint64_t* p_cigar_off = layout_.cigar_off.data(); const uint8_t* p_cigar = layout_.cigar.data();
-            static const uint8_t kNoByte = 0; static const uint32_t kNoWord = 0;
-            if (!all) {
-                so.n_overlaps = sel.size(); so.q_id = q_id.empty() ? &kNoWord : q_id.data(); so.t_id = t_id.empty() ? &kNoWord : t_id.data();
-                so.strand = strand.empty() ? &kNoByte : strand.data(); so.bp_off = bp_off.data();
-                so.bp_t = bp_t.empty() ? &kNoWord : bp_t.data(); so.bp_q = bp_q.empty() ? &kNoWord : bp_q.data();
-                p_q_start = q_start.data(); p_t_begin = t_begin.data(); p_t_end = t_end.data(); p_q_begin = q_begin.data(); p_q_end = q_end.data();
-                p_cigar_off = cigar_off.data(); p_cigar = cigar.empty() ? &kNoByte : cigar.data();
-            }
-            // The reads this shard's overlaps point into, and nothing else: every shard needs every target (their
-            // windows outside the range come out as bare backbones), but of the reads only its own -- one eighth of
-            // cfg3's 1.5 G bases per device instead of all of them on each (the reference's multi-device path keeps the
-            // reads on the host and packs per batch, src/cuda/cudapolisher.cpp:254-276).
-            rcn_read_set sr = r;
-            std::vector<uint64_t> r_seq_off; std::vector<uint8_t> r_bases, r_quals, r_hq;
-            if (!all && r.n_seqs > r.n_targets) {
-                constexpr uint32_t kUnused = 0xffffffffu;
-                std::vector<uint32_t> remap(r.n_seqs, kUnused), old_of;
-                for (uint64_t t = 0; t < r.n_targets; ++t) { remap[t] = static_cast<uint32_t>(t); old_of.push_back(static_cast<uint32_t>(t)); }
-                for (uint32_t& q : q_id) {
-                    if (remap[q] == kUnused) { remap[q] = static_cast<uint32_t>(old_of.size()); old_of.push_back(q); }
-                    q = remap[q];
-                }
-                uint64_t total = 0;
-                for (uint32_t old : old_of) total += r.seq_off[old + 1] - r.seq_off[old];
-                r_seq_off.assign(1, 0); r_seq_off.reserve(old_of.size() + 1);
-                r_bases.resize(total + 1); r_quals.resize(total + 1); r_hq.reserve(old_of.size());
-                for (uint32_t old : old_of) {
-                    const uint64_t a = r.seq_off[old], len = r.seq_off[old + 1] - a, d = r_seq_off.back();
-                    std::copy(r.bases + a, r.bases + a + len, r_bases.begin() + d);
-                    std::copy(r.quals + a, r.quals + a + len, r_quals.begin() + d);
-                    r_hq.push_back(r.seq_has_qual[old]);
-                    r_seq_off.push_back(d + len);
-                }
-                sr.n_seqs = old_of.size(); sr.seq_off = r_seq_off.data(); sr.bases = r_bases.data(); sr.quals = r_quals.data(); sr.seq_has_qual = r_hq.data();
-            }
-            // (the shards of one device run one after the other on its lane thread: they share the device's first engine)
-            const int32_t device = static_cast<int32_t>(sidx % static_cast<uint32_t>(n_devices));
-            auto engine = engines_[static_cast<size_t>(device)];
-            engine->set_fetch_range(wa, wb);                       // the strings of its own windows only
-            struct FetchAll { std::shared_ptr<HipEngine> e; ~FetchAll() { e->set_fetch_range(0, ~uint64_t(0)); } } fetch_all{engine};   // (also when a call below throws)
-            std::vector<std::string> c; std::vector<uint8_t> pl, ch;
-            auto take = [&]() {
-                if (c.size() != nw) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
-                for (uint64_t w = wa; w < wb; ++w) { cons[w].swap(c[w]); pol[w] = pl[w]; chim[w] = ch[w]; }
-            };
-            bool aligned_on_device = false;
-            std::vector<uint8_t> host_cigar; std::vector<uint64_t> host_cigar_off; std::vector<uint32_t> host_q_start;
-            if (device_align_) {
-                rcn_pair_set ps{};
-                ps.n_pairs = so.n_overlaps; ps.q_id = so.q_id; ps.t_id = so.t_id; ps.strand = so.strand;
-                ps.q_begin = p_q_begin; ps.q_end = p_q_end; ps.t_begin = p_t_begin; ps.t_end = p_t_end;
-                try {
-                    if (getenv("RACON_HIP_FORCE_ALIGN_FALLBACK")) throw FatalError("forced");      // (tests)
-                    engine->build(sr, ps, window_length_, quality_threshold_, layout_.window_type);
-                    aligned_on_device = true;
-                } catch (const FatalError&) {
-                    // The device aligner holds one op byte per row + column of every overlap and a per-wave scratch sized
-                    // for the longest read: an input it has no room for (RCN_E_CAPACITY / RCN_E_NOMEM; also a read beyond
-                    // its 3 Mbp limit) is aligned HERE instead, by the host's edlib-equivalent (reference
-                    // src/overlap.cpp:205-224) -- same paths, hence the same windows -- and goes on through the CIGAR path.
-                    if (!getenv("RACON_HIP_FORCE_ALIGN_FALLBACK") && engine->last_rc() != RCN_E_CAPACITY && engine->last_rc() != RCN_E_NOMEM) throw;
-                    static const struct Comp { char t[256]; Comp() { for (int i = 0; i < 256; ++i) t[i] = static_cast<char>(i); t['A'] = 'T'; t['T'] = 'A'; t['C'] = 'G'; t['G'] = 'C'; } } comp;
-                    const uint64_t n = so.n_overlaps;
-                    std::vector<std::string> cg(n);
-                    host_q_start.resize(n);
-                    parallel_for(n, num_threads_, [&](uint64_t k) {
-                        const uint64_t qa = sr.seq_off[so.q_id[k]], ql = sr.seq_off[so.q_id[k] + 1] - qa, ta = sr.seq_off[so.t_id[k]];
-                        std::string q(reinterpret_cast<const char*>(sr.bases + qa + p_q_begin[k]), p_q_end[k] - p_q_begin[k]);
-                        if (so.strand[k]) { std::reverse(q.begin(), q.end()); for (char& ch_ : q) ch_ = comp.t[static_cast<unsigned char>(ch_)]; }
-                        cg[k] = nwpath::align_cigar(q.data(), static_cast<uint32_t>(q.size()), reinterpret_cast<const char*>(sr.bases + ta + p_t_begin[k]), p_t_end[k] - p_t_begin[k]);
-                        host_q_start[k] = so.strand[k] ? static_cast<uint32_t>(ql - p_q_end[k]) : p_q_begin[k];       // reference src/overlap.cpp:241-242
-                    });
-                    host_cigar_off.assign(1, 0);
-                    for (const auto& s_ : cg) { host_cigar.insert(host_cigar.end(), s_.begin(), s_.end()); host_cigar_off.push_back(host_cigar.size()); }
-                }
-            }
-            if (device_align_ && !aligned_on_device) {
-                rcn_cigar_set a{};
-                static const uint8_t kNoCigar = 0;
-                a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
-                a.q_start = host_q_start.empty() ? &kNoWord : host_q_start.data(); a.t_begin = p_t_begin; a.t_end = p_t_end;
-                a.cigar_off = host_cigar_off.data(); a.cigar = host_cigar.empty() ? &kNoCigar : host_cigar.data();
-                engine->build(sr, a, window_length_, quality_threshold_, layout_.window_type);
-            } else if (device_align_) {
-            } else if (device_cigars_) {
-                rcn_cigar_set a{};
-                a.n_overlaps = so.n_overlaps; a.q_id = so.q_id; a.t_id = so.t_id; a.strand = so.strand;
-                a.q_start = p_q_start; a.t_begin = p_t_begin; a.t_end = p_t_end; a.cigar_off = p_cigar_off; a.cigar = p_cigar;
-                engine->build(sr, a, window_length_, quality_threshold_, layout_.window_type);
-            } else {
-                engine->build(sr, so, window_length_, quality_threshold_, layout_.window_type);
-            }
-            const bool timing = getenv("RACON_HIP_TIMING") != nullptr;
-            const double t_built = seconds_since(job_begin);
-            if (phase == 1) {                                      // the windows stay resident for polish()
-                engine->reserve_run();
-                if (timing) fprintf(stderr, "[racon::Polisher::initialize] timing: shard %u (windows %lu..%lu, %lu overlaps) built on device %d in %.1f ms, run reserved after %.1f ms, %.2f GB of HBM in use\n",
-                                    sidx, static_cast<unsigned long>(wa), static_cast<unsigned long>(wb), static_cast<unsigned long>(so.n_overlaps), device,
-                                    1e3 * (t_built - t_shard), 1e3 * (seconds_since(job_begin) - t_shard), HipEngine::UsedMemory(device % std::max(1, HipEngine::DeviceCount())) / 1e9);
-                return;
-            }
-            const uint64_t used_built = timing ? HipEngine::UsedMemory(device % std::max(1, HipEngine::DeviceCount())) : 0;
-            engine->run(trim_, &c, &pl, &ch);
-            take();
-            if (timing) {
-                const uint64_t used = std::max(used_built, HipEngine::UsedMemory(device % std::max(1, HipEngine::DeviceCount())));
-                fprintf(stderr, "[racon::Polisher::polish] timing: shard %u (windows %lu..%lu, %lu overlaps) on device %d: built in %.1f ms, consensus + results in %.1f ms (kernel %.1f), %.2f GB of HBM in use\n",
-                        sidx, static_cast<unsigned long>(wa), static_cast<unsigned long>(wb), static_cast<unsigned long>(so.n_overlaps), device,
-                        1e3 * (t_built - t_shard), 1e3 * (seconds_since(job_begin) - t_built), engine->last_kernel_ms(), used / 1e9);
-                std::lock_guard<std::mutex> lock(peak_mutex); peak_used = std::max(peak_used, used);
-            }
-        } catch (const std::exception& ex) { shard_errors[sidx] = ex.what(); }
-    };
-    {
-        // one thread per device; the shards of one device run one after the other on it
-        std::vector<std::thread> pool;
-        const uint32_t lanes = std::min<uint32_t>(n_shards, static_cast<uint32_t>(n_devices));
-        for (uint32_t l = 0; l < lanes; ++l) pool.emplace_back([&, l]() { FatalThrowsScope scope; for (uint32_t sidx = l; sidx < n_shards; sidx += lanes) run_shard(sidx); });
-        for (auto& th : pool) th.join();
-    }
-    for (const auto& e : shard_errors) if (!e.empty()) fatal(e);
-    if (peak_used) fprintf(stderr, "[racon::Polisher::polish] timing: %u shard(s), peak HBM in use %.2f GB\n", n_shards, peak_used / 1e9);
 }
 
 // ---------------------------------------------------------------- polish
@@ -851,7 +609,21 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
     if (device_windows_) {
         // windows built in HBM (device_job): by initialize() already where every shard has an engine of its own -- polish() is then
         // the consensus of resident windows --, otherwise built and polished here, shard after shard
-        device_job(device_built_ ? 2 : 0, &cons, &pol, &chim);
+        if (device_built_) device_job(2, &cons, &pol, &chim);
+        else {
+            // shard after shard inside polish(); a shard the device has no room for cuts the job finer (twice, four times ... the shards)
+            for (;;) {
+                std::string error;
+                { FatalThrowsScope scope; try { device_job(0, &cons, &pol, &chim); } catch (const std::exception& e) { error = e.what(); } }
+                if (error.empty()) break;
+                bool memory = false;
+                for (const auto& eng : engines_) memory = memory || eng->last_rc() == RCN_E_NOMEM || eng->last_rc() == RCN_E_CAPACITY;
+                const uint32_t now = device_shards();
+                if (!memory || now >= 1024 || now >= nw) fatal(error);
+                device_min_shards_ = 2 * now;
+                fprintf(stderr, "[racon::Polisher::polish] warning: no room on the device for a shard of the job (%s): cutting it into %u shards\n", error.c_str(), device_min_shards_);
+            }
+        }
         for (uint64_t i = 0; i < nw; ++i)
             if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
                                  static_cast<unsigned long>(windows_[i]->id()), windows_[i]->rank());
@@ -888,6 +660,7 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
             std::function<void(uint64_t, uint64_t)> polish_range = [&](uint64_t a, uint64_t b) {
                 refs.clear();
                 for (uint64_t i = a; i < b; ++i) refs.add(*windows_[rank[i]]);
+                engine->set_verify_ids([&rank, a](uint32_t j) { return static_cast<uint64_t>(rank[a + j]); });
                 try {
                     engine->consensus(refs, queued, trim_, &c, &p, &h);
                 } catch (const FatalError&) {
@@ -906,6 +679,7 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
                 bool done = false;
                 if (planned) {
                     try {
+                        engine->set_verify_ids([&rank, a0 = chunks[ci].first](uint32_t j) { return static_cast<uint64_t>(rank[a0 + j]); });
                         engine->consensus(planned_refs_[ci], queued, trim_, &c, &p, &h);
                         for (uint64_t i = chunks[ci].first, j = 0; i < chunks[ci].second; ++i, ++j) { const uint32_t w = rank[i]; cons[w].swap(c[j]); pol[w] = p[j]; chim[w] = h[j]; }
                         done = true;

@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/racon_hip.h"
 #include "window.hpp"
 
 namespace racon {
@@ -106,6 +107,36 @@ public:
         device_windows_ = on; device_cigars_ = on && (cigars || align); device_align_ = on && align; if (on) keep_layout_ = true;
     }
     const Layout& layout() const { return layout_; }
+    // ---- windows built on the device (device_job.cpp) ------------------------------------------------------------------------
+    // The cut of the job into shards: contiguous window ranges balanced by the overlaps over them (the reference hands window
+    // ranges to per-device batches, src/cuda/cudapolisher.cpp:228-240), the targets behind every range, and every shard's overlaps
+    // (indices into the layout, ascending; an overlap across a boundary is in both).  Pure host code.
+    struct DevicePlan {
+        uint32_t n_shards = 0;
+        std::vector<uint64_t> cut;                  // [n_shards + 1]: shard s owns windows [cut[s], cut[s + 1])
+        std::vector<uint64_t> target_lo, target_hi; // [n_shards]: ... which lie in targets [target_lo[s], target_hi[s])
+        std::vector<uint64_t> first_window;         // [targets + 1]
+        std::vector<uint64_t> bucket_off, bucket;   // overlaps of shard s: bucket[bucket_off[s] .. bucket_off[s + 1])
+    };
+    DevicePlan plan_device_job(uint32_t n_shards) const;
+    // What rcn_engine_build_windows* takes for one shard (include/racon_hip.h): its targets, the reads its overlaps point into
+    // (re-numbered), its overlaps' slices of the layout; `whole`: the one shard of an uncut job, views straight into the layout.
+    struct ShardInput {
+        uint32_t sidx = 0;
+        uint64_t wa = 0, wb = 0;        // the shard's windows (the job's numbering)
+        uint64_t window_base = 0;       // ... of which the engine's window 0 is this one
+        uint64_t n_local = 0;           // windows the engine builds (all windows of the shard's targets)
+        bool whole = false;
+        std::vector<uint32_t> q_id, t_id, bp_t, bp_q, q_start, t_begin, t_end, q_begin, q_end;
+        std::vector<uint8_t> strand, has_qual;
+        std::vector<uint64_t> bp_off, cigar_off, seq_off;
+        ByteBuf cigar, bases, quals;
+        rcn_read_set reads{}; rcn_overlap_set overlaps{};
+        const uint32_t *p_q_start = nullptr, *p_t_begin = nullptr, *p_t_end = nullptr, *p_q_begin = nullptr, *p_q_end = nullptr;
+        const uint64_t* p_cigar_off = nullptr; const uint8_t* p_cigar = nullptr;
+        double t_begin_s = 0, t_sliced_s = 0;       // (timing lines)
+    };
+    void make_shard_input(const DevicePlan& plan, uint32_t sidx, ShardInput* out) const;
     uint32_t window_length() const { return window_length_; }
     double quality_threshold() const { return quality_threshold_; }
     // Per-target concatenation + tags from per-window results (reference src/polisher.cpp:505-537).
@@ -164,8 +195,13 @@ protected:
     // windows built on the device (device_windows_): phase 1 at the end of initialize(), phase 2 in polish(); phase 0 = both in polish()
     void build_device_windows();
     void device_job(int phase, std::vector<std::string>* cons, std::vector<uint8_t>* pol, std::vector<uint8_t>* chim);
+    void build_shard(HipEngine& engine, const ShardInput& in);           // rcn_engine_build_windows* by mode, host aligner as the way out
+    void run_shard(HipEngine& engine, uint64_t window_base, uint64_t n_local, uint64_t wa, uint64_t wb,
+                   std::vector<std::string>& cons, std::vector<uint8_t>& pol, std::vector<uint8_t>& chim);
+    uint32_t device_shards() const;         // devices, RACON_HIP_DEVICE_SHARDS, or what a failed build raised it to
     bool device_built_ = false;             // initialize() left the windows resident on the engines
-    std::vector<uint64_t> device_cut_;      // ... cut into these window ranges, one per shard
+    DevicePlan device_plan_;                // ... cut like this
+    uint32_t device_min_shards_ = 1;        // raised when a build found no room on the device: the job is cut into more, smaller shards
     void reserve_for_windows();     // end of initialize(): the arenas sized for the windows that were built
     // polish()'s work list: windows ranked deepest first, cut into chunks (planned once, by reserve_for_windows or polish)
     std::vector<uint32_t> rank_;

@@ -59,6 +59,9 @@ def load_library():
     lib.rcnh_polisher_polish_seconds.argtypes = [C.c_void_p]
     lib.rcnh_polisher_polish_seconds.restype = C.c_double
     lib.rcnh_polisher_polish_plan.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.rcnh_polisher_device_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rcnh_polisher_shard_input.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(RcnReadSet), C.POINTER(RcnOverlapSet),
+                                              C.POINTER(RcnCigarSet), C.POINTER(RcnPairSet)]
     lib.rcnh_polisher_num_windows.argtypes = [C.c_void_p]
     lib.rcnh_polisher_num_windows.restype = C.c_uint64
     lib.rcnh_polisher_destroy.argtypes = [C.c_void_p]
@@ -169,6 +172,25 @@ class Polisher:
             return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True)
         return PairSet(arr(a.q_id, np.uint32), arr(a.t_id, np.uint32), arr(a.strand, np.uint8), arr(a.q_begin, np.uint32),
                        arr(a.q_end, np.uint32), arr(a.t_begin, np.uint32), arr(a.t_end, np.uint32))
+
+    def device_plan(self, n_shards: int) -> dict:
+        """The device-built path's cut of the job into `n_shards` window ranges (racon_amd/host/device_job.cpp): pure host code."""
+        import numpy as np
+        cut = np.zeros(n_shards + 1, np.uint64); lo = np.zeros(n_shards, np.uint64); hi = np.zeros(n_shards, np.uint64); no = np.zeros(n_shards, np.uint64)
+        n = self.lib.rcnh_polisher_device_plan(self.h, n_shards, cut.ctypes.data, lo.ctypes.data, hi.ctypes.data, no.ctypes.data)
+        if n < 0:
+            _check(n)
+        return {"n_shards": n, "cut": cut[:n + 1].astype(np.int64), "target_lo": lo[:n].astype(np.int64), "target_hi": hi[:n].astype(np.int64), "n_overlaps": no[:n].astype(np.int64)}
+
+    def shard_input(self, n_shards: int, shard: int):
+        """(dims, ReadSet, OverlapSet): one shard's input as its engine gets it -- its targets first, then the reads its overlaps point
+        into, re-numbered; the engine's window l is the job's window dims["window_base"] + l."""
+        import numpy as np
+        dims = np.zeros(4, np.uint64)
+        r, o = RcnReadSet(), RcnOverlapSet()
+        _check(self.lib.rcnh_polisher_shard_input(self.h, n_shards, shard, dims.ctypes.data, C.byref(r), C.byref(o), None, None))
+        d = dict(zip(("window_first", "window_last", "window_base", "n_windows_local"), (int(v) for v in dims)))
+        return d, ReadSet.from_c(r), OverlapSet.from_c(o)
 
     def windows(self) -> WindowBatch:
         cb = RcnBatch()
