@@ -611,6 +611,9 @@ inline void scan_symbols(const uint8_t* bases, uint64_t a, uint64_t z, int32_t& 
 // the bases anyway when it packs a piece.
 int prepare_host(rcn_engine* e, HostPrep& hp, uint32_t nw, uint32_t ns, const uint32_t* win_seq_off, const uint64_t* seq_off,
                  const uint32_t* seq_begin, const uint32_t* seq_end, const uint8_t* bases, int32_t nsym_all, bool acgt_all, bool scan = true) {
+    // (shapes, work order and output capacities below are what a dry run's cached preparation -- polish_view, pc_* -- stands on: whoever
+    //  recomputes them for another batch invalidates it)
+    e->pc_valid = false;
     hp.wflags.assign(nw, 0); hp.order.resize(ns); hp.full.assign(ns, 0);
     e->h_win_seq_off.assign(win_seq_off, win_seq_off + nw + 1);
     e->shapes.resize(nw);
@@ -1018,7 +1021,11 @@ static int collect(rcn_engine* e) {
     std::vector<uint32_t> retry_win;                 // windows whose bytes are in retry_cons, ascending
     {
         std::vector<std::pair<uint32_t, std::string>> redone;
-        const uint32_t n_first_small = static_cast<uint32_t>(retry.size()), n_first_k2 = static_cast<uint32_t>(retry_k2.size());
+        const uint32_t n_first_k2 = static_cast<uint32_t>(retry_k2.size());
+        // (windows the small-window kernel sent back although they HAD its shape: a pass may hold up to an eighth of windows outside the
+        //  shape from the start -- small_caps -- and those come back by design, they say nothing about the kernel's fit for the job)
+        uint32_t n_first_small = 0;
+        for (uint32_t w : retry) n_first_small += small_shape(e->shapes[w]) ? 1 : 0;
         uint32_t n_small_items = 0;
         for (uint8_t s : e->item_small) n_small_items += s;
         for (int tier = 0; tier < 2; ++tier) {
@@ -1221,7 +1228,9 @@ void materialize(const SrcView& v, HostBatch& h) {
 // records (capacities from the pieces' own shapes, slots, scratch placement); false when the scratch does not fit.
 struct PassPlan { int n = 0; uint32_t cut[rcn_engine::kMaxLaunches + 1] = {}; Launch L[rcn_engine::kMaxLaunches]; int tier[rcn_engine::kMaxLaunches] = {0, 2, 2};   /* split launch: 0 deep, 1 middle, 2 rest */ uint64_t scratch = 0; bool split = false, copied = false; };
 
-void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fast, uint32_t slots_left) {
+// `estimate`: a plan made for sizing only (every window taken for the usual alphabet): it leaves the engine's record of which work
+// items the small-window kernel polishes alone -- collect() sends a flagged window to the retry tier by that record.
+void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fast, uint32_t slots_left, bool estimate = false) {
     std::vector<WinShape> sh;
     sh.reserve(pp.cut[c + 1] - pp.cut[c]);
     for (uint32_t k = pp.cut[c]; k < pp.cut[c + 1]; ++k) sh.push_back(e->shapes[e->lpt[k]]);
@@ -1229,9 +1238,11 @@ void plan_piece(rcn_engine* e, PassPlan& pp, int c, const SplitPlan& sp, bool fa
     const bool small = fast && !sp.on && small_caps(e, sh.begin(), sh.end(), L.c);
     if (!small) L.c = first_pass_caps(sh.begin(), sh.end(), fast, e->caps_level, e->knobs.hrows_div);
     L.n_work = pp.cut[c + 1] - pp.cut[c]; L.work_base = pp.cut[c]; L.out_base = pp.cut[c]; L.ctr = c;
+    if (!estimate) {
+        if (small) e->pass_small = true;
+        for (uint32_t k = pp.cut[c]; k < pp.cut[c + 1] && k < e->item_small.size(); ++k) e->item_small[k] = small ? 1 : 0;
+    }
     if (small) {
-        e->pass_small = true;
-        for (uint32_t k = pp.cut[c]; k < pp.cut[c + 1] && k < e->item_small.size(); ++k) e->item_small[k] = 1;
         L.stream = e->sub_stream[c]; L.per_cu = L.c.per_cu;
         // (every piece may fill the device: its work-groups are persistent over a queue, the ones that find no room at first
         //  start as the earlier piece's retire -- a fixed share would idle once that piece is done)
@@ -1453,6 +1464,14 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
             const uint32_t i = static_cast<uint32_t>((static_cast<uint64_t>(q) * (ns - 1)) / 63);
             key[2] = (key[2] ^ reinterpret_cast<uintptr_t>(v.seq[i]) ^ (static_cast<uint64_t>(v.begin[i]) << 48) ^ (v.seq_off[i + 1] - v.seq_off[i])) * 1099511628211ull;
         }
+        // ... and everything the preparation is computed FROM, in full: the windows' sequence counts, every layer's length, begin and end
+        // (a caller that edits its tables between the dry run and the call gets a fresh preparation, not the old one)
+        {
+            uint64_t h = 14695981039346656037ull;
+            for (uint32_t w = 0; w <= nw; ++w) h = (h ^ v.win_seq_off[w]) * 1099511628211ull;
+            for (uint32_t i = 0; i < ns; ++i) h = (h ^ (v.seq_off[i + 1] - v.seq_off[i]) ^ (static_cast<uint64_t>(v.begin[i]) << 20) ^ (static_cast<uint64_t>(v.end[i]) << 42)) * 1099511628211ull;
+            key[3] ^= h;
+        }
         const bool hit = !dry && e->pc_valid && std::memcmp(key, e->pc_key, sizeof(key)) == 0 && e->pc_order.size() == ns && e->shapes.size() == nw && e->lpt.size() == nw;
         e->pc_valid = false;
         if (hit) {
@@ -1511,7 +1530,7 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         }
         for (uint32_t w = 0; w < nw; ++w) e->shapes[w].nsym = 5;
         uint32_t left = slots_total;
-        for (int c = 0; c < est.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left); left -= std::min(left, est.L[c].slots); }
+        for (int c = 0; c < est.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left, /*estimate=*/true); left -= std::min(left, est.L[c].slots); }
         if (est.scratch <= scratch_budget(e) && (rc = e->d_scratch.reserve(est.scratch))) return rc;
         if (dbg) fprintf(stderr, "[racon_hip] reserve: scratch arena (%.2f GB, %u + %u slots) at %.2f ms\n", est.scratch / 1e9, est.L[0].slots, est.L[1].slots, since());
         if ((rc = e->h_out.reserve(result_layout(nw).off_cons + e->out_off[nw] + 16))) return rc;
@@ -1593,7 +1612,7 @@ int polish_view(rcn_engine* e, const SrcView& v, bool dry = false) {
         std::vector<int32_t> keep(nw);
         for (uint32_t w = 0; w < nw; ++w) { keep[w] = e->shapes[w].nsym; e->shapes[w].nsym = 5; }
         uint32_t left = slots_total;
-        for (int c = 0; c < pp.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left); left -= std::min(left, est.L[c].slots); }
+        for (int c = 0; c < pp.n; ++c) { if (est.cut[c + 1] == est.cut[c]) continue; plan_piece(e, est, c, sp, fast, left, /*estimate=*/true); left -= std::min(left, est.L[c].slots); }
         for (uint32_t w = 0; w < nw; ++w) e->shapes[w].nsym = keep[w];
         if (est.scratch <= scratch_budget(e) && (rc = e->d_scratch.reserve(est.scratch))) return rc;
         if (dbg) fprintf(stderr, "[racon_hip] polish: scratch arena (%.2f GB) at %.2f ms\n", est.scratch / 1e9, since());

@@ -436,8 +436,12 @@ inline int upload_staged(DevBuf& d, const void* src, size_t bytes, hipStream_t s
     HostBuf& slots = slot_bufs[dev & 63];
     std::lock_guard<std::mutex> lock(mu);
     if ((rc = slots.reserve(2 * kChunk))) { HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, st)); return RCN_OK; }
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    for (auto& x : ev) HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    // (destroyed on every way out, an early return from the creation loop included; the staging pair itself stays for the life of the
+    //  process -- 64 MB of pinned memory per device that uploaded this way, released with the process: a static destructor would run
+    //  after the HIP runtime's own teardown)
+    struct Events { hipEvent_t e[2] = {nullptr, nullptr}; ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); } } events;
+    hipEvent_t* ev = events.e;
+    for (int q = 0; q < 2; ++q) HIP_TRY(hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
     const unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     const uint8_t* s8 = static_cast<const uint8_t*>(src);
     int rc_out = RCN_OK;
@@ -451,7 +455,6 @@ inline int upload_staged(DevBuf& d, const void* src, size_t bytes, hipStream_t s
         if (hipMemcpyAsync(static_cast<uint8_t*>(d.p) + off, slot, n, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k & 1], st) != hipSuccess) { rc_out = RCN_E_HIP; break; }
     }
     for (int q = 0; q < 2; ++q) if (k > static_cast<size_t>(q)) (void)hipEventSynchronize(ev[q]);          // the slots are free again when this returns
-    for (auto& x : ev) (void)hipEventDestroy(x);
     return rc_out;
 }
 

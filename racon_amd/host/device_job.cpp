@@ -16,8 +16,8 @@
 //
 // device_job() strings them together: phase 1 (end of initialize(): build + reserve, windows stay resident), phase 2 (polish() of
 // what phase 1 built), phase 0 (everything inside polish(), shard after shard -- a job cut into more window ranges than devices).
-// In phase 0 a device's shards are PIPELINED: while engine A polishes shard j, a helper thread slices shard j + 1 out of the layout
-// and the device's second engine uploads, aligns and builds it.
+// In phase 0 a device's shards are PIPELINED on the host side: while the engine builds and polishes shard j, a helper thread slices
+// shard j + 1 out of the layout (the device side too with RACON_HIP_SHARD_PIPELINE=1: measured slower, see device_job()).
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -93,8 +93,11 @@ Polisher::DevicePlan Polisher::plan_device_job(uint32_t n_shards) const {
 // ---------------------------------------------------------------- one shard's input
 void Polisher::make_shard_input(const DevicePlan& plan, uint32_t sidx, ShardInput* out) const {
     ShardInput& in = *out;
-    in = ShardInput();
+    // (the vectors of a recycled ShardInput keep their capacity: a device's shards take turns over two of them, and only the first
+    //  two page their buffers in -- fresh pages faulted in while the HIP runtime maps and unmaps device buffers on another thread wait
+    //  for the process's memory-map lock: a 30 ms slice was seen to take 2.3 s next to a running shard)
     in.sidx = sidx; in.wa = plan.cut[sidx]; in.wb = plan.cut[sidx + 1];
+    in.whole = false;
     const Layout& L = layout_;
     const uint64_t n_seq = L.seq_off.size() - 1;
     const uint64_t* sel = plan.bucket.data() + plan.bucket_off[sidx];
@@ -119,8 +122,10 @@ void Polisher::make_shard_input(const DevicePlan& plan, uint32_t sidx, ShardInpu
     // multi-device path keeps the reads on the host and packs per batch (src/cuda/cudapolisher.cpp:254-276); here a shard's engine
     // gets its own eighth of them.
     constexpr uint32_t kUnused = 0xffffffffu;
-    std::vector<uint32_t> remap(n_seq, kUnused), old_of;
+    std::vector<uint32_t>& remap = in.remap; std::vector<uint32_t>& old_of = in.old_of;
+    remap.assign(n_seq, kUnused); old_of.clear();
     old_of.reserve((t_b - t_a) + n_sel / 4 + 16);
+    const uint32_t copy_threads = std::min<uint32_t>(num_threads_, 8);
     for (uint64_t t = t_a; t < t_b; ++t) { remap[t] = static_cast<uint32_t>(t - t_a); old_of.push_back(static_cast<uint32_t>(t)); }
     in.q_id.resize(n_sel); in.t_id.resize(n_sel); in.strand.resize(n_sel);
     in.q_start.resize(n_sel); in.t_begin.resize(n_sel); in.t_end.resize(n_sel); in.q_begin.resize(n_sel); in.q_end.resize(n_sel);
@@ -135,7 +140,7 @@ void Polisher::make_shard_input(const DevicePlan& plan, uint32_t sidx, ShardInpu
         in.cigar_off[j + 1] = in.cigar_off[j] + (L.cigar_off[k + 1] - L.cigar_off[k]);
     }
     in.bp_t.resize(in.bp_off[n_sel]); in.bp_q.resize(in.bp_off[n_sel]); in.cigar.resize(in.cigar_off[n_sel] + 1);
-    parallel_for((n_sel + 4095) / 4096, num_threads_, [&](uint64_t blk) {
+    parallel_for((n_sel + 4095) / 4096, copy_threads, [&](uint64_t blk) {
         for (uint64_t j = blk * 4096, e = std::min<uint64_t>(n_sel, j + 4096); j < e; ++j) {
             const uint64_t k = sel[j];
             in.strand[j] = L.strand[k];
@@ -151,7 +156,7 @@ void Polisher::make_shard_input(const DevicePlan& plan, uint32_t sidx, ShardInpu
     in.seq_off.assign(n_new + 1, 0); in.has_qual.resize(n_new);
     for (uint64_t i = 0; i < n_new; ++i) { in.seq_off[i + 1] = in.seq_off[i] + (L.seq_off[old_of[i] + 1] - L.seq_off[old_of[i]]); in.has_qual[i] = L.seq_has_qual[old_of[i]]; }
     in.bases.resize(in.seq_off[n_new] + 1); in.quals.resize(in.seq_off[n_new] + 1);
-    parallel_for((n_new + 63) / 64, num_threads_, [&](uint64_t blk) {
+    parallel_for((n_new + 63) / 64, copy_threads, [&](uint64_t blk) {
         for (uint64_t i = blk * 64, e = std::min<uint64_t>(n_new, i + 64); i < e; ++i) {
             const uint64_t a = L.seq_off[old_of[i]], len = L.seq_off[old_of[i] + 1] - a;
             std::memcpy(in.bases.data() + in.seq_off[i], L.bases.data() + a, len);
@@ -267,7 +272,11 @@ void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::ve
         if (mine.empty()) return;
         const int32_t device = static_cast<int32_t>(l);
         std::shared_ptr<HipEngine> eng[2] = {engines_[static_cast<size_t>(l)], nullptr};
-        if (phase == 0 && mine.size() > 1 && engines_.size() >= static_cast<size_t>(l) + static_cast<size_t>(n_devices) + 1 && !getenv("RACON_HIP_NO_SHARD_PIPELINE"))
+        // RACON_HIP_SHARD_PIPELINE=1 (experiments): shard j + 1 is also BUILT -- uploaded, aligned, cut -- on the device's second engine while
+        // shard j's consensus runs.  Off: measured slower (cfg5 x 0.25 in four shards: polish() 6.7 s with, 6.1 s without;
+        // profiles/r06/b_shard_pipeline_ab.txt) -- aligner and consensus kernel are both bound by instruction issue, side by side each
+        // takes as much longer as the other runs, and two resident shards double the HBM in use.  The slicing on the host overlaps either way.
+        if (phase == 0 && mine.size() > 1 && engines_.size() >= static_cast<size_t>(l) + static_cast<size_t>(n_devices) + 1 && getenv("RACON_HIP_SHARD_PIPELINE"))
             eng[1] = engines_[static_cast<size_t>(l) + static_cast<size_t>(n_devices)];
         try {
             if (phase == 2) {
@@ -277,12 +286,14 @@ void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::ve
                 return;
             }
             // prepare (host, helper thread) -> build (device, this thread) -> run (device, helper thread on the other engine)
-            auto prepare = [&](uint32_t s) { FatalThrowsScope scope1; auto in = std::make_unique<ShardInput>(); in->t_begin_s = seconds_since(job_begin); make_shard_input(plan, s, in.get()); in->t_sliced_s = seconds_since(job_begin); return in; };
-            std::future<std::unique_ptr<ShardInput>> next = std::async(std::launch::async, prepare, mine[0]);
+            // (three inputs in turn: shard j + 1 is sliced while shard j is built and shard j - 1 may still be running)
+            std::shared_ptr<ShardInput> pool[3] = {std::make_shared<ShardInput>(), std::make_shared<ShardInput>(), std::make_shared<ShardInput>()};
+            auto prepare = [&](uint32_t s, std::shared_ptr<ShardInput> in) { FatalThrowsScope scope1; in->t_begin_s = seconds_since(job_begin); make_shard_input(plan, s, in.get()); in->t_sliced_s = seconds_since(job_begin); return in; };
+            std::future<std::shared_ptr<ShardInput>> next = std::async(std::launch::async, prepare, mine[0], pool[0]);
             std::future<void> running;
             for (size_t j = 0; j < mine.size(); ++j) {
-                std::shared_ptr<ShardInput> in(next.get().release());
-                if (j + 1 < mine.size()) next = std::async(std::launch::async, prepare, mine[j + 1]);
+                std::shared_ptr<ShardInput> in = next.get();
+                if (j + 1 < mine.size()) next = std::async(std::launch::async, prepare, mine[j + 1], pool[(j + 1) % 3]);
                 const std::shared_ptr<HipEngine> engine = eng[1] ? eng[j & 1] : eng[0];
                 if (!eng[1] && running.valid()) running.get();              // (one engine: its previous shard first)
                 const double t0 = seconds_since(job_begin);

@@ -1,5 +1,9 @@
 #include "parsers.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cctype>
@@ -160,11 +164,33 @@ Format format_of(const std::string& p) {
     return Format::kSam;
 }
 
+namespace {
+// An uncompressed regular file, mapped read-only (nullptr: gzip data, a pipe, an empty or unmappable file -- the zlib path takes those).
+struct Mapped {
+    const char* base = nullptr; size_t size = 0;
+    explicit Mapped(const std::string& path) {
+        if (getenv("RACON_HIP_NO_MMAP")) return;
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        unsigned char magic[2] = {0, 0};
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 2 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            void* p = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p != MAP_FAILED) { base = static_cast<const char*>(p); size = static_cast<size_t>(st.st_size); madvise(p, size, MADV_SEQUENTIAL); }
+        }
+        close(fd);
+    }
+    ~Mapped() { if (base) munmap(const_cast<char*>(base), size); }
+    Mapped(const Mapped&) = delete;
+};
+}  // namespace
+
 void read_batches(const std::string& path, Format format, uint32_t threads, const std::function<void(Batch&)>& work) {
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("[racon::io] error: unable to open file " + path + "!");
-    gzbuffer(f, 1 << 18);
-    struct Closer { gzFile f; ~Closer() { gzclose(f); } } closer{f};
+    const Mapped mapped(path);
+    gzFile f = mapped.base ? nullptr : gzopen(path.c_str(), "rb");
+    if (!mapped.base && !f) throw std::runtime_error("[racon::io] error: unable to open file " + path + "!");
+    if (f) gzbuffer(f, 1 << 18);
+    struct Closer { gzFile f; ~Closer() { if (f) gzclose(f); } } closer{f};
 
     // bounded queue between the inflating thread (this one) and the workers
     std::mutex m;
@@ -203,6 +229,38 @@ void read_batches(const std::string& path, Format format, uint32_t threads, cons
         std::string carry;                    // bytes after the last whole record of the previous block
         uint64_t number = 0, index = 0;
         bool eof = false;
+        auto hand_over = [&](Batch& b) -> bool {          // false: a worker failed, stop reading
+            b.number = number++; b.index0 = index; index += b.recs.size();
+            if (threads > 1) {
+                std::unique_lock<std::mutex> lock(m);
+                cv_full.wait(lock, [&] { return queue.size() < cap || error; });
+                if (error) return false;
+                queue.push_back(std::move(b));
+                lock.unlock();
+                cv_empty.notify_one();
+            } else {
+                work(b);
+            }
+            return true;
+        };
+        if (mapped.base) {
+            // framed in place: a window of a block's size from the first unframed byte, doubled while it holds no whole record
+            size_t pos = 0, want = kBlock;
+            while (pos < mapped.size) {
+                const size_t n = std::min(want, mapped.size - pos);
+                Batch b;
+                b.ptr = mapped.base + pos;
+                const size_t used = frame(format, b.ptr, n, pos + n == mapped.size, b.recs, path);
+                if (b.recs.empty()) {
+                    if (pos + n == mapped.size) break;                      // (trailing blank lines)
+                    if (used == 0) { want *= 2; continue; }
+                    pos += used; continue;
+                }
+                pos += used; want = kBlock;
+                if (!hand_over(b)) break;
+            }
+            eof = true;
+        }
         while (!eof) {
             Batch b;
             b.text.swap(carry);
@@ -224,17 +282,7 @@ void read_batches(const std::string& path, Format format, uint32_t threads, cons
             carry.assign(b.text, used, std::string::npos);
             b.text.resize(used);
             if (b.recs.empty()) continue;
-            b.number = number++; b.index0 = index; index += b.recs.size();
-            if (threads > 1) {
-                std::unique_lock<std::mutex> lock(m);
-                cv_full.wait(lock, [&] { return queue.size() < cap || error; });
-                if (error) break;
-                queue.push_back(std::move(b));
-                lock.unlock();
-                cv_empty.notify_one();
-            } else {
-                work(b);
-            }
+            if (!hand_over(b)) break;
         }
     } catch (...) {
         finish();
@@ -310,28 +358,28 @@ bool parse_sam(const char* s, size_t n, const std::string& path, SamRecord& r) {
 void read_fasta(const std::string& path, const std::function<void(const SeqRecord&)>& cb) {
     std::string data, qual;
     read_batches(path, Format::kFasta, 1, [&](Batch& b) {
-        for (const auto& rc : b.recs) { SeqRecord r; parse_seq(Format::kFasta, b.text.data() + rc.first, rc.second, path, data, qual, r); cb(r); }
+        for (const auto& rc : b.recs) { SeqRecord r; parse_seq(Format::kFasta, b.data() + rc.first, rc.second, path, data, qual, r); cb(r); }
     });
 }
 void read_fastq(const std::string& path, const std::function<void(const SeqRecord&)>& cb) {
     std::string data, qual;
     read_batches(path, Format::kFastq, 1, [&](Batch& b) {
-        for (const auto& rc : b.recs) { SeqRecord r; parse_seq(Format::kFastq, b.text.data() + rc.first, rc.second, path, data, qual, r); cb(r); }
+        for (const auto& rc : b.recs) { SeqRecord r; parse_seq(Format::kFastq, b.data() + rc.first, rc.second, path, data, qual, r); cb(r); }
     });
 }
 void read_paf(const std::string& path, const std::function<void(const PafRecord&)>& cb) {
     read_batches(path, Format::kPaf, 1, [&](Batch& b) {
-        for (const auto& rc : b.recs) { PafRecord r; parse_paf(b.text.data() + rc.first, rc.second, path, r); cb(r); }
+        for (const auto& rc : b.recs) { PafRecord r; parse_paf(b.data() + rc.first, rc.second, path, r); cb(r); }
     });
 }
 void read_mhap(const std::string& path, const std::function<void(const MhapRecord&)>& cb) {
     read_batches(path, Format::kMhap, 1, [&](Batch& b) {
-        for (const auto& rc : b.recs) { MhapRecord r; parse_mhap(b.text.data() + rc.first, rc.second, path, r); cb(r); }
+        for (const auto& rc : b.recs) { MhapRecord r; parse_mhap(b.data() + rc.first, rc.second, path, r); cb(r); }
     });
 }
 void read_sam(const std::string& path, const std::function<void(const SamRecord&)>& cb) {
     read_batches(path, Format::kSam, 1, [&](Batch& b) {
-        for (const auto& rc : b.recs) { SamRecord r; if (parse_sam(b.text.data() + rc.first, rc.second, path, r)) cb(r); }
+        for (const auto& rc : b.recs) { SamRecord r; if (parse_sam(b.data() + rc.first, rc.second, path, r)) cb(r); }
     });
 }
 

@@ -29,14 +29,18 @@ void read_mhap(const std::string& path, const std::function<void(const MhapRecor
 void read_sam(const std::string& path, const std::function<void(const SamRecord&)>& cb);
 
 // ---- parallel ingest (the reference parses on the calling thread, src/polisher.cpp:200-349) ----
-// One thread inflates the file and frames whole records into batches of a few MiB of text; `threads` workers take the
+// One thread inflates the file (an UNCOMPRESSED file is memory-mapped instead and framed in place: no copy through zlib's buffer, no
+// copy into the batch -- the framing thread then runs at memchr speed and the parse workers are the limit) and frames whole records
+// into batches of a few MiB of text; `threads` workers take the
 // batches (in any order) and call `work`: field parsing and object construction (upper-casing, quality checks, CIGAR
 // scans) leave the inflating thread.  Batch::number counts batches in file order and Batch::index0 is the ordinal of its
 // first record, so the caller can restore file order.  threads <= 1: everything on the calling thread, in order.
 // Exceptions thrown by `work` or by the reader are rethrown on the calling thread.
 enum class Format { kFasta, kFastq, kPaf, kMhap, kSam };
 struct Batch {
-    std::string text;
+    std::string text;                                // the batch's bytes (inflated input), or
+    const char* ptr = nullptr;                       // ... a view into the memory-mapped file (uncompressed input): valid inside `work`
+    const char* data() const { return ptr ? ptr : text.data(); }
     std::vector<std::pair<size_t, size_t>> recs;     // (offset, length) of every record in text, terminators stripped
     uint64_t number = 0, index0 = 0;
 };

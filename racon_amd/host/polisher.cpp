@@ -10,6 +10,8 @@
 #include <thread>
 #include <unordered_map>
 
+#include <sys/stat.h>
+
 #include "fatal.hpp"
 #include "hip_engine.hpp"
 #include "host_util.hpp"
@@ -114,7 +116,7 @@ void load_records(const std::string& path, uint32_t threads, std::vector<std::un
             std::vector<std::unique_ptr<T>> local;
             local.reserve(b.recs.size());
             std::string data, qual;
-            for (const auto& rc : b.recs) make(format, b.text.data() + rc.first, rc.second, data, qual, local);
+            for (const auto& rc : b.recs) make(format, b.data() + rc.first, rc.second, data, qual, local);
             std::lock_guard<std::mutex> lock(m);
             if (parts.size() <= b.number) parts.resize(b.number + 1);
             parts[b.number] = std::move(local);
@@ -168,7 +170,15 @@ void Polisher::initialize() {
     std::vector<std::unique_ptr<Overlap>> overlaps;
     std::exception_ptr reads_error, overlaps_error;
     std::thread reads_thread, overlaps_thread;
+    // Fragment correction is usually run as `racon -f reads overlaps reads`: targets and reads are ONE file.  Every read is then a
+    // duplicate of the target of its ordinal ("a read that is also a target is stored once", below) and parsing the file a second
+    // time only makes objects to throw away -- for cfg5, 2 GB of FASTQ: the read loop below walks the targets instead.
+    const bool reads_are_targets = [&] {
+        struct stat a, b;
+        return !getenv("RACON_HIP_NO_SAME_FILE") && stat(sequences_path_.c_str(), &a) == 0 && stat(target_path_.c_str(), &b) == 0 && a.st_dev == b.st_dev && a.st_ino == b.st_ino;
+    }();
     if (!serial_ingest) {
+        if (!reads_are_targets)
         reads_thread = std::thread([&] { FatalThrowsScope scope; try { load_sequences(sequences_path_, reads, parse_threads); } catch (...) { reads_error = std::current_exception(); } });
         overlaps_thread = std::thread([&] { FatalThrowsScope scope; try { load_overlaps(overlaps_path_, overlaps, parse_threads); } catch (...) { overlaps_error = std::current_exception(); } });
     }
@@ -187,20 +197,24 @@ void Polisher::initialize() {
     // ---- reads; a read that is also a target is stored once (reference src/polisher.cpp:223-278)
     uint64_t sequences_size = 0, total_sequences_length = 0;
     {
-        if (serial_ingest) load_sequences(sequences_path_, reads, 1);
+        if (reads_are_targets) {}
+        else if (serial_ingest) load_sequences(sequences_path_, reads, 1);
         else { reads_thread.join(); if (reads_error) fatal_from(reads_error); }
-        for (auto& read : reads) {
-            total_sequences_length += read->data().size();
-            const auto it = name_to_id.find(read->name() + "t");
+        const uint64_t n_reads = reads_are_targets ? targets_size : reads.size();
+        for (uint64_t k = 0; k < n_reads; ++k) {
+            // (one file: read k is the record target k was made from)
+            const Sequence& read = reads_are_targets ? *sequences_[k] : *reads[k];
+            total_sequences_length += read.data().size();
+            const auto it = name_to_id.find(read.name() + "t");
             uint64_t index;
             if (it != name_to_id.end()) {
                 const auto& twin = sequences_[it->second];
-                if (read->data().size() != twin->data().size() || read->quality().size() != twin->quality().size())
-                    fatal("[racon::Polisher::initialize] error: duplicate sequence " + read->name() + " with unequal data");
+                if (read.data().size() != twin->data().size() || read.quality().size() != twin->quality().size())
+                    fatal("[racon::Polisher::initialize] error: duplicate sequence " + read.name() + " with unequal data");
                 index = it->second;
             } else {
                 index = sequences_.size();
-                sequences_.emplace_back(std::move(read));
+                sequences_.emplace_back(std::move(reads[k]));
             }
             name_to_id[sequences_[index]->name() + "q"] = index;
             id_to_id[sequences_size << 1 | 0] = index;

@@ -134,6 +134,7 @@ public:
         rcn_read_set reads{}; rcn_overlap_set overlaps{};
         const uint32_t *p_q_start = nullptr, *p_t_begin = nullptr, *p_t_end = nullptr, *p_q_begin = nullptr, *p_q_end = nullptr;
         const uint64_t* p_cigar_off = nullptr; const uint8_t* p_cigar = nullptr;
+        std::vector<uint32_t> remap, old_of;        // (work arrays of make_shard_input)
         double t_begin_s = 0, t_sliced_s = 0;       // (timing lines)
     };
     void make_shard_input(const DevicePlan& plan, uint32_t sidx, ShardInput* out) const;

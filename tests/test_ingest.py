@@ -93,6 +93,11 @@ def test_framing_corner_cases(P, tmp_path, monkeypatch):
     wz, _ = _windows(P, paths["reads.fastq"] + ".gz", paths["ovl.paf"] + ".gz", paths["ctg.fasta"] + ".gz", "kC", 6, False, monkeypatch)
     _same(ws, wp)
     _same(ws, wz)
+    # uncompressed files are memory-mapped and framed in place (round 6); through zlib's transparent read instead: the same windows
+    monkeypatch.setenv("RACON_HIP_NO_MMAP", "1")
+    wn, _ = _windows(P, paths["reads.fastq"], paths["ovl.paf"], paths["ctg.fasta"], "kC", 6, False, monkeypatch)
+    monkeypatch.delenv("RACON_HIP_NO_MMAP")
+    _same(ws, wn)
     # and the content is what was written: every layer is an exact stretch of the contig with its own qualities
     assert ws.n_windows == 120
     want = {s: q for _, s, q, _, _, _ in reads}
@@ -143,3 +148,30 @@ def test_records_much_longer_than_a_block(P, tmp_path, monkeypatch):
     _same(ws, wp)
     assert wp.n_windows == 2 * (40_000_000 // 500) + 2 * 6
     assert tp < 20.0, tp          # (quadratic re-framing of a 40 MB record was ~10 rescans of up to 40 MB each: still seconds; the bound catches a regression on CI-sized boxes)
+
+
+def test_reads_and_targets_in_one_file_are_parsed_once(P, tmp_path, monkeypatch):
+    """`racon -f reads overlaps reads`: one file is both (same inode: a hard link counts, a copy does not).  The reads are then walked
+    as the targets they duplicate instead of being parsed a second time (polisher.cpp initialize): the same windows as with the second
+    parse (RACON_HIP_NO_SAME_FILE=1) and as with a byte-identical COPY of the file -- duplicate names included (reference
+    src/polisher.cpp:223-278: the last target of a name is the one a read of that name maps to)."""
+    import shutil
+    reads = str(tmp_path / "reads.fastq")
+    with gzip.open(DATA + "sample_reads.fastq.gz", "rb") as f:
+        blob = f.read()
+    second = blob.index(b"\n@2\n") + 1                    # (multi-line FASTQ: the first record ends where "@2" starts a line)
+    open(reads, "wb").write(blob + blob[:second])         # the first record once more at the end: a duplicate name with equal data
+    link, copy = str(tmp_path / "link.fastq"), str(tmp_path / "copy.fastq")
+    os.link(reads, link); shutil.copy(reads, copy)
+    ovl = str(tmp_path / "some.paf")                      # (every overlap costs a pairwise alignment: the first 400 of the 4 000 will do)
+    with gzip.open(DATA + "sample_ava_overlaps.paf.gz", "rb") as f:
+        open(ovl, "wb").write(b"".join(f.readlines()[:400]))
+    for threads, serial in ((8, False), (1, True)):
+        a, _ = _windows(P, reads, ovl, reads, "kF", threads, serial, monkeypatch)
+        b, _ = _windows(P, reads, ovl, link, "kF", threads, serial, monkeypatch)
+        c, _ = _windows(P, reads, ovl, copy, "kF", threads, serial, monkeypatch)
+        monkeypatch.setenv("RACON_HIP_NO_SAME_FILE", "1")
+        d, _ = _windows(P, reads, ovl, reads, "kF", threads, serial, monkeypatch)
+        monkeypatch.delenv("RACON_HIP_NO_SAME_FILE")
+        _same(a, b); _same(a, c); _same(a, d)
+        assert a.n_windows > 236 and int(a.win_seq_off[-1]) > a.n_windows + 300

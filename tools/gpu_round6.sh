@@ -30,6 +30,35 @@ if has tests; then
   timeout 3000 python -m pytest tests -m gpu -q -x --durations=15 > "$OUT/pytest_gpu.log" 2>&1
   echo "pytest exit $?" >> "$OUT/pytest_gpu.log"; tail -30 "$OUT/pytest_gpu.log"
 fi
+if has new; then
+  timeout 3000 python -m pytest tests/test_gpu_selfcheck.py tests/test_cli_e2e.py tests/test_gpu_product_path.py tests/test_gpu_pair_align.py tests/test_gpu_bench_contract.py \
+      -m gpu -q -x --durations=12 > "$OUT/pytest_new.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_new.log"; tail -30 "$OUT/pytest_new.log"
+fi
+if has shardtime; then
+  # where a shard's time goes when a job is cut into more window ranges than devices (cfg5 at a quarter of its size, four sequential shards)
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+from racon_amd.synth import simulate_fragment_files
+SC = float(os.environ.get("SHARD_SCALE", "0.25")); d = "/tmp/racon_amd_cache/cfg5_%g" % SC
+if not os.path.exists(d + "/.done"):
+    p = simulate_fragment_files(d, int(33_333_333 * SC), int(100_000 * SC), seed=20260924); open(d + "/.done", "w").write(str(p["n_overlaps"]))
+PY
+  F=/tmp/racon_amd_cache/cfg5_${SHARD_SCALE:-0.25}
+  for PIPE in "" "RACON_HIP_SHARD_PIPELINE=1"; do
+    env $PIPE RACON_HIP_DEVICE_SHARDS=${SHARD_N:-4} RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -f -t 32 --cudaaligner-batches 1 $F/reads.fastq $F/overlaps.paf $F/reads.fastq 2> "$OUT/shardtime.err" | md5sum
+    echo "== ${PIPE:-default}"; grep -E "racon::|racon_hip\] self" "$OUT/shardtime.err" | grep -v "piece\|collect\|pass of" | cut -c1-330 | tee "$OUT/shardtime_${PIPE:+device_pipeline}.txt" | tail -30
+  done
+fi
+if has cfg5; then
+  timeout ${CFG5_TIMEOUT:-2400} python tools/cfg5_whole.py ${CFG5_ARGS:---scale 1.0 --shards 8} > "$OUT/cfg5_whole.json" 2> "$OUT/cfg5_whole.err"
+  echo "cfg5 exit $?"; tail -3 "$OUT/cfg5_whole.err" | cut -c1-400; cut -c1-4500 "$OUT/cfg5_whole.json"
+fi
+if has cfg3bin; then
+  timeout 2400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu --no-upload-leg --product-contig 0 > "$OUT/bench_cfg3_1gpu.json" 2> "$OUT/bench_cfg3.err"
+  echo "cfg3 exit $?"; cut -c1-2500 "$OUT/bench_cfg3_1gpu.json"; tail -3 "$OUT/bench_cfg3.err"
+fi
 if has ab; then
   for k in 1 2; do
     python bench.py $QB 2>/dev/null | benchline "cfg2 as shipped ($k)"
