@@ -222,6 +222,9 @@ int  rcn_engine_has_windows(rcn_engine* e);
 /* upload+run over the windows added so far */
 int  rcn_engine_generate_consensus(rcn_engine* e);
 int  rcn_engine_reset(rcn_engine* e);
+/* A handle that goes on to ANOTHER job (the host layer keeps engines alive across Polishers): forgets what earlier batches taught it --
+ * the first-pass capacity level, the vote against the small-window kernel -- so that the next job starts as on a new engine.  Buffers stay. */
+int  rcn_engine_forget(rcn_engine* e);
 
 /* --- device-side window construction -----------------
  * Replaces the two serial host loops at the end of Polisher::initialize: targets

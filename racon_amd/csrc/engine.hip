@@ -1193,6 +1193,12 @@ static int begin_run(rcn_engine* e) {
     return RCN_OK;
 }
 
+int rcn_engine_forget(rcn_engine* e) {
+    if (!e) return RCN_E_ARG;
+    e->caps_level = 0; e->small_off = false; e->pc_valid = false; e->queued = false;
+    return RCN_OK;
+}
+
 }  // extern "C"
 
 namespace {

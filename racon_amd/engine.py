@@ -64,7 +64,7 @@ EXPORTS = ["rcn_engine_create", "rcn_engine_destroy", "rcn_engine_upload", "rcn_
            "rcn_engine_reset", "rcn_device_count", "rcn_strerror", "rcn_version",
            "rcn_engine_build_windows", "rcn_engine_build_windows_from_cigars", "rcn_engine_build_stats", "rcn_engine_batch_dims", "rcn_engine_export_batch", "rcn_engine_polish", "rcn_device_free_memory",
            "rcn_engine_align_pairs", "rcn_engine_alignment_cigars", "rcn_engine_align_stats", "rcn_engine_build_windows_from_pairs",
-           "rcn_engine_polish_refs", "rcn_engine_reserve", "rcn_engine_reserve_refs", "rcn_engine_reserve_run", "rcn_engine_verify"]
+           "rcn_engine_polish_refs", "rcn_engine_reserve", "rcn_engine_reserve_refs", "rcn_engine_reserve_run", "rcn_engine_verify", "rcn_engine_forget"]
 
 _lib = None
 

@@ -2,12 +2,16 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <mutex>
 
 #include "fatal.hpp"
+
+extern "C" char** environ;
 #include "window.hpp"
 
 namespace racon {
@@ -31,6 +35,7 @@ struct Abi {
     decltype(&rcn_engine_result) result = nullptr;
     decltype(&rcn_engine_stats) stats = nullptr;
     decltype(&rcn_engine_verify) verify = nullptr;
+    decltype(&rcn_engine_forget) forget = nullptr;
     decltype(&rcn_engine_set_trim) set_trim = nullptr;
     decltype(&rcn_engine_build_windows) build_windows = nullptr;
     decltype(&rcn_engine_build_windows_from_cigars) build_windows_from_cigars = nullptr;
@@ -68,7 +73,7 @@ const Abi& abi() {
 #define RCN_BIND(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); \
         if (!a.field) { a.error = std::string("missing symbol ") + name; dlclose(a.lib); a.lib = nullptr; return; }
         RCN_BIND(create, "rcn_engine_create") RCN_BIND(destroy, "rcn_engine_destroy") RCN_BIND(upload, "rcn_engine_upload")
-        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(reserve_refs, "rcn_engine_reserve_refs") RCN_BIND(reserve_run, "rcn_engine_reserve_run") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats") RCN_BIND(verify, "rcn_engine_verify")
+        RCN_BIND(run, "rcn_engine_run") RCN_BIND(polish, "rcn_engine_polish") RCN_BIND(polish_refs, "rcn_engine_polish_refs") RCN_BIND(reserve, "rcn_engine_reserve") RCN_BIND(reserve_refs, "rcn_engine_reserve_refs") RCN_BIND(reserve_run, "rcn_engine_reserve_run") RCN_BIND(free_memory, "rcn_device_free_memory") RCN_BIND(result, "rcn_engine_result") RCN_BIND(stats, "rcn_engine_stats") RCN_BIND(verify, "rcn_engine_verify") RCN_BIND(forget, "rcn_engine_forget")
         RCN_BIND(build_windows, "rcn_engine_build_windows") RCN_BIND(build_windows_from_cigars, "rcn_engine_build_windows_from_cigars")
         RCN_BIND(build_windows_from_pairs, "rcn_engine_build_windows_from_pairs")
         RCN_BIND(set_trim, "rcn_engine_set_trim") RCN_BIND(device_count, "rcn_device_count") RCN_BIND(strerror_, "rcn_strerror")
@@ -154,21 +159,56 @@ uint64_t HipEngine::FreeMemory(int32_t device) {
     return fr;
 }
 
+// Engines outlive the Polisher that used them: a handle given back in good order waits here for the next Create() with the same
+// device, scores and experiment switches (a process that runs one Polisher after the other -- bench.py's product leg, the tests --
+// otherwise frees a multi-GB arena and allocates it again each time, and the THIRD allocation was seen to wait 1.2 s for the driver to
+// recycle what the first two had freed: profiles/r06/c_second_polisher_in_one_process.txt).  At most four per key; what is left at
+// exit goes with the process.  RACON_HIP_NO_ENGINE_POOL=1: every Polisher creates and destroys its own.
+namespace {
+struct Pooled { std::string key; rcn_engine* handle; };
+std::mutex g_pool_mutex;
+std::vector<Pooled> g_pool;
+std::string pool_key(int32_t device, int8_t match, int8_t mismatch, int8_t gap) {
+    std::string k = std::to_string(device) + "/" + std::to_string(match) + "/" + std::to_string(mismatch) + "/" + std::to_string(gap);
+    // (the engine reads its RCN_* switches once, when it is created: another set of switches is another engine)
+    std::vector<std::string> sw;
+    for (char** ev = environ; ev && *ev; ++ev) if (!strncmp(*ev, "RCN_", 4)) sw.emplace_back(*ev);
+    std::sort(sw.begin(), sw.end());
+    for (const auto& v : sw) k += "|" + v;
+    return k;
+}
+}  // namespace
+
 std::shared_ptr<HipEngine> HipEngine::Create(int32_t device, int8_t match, int8_t mismatch, int8_t gap, uint64_t arena_bytes) {
     const Abi& a = abi();
     if (!a.lib)
         fatal("[racon::HipEngine::Create] error: unable to load libracon_hip.so (" + a.error +
               "); the consensus stage has no CPU fallback!");
+    std::shared_ptr<HipEngine> e(new HipEngine());
+    e->pool_key_ = getenv("RACON_HIP_NO_ENGINE_POOL") ? std::string() : pool_key(device, match, mismatch, gap);
+    if (!e->pool_key_.empty()) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].key == e->pool_key_) { e->handle_ = g_pool[i].handle; g_pool.erase(g_pool.begin() + static_cast<long>(i)); a.forget(e->handle_); return e; }
+    }
     rcn_engine_config cfg{};
     cfg.device = device; cfg.match = match; cfg.mismatch = mismatch; cfg.gap = gap; cfg.trim = 1; cfg.arena_bytes = arena_bytes;
-    std::shared_ptr<HipEngine> e(new HipEngine());
     const int rc = a.create(&cfg, &e->handle_);
     if (rc != RCN_OK)
         fatal(std::string("[racon::HipEngine::Create] error: ") + a.strerror_(rc) + "!");
     return e;
 }
 
-HipEngine::~HipEngine() { if (handle_) abi().destroy(handle_); }
+HipEngine::~HipEngine() {
+    if (!handle_) return;
+    if (!pool_key_.empty() && last_rc_ == RCN_OK) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t same = 0;
+        for (const auto& p : g_pool) same += p.key == pool_key_ ? 1 : 0;
+        if (same < 4) { g_pool.push_back({pool_key_, handle_}); return; }
+    }
+    abi().destroy(handle_);
+}
 
 void HipEngine::consensus(const PackedBatch& batch, bool trim, std::vector<std::string>* consensus,
                           std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric) {

@@ -120,6 +120,7 @@ private:
     uint64_t fetch_first_ = 0, fetch_last_ = ~uint64_t(0);
     std::function<uint64_t(uint32_t)> verify_ids_;
     uint64_t verified_windows_ = 0;
+    std::string pool_key_;           // non-empty: the handle goes back to the process-wide pool when this object dies (hip_engine.cpp)
 };
 
 }  // namespace racon

@@ -154,6 +154,10 @@ void Polisher::initialize() {
         return;
     }
     logger_->log();
+    // RACON_HIP_TIMING: initialize() by step, milliseconds since it began (the Logger's lines give the stages)
+    const bool timing_init = getenv("RACON_HIP_TIMING") != nullptr;
+    const auto init_begin = std::chrono::steady_clock::now();
+    auto step = [&](const char* what) { if (timing_init) fprintf(stderr, "[racon::Polisher::initialize] timing: %s at %.1f ms\n", what, 1e3 * seconds_since(init_begin)); };
     rank_.clear(); chunks_.clear(); planned_refs_.clear();       // (plans belong to one set of windows)
     if (!device_warmup_.joinable() && engines_.empty() && getenv("RACON_HIP_NO_WARMUP") == nullptr)
         device_warmup_ = std::thread([this] {
@@ -264,8 +268,7 @@ void Polisher::initialize() {
     logger_->log("[racon::Polisher::initialize] loaded overlaps");
     logger_->log();
 
-    parallel_for(sequences_.size(), num_threads_, [&](uint64_t j) { sequences_[j]->transmute(has_name[j], has_data[j], has_reverse_data[j]); });
-
+    step("overlaps resolved and filtered");
     {
         // Where the windows are built.  RACON_HIP_DEVICE_WINDOWS = 0 (host: Window::add_layer, packed per chunk inside polish()),
         // 1 / 2 / 3 (in HBM: from host breaking points / + the CIGAR walk / + the pairwise alignment), or auto -- what the
@@ -302,8 +305,21 @@ void Polisher::initialize() {
         for (const auto& o : overlaps) any_cigar = any_cigar || !o->cigar().empty();
         if (any_cigar) device_align_ = false;
     }
+    if (device_windows_) {
+        // The device cuts its layers out of the FORWARD strand of every read (it complements on the fly) and the flattened layout below
+        // holds nothing else: a reverse complement is only made for the reads the HOST aligner will look at (overlaps on the reverse
+        // strand that came without a CIGAR and are not left to the device aligner) -- for cfg3 that is none, and half of the reads
+        // (0.75 GB of bases and as many qualities) are not copied backwards for nothing.
+        std::vector<bool> host_rc(sequences_.size(), false);
+        if (!device_align_) for (const auto& o : overlaps) if (o->strand() && o->cigar().empty()) host_rc[o->q_id()] = true;
+        parallel_for(sequences_.size(), num_threads_, [&](uint64_t j) { sequences_[j]->transmute(has_name[j], has_data[j] || has_reverse_data[j], host_rc[j]); });
+    } else
+    parallel_for(sequences_.size(), num_threads_, [&](uint64_t j) { sequences_[j]->transmute(has_name[j], has_data[j], has_reverse_data[j]); });
+    step("sequences transmuted");
+
     find_overlap_breaking_points(overlaps);
     logger_->log();
+    step("breaking points");
 
     if (keep_layout_) {
         layout_ = Layout();
@@ -362,6 +378,7 @@ void Polisher::initialize() {
         }
     }
 
+    if (keep_layout_) step("layout flattened");
     // ---- windows over every target (reference src/polisher.cpp:388-403)
     std::vector<uint64_t> first_window(targets_size + 1, 0);
     for (uint64_t i = 0; i < targets_size; ++i) {
@@ -378,11 +395,14 @@ void Polisher::initialize() {
 
     // ---- layers (reference src/polisher.cpp:405-461): serial, in overlap order
     targets_coverages_.assign(targets_size, 0);
+    step("windows created");
     if (device_windows_) {                      // the layers are cut on the device, from layout_ (polish())
         for (auto& o : overlaps) { ++targets_coverages_[o->t_id()]; o.reset(); }
         // the reads now live in layout_ only (the targets stay: windows_ point into their backbones)
         for (uint64_t i = targets_size; i < sequences_.size(); ++i) sequences_[i]->release_data();
+        step("overlaps and reads released");
         build_device_windows();
+        step("device windows built");
         logger_->log(device_built_ ? "[racon::Polisher::initialize] transformed data into windows (on the device)"
                                    : "[racon::Polisher::initialize] transformed data into windows");
         return;

@@ -59,6 +59,47 @@ if has cfg3bin; then
   timeout 2400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu --no-upload-leg --product-contig 0 > "$OUT/bench_cfg3_1gpu.json" 2> "$OUT/bench_cfg3.err"
   echo "cfg3 exit $?"; cut -c1-2500 "$OUT/bench_cfg3_1gpu.json"; tail -3 "$OUT/bench_cfg3.err"
 fi
+if has inittime; then
+  # initialize() by phase at size (the Logger's own lines + RACON_HIP_TIMING): cfg3 whole (50 Mbp: 1.5 GB FASTQ + 3 GB SAM) and cfg5 whole
+  # (-f, 2 GB FASTQ that is reads and targets, 4.8 M PAF overlaps left to the device aligner); second run of each = warm page cache
+  python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print(bench.product_files(50_000_000, 30.0, 20260922, 32))
+PY
+  F=/tmp/racon_amd_cache/files_50000000_30_20260922
+  for k in 1 2; do
+    RACON_HIP_TIMING=1 racon_amd/host/racon_hip -t 32 $F/reads.fastq $F/overlaps.sam $F/targets.fasta 2> "$OUT/inittime_cfg3_$k.err" | md5sum | cut -c1-8
+    grep -E "racon::Polisher::(initialize|polish|)\]" "$OUT/inittime_cfg3_$k.err" | grep -v "chunk\|shard " | cut -c1-200
+  done 2>&1 | tee "$OUT/inittime_cfg3.txt"
+  G=/tmp/racon_amd_cache/cfg5_1
+  if [ -f $G/reads.fastq ]; then
+    for k in 1 2; do
+      RACON_HIP_DEVICE_SHARDS=8 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -f -t 32 --cudaaligner-batches 1 $G/reads.fastq $G/overlaps.paf $G/reads.fastq 2> "$OUT/inittime_cfg5_$k.err" | md5sum | cut -c1-8
+      grep -E "racon::Polisher::(initialize|polish|)\]" "$OUT/inittime_cfg5_$k.err" | cut -c1-330
+    done 2>&1 | tee "$OUT/inittime_cfg5.txt"
+  fi
+fi
+if has twice; then
+  # two Polishers one after the other in ONE process (bench.py's product leg does that): what the second one pays, by phase
+  RACON_HIP_TIMING=1 RCN_DEBUG=1 python - > "$OUT/twice.txt" 2>&1 <<'PY'
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import bench
+from racon_amd.polisher import Polisher
+f = bench.product_files(1_000_000, 30.0, 20260921, 32)
+os.environ["RACON_HIP_DEVICE_WINDOWS"] = "auto"
+for k in range(3):
+    sys.stderr.write("======== Polisher %d\n" % k); sys.stderr.flush()
+    p = Polisher(f["reads"], f["sam"], f["targets"], "kC", 500, 10.0, 0.3, True, 3, -5, -4, 32, 1)
+    t = time.perf_counter(); p.initialize(); ti = time.perf_counter() - t
+    p.polish(True)
+    sys.stderr.write("======== initialize %.3f s, polish %.4f s\n" % (ti, p.polish_seconds())); sys.stderr.flush()
+    t = time.perf_counter(); p.close(); sys.stderr.write("======== close %.3f s\n" % (time.perf_counter() - t)); sys.stderr.flush()
+PY
+  grep -E "========|racon::Polisher::initialize\]|timing" "$OUT/twice.txt" | cut -c1-260
+fi
 if has ab; then
   for k in 1 2; do
     python bench.py $QB 2>/dev/null | benchline "cfg2 as shipped ($k)"
