@@ -312,6 +312,26 @@ void parse_seq(Format format, const char* s, size_t n, const std::string& path, 
         r = SeqRecord{s + 1, name_len, data.data(), static_cast<uint32_t>(data.size()), nullptr, 0};
         return;
     }
+    {
+        // the usual record -- header, ONE line of bases, '+', ONE line of qualities -- is handed on in place: no copy into data / qual
+        const char* e1 = static_cast<const char*>(memchr(s + pos, '\n', n - pos));
+        if (e1) {
+            const size_t b0 = pos, b1 = static_cast<size_t>(e1 - s), blen = rstrip(s + b0, b1 - b0);
+            const size_t p0 = b1 + 1;
+            const char* e2 = p0 < n ? static_cast<const char*>(memchr(s + p0, '\n', n - p0)) : nullptr;
+            if (e2 && s[p0] == '+' && blen && s[b0] != '+') {
+                const size_t q0 = static_cast<size_t>(e2 - s) + 1;
+                if (q0 < n) {
+                    const char* e3 = static_cast<const char*>(memchr(s + q0, '\n', n - q0));
+                    const size_t q1 = e3 ? static_cast<size_t>(e3 - s) : n, qlen = rstrip(s + q0, q1 - q0);
+                    if (qlen == blen && name_len && rstrip(s + q0, n - q0) == qlen) {          // (nothing but white space behind the quality line)
+                        r = SeqRecord{s + 1, name_len, s + b0, static_cast<uint32_t>(blen), s + q0, static_cast<uint32_t>(qlen)};
+                        return;
+                    }
+                }
+            }
+        }
+    }
     while (pos < n) {
         const char* e = static_cast<const char*>(memchr(s + pos, '\n', n - pos));
         const size_t end = e ? static_cast<size_t>(e - s) : n;

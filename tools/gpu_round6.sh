@@ -46,9 +46,10 @@ if not os.path.exists(d + "/.done"):
     p = simulate_fragment_files(d, int(33_333_333 * SC), int(100_000 * SC), seed=20260924); open(d + "/.done", "w").write(str(p["n_overlaps"]))
 PY
   F=/tmp/racon_amd_cache/cfg5_${SHARD_SCALE:-0.25}
-  for PIPE in "" "RACON_HIP_SHARD_PIPELINE=1"; do
+  for PIPE in ${SHARD_PIPES:-none}; do
+    [ "$PIPE" = none ] && PIPE=""
     env $PIPE RACON_HIP_DEVICE_SHARDS=${SHARD_N:-4} RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -f -t 32 --cudaaligner-batches 1 $F/reads.fastq $F/overlaps.paf $F/reads.fastq 2> "$OUT/shardtime.err" | md5sum
-    echo "== ${PIPE:-default}"; grep -E "racon::|racon_hip\] self" "$OUT/shardtime.err" | grep -v "piece\|collect\|pass of" | cut -c1-330 | tee "$OUT/shardtime_${PIPE:+device_pipeline}.txt" | tail -30
+    echo "== ${PIPE:-default}"; grep -E "racon::|racon_hip\] (self|pairs)" "$OUT/shardtime.err" | grep -v "piece\|collect\|pass of" | cut -c1-330 | tee "$OUT/shardtime_${PIPE:+device_pipeline}.txt" | tail -30
   done
 fi
 if has cfg5; then
