@@ -29,6 +29,7 @@
 // order -- and either run-length encoded on the host (tests, rcn_engine_alignment_cigars) or walked on the device into
 // breaking points (k_ops_breaking_points) without leaving HBM.
 #pragma once
+#include "pair_cell.hpp"
 
 namespace rcn {
 
@@ -79,13 +80,6 @@ __host__ __device__ __forceinline__ uint64_t pair_leaf_bytes(uint64_t m_cap) {
     return 16ull * (52429ull + 64ull * (nb + 64)) + 4096;
 }
 
-template <int NPL>
-struct PairLane {                    // what a lane keeps of its word between the steps of a pass
-    unsigned long long plane[NPL];
-    unsigned long long valid;
-    unsigned long long Pv, Mv;
-};
-
 // What one lane of the wave stored, another lane of the SAME wave loads next: the stores must have been performed, nothing
 // else -- a work-group-scope fence (its waves share the CU's vector L1, which takes write hits: s_waitcnt only).  The
 // agent-scope __threadfence() that stood here wrote the L2 back and invalidated the caches (buffer_wbl2 sc1 + buffer_inv sc1)
@@ -95,49 +89,30 @@ __device__ __forceinline__ void pair_wave_fence() { __builtin_amdgcn_fence(__ATO
 __device__ __forceinline__ int pair_shr1(int fill, int v) {      // lane l <- lane l - 1, lane 0 <- fill
     return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
 }
+__device__ __forceinline__ uint32_t pair_shr1_zero(uint32_t v) {  // ... lane 0 <- 0 (no move for the fill: the DPP's own zero fill)
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x138, 0xf, 0xf, true));
+}
+// carry byte of a column as the passes hand it on through HBM (bit 0 = +1, bit 1 = -1) <-> the cell's form (pair_cell.hpp)
+__device__ __forceinline__ PairCarry pair_carry_of(int h) { return PairCarry{static_cast<uint32_t>((~h) & 1) << 31, static_cast<uint32_t>(h & 2) << 30}; }
+__device__ __forceinline__ int pair_carry_byte(PairCarry c) { return static_cast<int>((~c.np) >> 31) | (static_cast<int>(c.mn >> 31) << 1); }
 
 // One pass of the recurrence: words [w0, w0 + nwp) of the rows, all n columns.
 //   rows: logical row r of this sub-problem = Q[q0 + r], or Q[q0 + m - 1 - r] when flipped (the backward half of a split)
 //   columns likewise.  hin_buf / hout_buf: carries of the word above / for the word below (one byte per column:
-//   bit 0 = +1, bit 1 = -1); hin_buf == nullptr: the top boundary (+1 per column).  store != nullptr: leaf, (Pv, Ph)
+//   bit 0 = +1, bit 1 = -1); hin_buf == nullptr: the top boundary (+1 per column).  store != nullptr: leaf, (Pv, ~Ph)
 //   of the cell of lane l at step s goes to store[s * nwp + l].
-// One cell of the recurrence: this lane's word against the column symbol `tc`, horizontal carry `hin` (bit 0 = +1, bit 1 = -1) from
-// the word above.  Returns the carry for the word below; Ph0 = the horizontal plus-deltas of the word's rows (a leaf stores them).
-template <int NPL>
-__device__ __forceinline__ int pair_cell(PairLane<NPL>& L, int tc, int hin, unsigned long long& Ph0) {
-    // Eq: rows whose code agrees with the column's in every plane (32-bit halves: one sign-extended bit-field
-    // extract per plane makes the 0 / ~0 mask of both halves)
-    uint32_t dlo = 0u, dhi = 0u;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) {
-        const uint32_t mk = static_cast<uint32_t>((tc << (31 - k)) >> 31);
-        dlo |= static_cast<uint32_t>(L.plane[k]) ^ mk; dhi |= static_cast<uint32_t>(L.plane[k] >> 32) ^ mk;
-    }
-    unsigned long long Eq = ~((static_cast<unsigned long long>(dhi) << 32) | dlo) & L.valid;
-    const unsigned long long hin_p = static_cast<unsigned long long>(hin & 1), hin_n = static_cast<unsigned long long>((hin >> 1) & 1);
-    const unsigned long long Xv = Eq | L.Mv;
-    Eq |= hin_n;
-    const unsigned long long Xh = (((Eq & L.Pv) + L.Pv) ^ L.Pv) | Eq;
-    unsigned long long Ph = L.Mv | ~(Xh | L.Pv);
-    unsigned long long Mh = L.Pv & Xh;
-    const int hout = static_cast<int>(Ph >> 63) | (static_cast<int>(Mh >> 63) << 1);
-    Ph0 = Ph;
-    Ph = (Ph << 1) | hin_p; Mh = (Mh << 1) | hin_n;
-    L.Pv = Mh | ~(Xv | Ph);
-    L.Mv = Ph & Xv;
-    return hout;
-}
-
-template <int NPL, bool STORE>
-__device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
-                                          int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
-                                          ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out,
-                                          int nsnap = 0, int sc0 = 0, int sc1 = 0, int sc2 = 0, ulonglong2* snapbuf = nullptr) {
+// HIN / HB: the pass has a word above / below it (a query of more than 4096 rows); the common single pass pays for neither the
+// per-step injection at lane 0 nor the collection of the last word's carries.
+template <int NPL, bool STORE, bool HIN, bool HB>
+__device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
+                                               int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
+                                               ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out,
+                                               int nsnap, int sc0, int sc1, int sc2, ulonglong2* snapbuf) {
     const int lane = threadIdx.x & 63;
     PairLane<NPL> L;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) L.plane[k] = 0ull;
-    L.valid = 0ull; L.Pv = ~0ull; L.Mv = 0ull;
+    for (int k = 0; k < NPL; ++k) { L.pl[k] = 0u; L.ph[k] = 0u; }
+    L.vl = 0u; L.vh = 0u; L.Pvl = ~0u; L.Pvh = ~0u; L.Mvl = 0u; L.Mvh = 0u;
     if (lane < nwp) {
         // this lane's 64 rows are 64 consecutive bytes of the stored read, up or down; sixteen loads in flight at a time
         // (one load, one wait and a branchy complement per row was 64 memory round trips before the first step of a pass),
@@ -147,6 +122,9 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
         const int64_t l0 = qflip ? q0 + m - 1 - r0 : q0 + r0;                  // logical position of row r0; row r0 + r: l0 -/+ r
         const int64_t i0 = Q.rc ? Q.n - 1 - l0 : l0;
         const int64_t step = (qflip != Q.rc) ? -1 : 1;
+        unsigned long long plane[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) plane[k] = 0ull;
 #pragma unroll 1
         for (int rb = 0; rb < 64; rb += 16) {
             uint32_t raw[16];
@@ -156,24 +134,27 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
             for (int u = 0; u < 16; ++u) {
                 const uint32_t code = codes[raw[u]];
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) L.plane[k] |= static_cast<unsigned long long>((code >> k) & 1u) << (rb + u);
+                for (int k = 0; k < NPL; ++k) plane[k] |= static_cast<unsigned long long>((code >> k) & 1u) << (rb + u);
             }
         }
-        L.valid = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);                 // (rows past the end repeat the last one: masked here)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) { L.pl[k] = static_cast<uint32_t>(plane[k]); L.ph[k] = static_cast<uint32_t>(plane[k] >> 32); }
+        const unsigned long long valid = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);     // (rows past the end repeat the last one: masked here)
+        L.vl = static_cast<uint32_t>(valid); L.vh = static_cast<uint32_t>(valid >> 32);
     }
     // the target is stored forwards (PairView::rc is the query's): column `col` of this pass
     auto tcol = [&](int col) -> uint32_t { return T.p[tflip ? t0 + n - 1 - col : t0 + col]; };
     uint32_t traw = lane < n ? tcol(lane) : 0u;                                  // raw symbol / carry-in of the block's columns, fetched a block ahead
-    int hraw = (hin_buf && lane < n) ? hin_buf[lane] : 1;
-    int tbuf = 0, hbuf = 0;          // columns s0 .. s0 + 63: symbol code / carry-in of the top word, one per lane
-    int tc = 0, hc = 0;              // this lane's column symbol; carry pair of the lane above from the previous step
+    int hraw = (HIN && lane < n) ? hin_buf[lane] : 1;
+    int tbuf = 0, hbuf = 1;          // columns s0 .. s0 + 63: symbol code / carry-in byte of the top word, one per lane
+    int tc = 0;                      // this lane's column symbol
+    PairCarry hc{0x80000000u, 0u};   // what the cell of this lane handed down at the previous step
     const int steps = n + nwp - 1;
-    const bool hb = hout_buf != nullptr;
     for (int s0 = 0; s0 < steps; s0 += 64) {
         {   // the 64 columns that enter at lane 0 during this block; the next block's are requested now and looked at then
             const int col = s0 + lane;
             traw = col < n ? tcol(col) : 0u;
-            hraw = (hin_buf && col < n) ? hin_buf[col] : 1;
+            hraw = (HIN && col < n) ? hin_buf[col] : 1;
             tbuf = col < n ? static_cast<int>(codes[256 + traw]) : 7;
             hbuf = hraw;
         }
@@ -185,35 +166,48 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
         if (s0 >= nwp - 1 && s0 + 63 < n && !snap_here) {
             // steady state: at every step of the block every word of the pass has a column in [0, n) -- no range tests, no
             // exec-mask regions (lanes past the pass's words compute on valid = 0; nobody reads them).  The carries out of the
-            // last word: every lane shifts its own two bits per step into a register, and at the end of the block the last
-            // word's 2 x 64 bits are handed out, one column per lane, and stored once.
-            unsigned long long hq[2];
+            // last word: every lane shifts its own two bits per step into two registers (one v_alignbit each), and at the end
+            // of the block the last word's 2 x 64 bits are handed out, one column per lane, and stored once.
+            uint32_t accP[2] = {0u, 0u}, accN[2] = {0u, 0u};
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                unsigned long long acc = 0ull;
+                uint32_t aP = 0u, aN = 0u;
 #pragma unroll 2
                 for (int kk = 0; kk < 32; ++kk) {
                     const int k = 32 * half + kk;
-                    const int t_new = __builtin_amdgcn_readlane(tbuf, k), h_new = __builtin_amdgcn_readlane(hbuf, k);
+                    const int t_new = __builtin_amdgcn_readlane(tbuf, k);
                     tc = pair_shr1(t_new, tc);
-                    const int hin = pair_shr1(h_new, hc);
-                    unsigned long long Ph0;
-                    const int hout = pair_cell<NPL>(L, tc, hin, Ph0);
-                    if (STORE) { if (lane < nwp) { ulonglong2 v; v.x = L.Pv; v.y = Ph0; store[static_cast<int64_t>(s0 + k) * nwp + lane] = v; } }
-                    acc = (acc << 2) | static_cast<unsigned long long>(static_cast<uint32_t>(hout));
-                    hc = hout;
+                    PairCarry cin;
+                    if (HIN) {
+                        const PairCarry top = pair_carry_of(__builtin_amdgcn_readlane(hbuf, k));
+                        cin.np = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.np), static_cast<int>(hc.np)));
+                        cin.mn = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.mn), static_cast<int>(hc.mn)));
+                    } else {
+                        cin.np = pair_shr1_zero(hc.np); cin.mn = pair_shr1_zero(hc.mn);
+                    }
+                    uint32_t nl, nh;
+                    hc = pair_cell<NPL>(L, tc, cin, nl, nh);
+                    if (STORE) {
+                        if (lane < nwp) {
+                            ulonglong2 v;
+                            v.x = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl; v.y = (static_cast<unsigned long long>(nh) << 32) | nl;
+                            store[static_cast<int64_t>(s0 + k) * nwp + lane] = v;
+                        }
+                    }
+                    if (HB) { aP = pc_alignbit(aP, hc.np, 31); aN = pc_alignbit(aN, hc.mn, 31); }
                 }
-                hq[half] = acc;
+                accP[half] = aP; accN[half] = aN;
             }
-            if (hb) {
-                // the last word was at column s0 + k - (nwp - 1) at step k; step k = 32 half + kk sits at bits 2 (31 - kk) of its half
+            if (HB) {
+                // the last word was at column s0 + k - (nwp - 1) at step k; step k = 32 half + kk sits at bit 31 - kk of its half
                 const int src = nwp - 1;
-                const uint32_t a0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[0]), src));
-                const uint32_t a1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[0] >> 32), src));
-                const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[1]), src));
-                const uint32_t b1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hq[1] >> 32), src));
-                const unsigned long long a = lane < 32 ? ((static_cast<unsigned long long>(a1) << 32) | a0) : ((static_cast<unsigned long long>(b1) << 32) | b0);
-                hout_buf[s0 + lane - (nwp - 1)] = static_cast<uint8_t>((a >> (2 * (31 - (lane & 31)))) & 3ull);
+                const uint32_t p0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accP[0]), src));
+                const uint32_t p1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accP[1]), src));
+                const uint32_t n0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accN[0]), src));
+                const uint32_t n1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accN[1]), src));
+                const uint32_t wp = lane < 32 ? p0 : p1, wn = lane < 32 ? n0 : n1;
+                const int sh = 31 - (lane & 31);
+                hout_buf[s0 + lane - (nwp - 1)] = static_cast<uint8_t>(((~wp >> sh) & 1u) | (((wn >> sh) & 1u) << 1));
             }
             continue;
         }
@@ -221,27 +215,46 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
         for (int k = 0; k < kend; ++k) {
             const int s = s0 + k;
             // lane l takes over the column lane l - 1 had; lane 0 starts column s
-            const int t_new = __builtin_amdgcn_readlane(tbuf, k), h_new = __builtin_amdgcn_readlane(hbuf, k);
+            const int t_new = __builtin_amdgcn_readlane(tbuf, k);
             tc = pair_shr1(t_new, tc);
-            const int hin = pair_shr1(h_new, hc);
+            const PairCarry top = pair_carry_of(__builtin_amdgcn_readlane(hbuf, k));
+            PairCarry cin;
+            cin.np = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.np), static_cast<int>(hc.np)));
+            cin.mn = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.mn), static_cast<int>(hc.mn)));
             const int j = s - lane;
-            int hout = 0;
+            PairCarry out{0x80000000u, 0u};
             if (lane < nwp && j >= 0 && j < n) {
-                unsigned long long Ph0;
-                hout = pair_cell<NPL>(L, tc, hin, Ph0);
-                if (STORE) { ulonglong2 v; v.x = L.Pv; v.y = Ph0; store[static_cast<int64_t>(s) * nwp + lane] = v; }
-                if (hb && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(hout);
+                uint32_t nl, nh;
+                out = pair_cell<NPL>(L, tc, cin, nl, nh);
+                const unsigned long long pv64 = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl;
+                if (STORE) { ulonglong2 v; v.x = pv64; v.y = (static_cast<unsigned long long>(nh) << 32) | nl; store[static_cast<int64_t>(s) * nwp + lane] = v; }
+                if (HB && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(pair_carry_byte(out));
                 if (snap_here) {
-                    ulonglong2 v; v.x = L.Pv; v.y = L.Mv;
+                    ulonglong2 v; v.x = pv64; v.y = (static_cast<unsigned long long>(L.Mvh) << 32) | L.Mvl;
                     if (nsnap > 0 && j == sc0 - 1) snapbuf[lane] = v;
                     if (nsnap > 1 && j == sc1 - 1) snapbuf[64 + lane] = v;
                     if (nsnap > 2 && j == sc2 - 1) snapbuf[128 + lane] = v;
                 }
             }
-            hc = hout;
+            hc = out;
         }
     }
-    Pv_out = L.Pv; Mv_out = L.Mv;
+    Pv_out = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl; Mv_out = (static_cast<unsigned long long>(L.Mvh) << 32) | L.Mvl;
+}
+
+template <int NPL, bool STORE>
+__device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
+                                          int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
+                                          ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out,
+                                          int nsnap = 0, int sc0 = 0, int sc1 = 0, int sc2 = 0, ulonglong2* snapbuf = nullptr) {
+    if (hin_buf == nullptr && hout_buf == nullptr)
+        pair_pass_impl<NPL, STORE, false, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
+    else if (hin_buf == nullptr)
+        pair_pass_impl<NPL, STORE, false, true>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
+    else if (hout_buf == nullptr)
+        pair_pass_impl<NPL, STORE, true, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
+    else
+        pair_pass_impl<NPL, STORE, true, true>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
 }
 
 // Last column of the sub-problem's matrix: out[i] = ED(rows[:i], all columns), i = 0 .. m.  Returns out[m].
@@ -327,7 +340,7 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
     // at once, and only the cells that end a run are taken singly.  i, j and everything derived from them are wave-uniform.
     int i = m, j = n;                                 // current cell (rows 1..m, columns 1..n; 0 = boundary)
     int cw = -1, cj0 = -1;                            // cache: lane c holds cell (word cw, column cj0 - c)
-    uint32_t pv_lo = 0, pv_hi = 0, ph_lo = 0, ph_hi = 0;
+    uint32_t pv_lo = 0, pv_hi = 0, ph_lo = 0, ph_hi = 0;        // (ph_*: the complement of the horizontal plus-deltas, as stored)
     const int64_t base = q0 + t0;
     while (i > 0 && j > 0) {
         const int w = (i - 1) >> 6, b = (i - 1) & 63;
@@ -347,7 +360,7 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
         const int t = lane - c, bit = b - t;          // this lane's cell of the diagonal: (i - t, j - t), bit `bit` of word w
         const bool ok = t >= 0 && bit >= 0 && j - t >= 1;
         const uint32_t pw = (bit & 32) ? pv_hi : pv_lo, hw = (bit & 32) ? ph_hi : ph_lo;
-        const bool up = ok && ((pw >> (bit & 31)) & 1u) != 0u, left = ok && ((hw >> (bit & 31)) & 1u) != 0u;
+        const bool up = ok && ((pw >> (bit & 31)) & 1u) != 0u, left = ok && ((hw >> (bit & 31)) & 1u) == 0u;     // (the store holds ~Ph: pair_cell.hpp)
         const unsigned long long diag = __ballot(ok && !up && !left) >> c;
         const int run = diag == ~0ull ? 64 : __builtin_ctzll(~diag);
         if (run > 0) {
@@ -440,11 +453,6 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
     // and the right vector of a RIGHT child is a column of the parent's backward pass.  Every computed pass therefore also
     // leaves the columns its next kPairSnap descendants down that side will ask for, and below the root a split costs one
     // pass instead of two (edlib computes both every time; the values are the same numbers).
-    auto run_pass = [&](const PairTask& t, const PairSplitPlan& pl, bool forward, int32_t* out, int off) {
-        const int lw = t.n / 2, rw = t.n - lw;
-        if (forward) pair_columns<NPL>(Q, t.q0, t.m, false, T, t.t0, lw, false, codes, hbuf0, hbuf1, out, pl.nsf, pl.fc[0], pl.fc[1], pl.fc[2], arena + off, t.m + 1, snapbuf);
-        else pair_columns<NPL>(Q, t.q0, t.m, true, T, t.t0 + lw, rw, true, codes, hbuf0, hbuf1, out, pl.nsb, pl.bc[0], pl.bc[1], pl.bc[2], arena + off + pl.nsf * (t.m + 1), t.m + 1, snapbuf);
-    };
     // where the optimal path crosses the middle column (the smallest such row), and the two sub-problems; false: no such row
     auto cut = [&](const PairTask& t, const PairSplitPlan& pl, int off, const int32_t* Lv, const int32_t* Rv, int& best, PairTask& lc, PairTask& rc) -> bool {
         const int m = t.m, lw = t.n / 2, rw = t.n - lw;
@@ -482,32 +490,18 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         return true;
     };
 
+    // A round: the wave decides what it has to do -- at most one pass over a sub-problem's rows (pair_columns) and at most one leaf
+    // (pair_leaf) --, does it at ONE call site each (the pass is inlined in its four carry variants per symbol-plane count: every
+    // further call site is another copy of all of them), and the round's kind decides what happens to the result.
     while (sp > 0) {
         __syncthreads();                               // the stack as the last round left it; left[] / right[] are no longer read
         const PairTask A = pair_task_uniform(stack[sp - 1]);
         const bool A_splits = pair_task_splits(A);
-        if (A_splits && A.lf < 0 && A.rt < 0) {
-            // ---- both vectors to compute (the root; a sub-problem whose ancestors' columns ran out): one pass per wave ----
-            --sp;
-            PairSplitPlan pl = pair_split_plan(A);
-            if (atop + pl.need > acap) { pl.nsf = 0; pl.nsb = 0; pl.need = 0; }
-            const int off = atop;
-            atop += pl.need;
-            run_pass(A, pl, wv == 0, wv == 0 ? left : right, off);
-            __syncthreads();                           // (work-group fence + barrier: the other wave's vector is in HBM scratch)
-            int best = A.best;
-            PairTask lc, rc;
-            const bool ok = cut(A, pl, off, left, right, best, lc, rc);
-            if (A.best < 0) distance = best;
-            if (!ok || sp + 2 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
-            if (threadIdx.x == 0) { stack[sp] = rc; stack[sp + 1] = lc; }
-            sp += 2;
-            continue;
-        }
-        // ---- a round of sub-problems that need one wave each: a leaf, an empty one, a split with an inherited vector ----
+        const bool both = A_splits && A.lf < 0 && A.rt < 0;      // both vectors to compute (the root; a sub-problem whose ancestors' columns ran out): one pass per wave
         PairTask B = A;
         bool two = false, B_splits = false;
-        if (sp >= 2) {
+        if (!both && sp >= 2) {
+            // a round of sub-problems that need one wave each: a leaf, an empty one, a split with an inherited vector
             B = pair_task_uniform(stack[sp - 2]);
             B_splits = pair_task_splits(B);
             two = !(B_splits && B.lf < 0 && B.rt < 0);
@@ -520,28 +514,52 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
         if (!two || !B_splits || atop + pb.need > acap) { pb.nsf = 0; pb.nsb = 0; pb.need = 0; }
         const int offb = atop;
         atop += pb.need;
+        // this wave's sub-problem
+        const bool mine_is_A = both || wv == 0;
+        const bool active = both || wv == 0 || two;
+        const PairTask& t = mine_is_A ? A : B;
+        const PairSplitPlan& pl = mine_is_A ? pa : pb;
+        const int off = mine_is_A ? offa : offb;
+        const bool splits = mine_is_A ? A_splits : B_splits;
+        int32_t* mine = wv == 0 ? left : right;                  // the vector this wave computes
+        const int64_t base = static_cast<int64_t>(t.q0) + t.t0;
+        const bool empty = t.m == 0 || t.n == 0;
+        const bool leaf = active && !empty && !splits;
+        // the pass: a split's forward / backward half (in a `both` round wave 0 goes forwards, wave 1 backwards; otherwise the side
+        // that is not inherited), or -- a leaf at the root, whose distance no split has provided -- forwards over all the columns
+        const bool do_pass = active && !empty && (splits || t.best < 0);
+        if (do_pass) {
+            const int lw = splits ? t.n / 2 : t.n, rw = t.n - lw;
+            const bool forward = !splits || (both ? wv == 0 : !pl.have_l);
+            const int ns = !splits ? 0 : forward ? pl.nsf : pl.nsb;
+            const int* sc = forward ? pl.fc : pl.bc;
+            const int d = pair_columns<NPL>(Q, t.q0, t.m, !forward, T, forward ? t.t0 : t.t0 + lw, forward ? lw : rw, !forward, codes, hbuf0, hbuf1, mine,
+                                            ns, sc[0], sc[1], sc[2], arena + off + (forward ? 0 : pl.nsf * (t.m + 1)), t.m + 1, snapbuf);
+            if (!splits) distance = d;
+        }
+        if (leaf) pair_leaf<NPL>(Q, t.q0, t.m, T, t.t0, t.n, codes, hbuf0, hbuf1, store, ops);
+        if (active && empty) {
+            if (t.m == 0) { for (int k = lane; k < t.n; k += 64) ops[base + k] = 'D'; if (t.best < 0) distance = t.n; }
+            else { for (int k = lane; k < t.m; k += 64) ops[base + k] = 'I'; if (t.best < 0) distance = t.m; }
+        }
+        if (both) {
+            __syncthreads();                           // (work-group fence + barrier: the other wave's vector is in HBM scratch)
+            int best = A.best;
+            PairTask lc, rc;
+            const bool ok = cut(A, pa, offa, left, right, best, lc, rc);
+            if (A.best < 0) distance = best;
+            if (!ok || sp + 2 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
+            if (threadIdx.x == 0) { stack[sp] = rc; stack[sp + 1] = lc; }
+            sp += 2;
+            continue;
+        }
         int nk = 0;
         PairTask k0 = A, k1 = A;
-        if (wv == 0 || two) {
-            const PairTask& t = wv == 0 ? A : B;
-            const PairSplitPlan& pl = wv == 0 ? pa : pb;
-            const int off = wv == 0 ? offa : offb;
-            const bool splits = wv == 0 ? A_splits : B_splits;
-            const int64_t base = static_cast<int64_t>(t.q0) + t.t0;
-            if (t.m == 0) { for (int k = lane; k < t.n; k += 64) ops[base + k] = 'D'; if (t.best < 0) distance = t.n; }
-            else if (t.n == 0) { for (int k = lane; k < t.m; k += 64) ops[base + k] = 'I'; if (t.best < 0) distance = t.m; }
-            else if (!splits) {
-                // a leaf at the root: the distance is not known from a split; one extra forward pass provides it
-                if (t.best < 0) distance = pair_columns<NPL>(Q, t.q0, t.m, false, T, t.t0, t.n, false, codes, hbuf0, hbuf1, left);
-                pair_leaf<NPL>(Q, t.q0, t.m, T, t.t0, t.n, codes, hbuf0, hbuf1, store, ops);
-            } else {
-                int32_t* mine = wv == 0 ? left : right;          // the one vector this sub-problem computes
-                run_pass(t, pl, !pl.have_l, mine, off);
-                const int32_t* Lv = pl.have_l ? arena + t.lf : mine;
-                const int32_t* Rv = pl.have_r ? arena + t.rt : mine;
-                int best = t.best;
-                nk = cut(t, pl, off, Lv, Rv, best, k1, k0) ? 2 : -1;
-            }
+        if (active && splits) {
+            const int32_t* Lv = pl.have_l ? arena + t.lf : mine;
+            const int32_t* Rv = pl.have_r ? arena + t.rt : mine;
+            int best = t.best;
+            nk = cut(t, pl, off, Lv, Rv, best, k1, k0) ? 2 : -1;
         }
         if (lane == 0) { kids[wv].k[0] = k0; kids[wv].k[1] = k1; nkids[wv] = nk; }
         __syncthreads();
@@ -557,8 +575,13 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
     return distance;
 }
 
-// One team (two waves) per overlap, persistent over the work queue.
+// One team (two waves) per overlap, persistent over the work queue.  The kernels of this file are compiled in a translation unit of
+// their own (engine_pair.hip: the passes are inlined in four carry variants per symbol-plane count, two minutes of compile time that
+// engine.hip's other kernels need not wait for); engine.hip sees the declarations and launches them.
 constexpr int kPairThreads = 128;
+#if !defined(RCN_PAIR_TU) && !defined(RCN_ONE_TU)
+__global__ void k_pair_align(PairParams P);
+#else
 __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
     __shared__ uint8_t codes[512];          // [raw query byte] -> plane code of the (complemented) symbol; [256 + raw target byte] -> plane code
     __shared__ uint8_t present[256];        // raw bytes of the stored query segment
@@ -634,6 +657,8 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
     }
 }
 
+#endif  // RCN_PAIR_TU
+
 // ---- breaking points from the op bytes (Overlap::find_breaking_points' walk, reference src/overlap.cpp:226-292) ----
 // One wave per overlap, 64 path positions per step: two wave scans turn "consumes a target base" / "consumes a query
 // base" into positions; the match columns of a step that fall into one window are a contiguous lane range, its first
@@ -647,6 +672,9 @@ struct OpsWalkParams {
     uint64_t n_overlaps; uint64_t W;
 };
 
+#if !defined(RCN_PAIR_TU) && !defined(RCN_ONE_TU)
+__global__ void k_ops_breaking_points(OpsWalkParams C);
+#else
 __global__ __launch_bounds__(256) void k_ops_breaking_points(OpsWalkParams C) {
     const int lane = threadIdx.x & 63;
     const uint64_t o = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -696,5 +724,7 @@ __global__ __launch_bounds__(256) void k_ops_breaking_points(OpsWalkParams C) {
         }
     }
 }
+
+#endif  // RCN_PAIR_TU
 
 }  // namespace rcn

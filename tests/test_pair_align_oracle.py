@@ -31,3 +31,18 @@ def test_oracle_edge_cases(P):
                  (b"ACGTNNACGT", b"ACGTACGT"), (b"GATTACA" * 30, b"GATACA" * 30)]:
         assert nw_oracle.cigar(q, t)[0] == P.align_cigar(q, t).encode(), (q, t)
     assert nw_oracle.reverse_complement(b"AACGTN") == b"NACGTT"
+
+
+def test_device_cell_form_equals_the_textbook_recurrence(tmp_path):
+    """racon_amd/csrc/pair_cell.hpp -- the cell of the device aligner as it is issued on gfx950 (three-input bit operations, the
+    horizontal plus-word complemented, carries handed over in bit 31) -- compiled for the CPU: every word of every column equals the
+    64-bit textbook form (state, stored deltas, carries), and the column scores equal a plain edit-distance DP, for 2 / 3 / 8 symbol
+    planes and symbols the query lacks (tests/emul/pair_cell_main.cpp)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "pair_cell_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(here, "emul", "pair_cell_main.cpp")])
+    out = subprocess.run([exe, "150"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "pair_cell ok" in out.stdout

@@ -35,6 +35,12 @@ if has new; then
       -m gpu -q -x --durations=12 > "$OUT/pytest_new.log" 2>&1
   echo "pytest exit $?" >> "$OUT/pytest_new.log"; tail -30 "$OUT/pytest_new.log"
 fi
+if has align; then
+  # the device pairwise aligner: its parity tests, the cfg2-shaped bench line (3000 overlaps), TCUPS at size come with `shardtime`
+  timeout 1500 python -m pytest tests/test_gpu_pair_align.py -m gpu -q -x --durations=5 > "$OUT/pytest_align.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_align.log"; tail -12 "$OUT/pytest_align.log"
+  timeout 900 python tools/align_bench.py > "$OUT/align_bench.json" 2> "$OUT/align_bench.err"; echo "align_bench exit $?"; cut -c1-900 "$OUT/align_bench.json"
+fi
 if has shardtime; then
   # where a shard's time goes when a job is cut into more window ranges than devices (cfg5 at a quarter of its size, four sequential shards)
   python - <<'PY'
