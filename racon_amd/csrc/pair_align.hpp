@@ -107,8 +107,15 @@ template <int NPL, bool STORE, bool HIN, bool HB>
 __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
                                                int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
                                                ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out,
-                                               int nsnap, int sc0, int sc1, int sc2, ulonglong2* snapbuf) {
+                                               int nsnap, int sc0, int sc1, int sc2, ulonglong2* snapbuf, uint32_t* ring) {
     const int lane = threadIdx.x & 63;
+    // The column symbols on their way down the lanes.  Lane l works on column s - l at step s; the code used to travel with it (one
+    // v_readlane + v_mov + DPP shift per step, then one bit-field extract per plane for the cell's masks).  Up to four planes the
+    // masks now stand ready-made in a ring in LDS -- this wave's, 128 columns + a mirror of the first 64 so that a block's 64 steps
+    // read ring[((s0 - l) & 127) + k] without wrapping -- written once per block of 64 columns, read by every lane once per step:
+    // no vector instruction per step at all (the LDS port is otherwise idle: 8 or 16 bytes per lane and step are ~15-25 % of it).
+    constexpr bool RING = NPL <= 4;
+    constexpr int EW = NPL <= 2 ? 2 : 4;             // dwords per ring entry
     PairLane<NPL> L;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) { L.pl[k] = 0u; L.ph[k] = 0u; }
@@ -157,6 +164,16 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
             hraw = (HIN && col < n) ? hin_buf[col] : 1;
             tbuf = col < n ? static_cast<int>(codes[256 + traw]) : 7;
             hbuf = hraw;
+            if (RING) {
+                const PairSym<NPL> y = pair_sym_of<NPL>(tbuf);
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int k = 0; k < NPL && k < 4; ++k) w[k] = y.mk[k];
+                const int slot = (s0 >> 6) & 1;
+                uint32_t* e = ring + (slot * 64 + lane) * EW;
+                if (EW == 2) { *reinterpret_cast<uint2*>(e) = make_uint2(w[0], w[1]); if (slot == 0) *reinterpret_cast<uint2*>(e + 128 * EW) = make_uint2(w[0], w[1]); }
+                else { *reinterpret_cast<uint4*>(e) = make_uint4(w[0], w[1], w[2], w[3]); if (slot == 0) *reinterpret_cast<uint4*>(e + 128 * EW) = make_uint4(w[0], w[1], w[2], w[3]); }
+            }
         }
         // a column whose vector a later sub-problem inherits (pair_align_one): its words pass it during [c - 1, c - 1 + nwp - 1]
         bool snap_here = false;
@@ -169,34 +186,68 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
             // last word: every lane shifts its own two bits per step into two registers (one v_alignbit each), and at the end
             // of the block the last word's 2 x 64 bits are handed out, one column per lane, and stored once.
             uint32_t accP[2] = {0u, 0u}, accN[2] = {0u, 0u};
+            const uint32_t* rp = ring + ((s0 - lane) & 127) * EW;          // this lane's column at step s0; + one entry per step
+            auto ring_at = [&](int k) -> PairSym<NPL> {
+                PairSym<NPL> y;
+                uint32_t w[4];
+                if (EW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(rp + k * EW); w[0] = v.x; w[1] = v.y; w[2] = 0u; w[3] = 0u; }
+                else { const uint4 v = *reinterpret_cast<const uint4*>(rp + k * EW); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) y.mk[q] = w[q & 3];
+                return y;
+            };
+            // two steps' masks per read (one ds_read2_b64 with two planes), two such pairs in flight: a pair is read again as soon as
+            // its two steps are done and used two steps later -- no copies, the LDS latency under ~60 vector instructions
+            PairSym<NPL> ya[2], yb[2];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) { ya[0].mk[q] = 0u; ya[1].mk[q] = 0u; yb[0].mk[q] = 0u; yb[1].mk[q] = 0u; }
+            if (RING) { ya[0] = ring_at(0); ya[1] = ring_at(1); yb[0] = ring_at(2); yb[1] = ring_at(3); }
+            auto step = [&](int k, const PairSym<NPL>& yk, uint32_t& aP, uint32_t& aN) {
+                PairSym<NPL> y = yk;
+                if (!RING) {
+                    const int t_new = __builtin_amdgcn_readlane(tbuf, k);
+                    tc = pair_shr1(t_new, tc);
+                    y = pair_sym_of<NPL>(tc);
+                }
+                PairCarry cin;
+                if (HIN) {
+                    const PairCarry top = pair_carry_of(__builtin_amdgcn_readlane(hbuf, k));
+                    cin.np = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.np), static_cast<int>(hc.np)));
+                    cin.mn = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.mn), static_cast<int>(hc.mn)));
+                } else {
+                    cin.np = pair_shr1_zero(hc.np); cin.mn = pair_shr1_zero(hc.mn);
+                }
+                uint32_t nl, nh;
+                hc = pair_cell<NPL>(L, y, cin, nl, nh);
+                if (STORE) {
+                    if (lane < nwp) {
+                        ulonglong2 v;
+                        v.x = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl; v.y = (static_cast<unsigned long long>(nh) << 32) | nl;
+                        store[static_cast<int64_t>(s0 + k) * nwp + lane] = v;
+                    }
+                }
+                if (HB) { aP = pc_alignbit(aP, hc.np, 31); aN = pc_alignbit(aN, hc.mn, 31); }
+            };
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 uint32_t aP = 0u, aN = 0u;
-#pragma unroll 2
-                for (int kk = 0; kk < 32; ++kk) {
+#pragma unroll 1
+                for (int kk = 0; kk < 32; kk += 4) {
                     const int k = 32 * half + kk;
-                    const int t_new = __builtin_amdgcn_readlane(tbuf, k);
-                    tc = pair_shr1(t_new, tc);
-                    PairCarry cin;
-                    if (HIN) {
-                        const PairCarry top = pair_carry_of(__builtin_amdgcn_readlane(hbuf, k));
-                        cin.np = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.np), static_cast<int>(hc.np)));
-                        cin.mn = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.mn), static_cast<int>(hc.mn)));
-                    } else {
-                        cin.np = pair_shr1_zero(hc.np); cin.mn = pair_shr1_zero(hc.mn);
-                    }
-                    uint32_t nl, nh;
-                    hc = pair_cell<NPL>(L, tc, cin, nl, nh);
-                    if (STORE) {
-                        if (lane < nwp) {
-                            ulonglong2 v;
-                            v.x = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl; v.y = (static_cast<unsigned long long>(nh) << 32) | nl;
-                            store[static_cast<int64_t>(s0 + k) * nwp + lane] = v;
-                        }
-                    }
-                    if (HB) { aP = pc_alignbit(aP, hc.np, 31); aN = pc_alignbit(aN, hc.mn, 31); }
+                    step(k, ya[0], aP, aN); step(k + 1, ya[1], aP, aN);
+                    if (RING) { ya[0] = ring_at(k + 4); ya[1] = ring_at(k + 5); }      // (the block's last trip reads four entries past it: the ring has them)
+                    step(k + 2, yb[0], aP, aN); step(k + 3, yb[1], aP, aN);
+                    if (RING) { yb[0] = ring_at(k + 6); yb[1] = ring_at(k + 7); }
                 }
                 accP[half] = aP; accN[half] = aN;
+            }
+            if (RING) {
+                // the ramp after the block hands the code on lane by lane again: this lane's column of the block's last step
+                const PairSym<NPL> y = ring_at(63);
+                int code = 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) code |= static_cast<int>(y.mk[q] & (1u << q));
+                tc = code;
             }
             if (HB) {
                 // the last word was at column s0 + k - (nwp - 1) at step k; step k = 32 half + kk sits at bit 31 - kk of its half
@@ -225,7 +276,7 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
             PairCarry out{0x80000000u, 0u};
             if (lane < nwp && j >= 0 && j < n) {
                 uint32_t nl, nh;
-                out = pair_cell<NPL>(L, tc, cin, nl, nh);
+                out = pair_cell<NPL>(L, pair_sym_of<NPL>(tc), cin, nl, nh);
                 const unsigned long long pv64 = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl;
                 if (STORE) { ulonglong2 v; v.x = pv64; v.y = (static_cast<unsigned long long>(nh) << 32) | nl; store[static_cast<int64_t>(s) * nwp + lane] = v; }
                 if (HB && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(pair_carry_byte(out));
@@ -245,16 +296,16 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
 template <int NPL, bool STORE>
 __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
                                           int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
-                                          ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out,
+                                          ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out, uint32_t* ring,
                                           int nsnap = 0, int sc0 = 0, int sc1 = 0, int sc2 = 0, ulonglong2* snapbuf = nullptr) {
     if (hin_buf == nullptr && hout_buf == nullptr)
-        pair_pass_impl<NPL, STORE, false, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
+        pair_pass_impl<NPL, STORE, false, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf, ring);
     else if (hin_buf == nullptr)
-        pair_pass_impl<NPL, STORE, false, true>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
+        pair_pass_impl<NPL, STORE, false, true>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf, ring);
     else if (hout_buf == nullptr)
-        pair_pass_impl<NPL, STORE, true, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
+        pair_pass_impl<NPL, STORE, true, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf, ring);
     else
-        pair_pass_impl<NPL, STORE, true, true>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf);
+        pair_pass_impl<NPL, STORE, true, true>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin_buf, hout_buf, store, Pv_out, Mv_out, nsnap, sc0, sc1, sc2, snapbuf, ring);
 }
 
 // Last column of the sub-problem's matrix: out[i] = ED(rows[:i], all columns), i = 0 .. m.  Returns out[m].
@@ -262,7 +313,7 @@ __device__ __forceinline__ void pair_pass(const PairView& Q, int64_t q0, int m, 
 constexpr int kPairSnap = 3;
 template <int NPL>
 __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
-                                            const uint8_t* codes, uint8_t* hbuf0, uint8_t* hbuf1, int32_t* out,
+                                            const uint8_t* codes, uint8_t* hbuf0, uint8_t* hbuf1, int32_t* out, uint32_t* ring,
                                             int nsnap = 0, int sc0 = 0, int sc1 = 0, int sc2 = 0, int32_t* snap_out = nullptr, int snap_stride = 0,
                                             ulonglong2* snapbuf = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -280,7 +331,7 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
         const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
         uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
         unsigned long long Pv, Mv;
-        pair_pass<NPL, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv, nsnap, sc0, sc1, sc2, snapbuf);
+        pair_pass<NPL, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv, ring, nsnap, sc0, sc1, sc2, snapbuf);
         pair_wave_fence();                             // the carries of this pass are read (by other lanes) in the next one
         // scores of this pass's rows: running sum of the vertical deltas down the column
         const int rows_here = lane < nwp ? min(64, m - (w0 + lane) * 64) : 0;
@@ -315,7 +366,7 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
 // plain traceback of a leaf (up, then left, else diagonal) over the stored delta words
 template <int NPL>
 __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, const PairView& T, int64_t t0, int n, const uint8_t* codes,
-                                          uint8_t* hbuf0, uint8_t* hbuf1, ulonglong2* store, uint8_t* ops) {
+                                          uint8_t* hbuf0, uint8_t* hbuf1, ulonglong2* store, uint8_t* ops, uint32_t* ring) {
     const int lane = threadIdx.x & 63;
     const int nb = (m + 63) / 64;
     // forward passes with the (Pv, Ph) store; pass p starts at store + pass_off(p)
@@ -326,7 +377,7 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
             const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
             uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
             unsigned long long Pv, Mv;
-            pair_pass<NPL, true>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv);
+            pair_pass<NPL, true>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv, ring);
             pair_wave_fence();
             off += static_cast<int64_t>(n + nwp - 1) * nwp;
         }
@@ -425,7 +476,7 @@ struct PairKids { PairTask k[2]; };
 
 template <int NPL>
 __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairView& Q, const PairView& T, const uint8_t* codes, PairTask* stack,
-                                              PairKids* kids, int* nkids, uint8_t* slot, uint8_t* ops) {
+                                              PairKids* kids, int* nkids, uint8_t* slot, uint8_t* ops, uint32_t* ring) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     // scratch of this team: left[] / right[] and the arena are shared (one wave writes, both read after the barrier), the carry
     // buffers, the leaf store and the snapshot words are per wave
@@ -533,11 +584,11 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
             const bool forward = !splits || (both ? wv == 0 : !pl.have_l);
             const int ns = !splits ? 0 : forward ? pl.nsf : pl.nsb;
             const int* sc = forward ? pl.fc : pl.bc;
-            const int d = pair_columns<NPL>(Q, t.q0, t.m, !forward, T, forward ? t.t0 : t.t0 + lw, forward ? lw : rw, !forward, codes, hbuf0, hbuf1, mine,
+            const int d = pair_columns<NPL>(Q, t.q0, t.m, !forward, T, forward ? t.t0 : t.t0 + lw, forward ? lw : rw, !forward, codes, hbuf0, hbuf1, mine, ring,
                                             ns, sc[0], sc[1], sc[2], arena + off + (forward ? 0 : pl.nsf * (t.m + 1)), t.m + 1, snapbuf);
             if (!splits) distance = d;
         }
-        if (leaf) pair_leaf<NPL>(Q, t.q0, t.m, T, t.t0, t.n, codes, hbuf0, hbuf1, store, ops);
+        if (leaf) pair_leaf<NPL>(Q, t.q0, t.m, T, t.t0, t.n, codes, hbuf0, hbuf1, store, ops, ring);
         if (active && empty) {
             if (t.m == 0) { for (int k = lane; k < t.n; k += 64) ops[base + k] = 'D'; if (t.best < 0) distance = t.n; }
             else { for (int k = lane; k < t.m; k += 64) ops[base + k] = 'I'; if (t.best < 0) distance = t.m; }
@@ -579,6 +630,7 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
 // their own (engine_pair.hip: the passes are inlined in four carry variants per symbol-plane count, two minutes of compile time that
 // engine.hip's other kernels need not wait for); engine.hip sees the declarations and launches them.
 constexpr int kPairThreads = 128;
+constexpr int kPairRing = 198;       // entries of a wave's symbol ring: 128 columns, the mirror of the first 64, the read-ahead of a block's last trip
 #if !defined(RCN_PAIR_TU) && !defined(RCN_ONE_TU)
 __global__ void k_pair_align(PairParams P);
 #else
@@ -592,6 +644,7 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
     __shared__ unsigned int s_work;
     __shared__ int s_nsym;
     __shared__ int s_foreign;               // the target segment holds a symbol the query does not
+    __shared__ __attribute__((aligned(16))) uint32_t symring[2][kPairRing * 4];     // per wave: the column symbols' plane masks on their way down the lanes (pair_pass_impl)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t* slot = P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes;
     for (;;) {
@@ -650,9 +703,9 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
         }
         __syncthreads();
         int d;
-        if (nsym <= 4 && __builtin_amdgcn_readfirstlane(s_foreign) == 0) d = pair_align_one<2>(P, Q, T, codes, stack, kids, nkids, slot, ops);
-        else if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, kids, nkids, slot, ops);
-        else d = pair_align_one<8>(P, Q, T, codes, stack, kids, nkids, slot, ops);
+        if (nsym <= 4 && __builtin_amdgcn_readfirstlane(s_foreign) == 0) d = pair_align_one<2>(P, Q, T, codes, stack, kids, nkids, slot, ops, symring[wv]);
+        else if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, kids, nkids, slot, ops, symring[wv]);
+        else d = pair_align_one<8>(P, Q, T, codes, stack, kids, nkids, slot, ops, symring[wv]);
         if (tid == 0) P.dist[o] = d;
     }
 }

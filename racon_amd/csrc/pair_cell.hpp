@@ -60,20 +60,33 @@ struct PairLane {                    // what a lane keeps of its word between th
 // whatever the words held.  The top boundary (+1 per column) is {0, 0}.
 struct PairCarry { uint32_t np, mn; };
 
-// One cell: the lane's word against the column whose symbol code is `tc` (bit k of tc = plane k), carry `cin` from the word above.
+// The column's symbol code as the cell takes it: one 0 / ~0 mask per plane (bit k of the code).  The steady state of a pass reads
+// them ready-made from LDS (pair_align.hpp), the ramps make them with one sign-extending bit-field extract per plane.
+template <int NPL>
+struct PairSym { uint32_t mk[NPL]; };
+template <int NPL>
+RCN_PC_HD PairSym<NPL> pair_sym_of(int tc) {
+    PairSym<NPL> y;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NPL; ++k) y.mk[k] = static_cast<uint32_t>((tc << (31 - k)) >> 31);
+    return y;
+}
+
+// One cell: the lane's word against the column with the plane masks `y`, carry `cin` from the word above.
 // Returns the carry for the word below; nph_l / nph_h = the COMPLEMENT of the word's horizontal plus-deltas before the shift (a
 // leaf stores them for its traceback).
 template <int NPL>
-RCN_PC_HD PairCarry pair_cell(PairLane<NPL>& L, int tc, PairCarry cin, uint32_t& nph_l, uint32_t& nph_h) {
+RCN_PC_HD PairCarry pair_cell(PairLane<NPL>& L, const PairSym<NPL>& y, PairCarry cin, uint32_t& nph_l, uint32_t& nph_h) {
     // Eq: rows whose code agrees with the column's in every plane
     uint32_t el = L.vl, eh = L.vh;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < NPL; ++k) {
-        const uint32_t mk = static_cast<uint32_t>((tc << (31 - k)) >> 31);                  // 0 / ~0 (one sign-extending bit-field extract)
-        el = pc_bitop3<RCN_TT(kTA & ~(kTB ^ kTC))>(el, L.pl[k], mk);
-        eh = pc_bitop3<RCN_TT(kTA & ~(kTB ^ kTC))>(eh, L.ph[k], mk);
+        el = pc_bitop3<RCN_TT(kTA & ~(kTB ^ kTC))>(el, L.pl[k], y.mk[k]);
+        eh = pc_bitop3<RCN_TT(kTA & ~(kTB ^ kTC))>(eh, L.ph[k], y.mk[k]);
     }
     const uint32_t hn = cin.mn >> 31;
     const uint32_t xvl = el | L.Mvl, xvh = eh | L.Mvh;                                      // Xv = Eq | Mv

@@ -60,7 +60,7 @@ static int run(std::mt19937_64& rng, int m, int n, int nsym, double sim) {
             int op, on; uint64_t Ph0;
             ref_cell(R[w], Eq, hp, hn, op, on, Ph0);
             uint32_t nl, nh;
-            const PairCarry o = pair_cell<NPL>(L[w], code, c, nl, nh);
+            const PairCarry o = pair_cell<NPL>(L[w], pair_sym_of<NPL>(code), c, nl, nh);
             const uint64_t Pv = (static_cast<uint64_t>(L[w].Pvh) << 32) | L[w].Pvl, Mv = (static_cast<uint64_t>(L[w].Mvh) << 32) | L[w].Mvl;
             const uint64_t nPh = (static_cast<uint64_t>(nh) << 32) | nl;
             // rows past the end of the query hold garbage in both forms; the recurrence only carries upwards, so the rows that exist agree
