@@ -33,6 +33,18 @@
 
 namespace rcn {
 
+#ifdef RCN_PROF_PAIR
+// profiling build (make pairprof): wave clocks by phase, summed over all waves since the library was loaded
+//  0 steady blocks  1 ramp / tail / snapshot blocks  2 row load  3 emit (scores of a pass)  4 leaf walk  5 cut  6 symbol set-up
+//  7 whole overlap (per wave)  8 barriers  9 steady steps  10 general steps  11 passes  12 leaves  13 cuts  14 sum of words per steady step (lane use)
+__device__ unsigned long long g_pairprof[16];
+#define RCN_PP_T(var) const long long var = clock64()
+#define RCN_PP_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_pairprof[k], static_cast<unsigned long long>(v)); } while (0)
+#else
+#define RCN_PP_T(var) do {} while (0)
+#define RCN_PP_ADD(k, v) do {} while (0)
+#endif
+
 struct PairParams {
     const uint8_t* bases;            // resident read set (forward strand)
     const uint64_t* q_pos;           // [n] byte offset of the first base of the query segment (forward storage)
@@ -107,8 +119,11 @@ template <int NPL, bool STORE, bool HIN, bool HB>
 __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, int m, bool qflip, const PairView& T, int64_t t0, int n, bool tflip,
                                                int w0, int nwp, const uint8_t* codes, const uint8_t* hin_buf, uint8_t* hout_buf,
                                                ulonglong2* store, unsigned long long& Pv_out, unsigned long long& Mv_out,
-                                               int nsnap, int sc0, int sc1, int sc2, ulonglong2* snapbuf, uint32_t* ring) {
+                                               int nsnap_, int sc0_, int sc1_, int sc2_, ulonglong2* snapbuf, uint32_t* ring) {
     const int lane = threadIdx.x & 63;
+    // (all of these are the same in every lane; said so, the loop counters and range tests stay in scalar registers)
+    m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n); w0 = __builtin_amdgcn_readfirstlane(w0); nwp = __builtin_amdgcn_readfirstlane(nwp);
+    const int nsnap = __builtin_amdgcn_readfirstlane(nsnap_), sc0 = __builtin_amdgcn_readfirstlane(sc0_), sc1 = __builtin_amdgcn_readfirstlane(sc1_), sc2 = __builtin_amdgcn_readfirstlane(sc2_);
     // The column symbols on their way down the lanes.  Lane l works on column s - l at step s; the code used to travel with it (one
     // v_readlane + v_mov + DPP shift per step, then one bit-field extract per plane for the cell's masks).  Up to four planes the
     // masks now stand ready-made in a ring in LDS -- this wave's, 128 columns + a mirror of the first 64 so that a block's 64 steps
@@ -116,6 +131,10 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
     // no vector instruction per step at all (the LDS port is otherwise idle: 8 or 16 bytes per lane and step are ~15-25 % of it).
     constexpr bool RING = NPL <= 4;
     constexpr int EW = NPL <= 2 ? 2 : 4;             // dwords per ring entry
+    RCN_PP_T(pp0__);
+#ifdef RCN_PROF_PAIR
+    long long pp_steady__ = 0, pp_nsteady__ = 0;
+#endif
     PairLane<NPL> L;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) { L.pl[k] = 0u; L.ph[k] = 0u; }
@@ -149,6 +168,7 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
         const unsigned long long valid = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);     // (rows past the end repeat the last one: masked here)
         L.vl = static_cast<uint32_t>(valid); L.vh = static_cast<uint32_t>(valid >> 32);
     }
+    RCN_PP_T(pp1__);
     // the target is stored forwards (PairView::rc is the query's): column `col` of this pass
     auto tcol = [&](int col) -> uint32_t { return T.p[tflip ? t0 + n - 1 - col : t0 + col]; };
     uint32_t traw = lane < n ? tcol(lane) : 0u;                                  // raw symbol / carry-in of the block's columns, fetched a block ahead
@@ -180,22 +200,23 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
         if (nsnap > 0) snap_here |= sc0 - 1 <= s0 + 63 && sc0 + nwp - 2 >= s0;
         if (nsnap > 1) snap_here |= sc1 - 1 <= s0 + 63 && sc1 + nwp - 2 >= s0;
         if (nsnap > 2) snap_here |= sc2 - 1 <= s0 + 63 && sc2 + nwp - 2 >= s0;
+        const uint32_t* rp = ring + ((s0 - lane) & 127) * EW;              // this lane's column at step s0; + one entry per step
+        auto ring_at = [&](int k) -> PairSym<NPL> {
+            PairSym<NPL> y;
+            uint32_t w[4];
+            if (EW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(rp + k * EW); w[0] = v.x; w[1] = v.y; w[2] = 0u; w[3] = 0u; }
+            else { const uint4 v = *reinterpret_cast<const uint4*>(rp + k * EW); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) y.mk[q] = w[q & 3];
+            return y;
+        };
         if (s0 >= nwp - 1 && s0 + 63 < n && !snap_here) {
             // steady state: at every step of the block every word of the pass has a column in [0, n) -- no range tests, no
             // exec-mask regions (lanes past the pass's words compute on valid = 0; nobody reads them).  The carries out of the
             // last word: every lane shifts its own two bits per step into two registers (one v_alignbit each), and at the end
             // of the block the last word's 2 x 64 bits are handed out, one column per lane, and stored once.
+            RCN_PP_T(ppb__);
             uint32_t accP[2] = {0u, 0u}, accN[2] = {0u, 0u};
-            const uint32_t* rp = ring + ((s0 - lane) & 127) * EW;          // this lane's column at step s0; + one entry per step
-            auto ring_at = [&](int k) -> PairSym<NPL> {
-                PairSym<NPL> y;
-                uint32_t w[4];
-                if (EW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(rp + k * EW); w[0] = v.x; w[1] = v.y; w[2] = 0u; w[3] = 0u; }
-                else { const uint4 v = *reinterpret_cast<const uint4*>(rp + k * EW); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) y.mk[q] = w[q & 3];
-                return y;
-            };
             // two steps' masks per read (one ds_read2_b64 with two planes), two such pairs in flight: a pair is read again as soon as
             // its two steps are done and used two steps later -- no copies, the LDS latency under ~60 vector instructions
             PairSym<NPL> ya[2], yb[2];
@@ -241,14 +262,6 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
                 }
                 accP[half] = aP; accN[half] = aN;
             }
-            if (RING) {
-                // the ramp after the block hands the code on lane by lane again: this lane's column of the block's last step
-                const PairSym<NPL> y = ring_at(63);
-                int code = 0;
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) code |= static_cast<int>(y.mk[q] & (1u << q));
-                tc = code;
-            }
             if (HB) {
                 // the last word was at column s0 + k - (nwp - 1) at step k; step k = 32 half + kk sits at bit 31 - kk of its half
                 const int src = nwp - 1;
@@ -260,37 +273,83 @@ __device__ __forceinline__ void pair_pass_impl(const PairView& Q, int64_t q0, in
                 const int sh = 31 - (lane & 31);
                 hout_buf[s0 + lane - (nwp - 1)] = static_cast<uint8_t>(((~wp >> sh) & 1u) | (((wn >> sh) & 1u) << 1));
             }
+#ifdef RCN_PROF_PAIR
+            pp_steady__ += clock64() - ppb__; pp_nsteady__ += 64;
+#endif
             continue;
         }
+        // An edge block: the ramp at the start of a pass (words still waiting for their first column), its tail (words that are
+        // through), a block that holds a column whose vector a later sub-problem inherits.  Same straight-line step as the steady
+        // state -- every lane computes -- and a lane whose column is outside [0, n) keeps its state by four selects; no exec-mask
+        // region around the cell, no taken branch per step (as branches the edge blocks cost 3.2 x a steady step each, and with
+        // three inherited columns per pass they were a quarter of all steps: profiles/r06/g_pair_phase_clocks.txt).  The carry
+        // variants are decided at run time here (injection from hbuf, which holds the top boundary when no word is above).
         const int kend = min(64, steps - s0);
-        for (int k = 0; k < kend; ++k) {
-            const int s = s0 + k;
-            // lane l takes over the column lane l - 1 had; lane 0 starts column s
-            const int t_new = __builtin_amdgcn_readlane(tbuf, k);
-            tc = pair_shr1(t_new, tc);
-            const PairCarry top = pair_carry_of(__builtin_amdgcn_readlane(hbuf, k));
-            PairCarry cin;
-            cin.np = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.np), static_cast<int>(hc.np)));
-            cin.mn = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.mn), static_cast<int>(hc.mn)));
-            const int j = s - lane;
-            PairCarry out{0x80000000u, 0u};
-            if (lane < nwp && j >= 0 && j < n) {
+        const bool hb = hout_buf != nullptr;
+        uint32_t accP[2] = {0u, 0u}, accN[2] = {0u, 0u};
+        PairSym<NPL> yn;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) yn.mk[q] = 0u;
+        if (RING) yn = ring_at(0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t aP = 0u, aN = 0u;
+            const int kk_end = min(32, kend - 32 * half);
+#pragma unroll 2
+            for (int kk = 0; kk < kk_end; ++kk) {
+                const int k = 32 * half + kk;
+                PairSym<NPL> y = yn;
+                if (RING) yn = ring_at(k + 1);
+                else {
+                    const int t_new = __builtin_amdgcn_readlane(tbuf, k);      // lane l takes over the column lane l - 1 had; lane 0 starts column s
+                    tc = pair_shr1(t_new, tc);
+                    y = pair_sym_of<NPL>(tc);
+                }
+                const PairCarry top = pair_carry_of(__builtin_amdgcn_readlane(hbuf, k));
+                PairCarry cin;
+                cin.np = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.np), static_cast<int>(hc.np)));
+                cin.mn = static_cast<uint32_t>(pair_shr1(static_cast<int>(top.mn), static_cast<int>(hc.mn)));
+                const int j = s0 + k - lane;
+                const bool active = lane < nwp && static_cast<unsigned>(j) < static_cast<unsigned>(n);
+                PairLane<NPL> Lt = L;
                 uint32_t nl, nh;
-                out = pair_cell<NPL>(L, pair_sym_of<NPL>(tc), cin, nl, nh);
-                const unsigned long long pv64 = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl;
-                if (STORE) { ulonglong2 v; v.x = pv64; v.y = (static_cast<unsigned long long>(nh) << 32) | nl; store[static_cast<int64_t>(s) * nwp + lane] = v; }
-                if (HB && lane == nwp - 1) hout_buf[j] = static_cast<uint8_t>(pair_carry_byte(out));
-                if (snap_here) {
-                    ulonglong2 v; v.x = pv64; v.y = (static_cast<unsigned long long>(L.Mvh) << 32) | L.Mvl;
-                    if (nsnap > 0 && j == sc0 - 1) snapbuf[lane] = v;
-                    if (nsnap > 1 && j == sc1 - 1) snapbuf[64 + lane] = v;
-                    if (nsnap > 2 && j == sc2 - 1) snapbuf[128 + lane] = v;
+                hc = pair_cell<NPL>(Lt, y, cin, nl, nh);           // (a lane outside its columns hands down garbage: nobody inside takes it)
+                L.Pvl = active ? Lt.Pvl : L.Pvl; L.Pvh = active ? Lt.Pvh : L.Pvh; L.Mvl = active ? Lt.Mvl : L.Mvl; L.Mvh = active ? Lt.Mvh : L.Mvh;
+                if (hb) { aP = pc_alignbit(aP, hc.np, 31); aN = pc_alignbit(aN, hc.mn, 31); }
+                if (STORE || snap_here) {
+                    if (active) {
+                        const unsigned long long pv64 = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl;
+                        if (STORE) { ulonglong2 v; v.x = pv64; v.y = (static_cast<unsigned long long>(nh) << 32) | nl; store[static_cast<int64_t>(s0 + k) * nwp + lane] = v; }
+                        if (snap_here) {
+                            ulonglong2 v; v.x = pv64; v.y = (static_cast<unsigned long long>(L.Mvh) << 32) | L.Mvl;
+                            if (nsnap > 0 && j == sc0 - 1) snapbuf[lane] = v;
+                            if (nsnap > 1 && j == sc1 - 1) snapbuf[64 + lane] = v;
+                            if (nsnap > 2 && j == sc2 - 1) snapbuf[128 + lane] = v;
+                        }
+                    }
                 }
             }
-            hc = out;
+            if (kk_end > 0 && kk_end < 32) { aP <<= (32 - kk_end); aN <<= (32 - kk_end); }      // step kk of a half sits at bit 31 - kk
+            accP[half] = aP; accN[half] = aN;
+        }
+        if (hb) {
+            const int src = nwp - 1;
+            const uint32_t p0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accP[0]), src));
+            const uint32_t p1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accP[1]), src));
+            const uint32_t n0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accN[0]), src));
+            const uint32_t n1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(accN[1]), src));
+            const uint32_t wp = lane < 32 ? p0 : p1, wn = lane < 32 ? n0 : n1;
+            const int sh = 31 - (lane & 31);
+            const int col = s0 + lane - (nwp - 1);                 // the last word's column at step `lane` of the block
+            if (lane < kend && col >= 0 && col < n) hout_buf[col] = static_cast<uint8_t>(((~wp >> sh) & 1u) | (((wn >> sh) & 1u) << 1));
         }
     }
     Pv_out = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl; Mv_out = (static_cast<unsigned long long>(L.Mvh) << 32) | L.Mvl;
+#ifdef RCN_PROF_PAIR
+    { const long long pp2__ = clock64();
+      RCN_PP_ADD(0, pp_steady__); RCN_PP_ADD(1, pp2__ - pp1__ - pp_steady__); RCN_PP_ADD(2, pp1__ - pp0__); RCN_PP_ADD(9, pp_nsteady__); RCN_PP_ADD(10, steps - pp_nsteady__);
+      RCN_PP_ADD(11, 1); RCN_PP_ADD(14, pp_nsteady__ * nwp); }
+#endif
 }
 
 template <int NPL, bool STORE>
@@ -333,6 +392,7 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
         unsigned long long Pv, Mv;
         pair_pass<NPL, false>(Q, q0, m, qflip, T, t0, n, tflip, w0, nwp, codes, hin, hout, nullptr, Pv, Mv, ring, nsnap, sc0, sc1, sc2, snapbuf);
         pair_wave_fence();                             // the carries of this pass are read (by other lanes) in the next one
+        RCN_PP_T(ppe0__);
         // scores of this pass's rows: running sum of the vertical deltas down the column
         const int rows_here = lane < nwp ? min(64, m - (w0 + lane) * 64) : 0;
         const unsigned long long vmask = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
@@ -358,6 +418,9 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
                 emit(v.x, v.y, scarry[k], snap_out + static_cast<int64_t>(k) * snap_stride);
             }
         }
+#ifdef RCN_PROF_PAIR
+        RCN_PP_ADD(3, clock64() - ppe0__);
+#endif
     }
     pair_wave_fence();                                 // out[] is read by other lanes than the ones that wrote it
     return carry;
@@ -384,6 +447,7 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
     }
     // every full pass has 64 words: pass p starts at p * (n + 63) * 64
     const int64_t pass_stride = static_cast<int64_t>(n + 63) * 64;
+    RCN_PP_T(ppw0__);
     // The walk.  One move at a time it was ~70 instructions per move with one useful lane -- nearly half of all the kernel's
     // instructions on 10 kb reads -- and nine moves in ten are diagonal: lane l of the cache already holds the cell l columns to
     // the left, so every lane tests ITS cell of the current diagonal (bit b - t of its words), one ballot gives the length of the
@@ -427,6 +491,9 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
     }
     for (int k = lane; k < i; k += 64) ops[base + k] = 'I';          // column 0: D[k][0] = k, only "up" is possible
     for (int k = lane; k < j; k += 64) ops[base + k] = 'D';          // row 0
+#ifdef RCN_PROF_PAIR
+    RCN_PP_ADD(4, clock64() - ppw0__); RCN_PP_ADD(12, 1);
+#endif
 }
 
 // A sub-problem: rows [q0, q0 + m) x columns [t0, t0 + n), `best` = its distance (-1: the root).  lf / rt >= 0: its left / right
@@ -594,10 +661,18 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
             else { for (int k = lane; k < t.m; k += 64) ops[base + k] = 'I'; if (t.best < 0) distance = t.m; }
         }
         if (both) {
+            RCN_PP_T(ppb0__);
             __syncthreads();                           // (work-group fence + barrier: the other wave's vector is in HBM scratch)
+#ifdef RCN_PROF_PAIR
+            RCN_PP_ADD(8, clock64() - ppb0__);
+#endif
             int best = A.best;
             PairTask lc, rc;
+            RCN_PP_T(ppc0__);
             const bool ok = cut(A, pa, offa, left, right, best, lc, rc);
+#ifdef RCN_PROF_PAIR
+            RCN_PP_ADD(5, clock64() - ppc0__); RCN_PP_ADD(13, 1);
+#endif
             if (A.best < 0) distance = best;
             if (!ok || sp + 2 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
             if (threadIdx.x == 0) { stack[sp] = rc; stack[sp + 1] = lc; }
@@ -610,10 +685,18 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
             const int32_t* Lv = pl.have_l ? arena + t.lf : mine;
             const int32_t* Rv = pl.have_r ? arena + t.rt : mine;
             int best = t.best;
+            RCN_PP_T(ppc1__);
             nk = cut(t, pl, off, Lv, Rv, best, k1, k0) ? 2 : -1;
+#ifdef RCN_PROF_PAIR
+            RCN_PP_ADD(5, clock64() - ppc1__); RCN_PP_ADD(13, 1);
+#endif
         }
         if (lane == 0) { kids[wv].k[0] = k0; kids[wv].k[1] = k1; nkids[wv] = nk; }
+        RCN_PP_T(ppb1__);
         __syncthreads();
+#ifdef RCN_PROF_PAIR
+        RCN_PP_ADD(8, clock64() - ppb1__);
+#endif
         const int n0 = __builtin_amdgcn_readfirstlane(nkids[0]), n1 = __builtin_amdgcn_readfirstlane(nkids[1]);
         if (n0 < 0 || n1 < 0 || sp + n0 + n1 > kPairStack) { if (threadIdx.x == 0) atomicAdd(P.err, 1u); break; }
         if (threadIdx.x == 0) {
@@ -653,6 +736,7 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
         __syncthreads();
         const unsigned int wi = __builtin_amdgcn_readfirstlane(s_work);
         if (wi >= P.n_pairs) break;
+        RCN_PP_T(ppk0__);
         const uint32_t o = P.order[wi];
         PairView Q{P.bases + P.q_pos[o], P.q_rc[o] != 0, static_cast<int64_t>(P.q_len[o])};
         PairView T{P.bases + P.t_pos[o], false, static_cast<int64_t>(P.t_len[o])};
@@ -702,11 +786,15 @@ __global__ __launch_bounds__(kPairThreads, 4) void k_pair_align(PairParams P) {
             codes[256 + k] = nsym <= 7 ? lcode[k] : static_cast<uint8_t>(k);
         }
         __syncthreads();
+        RCN_PP_T(ppk1__);
         int d;
         if (nsym <= 4 && __builtin_amdgcn_readfirstlane(s_foreign) == 0) d = pair_align_one<2>(P, Q, T, codes, stack, kids, nkids, slot, ops, symring[wv]);
         else if (nsym <= 7) d = pair_align_one<3>(P, Q, T, codes, stack, kids, nkids, slot, ops, symring[wv]);
         else d = pair_align_one<8>(P, Q, T, codes, stack, kids, nkids, slot, ops, symring[wv]);
         if (tid == 0) P.dist[o] = d;
+#ifdef RCN_PROF_PAIR
+        RCN_PP_ADD(6, ppk1__ - ppk0__); RCN_PP_ADD(7, clock64() - ppk0__);
+#endif
     }
 }
 

@@ -757,6 +757,15 @@ inline int align_pairs(rcn_engine* e, const rcn_read_set& R, const rcn_pair_set&
     HIP_TRY(hipMemcpyAsync(h_ctr, A[kACtr].p, 64, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (h_ctr[4]) { fprintf(stderr, "[racon_hip] pairwise alignment: internal error on %u overlap(s)\n", h_ctr[4]); return RCN_E_STATE; }
+#ifdef RCN_PROF_PAIR
+    { unsigned long long pp[16]; HIP_TRY(hipMemcpyFromSymbol(pp, HIP_SYMBOL(rcn::g_pairprof), sizeof(pp)));
+      const double tot = static_cast<double>(std::max(1ull, pp[7]));
+      fprintf(stderr, "[racon_hip] pair aligner, wave clocks since load: steady blocks %.1f %% (%.1f clocks per step, %.1f of 64 lanes hold a word), ramps / tails / snapshot blocks %.1f %% (%.1f per step), "
+                      "row load %.1f %%, scores of a pass %.1f %%, leaf walk %.1f %% (%.0f clocks per leaf), cut %.1f %% (%.0f each), symbol set-up %.1f %%, barriers %.1f %%; %llu passes, %llu leaves\n",
+              100.0 * pp[0] / tot, static_cast<double>(pp[0]) / std::max(1ull, pp[9]), static_cast<double>(pp[14]) / std::max(1ull, pp[9]), 100.0 * pp[1] / tot, static_cast<double>(pp[1]) / std::max(1ull, pp[10]),
+              100.0 * pp[2] / tot, 100.0 * pp[3] / tot, 100.0 * pp[4] / tot, static_cast<double>(pp[4]) / std::max(1ull, pp[12]), 100.0 * pp[5] / tot, static_cast<double>(pp[5]) / std::max(1ull, pp[13]),
+              100.0 * pp[6] / tot, 100.0 * pp[8] / tot, pp[11], pp[12]); }
+#endif
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, tc.a, tc.b)); e->astats.h2d_ms = ms;
     if (n) { HIP_TRY(hipEventElapsedTime(&ms, tk.a, tk.b)); e->astats.kernel_ms = ms; }

@@ -55,7 +55,7 @@ PY
   for PIPE in ${SHARD_PIPES:-none}; do
     [ "$PIPE" = none ] && PIPE=""
     env $PIPE RACON_HIP_DEVICE_SHARDS=${SHARD_N:-4} RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -f -t 32 --cudaaligner-batches 1 $F/reads.fastq $F/overlaps.paf $F/reads.fastq 2> "$OUT/shardtime.err" | md5sum
-    echo "== ${PIPE:-default}"; grep -E "racon::|racon_hip\] (self|pairs)" "$OUT/shardtime.err" | grep -v "piece\|collect\|pass of" | cut -c1-330 | tee "$OUT/shardtime_${PIPE:+device_pipeline}.txt" | tail -30
+    echo "== ${PIPE:-default}"; grep -E "racon::|racon_hip\] (self|pairs|pair aligner)" "$OUT/shardtime.err" | grep -v "piece\|collect\|pass of" | cut -c1-330 | tee "$OUT/shardtime_${PIPE:+device_pipeline}.txt" | tail -30
   done
 fi
 if has cfg5; then
