@@ -67,9 +67,14 @@ struct HostBuf {                       // pinned host staging (D2H of the consen
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap && p) return RCN_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        if (hipHostMalloc(&p, std::max<size_t>(bytes, 256), hipHostMallocDefault) != hipSuccess) { p = nullptr; return RCN_E_NOMEM; }
-        cap = std::max<size_t>(bytes, 256); return RCN_OK;
+        // (a block that has to grow gets an eighth on top: the shards of a job differ by a few per cent, and every regrowth is a
+        //  hipHostFree + hipHostMalloc of > 100 MB -- 45-95 ms with the device idle, profiles/r06/j_run_breakdown.txt)
+        size_t want = std::max<size_t>(bytes, 256);
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; want += want / 8; }
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            if (want == std::max<size_t>(bytes, 256) || hipHostMalloc(&p, want = std::max<size_t>(bytes, 256), hipHostMallocDefault) != hipSuccess) { p = nullptr; return RCN_E_NOMEM; }
+        }
+        cap = want; return RCN_OK;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return static_cast<T*>(p); }
@@ -1322,7 +1327,9 @@ static int run_resident(rcn_engine* e, bool dry) {
         return RCN_OK;
     }
     int rc;
+    const auto r0__ = std::chrono::steady_clock::now();
     if ((rc = begin_run(e))) return rc;
+    if (e->knobs.debug && !dry) fprintf(stderr, "[racon_hip] run: begin_run (result block, counters) took %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0__).count());
     auto warm_out = [&]() -> int {
         // the arena's first touch (what AlignmentEngine::Prealloc does to its matrices, reference src/polisher.cpp:180-182): the
         // launches of the run then find its pages mapped and their translations fresh
@@ -1377,6 +1384,7 @@ static int run_resident(rcn_engine* e, bool dry) {
         return warm_out();
     }
     if ((rc = run_pass(e, c1, ids, nw))) return rc;
+    if (e->knobs.debug) fprintf(stderr, "[racon_hip] run: pass done %.2f ms after the call\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0__).count());
     return collect(e);
 }
 

@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "fatal.hpp"
+#include "host_util.hpp"
 
 extern "C" char** environ;
 #include "window.hpp"
@@ -301,7 +302,9 @@ void HipEngine::consensus(const rcn_read_set& reads, const rcn_pair_set& pairs, 
 
 void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<uint8_t>* polished, std::vector<uint8_t>* chimeric, bool run) {
     const Abi& a = abi();
+    const auto f0 = std::chrono::steady_clock::now();
     if (rc == RCN_OK && run) rc = a.run(handle_);
+    const double t_run = seconds_since(f0);
     rcn_result r{};
     if (rc == RCN_OK) rc = a.result(handle_, &r);
     last_rc_ = rc;
@@ -310,6 +313,7 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
     static const bool want_stats = getenv("RACON_HIP_TIMING") != nullptr;
     rcn_run_stats st{};
     if (want_stats && a.stats(handle_, &st) == RCN_OK) last_kernel_ms_ = st.kernel_ms;
+    const double t_stats = seconds_since(f0);
     // RACON_HIP_VERIFY=<fraction> (product option, off by default): that share of every batch's windows is polished a second time
     // on the GPU with every shortcut rule of the kernels switched off (rcn_engine_verify) -- a window that comes out differently is
     // a bug in a rule, and fatal
@@ -328,12 +332,19 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
         if (say) fprintf(stderr, "[racon_hip] self-check: %u windows re-polished on the exact paths in %.1f ms (%u through the int32 kernel), none differs\n", rep.n_checked, rep.ms, rep.n_int32);
     }
     consensus->resize(r.n_windows); polished->resize(r.n_windows); chimeric->resize(r.n_windows);
-    for (uint32_t w = 0; w < r.n_windows; ++w) {
-        if (w >= fetch_first_ && w < fetch_last_)
-            (*consensus)[w].assign(reinterpret_cast<const char*>(r.cons + r.cons_off[w]), r.cons_off[w + 1] - r.cons_off[w]);
-        else (*consensus)[w].clear();
-        (*polished)[w] = r.polished[w]; (*chimeric)[w] = r.chimeric[w];
-    }
+    // (a shard of cfg5 hands back 250 000 strings: on one thread that is 60-100 ms between two shards with the device idle)
+    const uint32_t blocks = (r.n_windows + 4095) / 4096;
+    parallel_for(blocks, r.n_windows >= 32768 ? 8 : 1, [&](uint64_t blk) {
+        for (uint32_t w = static_cast<uint32_t>(blk) * 4096, e = std::min<uint32_t>(r.n_windows, w + 4096); w < e; ++w) {
+            if (w >= fetch_first_ && w < fetch_last_)
+                (*consensus)[w].assign(reinterpret_cast<const char*>(r.cons + r.cons_off[w]), r.cons_off[w + 1] - r.cons_off[w]);
+            else (*consensus)[w].clear();
+            (*polished)[w] = r.polished[w]; (*chimeric)[w] = r.chimeric[w];
+        }
+    });
+    if (want_stats && r.n_windows >= 32768)
+        fprintf(stderr, "[racon::HipEngine::run] timing: engine run %.1f ms (kernel %.1f), result + stats %.1f ms, %u strings %.1f ms\n", 1e3 * t_run, last_kernel_ms_,
+                1e3 * (t_stats - t_run), r.n_windows, 1e3 * (seconds_since(f0) - t_stats));
 }
 
 }  // namespace racon

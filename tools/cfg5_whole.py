@@ -33,6 +33,7 @@ ap.add_argument("--sample", type=float, default=0.01, help="fraction of the read
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--dir", default=os.environ.get("RACON_AMD_CACHE", "/tmp/racon_amd_cache"))
 ap.add_argument("--keep-fasta", default="")
+ap.add_argument("--record-md5", default="", help="write the md5 of every FASTA record of the big run (one row per read, zeros = no record) as .npy: tools/cfg5_full_check.py compares ALL of them with host layer + oracle on a CPU box")
 a = ap.parse_args()
 EXE = os.path.join(ROOT, "racon_amd", "host", "racon_hip")
 
@@ -99,6 +100,13 @@ if run["rc"] != 0:
     print(json.dumps(out)); sys.exit(1)
 big_rec = records(fasta_path)
 n_targets = int(100_000 * a.scale)
+if a.record_md5:
+    dig = np.zeros((n_targets, 16), np.uint8)
+    for name, (h, sq) in big_rec.items():
+        dig[int(name[1:].rstrip(b"r"))] = np.frombuffer(hashlib.md5(h + b"\n" + sq).digest(), np.uint8)
+    os.makedirs(os.path.dirname(os.path.abspath(a.record_md5)), exist_ok=True)
+    np.save(a.record_md5, dig)
+    out["record_md5_file"] = os.path.basename(a.record_md5)
 out["fasta_records"] = len(big_rec)
 out["fasta_bases"] = int(sum(len(s) for _, s in big_rec.values()))
 # windows of the job: ceil(read length / 500) per read (the targets are the reads)

@@ -55,11 +55,11 @@ PY
   for PIPE in ${SHARD_PIPES:-none}; do
     [ "$PIPE" = none ] && PIPE=""
     env $PIPE RACON_HIP_DEVICE_SHARDS=${SHARD_N:-4} RCN_DEBUG=1 RACON_HIP_TIMING=1 racon_amd/host/racon_hip -f -t 32 --cudaaligner-batches 1 $F/reads.fastq $F/overlaps.paf $F/reads.fastq 2> "$OUT/shardtime.err" | md5sum
-    echo "== ${PIPE:-default}"; grep -E "racon::|racon_hip\] (self|pairs|pair aligner)" "$OUT/shardtime.err" | grep -v "piece\|collect\|pass of" | cut -c1-330 | tee "$OUT/shardtime_${PIPE:+device_pipeline}.txt" | tail -30
+    echo "== ${PIPE:-default}"; grep -E "racon::|racon_hip\] (self|pairs|pair aligner|run:)" "$OUT/shardtime.err" | grep -v "piece\|collect\|pass of" | cut -c1-330 | tee "$OUT/shardtime_${PIPE:+device_pipeline}.txt" | tail -30
   done
 fi
 if has cfg5; then
-  timeout ${CFG5_TIMEOUT:-2400} python tools/cfg5_whole.py ${CFG5_ARGS:---scale 1.0 --shards 8} > "$OUT/cfg5_whole.json" 2> "$OUT/cfg5_whole.err"
+  timeout ${CFG5_TIMEOUT:-2400} python tools/cfg5_whole.py ${CFG5_ARGS:---scale 1.0 --shards 8} --record-md5 "$OUT/cfg5_record_md5.npy" > "$OUT/cfg5_whole.json" 2> "$OUT/cfg5_whole.err"
   echo "cfg5 exit $?"; tail -3 "$OUT/cfg5_whole.err" | cut -c1-400; cut -c1-4500 "$OUT/cfg5_whole.json"
 fi
 if has cfg3bin; then
