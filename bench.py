@@ -516,7 +516,7 @@ def main():
             # N-GPU number has to be read against is THE SAME JOB on one GPU (cfg3 whole: `bench.py --config cfg3`), printed here.
             out["per_gpu_value"] = out["value"] / world
             n1 = {"workload": "cfg3 whole (50 Mbp, 100 000 windows) on ONE GPU: `python bench.py --config cfg3`", "measured_in_this_run": False}
-            for f in ("profiles/r05/bench_cfg3_1gpu.json", "profiles/r03/h_bench_cfg3_1gpu.json"):
+            for f in ("profiles/r06/bench_cfg3_1gpu.json", "profiles/r05/bench_cfg3_1gpu.json", "profiles/r03/h_bench_cfg3_1gpu.json"):
                 try:
                     j1 = json.load(open(os.path.join(ROOT, f)))
                     n1.update({"value": j1["value"], "ms_per_step": j1["ms_per_step"], "source": f})

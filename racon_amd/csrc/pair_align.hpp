@@ -65,6 +65,7 @@ struct PairParams {
     uint32_t* err;                   // [0] != 0: internal error (no optimal split found / stack overflow)
 };
 
+constexpr int kPairRing = 198;       // entries of a wave's symbol ring: 128 columns, the mirror of the first 64, the read-ahead of a block's last trip
 constexpr int kPairStack = 64;       // Hirschberg tasks pending per overlap (depth ~ log2 columns, two pushes per level)
 
 struct PairView {                    // a sequence read forwards, or backwards and complemented
@@ -426,25 +427,9 @@ __device__ __forceinline__ int pair_columns(const PairView& Q, int64_t q0, int m
     return carry;
 }
 
-// plain traceback of a leaf (up, then left, else diagonal) over the stored delta words
-template <int NPL>
-__device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, const PairView& T, int64_t t0, int n, const uint8_t* codes,
-                                          uint8_t* hbuf0, uint8_t* hbuf1, ulonglong2* store, uint8_t* ops, uint32_t* ring) {
+// plain traceback of a leaf (up, then left, else diagonal) over the stored delta words (Pv, ~Ph) of its forward passes
+__device__ __forceinline__ void pair_leaf_walk(const ulonglong2* store, int nb, int m, int n, int64_t base, uint8_t* ops) {
     const int lane = threadIdx.x & 63;
-    const int nb = (m + 63) / 64;
-    // forward passes with the (Pv, Ph) store; pass p starts at store + pass_off(p)
-    {
-        int64_t off = 0;
-        for (int w0 = 0, pass = 0; w0 < nb; w0 += 64, ++pass) {
-            const int nwp = min(64, nb - w0);
-            const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
-            uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
-            unsigned long long Pv, Mv;
-            pair_pass<NPL, true>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv, ring);
-            pair_wave_fence();
-            off += static_cast<int64_t>(n + nwp - 1) * nwp;
-        }
-    }
     // every full pass has 64 words: pass p starts at p * (n + 63) * 64
     const int64_t pass_stride = static_cast<int64_t>(n + 63) * 64;
     RCN_PP_T(ppw0__);
@@ -456,7 +441,6 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
     int i = m, j = n;                                 // current cell (rows 1..m, columns 1..n; 0 = boundary)
     int cw = -1, cj0 = -1;                            // cache: lane c holds cell (word cw, column cj0 - c)
     uint32_t pv_lo = 0, pv_hi = 0, ph_lo = 0, ph_hi = 0;        // (ph_*: the complement of the horizontal plus-deltas, as stored)
-    const int64_t base = q0 + t0;
     while (i > 0 && j > 0) {
         const int w = (i - 1) >> 6, b = (i - 1) & 63;
         if (w != cw || j > cj0 || j <= cj0 - 64) {
@@ -496,6 +480,176 @@ __device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, 
 #endif
 }
 
+// a leaf: forward passes with the (Pv, ~Ph) store, then the walk
+template <int NPL>
+__device__ __forceinline__ void pair_leaf(const PairView& Q, int64_t q0, int m, const PairView& T, int64_t t0, int n, const uint8_t* codes,
+                                          uint8_t* hbuf0, uint8_t* hbuf1, ulonglong2* store, uint8_t* ops, uint32_t* ring) {
+    const int nb = (m + 63) / 64;
+    // forward passes with the (Pv, Ph) store; pass p starts at store + pass_off(p)
+    {
+        int64_t off = 0;
+        for (int w0 = 0, pass = 0; w0 < nb; w0 += 64, ++pass) {
+            const int nwp = min(64, nb - w0);
+            const uint8_t* hin = w0 == 0 ? nullptr : ((pass & 1) ? hbuf0 : hbuf1);
+            uint8_t* hout = w0 + 64 < nb ? ((pass & 1) ? hbuf1 : hbuf0) : nullptr;
+            unsigned long long Pv, Mv;
+            pair_pass<NPL, true>(Q, q0, m, false, T, t0, n, false, w0, nwp, codes, hin, hout, store + off, Pv, Mv, ring);
+            pair_wave_fence();
+            off += static_cast<int64_t>(n + nwp - 1) * nwp;
+        }
+    }
+    pair_leaf_walk(store, nb, m, n, static_cast<int64_t>(q0) + t0, ops);
+}
+
+// TWO leaves in one wave.  Below the root the sub-problems have fewer words than a wave has lanes (a leaf of a 6 kb overlap: ~25; over a
+// shard of cfg5 39 of 64 lanes held a word in the steady state, profiles/r06/g_pair_phase_clocks.txt), and the kernel is bound by vector
+// instructions issued, whatever the lanes hold.  Two leaves of one overlap whose words fit a wave together (nbA + nbB <= 64) therefore
+// run their forward pass side by side: leaf A in lanes [0, nbA), leaf B in lanes [nbA, nbA + nbB), each with its own rows, columns, symbol
+// ring and store; the lane that starts B takes the top boundary instead of its neighbour's carry (two selects per step); a lane whose
+// leaf has run out of columns keeps its state as in any edge block.  Then the two walks, one after the other.  (Two symbol planes only:
+// the second ring takes the LDS the wider entries of three planes would.)
+struct PairLeafJob { int q0, m, t0, n; };
+__device__ __forceinline__ bool pair_leaf_pairs(int nbA, int nbB) { return nbA + nbB <= 64; }
+
+template <int NPL>
+__device__ __forceinline__ void pair_leaf_two(const PairView& Q, const PairView& T, const uint8_t* codes, PairLeafJob A, PairLeafJob B,
+                                              ulonglong2* store, uint8_t* ops, uint32_t* ring) {
+    static_assert(NPL == 2, "two rings of 8-byte entries share a wave's LDS");
+    constexpr int EW = 2;
+    const int lane = threadIdx.x & 63;
+    A.q0 = __builtin_amdgcn_readfirstlane(A.q0); A.m = __builtin_amdgcn_readfirstlane(A.m); A.t0 = __builtin_amdgcn_readfirstlane(A.t0); A.n = __builtin_amdgcn_readfirstlane(A.n);
+    B.q0 = __builtin_amdgcn_readfirstlane(B.q0); B.m = __builtin_amdgcn_readfirstlane(B.m); B.t0 = __builtin_amdgcn_readfirstlane(B.t0); B.n = __builtin_amdgcn_readfirstlane(B.n);
+    const int nbA = (A.m + 63) / 64, nbB = (B.m + 63) / 64;
+    ulonglong2* storeA = store;
+    ulonglong2* storeB = store + static_cast<int64_t>(A.n + nbA - 1) * nbA;
+    {
+        RCN_PP_T(pp0__);
+        const bool sb = lane >= nbA;                               // this lane's leaf
+        const int ll = sb ? lane - nbA : lane;                     // its word
+        const int nw_l = sb ? nbB : nbA, m_l = sb ? B.m : A.m, n_l = sb ? B.n : A.n;
+        const int64_t q0_l = sb ? B.q0 : A.q0;
+        ulonglong2* sp = (sb ? storeB : storeA) + ll;              // + step * nw_l
+        PairLane<NPL> L;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) { L.pl[k] = 0u; L.ph[k] = 0u; }
+        L.vl = 0u; L.vh = 0u; L.Pvl = ~0u; L.Pvh = ~0u; L.Mvl = 0u; L.Mvh = 0u;
+        if (ll < nw_l) {
+            const int64_t r0 = static_cast<int64_t>(ll) * 64;
+            const int nrow = static_cast<int>(min(static_cast<int64_t>(64), static_cast<int64_t>(m_l) - r0));
+            const int64_t l0 = q0_l + r0;
+            const int64_t i0 = Q.rc ? Q.n - 1 - l0 : l0;
+            const int64_t step = Q.rc ? -1 : 1;
+            unsigned long long plane[NPL];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) plane[k] = 0ull;
+#pragma unroll 1
+            for (int rb = 0; rb < 64; rb += 16) {
+                uint32_t raw[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) raw[u] = Q.p[i0 + step * min(rb + u, nrow - 1)];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t code = codes[raw[u]];
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) plane[k] |= static_cast<unsigned long long>((code >> k) & 1u) << (rb + u);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) { L.pl[k] = static_cast<uint32_t>(plane[k]); L.ph[k] = static_cast<uint32_t>(plane[k] >> 32); }
+            const unsigned long long valid = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);
+            L.vl = static_cast<uint32_t>(valid); L.vh = static_cast<uint32_t>(valid >> 32);
+        }
+        RCN_PP_T(pp1__);
+#ifdef RCN_PROF_PAIR
+        long long pp_steady__ = 0, pp_nsteady__ = 0;
+#endif
+        uint32_t* ringA = ring;
+        uint32_t* ringB = ring + kPairRing * EW;
+        const uint32_t first_b = lane == nbA ? 0u : ~0u;           // the lane that starts leaf B takes the top boundary {0, 0}
+        PairCarry hc{0x80000000u, 0u};
+        const int steps = max(A.n + nbA, B.n + nbB) - 1;
+        const int nw_max = max(nbA, nbB), n_min = min(A.n, B.n);
+        for (int s0 = 0; s0 < steps; s0 += 64) {
+            {   // the 64 columns of each leaf that enter at its first lane during this block
+                const int col = s0 + lane;
+                const uint32_t ra = col < A.n ? T.p[A.t0 + col] : 0u, rb_ = col < B.n ? T.p[B.t0 + col] : 0u;
+                const PairSym<NPL> ya = pair_sym_of<NPL>(col < A.n ? static_cast<int>(codes[256 + ra]) : 7);
+                const PairSym<NPL> yb = pair_sym_of<NPL>(col < B.n ? static_cast<int>(codes[256 + rb_]) : 7);
+                const int slot = (s0 >> 6) & 1;
+                uint32_t* ea = ringA + (slot * 64 + lane) * EW;
+                uint32_t* eb = ringB + (slot * 64 + lane) * EW;
+                *reinterpret_cast<uint2*>(ea) = make_uint2(ya.mk[0], ya.mk[1]); *reinterpret_cast<uint2*>(eb) = make_uint2(yb.mk[0], yb.mk[1]);
+                if (slot == 0) { *reinterpret_cast<uint2*>(ea + 128 * EW) = make_uint2(ya.mk[0], ya.mk[1]); *reinterpret_cast<uint2*>(eb + 128 * EW) = make_uint2(yb.mk[0], yb.mk[1]); }
+            }
+            const uint32_t* rp = (sb ? ringB : ringA) + ((s0 - ll) & 127) * EW;
+            auto ring_at = [&](int k) -> PairSym<NPL> {
+                PairSym<NPL> y;
+                const uint2 v = *reinterpret_cast<const uint2*>(rp + k * EW);
+                y.mk[0] = v.x; y.mk[1] = v.y;
+                return y;
+            };
+            auto cell = [&](const PairSym<NPL>& y, PairLane<NPL>& Lw, uint32_t& nl, uint32_t& nh) {
+                PairCarry cin;
+                cin.np = pair_shr1_zero(hc.np) & first_b; cin.mn = pair_shr1_zero(hc.mn) & first_b;
+                hc = pair_cell<NPL>(Lw, y, cin, nl, nh);
+            };
+            if (s0 >= nw_max - 1 && s0 + 63 < n_min) {
+                RCN_PP_T(ppb__);
+                PairSym<NPL> ya[2] = {ring_at(0), ring_at(1)}, yb[2] = {ring_at(2), ring_at(3)};
+                auto step = [&](int k, const PairSym<NPL>& y) {
+                    uint32_t nl, nh;
+                    cell(y, L, nl, nh);
+                    if (ll < nw_l) {
+                        ulonglong2 v;
+                        v.x = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl; v.y = (static_cast<unsigned long long>(nh) << 32) | nl;
+                        sp[static_cast<int64_t>(s0 + k) * nw_l] = v;
+                    }
+                };
+#pragma unroll 1
+                for (int k = 0; k < 64; k += 4) {
+                    step(k, ya[0]); step(k + 1, ya[1]);
+                    ya[0] = ring_at(k + 4); ya[1] = ring_at(k + 5);
+                    step(k + 2, yb[0]); step(k + 3, yb[1]);
+                    yb[0] = ring_at(k + 6); yb[1] = ring_at(k + 7);
+                }
+#ifdef RCN_PROF_PAIR
+                pp_steady__ += clock64() - ppb__; pp_nsteady__ += 64;
+#endif
+                continue;
+            }
+            const int kend = min(64, steps - s0);
+            PairSym<NPL> yn = ring_at(0);
+#pragma unroll 2
+            for (int k = 0; k < kend; ++k) {
+                const PairSym<NPL> y = yn;
+                yn = ring_at(k + 1);
+                const int j = s0 + k - ll;
+                const bool active = ll < nw_l && static_cast<unsigned>(j) < static_cast<unsigned>(n_l);
+                PairLane<NPL> Lt = L;
+                uint32_t nl, nh;
+                cell(y, Lt, nl, nh);
+                L.Pvl = active ? Lt.Pvl : L.Pvl; L.Pvh = active ? Lt.Pvh : L.Pvh; L.Mvl = active ? Lt.Mvl : L.Mvl; L.Mvh = active ? Lt.Mvh : L.Mvh;
+                if (active) {
+                    ulonglong2 v;
+                    v.x = (static_cast<unsigned long long>(L.Pvh) << 32) | L.Pvl; v.y = (static_cast<unsigned long long>(nh) << 32) | nl;
+                    sp[static_cast<int64_t>(s0 + k) * nw_l] = v;
+                }
+            }
+        }
+#ifdef RCN_PROF_PAIR
+        { const long long pp2__ = clock64();
+          RCN_PP_ADD(0, pp_steady__); RCN_PP_ADD(1, pp2__ - pp1__ - pp_steady__); RCN_PP_ADD(2, pp1__ - pp0__); RCN_PP_ADD(9, pp_nsteady__); RCN_PP_ADD(10, steps - pp_nsteady__);
+          RCN_PP_ADD(11, 1); RCN_PP_ADD(14, pp_nsteady__ * (nbA + nbB)); }
+#endif
+    }
+    pair_wave_fence();
+#pragma unroll 1
+    for (int u = 0; u < 2; ++u) {
+        const PairLeafJob& J = u ? B : A;
+        pair_leaf_walk(u ? storeB : storeA, (J.m + 63) / 64, J.m, J.n, static_cast<int64_t>(J.q0) + J.t0, ops);
+    }
+}
+
 // A sub-problem: rows [q0, q0 + m) x columns [t0, t0 + n), `best` = its distance (-1: the root).  lf / rt >= 0: its left / right
 // column vector is INHERITED -- it already stands in the team's arena at that offset (lf_more / rt_more further vectors of the
 // same pass follow at lf_stride / rt_stride: the next sub-problems down the same side).
@@ -505,9 +659,9 @@ struct PairTask { int q0, m, t0, n, best, lf, lf_more, lf_stride, rt, rt_more, r
 // finds the arena full stores nothing and its sub-problems compute both their vectors
 __host__ __device__ __forceinline__ uint64_t pair_arena_ints(uint64_t m_cap) { return 40ull * (m_cap + 64); }
 
-// bytes of a team's scratch: two last-column vectors; two carry buffers, a leaf store and the snapshot words per wave; the arena
+// bytes of a team's scratch: two last-column vectors; two carry buffers, a store for two leaves and the snapshot words per wave; the arena
 __host__ __device__ __forceinline__ uint64_t pair_slot_bytes(uint64_t m_cap, uint64_t n_cap) {       // (m_cap, n_cap: multiples of 16)
-    return ((2 * 4 * (m_cap + 64) + 4 * (n_cap + 64) + 2 * pair_leaf_bytes(m_cap) + 2 * kPairSnap * 64 * 16 + 4 * pair_arena_ints(m_cap)) + 255) & ~uint64_t(255);
+    return ((2 * 4 * (m_cap + 64) + 4 * (n_cap + 64) + 4 * pair_leaf_bytes(m_cap) + 2 * kPairSnap * 64 * 16 + 4 * pair_arena_ints(m_cap)) + 255) & ~uint64_t(255);
 }
 
 __device__ __forceinline__ PairTask pair_task_uniform(const PairTask& t) {
@@ -553,8 +707,8 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
     uint8_t* hbuf0 = after + static_cast<uint64_t>(wv) * 2 * (P.n_cap + 64);
     uint8_t* hbuf1 = hbuf0 + (P.n_cap + 64);
     after += 4ull * (P.n_cap + 64);
-    ulonglong2* store = reinterpret_cast<ulonglong2*>(after + static_cast<uint64_t>(wv) * P.leaf_bytes);
-    after += 2 * P.leaf_bytes;
+    ulonglong2* store = reinterpret_cast<ulonglong2*>(after + static_cast<uint64_t>(wv) * 2 * P.leaf_bytes);       // (room for two leaves: pair_leaf_two)
+    after += 4 * P.leaf_bytes;
     ulonglong2* snapbuf = reinterpret_cast<ulonglong2*>(after) + wv * (kPairSnap * 64);
     after += 2 * kPairSnap * 64 * 16;
     int32_t* arena = reinterpret_cast<int32_t*>(after);
@@ -624,7 +778,24 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
             B_splits = pair_task_splits(B);
             two = !(B_splits && B.lf < 0 && B.rt < 0);
         }
-        sp -= two ? 2 : 1;
+        // partners: a leaf below the root runs side by side with another leaf of the stack when their words fit a wave together
+        // (pair_leaf_two); candidates are the entries right below the round's own, offered to wave 0's leaf first
+        bool pairA = false, pairB = false;
+        PairTask C = A, D = A;
+        if (NPL == 2 && !both) {
+            auto leafy = [&](const PairTask& t) { return t.m > 0 && t.n > 0 && t.best >= 0 && !pair_task_splits(t); };
+            auto words = [&](const PairTask& t) { return (t.m + 63) / 64; };
+            int ci = sp - (two ? 2 : 1) - 1;
+            if (ci >= 0 && leafy(A)) {
+                const PairTask X = pair_task_uniform(stack[ci]);
+                if (leafy(X) && pair_leaf_pairs(words(A), words(X))) { C = X; pairA = true; --ci; }
+            }
+            if (ci >= 0 && two && leafy(B)) {
+                const PairTask X = pair_task_uniform(stack[ci]);
+                if (leafy(X) && pair_leaf_pairs(words(B), words(X))) { D = X; pairB = true; --ci; }
+            }
+        }
+        sp -= (two ? 2 : 1) + (pairA ? 1 : 0) + (pairB ? 1 : 0);
         PairSplitPlan pa = pair_split_plan(A), pb = pair_split_plan(B);
         if (!A_splits || atop + pa.need > acap) { pa.nsf = 0; pa.nsb = 0; pa.need = 0; }
         const int offa = atop;
@@ -655,7 +826,13 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
                                             ns, sc[0], sc[1], sc[2], arena + off + (forward ? 0 : pl.nsf * (t.m + 1)), t.m + 1, snapbuf);
             if (!splits) distance = d;
         }
-        if (leaf) pair_leaf<NPL>(Q, t.q0, t.m, T, t.t0, t.n, codes, hbuf0, hbuf1, store, ops, ring);
+        const bool with_partner = mine_is_A ? pairA : pairB;
+        if (NPL == 2 && leaf && with_partner) {
+            if constexpr (NPL == 2) {
+                const PairTask& u = mine_is_A ? C : D;
+                pair_leaf_two<NPL>(Q, T, codes, PairLeafJob{t.q0, t.m, t.t0, t.n}, PairLeafJob{u.q0, u.m, u.t0, u.n}, store, ops, ring);
+            }
+        } else if (leaf) pair_leaf<NPL>(Q, t.q0, t.m, T, t.t0, t.n, codes, hbuf0, hbuf1, store, ops, ring);
         if (active && empty) {
             if (t.m == 0) { for (int k = lane; k < t.n; k += 64) ops[base + k] = 'D'; if (t.best < 0) distance = t.n; }
             else { for (int k = lane; k < t.m; k += 64) ops[base + k] = 'I'; if (t.best < 0) distance = t.m; }
@@ -713,7 +890,6 @@ __device__ __forceinline__ int pair_align_one(const PairParams& P, const PairVie
 // their own (engine_pair.hip: the passes are inlined in four carry variants per symbol-plane count, two minutes of compile time that
 // engine.hip's other kernels need not wait for); engine.hip sees the declarations and launches them.
 constexpr int kPairThreads = 128;
-constexpr int kPairRing = 198;       // entries of a wave's symbol ring: 128 columns, the mirror of the first 64, the read-ahead of a block's last trip
 #if !defined(RCN_PAIR_TU) && !defined(RCN_ONE_TU)
 __global__ void k_pair_align(PairParams P);
 #else

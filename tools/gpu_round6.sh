@@ -117,6 +117,42 @@ if has ab; then
   python bench.py --config w1000 $QB 2>/dev/null | benchline "w1000 as shipped" | tee -a "$OUT/ab.txt"
   python bench.py --config cfg4 $QB 2>/dev/null | benchline "cfg4 as shipped" | tee -a "$OUT/ab.txt"
 fi
+sqpasses() {   # $1 = label, rest = bench arguments
+  local label=$1; shift
+  local n=0
+  for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
+             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_I8 SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+    n=$((n + 1))
+    timeout 600 rocprofv3 --pmc $SET --output-format csv -d "$OUT/sq_${label}_$n" -o pmc -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu --no-product --no-upload-leg > "$OUT/sq_${label}_$n.json" 2> "$OUT/sq_${label}_$n.err"
+    echo "sq $label pass $n exit $?"; tail -2 "$OUT/sq_${label}_$n.err" | cut -c1-200
+  done
+  python tools/sq_summary.py "$OUT" "$label" > "$OUT/sq_${label}_summary.txt" 2>&1; cat "$OUT/sq_${label}_summary.txt"
+}
+if has final; then
+  BP="--steps 3 --warmup 1 --no-cpu --no-upload-leg --no-product"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python bench.py $BP > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+  find "$OUT/prof" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \; ; head -6 "$OUT/kernel_stats.csv" | cut -c1-200
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof4" -o trace -- python bench.py --config cfg4 $BP > "$OUT/prof_bench_cfg4.json" 2> "$OUT/prof4.err"
+  find "$OUT/prof4" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_cfg4.csv" \; ; head -5 "$OUT/kernel_stats_cfg4.csv" | cut -c1-200
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python bench.py $BP > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"; echo "pmc $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; tail -3 "$OUT/pmc_summary.txt"
+  mkdir -p "$OUT/c4"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/c4/pmc_$C" -o pmc -- python bench.py --config cfg4 $BP > "$OUT/c4/pmc_$C.json" 2> "$OUT/c4/pmc_$C.err"; echo "pmc cfg4 $C exit $?"
+  done
+  python tools/pmc_summary.py "$OUT/c4" > "$OUT/pmc_summary_cfg4.txt" 2>&1; tail -3 "$OUT/pmc_summary_cfg4.txt"
+  sqpasses cfg4 --config cfg4
+  sqpasses cfg2
+  timeout 900 python bench.py --config cfg4 --steps 10 --warmup 2 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4_full.err"; benchline cfg4 < "$OUT/bench_cfg4.json"
+  timeout 900 python bench.py --config w1000 --steps 5 --warmup 1 --no-product --no-upload-leg 2> "$OUT/bench_w1000.err" | tee "$OUT/bench_w1000.json" | benchline w1000
+  timeout 900 python bench.py --config cfg5x0.004 --steps 5 --warmup 1 --no-product --no-upload-leg 2> "$OUT/bench_cfg5.err" | tee "$OUT/bench_cfg5x0.004.json" | benchline cfg5x0.004
+  timeout 900 python bench.py --contig 4000000 --steps 5 --warmup 1 --no-cpu --no-product --no-upload-leg 2> "$OUT/bench_4mbp.err" | tee "$OUT/bench_4mbp.json" | benchline 4mbp
+fi
+if has sq2; then sqpasses cfg2; fi
+if has sq4; then sqpasses cfg4 --config cfg4; fi
 if has bench; then
   timeout 1500 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
   echo "bench exit $?"; cut -c1-3000 "$OUT/bench.json"; tail -5 "$OUT/bench.err"
@@ -127,3 +163,6 @@ if has fuzz; then
   timeout 1500 python tools/fuzz_sweep.py --no-small --first-seed 9000 --seeds ${FUZZ_K2_SEEDS:-60} --out "$OUT/fuzz_sweep_kernel2.json" > "$OUT/fuzz_sweep_kernel2.log" 2>&1
   echo "fuzz (kernel2) exit $?"; tail -2 "$OUT/fuzz_sweep_kernel2.log" | cut -c1-1200
 fi
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+find "$OUT" -name "*.db" -delete 2>/dev/null
+du -sh "$OUT" | tail -1
