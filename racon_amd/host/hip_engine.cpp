@@ -188,9 +188,21 @@ std::shared_ptr<HipEngine> HipEngine::Create(int32_t device, int8_t match, int8_
     std::shared_ptr<HipEngine> e(new HipEngine());
     e->pool_key_ = getenv("RACON_HIP_NO_ENGINE_POOL") ? std::string() : pool_key(device, match, mismatch, gap);
     if (!e->pool_key_.empty()) {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        for (size_t i = 0; i < g_pool.size(); ++i)
-            if (g_pool[i].key == e->pool_key_) { e->handle_ = g_pool[i].handle; g_pool.erase(g_pool.begin() + static_cast<long>(i)); a.forget(e->handle_); return e; }
+        std::vector<rcn_engine*> evict;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            for (size_t i = 0; i < g_pool.size(); ++i)
+                if (g_pool[i].key == e->pool_key_) { e->handle_ = g_pool[i].handle; g_pool.erase(g_pool.begin() + static_cast<long>(i)); a.forget(e->handle_); return e; }
+            // No engine of this kind waits: the ones of OTHER kinds on this device (other scores, other switches) only hold HBM that the new
+            // engine is about to ask for -- a test process that goes through a dozen configurations had 40 engines with multi-GB arenas pooled,
+            // hipMalloc failed, and the runtime's attempt to trim scratch memory crashed inside ROCr (profiles/r06/m_gpu_suite_crash_backtrace.txt).
+            const std::string dev = std::to_string(device) + "/";
+            for (size_t i = 0; i < g_pool.size();) {
+                if (g_pool[i].key.compare(0, dev.size(), dev) == 0) { evict.push_back(g_pool[i].handle); g_pool.erase(g_pool.begin() + static_cast<long>(i)); }
+                else ++i;
+            }
+        }
+        for (rcn_engine* h : evict) a.destroy(h);
     }
     rcn_engine_config cfg{};
     cfg.device = device; cfg.match = match; cfg.mismatch = mismatch; cfg.gap = gap; cfg.trim = 1; cfg.arena_bytes = arena_bytes;
