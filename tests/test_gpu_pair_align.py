@@ -119,6 +119,30 @@ def test_two_plane_pairs_and_symbols_only_the_target_has(P):
         assert d == P.edit_distance(qs, t)
 
 
+def test_leaf_pairs_of_uneven_shapes(P):
+    """Two leaves of one overlap run side by side in one wave when their words fit it together (pair_leaf_two: ACGT reads, two symbol
+    planes): rectangles of every aspect -- leaves of unequal word counts, leaves that end at different columns, a leaf next to a split,
+    both strands -- against the host aligner, CIGAR for CIGAR."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(9260)
+    pairs, strands = [], []
+    for (m, n) in [(3000, 9000), (9000, 3000), (4100, 4100), (2500, 7000), (7000, 2500), (5000, 3500), (3700, 5200), (12000, 2000), (2000, 12000),
+                   (6400, 6300), (8200, 4000), (1900, 3900), (3900, 1900)]:
+        t = random_seq(rng, n)
+        q = mutate(rng, (t * (m // n + 1))[:m] if m > n else t[:m], 0.1)
+        if m > n:                                     # a query longer than the target: the tail is unrelated sequence (long runs of I)
+            q = q[:n] + random_seq(rng, m - n)
+        k = len(pairs)
+        pairs.append((q, t)); strands.append(0)
+        if k % 2 == 0:
+            pairs.append((nw_oracle.reverse_complement(q), t)); strands.append(1)
+    cig, dist, _ = _run(pairs, strands)
+    for k, ((q, t), c, d) in enumerate(zip(pairs, cig, dist)):
+        qs = nw_oracle.reverse_complement(q) if strands[k] else q
+        assert c == P.align_cigar(qs, t).encode(), (k, len(q), len(t))
+        assert d == P.edit_distance(qs, t)
+
+
 def test_degenerate_shapes_and_wide_alphabets(P):
     rng = np.random.default_rng(9300)
     iupac = b"ACGTNRYKMSWBDHV"
