@@ -51,9 +51,13 @@ struct DevBuf {
         // shards of a job cut to fit one device: cfg5 whole, eight of them) differs by fractions of a percent, and every
         // regrowth of a multi-GB buffer is a hipFree + hipMalloc that waits for the driver's page clearing (0.6-2.4 s,
         // tools/probe/malloc_time.hip).  The first allocation is exact.
-        const bool regrow = p != nullptr;
+        // Round 6: so does a FIRST allocation of a GiB or more while the device has three times that free -- the one regrowth a
+        // sharded job was left with (its second shard's arena a few per cent above the first's) cost cfg5 whole 2.1 s in one run
+        // and 1.7 s in another, and nothing in a third (profiles/r06/o_cfg5_whole_one_gpu.json, c_, i_).
+        bool regrow = p != nullptr;
         if (p) { if (hipFree(p) != hipSuccess) return RCN_E_HIP; p = nullptr; cap = 0; }
         size_t want = std::max<size_t>(bytes, 256);
+        if (!regrow && bytes >= (size_t(1) << 30)) { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= 3 * want) regrow = true; else (void)hipGetLastError(); }
         if (regrow && bytes >= (64u << 20) && hipMalloc(&p, want + want / 8) == hipSuccess) { cap = want + want / 8; return RCN_OK; }
         (void)hipGetLastError();
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return RCN_E_NOMEM; }
