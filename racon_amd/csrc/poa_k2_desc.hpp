@@ -10,7 +10,11 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 __host__ __device__ constexpr int dp2_ring_rows_band(int np, bool tab);
 
 // ---- phase: row descriptors (all 256 threads) + row 0 of Z ----
-__device__ __noinline__ void phase_desc2() {
+// zero_row0: also write row 0 of Z (all zeros) -- what every alignment needs BEFORE its DP.  The rebuild of the descriptors after a sink tie's
+// closure sweep (poa_kernel2.hpp: the sweep borrows the descriptor array) comes AFTER the DP and must leave the matrix alone: with move codes in
+// it (one byte per cell) the 2 * hstride bytes of the int16 row 0 are the code rows 0 AND 1, and a traceback that reached row 1 with anything but
+// a diagonal move read a zeroed code there (one window in 1.34 M of cfg5 whole: found by tools/cfg5_full_check.py, read f8913, round 6).
+__device__ __noinline__ void phase_desc2(bool zero_row0 = true) {
     const int t = threadIdx.x;
     const Ctx c = ctx_load<Block4>();
     Win g = ctx_win(c);
@@ -145,8 +149,10 @@ __device__ __noinline__ void phase_desc2() {
             }
         }
     }
-    RCN_G uint32_t* H = reinterpret_cast<RCN_G uint32_t*>(g.H.ptr());
-    for (int j = t; j < (g.hstride >> 1); j += kThreads2) H[j] = 0u;
+    if (zero_row0) {
+        RCN_G uint32_t* H = reinterpret_cast<RCN_G uint32_t*>(g.H.ptr());
+        for (int j = t; j < (g.hstride >> 1); j += kThreads2) H[j] = 0u;
+    }
     Block4::sync();
 }
 

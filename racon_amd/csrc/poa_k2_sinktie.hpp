@@ -133,6 +133,10 @@ __device__ __noinline__ void phase_sink_tie_starts() {
         o->tb_i = pstar;
         if (cnt == 1) { o->best_row = nr[who] + 1; status = 0; }
         else status = 3;
+#ifdef RCN_PROF_TIE
+        for (int k = 0; k < c.tied; ++k) printf("[tie-starts] V %d sink row %d node %d p %d\n", c.V, (k == 0 ? c.best_row : o->tie_rows[k]), vs[k], ps[k]);
+        printf("[tie-starts] V %d pstar %d cnt %d -> status %d\n", c.V, pstar, cnt, status);
+#endif
         // the local DFS only has to look at the sinks that share p*
         int m = 0;
         for (int k = 0; k < c.tied; ++k) if (ps[k] == pstar) stack[512 + m++] = vs[k];
@@ -200,6 +204,9 @@ __device__ __noinline__ void phase_sink_tie_local() {
             if (valid) --sp;
         }
     }
+#ifdef RCN_PROF_TIE
+    printf("[tie-local] V %d pstar %d ncand %d cands %d %d %d -> winner node %d row %d\n", c.V, pstar, ncand, ncand > 0 ? cand[0] : -1, ncand > 1 ? cand[1] : -1, ncand > 2 ? cand[2] : -1, winner, winner >= 0 ? nr[winner] + 1 : -1);
+#endif
     if (winner >= 0) { o->best_row = nr[winner] + 1; o->tb_n = 0; } else { o->tb_n = 2; o->tie_why = 4; }
 }
 
@@ -217,6 +224,9 @@ __device__ __noinline__ void phase_sink_tie_full() {
     for (int r = 0; r < nx; ++r) {
         const int row = nr[g.rank_x[r]] + 1;
         const int zend = c.coded ? g.path_node[row] : H[static_cast<int64_t>(row) * hs + c.len];    // coded: the DP kept the sinks' end scores
+#ifdef RCN_PROF_TIE
+        if ((g.desc[row - 1].meta & 256) && zend == c.best) printf("[tie-full] V %d tied sink row %d node %d at DFS rank %d\n", c.V, row, g.rank_x[r], r);
+#endif
         if ((g.desc[row - 1].meta & 256) && zend == c.best) { o->best_row = row; break; }
     }
     o->ties += 1;

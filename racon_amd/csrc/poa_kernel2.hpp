@@ -245,7 +245,7 @@ __device__ __forceinline__ void poa_window_body(const KParams& P) {
                             Block4::sync();
                             if (t == 0) { ctx->begin = sv_begin; ctx->end = sv_end; ctx->tb_j = sv_j; ctx->tb_i = pstar; }
                             Block4::sync();
-                            phase_desc2();
+                            phase_desc2(false);                      // (after the DP: the matrix -- scores or move codes -- stays as it is)
                         } else {
                             Win g;
                             win_bind(g, gcast(P.scratch + static_cast<uint64_t>(blockIdx.x) * P.slot_bytes), P.ncap, P.ecap, P.ring, P.lmax, P.hstride, 4, P.hrows);
