@@ -132,6 +132,38 @@ def test_band_with_forced_sink_tie_levels(oracle, level, monkeypatch):
     assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), f"coded band, forced tie level {level}")
 
 
+def test_sink_tie_through_the_closure_sweep_before_a_coded_traceback(oracle):
+    """Round 6, found by the all-records check of cfg5 whole (one window in 1.34 M): several sinks tie, the rule does not decide, the tie
+    goes through the closure sweep -- which borrows the descriptor array and has it rebuilt -- and the rebuild wrote 'row 0 of Z' into a
+    matrix that held move codes (code rows 0 and 1); a traceback that reached row 1 with an insertion then went wrong.  The window it
+    happened in (tests/golden/tie_closure_sweep_then_coded_traceback.npz, window 1) and 150 variations of it: layers dropped, reordered,
+    bases put in front of some (paths that start with an insertion)."""
+    import os
+    from racon_amd.engine import HipEngine
+    b0 = WindowBatch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tie_closure_sweep_then_coded_traceback.npz"))
+    W = b0.window(1)
+    rng = np.random.default_rng(7600)
+    wins = [W]
+    for k in range(150):
+        seqs = list(W["seqs"][1:])
+        keep = sorted(rng.choice(len(seqs), int(rng.integers(len(seqs) - 4, len(seqs) + 1)), replace=False).tolist())
+        if k % 3 == 0:
+            rng.shuffle(keep)
+        lay = []
+        for i in keep:
+            s, q, bg, en = seqs[i]
+            if rng.random() < 0.3:
+                n = int(rng.integers(1, 3))
+                s = bytes(rng.choice(list(b"ACGT"), n).tolist()) + s
+                q = None if q is None else bytes([int(q[0])] * n) + q
+            lay.append((s, q, bg, en))
+        wins.append({"type": W["type"], "seqs": [W["seqs"][0]] + lay})
+    b = WindowBatch.from_windows(wins)
+    eng = HipEngine(3, -5, -4, True)
+    assert_same(eng.consensus(b), oracle.consensus(b, 3, -5, -4, True, 0), "tie through the closure sweep, coded traceback")
+    assert eng.stats()["n_banded"] > 1000             # (a build with the old rebuild fails five of these windows and the fixture: profiles/r06/v_regression_old_and_fixed.txt)
+
+
 def fan_in_window(rng, n_variants):
     """A deep window in which the node after every hot spot collects `n_variants` + 1 in-edges (backbone edge + one per
     local variant: inserted bases, deletions of 1..3 bases, substitutions of the base in front): rows with seven and
