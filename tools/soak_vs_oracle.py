@@ -15,12 +15,15 @@ ap.add_argument("--mbp", type=float, default=6.0)
 ap.add_argument("--workers", type=int, default=16)
 ap.add_argument("--seed", type=int, default=20260930)
 ap.add_argument("--out", default="gpurun_out/soak")
+ap.add_argument("--fragment", action="store_true", help="fragment-correction windows (racon -f: the reads are the targets, dual overlaps) instead: cfg5's shape with drawn read lengths, depths and error rates")
 a = ap.parse_args()
 
 
 def piece(job):
-    from racon_amd.synth import simulate_windows
+    from racon_amd.synth import simulate_windows, simulate_fragment_windows
     n, kw = job
+    if "n_reads" in kw:
+        return simulate_fragment_windows(n, **kw)
     return simulate_windows(n, **kw)
 
 
@@ -46,6 +49,14 @@ def main():
         trim = bool(rng.random() < 0.8)
         npieces = max(1, int(a.mbp * (30.0 / kw["coverage"]) * (0.5 if w >= 700 else 1.0)))
         jobs = [(1_000_000 if not short else 300_000, dict(kw, seed=int(rng.integers(1, 2**31)))) for _ in range(npieces)]
+        if a.fragment:
+            rl = int(rng.choice([3000, 6000, 10000, 10000]))
+            depth = float(rng.choice([10, 20, 30, 30, 40]))            # reads x read length / genome
+            glen = 200_000
+            fk = dict(n_reads=int(depth * glen / rl), read_len=rl, window_len=int(rng.choice([300, 500, 500, 500, 800])), sub=kw["sub"] if not short else 0.03,
+                      ins=kw["ins"] if not short else 0.03, dele=kw["dele"] if not short else 0.04, min_overlap=int(rng.choice([500, 2000])))
+            kw = dict(fk, coverage=depth); w = fk["window_len"]
+            jobs = [(glen, dict(fk, seed=int(rng.integers(1, 2**31)))) for _ in range(a.workers)]
         tg = time.time()
         with mp.get_context("fork").Pool(min(a.workers, len(jobs))) as pool:
             parts = pool.map(piece, jobs)
@@ -65,7 +76,7 @@ def main():
         if bad and len(first) < 10:
             first.append({"round": k, "windows": bad[:5], "workload": kw, "scores": scores, "trim": trim})
         rounds.append({"round": k, "windows": b.n_windows, "differ": len(bad), "w": w, "coverage": kw["coverage"], "read_len": kw["read_len"], "sub_ins_del": [kw["sub"], kw["ins"], kw["dele"]],
-                       "backbone_errors": kw["backbone_errors"], "quality": kw["with_quality"], "scores": scores, "trim": trim, "s_generate_gpu_cpu": [round(t_gen, 1), round(t_gpu, 1), round(t_cpu, 1)]})
+                       "backbone_errors": kw.get("backbone_errors"), "quality": kw.get("with_quality"), "fragment": bool(a.fragment), "scores": scores, "trim": trim, "s_generate_gpu_cpu": [round(t_gen, 1), round(t_gpu, 1), round(t_cpu, 1)]})
         sys.stderr.write("round %d: %d windows (w %d, %gx, reads %d), %d differ; %.0f s so far\n" % (k, b.n_windows, w, kw["coverage"], kw["read_len"], len(bad), time.time() - t0)); sys.stderr.flush()
     print(json.dumps({"what": "synthetic windows of drawn shapes, HIP engine against the CPU oracle, every window", "rounds": len(rounds), "windows": total, "windows_differ": differ,
                       "first": first, "seconds": round(time.time() - t0, 1), "per_round": rounds}))
