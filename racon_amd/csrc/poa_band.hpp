@@ -131,6 +131,10 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 // profiling build: clocks and counts of the banded DP's rows by class (0 chain, 1 / 2 / 3 = fast rows with one / two /
 // three or four predecessors, 4 medium, 5 general, 6 rows where the window moved, 7 sink rows, 8 rows inside octets), spread over 256 copies
 __device__ unsigned long long g_rowprof[256][20];
+// sections of the rare rows: 0 window shift up to the re-based register window, 1 the rest of it (cold state, columns, tables), 2 general row: cold
+// state, 3 general row: predecessors combined, 4 general / medium row: the tail, 5 medium row: predecessors; 8 + k = how often
+__device__ unsigned long long g_secprof[256][16];
+#define RCN_SEC(k, dt) do { if (CODE && lane == 0) { atomicAdd(&g_secprof[blockIdx.x & 255][(k)], static_cast<unsigned long long>(dt)); atomicAdd(&g_secprof[blockIdx.x & 255][8 + (k)], 1ull); } } while (0)
 #endif
 // ---- the banded one-wave DP (wave 0 of the work-group) ----
 // CODE: instead of the row of scores the wave stores, per cell, what the traceback would find out from the scores (one
@@ -263,12 +267,18 @@ __device__ __forceinline__ void dp2_rows_band_body() {
     asm volatile("" : "+v"(coff));
     RCN_G int32_t* sinkz = g.path_node.ptr();   // CODE: end score (column len) of the sink rows, for phase_sink_tie_full
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
+#ifdef RCN_PROF_ROWS
+    long long sec_t = 0;
+#endif
     unsigned int fast8 = 0u;                    // octets of the current descriptor block that consist of ordinary chain / fast rows
 
     // the window moves to new_off before row i is computed
     auto shift_to = [&](int i_in, int new_off) {
         int i = i_in, Vs = V;
         asm volatile("; window shift (rare): nothing of it is carried in the row loop" : "+s"(i), "+s"(Vs));
+#ifdef RCN_PROF_ROWS
+        const long long sh_t0 = clock64();
+#endif
         flush_edge();
         const int woff = cold_get(&cold->woff);
         const int delta = new_off - woff, dl = delta / LPC;
@@ -296,6 +306,10 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                 prev[q] = keep ? v : NEGP;
             }
         }
+#ifdef RCN_PROF_ROWS
+        const long long sh_t1 = clock64() + (static_cast<int>(prev[0]) & 0);
+        RCN_SEC(0, sh_t1 - sh_t0);
+#endif
         // guards in HBM (score matrix only): the cell left of the window for every row still to come ...
         if (!CODE) for (int r = i + lane; r <= Vs; r += NTH) H16w[static_cast<int64_t>(r) * hs + new_off - 1] = static_cast<int16_t>(kNeg16);
         if (!CODE) {   // ... and the columns this shift adds, for the rows later rows can still name as predecessors
@@ -313,6 +327,9 @@ __device__ __forceinline__ void dp2_rows_band_body() {
         hrow = H + static_cast<int64_t>(i) * hs2 + (new_off >> 1);
         coff = static_cast<uint32_t>(i) * static_cast<uint32_t>(hs) + static_cast<uint32_t>(new_off) + 4u * static_cast<uint32_t>(t);
         set_columns();
+#ifdef RCN_PROF_ROWS
+        RCN_SEC(1, clock64() + (static_cast<int>(sqx[0]) & 0) - sh_t1);
+#endif
     };
 
 #pragma unroll 1
@@ -533,11 +550,18 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                     } else {
                         // ---- general row: any number of predecessors from the LDS ring, each in the coordinates it was
                         //      written in (window offsets of the last two shifts are kept) ----
+#ifdef RCN_PROF_ROWS
+                        const long long gn_t0 = clock64();
+#endif
                         const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
                         const int er = __builtin_amdgcn_readlane(dl_er, k);
                         const int woff = cold_get(&cold->woff), s_row1 = cold_get(&cold->s_row1), s_row2 = cold_get(&cold->s_row2), s_row3 = cold_get(&cold->s_row3);
                         const int off1 = cold_get(&cold->off1), off2 = cold_get(&cold->off2);
                         const int np = (meta >> 9) & 7;
+#ifdef RCN_PROF_ROWS
+                        const long long gn_t1 = clock64() + ((woff + s_row1 + s_row2 + s_row3 + off1 + off2) & 0);
+                        RCN_SEC(2, gn_t1 - gn_t0);
+#endif
                         bool first = true;
                         int nq = 0;                          // ordinal of the predecessor being combined (= its index in the descriptor)
                         auto combine = [&](int p) {
@@ -613,8 +637,14 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                         if (CODE && nq > 8) bfail |= 8;                   // move codes name predecessors 0..7 (three bits)
 #pragma unroll
                         for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
+#ifdef RCN_PROF_ROWS
+                        RCN_SEC(3, clock64() + (static_cast<int>(M[0]) & 0) - gn_t1);
+#endif
                     }
 
+#ifdef RCN_PROF_ROWS
+                    sec_t = clock64() + (static_cast<int>(M[0]) & 0);
+#endif
                     {
 #define RCN_TAIL_MULTI 2
 #define RCN_TAIL_SINK 1

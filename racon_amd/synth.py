@@ -44,13 +44,40 @@ def _sim_read(rng, contig: np.ndarray, read_len: int, sub: float, ins: float, de
     return ts, te, read, q, deleted, has_ins, mcols, qpos
 
 
+def _low_complexity(contig: np.ndarray, share: float, n_rate: float, seed: int) -> np.ndarray:
+    """Overwrite about `share` of a random contig with what real genomes hold and a uniform one never does: homopolymer
+    runs, short tandem repeats (units of 2-6 bases), stretches over a two-letter alphabet -- alignments over these have many
+    co-optimal paths, i.e. score ties at every level (predecessor choice, move priority, tied sinks) -- and, with `n_rate`,
+    N bases (a fifth symbol: racon takes any byte, reference src/sequence.cpp:24-27).  A random stream of its own: the
+    seeded workloads without these options are unchanged."""
+    r = np.random.default_rng([seed, 0x10c0]); out = contig.copy(); n = len(out); pos = 0
+    while pos < n:
+        if r.random() >= share:
+            pos += int(r.integers(10, 120)); continue
+        kind = int(r.integers(0, 3))
+        if kind == 0:
+            ln = int(r.integers(3, 40)); out[pos:pos + ln] = _ACGT[r.integers(0, 4)]
+        elif kind == 1:
+            unit = _ACGT[r.integers(0, 4, int(r.integers(2, 7)))]; ln = len(unit) * int(r.integers(3, 30))
+            out[pos:pos + ln] = np.resize(unit, ln)[:max(0, min(ln, n - pos))]
+        else:
+            two = _ACGT[r.choice(4, 2, replace=False)]; ln = int(r.integers(10, 150))
+            out[pos:pos + ln] = two[r.integers(0, 2, ln)][:max(0, min(ln, n - pos))]
+        pos += ln
+    if n_rate > 0:
+        out[r.random(n) < n_rate] = ord("N")
+    return out
+
+
 def simulate_windows(contig_len: int, window_len: int = 500, coverage: float = 30.0, read_len: int = 10000,
                      sub: float = 0.03, ins: float = 0.03, dele: float = 0.04, seed: int = 20260921,
                      phred_mean: float = 15.0, phred_sd: float = 4.0, phred_lo: int = 5, phred_hi: int = 30,
                      with_quality: bool = True, quality_threshold: float = 10.0, tgs: bool | None = None,
-                     backbone_errors: float = 0.0) -> WindowBatch:
+                     backbone_errors: float = 0.0, low_complexity: float = 0.0, n_rate: float = 0.0) -> WindowBatch:
     rng = np.random.default_rng(seed)
     contig = _ACGT[rng.integers(0, 4, contig_len)]
+    if low_complexity > 0 or n_rate > 0:
+        contig = _low_complexity(contig, low_complexity, n_rate, seed)
     # the backbone (draft assembly) may itself carry substitution errors
     backbone = contig.copy()
     if backbone_errors > 0:

@@ -16,6 +16,8 @@ ap.add_argument("--workers", type=int, default=16)
 ap.add_argument("--seed", type=int, default=20260930)
 ap.add_argument("--out", default="gpurun_out/soak")
 ap.add_argument("--fragment", action="store_true", help="fragment-correction windows (racon -f: the reads are the targets, dual overlaps) instead: cfg5's shape with drawn read lengths, depths and error rates")
+ap.add_argument("--lowcomplexity", action="store_true", help="contigs with homopolymer runs, short tandem repeats and two-letter stretches (many co-optimal alignments: ties at every level), "
+                "some with N bases, some at 80-150x (ninth in-edges, full rings), higher error rates")
 a = ap.parse_args()
 
 
@@ -45,6 +47,12 @@ def main():
                   sub=float(rng.choice([0.003, 0.01]) if short else rng.choice([0.01, 0.03, 0.05])), ins=float(rng.choice([0.0005, 0.002]) if short else rng.choice([0.01, 0.03, 0.05])),
                   dele=float(rng.choice([0.0005, 0.002]) if short else rng.choice([0.01, 0.04, 0.06])), backbone_errors=float(rng.choice([0.0, 0.0, 0.01, 0.03])),
                   with_quality=bool(rng.random() < 0.8))
+        if a.lowcomplexity:
+            kw["low_complexity"] = float(rng.choice([0.3, 0.6, 0.9, 1.0])); kw["n_rate"] = float(rng.choice([0.0, 0.0, 0.002, 0.02]))
+            if rng.random() < 0.3:
+                kw["coverage"] = float(rng.choice([80, 100, 150]))
+            if not short and rng.random() < 0.3:
+                kw.update(sub=0.08, ins=0.06, dele=0.08)
         scores = [(3, -5, -4), (5, -4, -8), (1, -1, -1), (2, -3, -2)][int(rng.integers(0, 4))]
         trim = bool(rng.random() < 0.8)
         npieces = max(1, int(a.mbp * (30.0 / kw["coverage"]) * (0.5 if w >= 700 else 1.0)))
@@ -76,7 +84,7 @@ def main():
         if bad and len(first) < 10:
             first.append({"round": k, "windows": bad[:5], "workload": kw, "scores": scores, "trim": trim})
         rounds.append({"round": k, "windows": b.n_windows, "differ": len(bad), "w": w, "coverage": kw["coverage"], "read_len": kw["read_len"], "sub_ins_del": [kw["sub"], kw["ins"], kw["dele"]],
-                       "backbone_errors": kw.get("backbone_errors"), "quality": kw.get("with_quality"), "fragment": bool(a.fragment), "scores": scores, "trim": trim, "s_generate_gpu_cpu": [round(t_gen, 1), round(t_gpu, 1), round(t_cpu, 1)]})
+                       "backbone_errors": kw.get("backbone_errors"), "quality": kw.get("with_quality"), "fragment": bool(a.fragment), "low_complexity": kw.get("low_complexity"), "n_rate": kw.get("n_rate"), "scores": scores, "trim": trim, "s_generate_gpu_cpu": [round(t_gen, 1), round(t_gpu, 1), round(t_cpu, 1)]})
         sys.stderr.write("round %d: %d windows (w %d, %gx, reads %d), %d differ; %.0f s so far\n" % (k, b.n_windows, w, kw["coverage"], kw["read_len"], len(bad), time.time() - t0)); sys.stderr.flush()
     print(json.dumps({"what": "synthetic windows of drawn shapes, HIP engine against the CPU oracle, every window", "rounds": len(rounds), "windows": total, "windows_differ": differ,
                       "first": first, "seconds": round(time.time() - t0, 1), "per_round": rounds}))
