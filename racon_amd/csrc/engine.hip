@@ -1117,9 +1117,11 @@ static int collect(rcn_engine* e) {
       for (int k = 0; k < 9; ++k) if (cnt[k]) fprintf(stderr, "  %-16s rows %5.1f %%  clocks %5.1f %%  %7.0f clocks/row\n", names[k], 100.0 * cnt[k] / std::max(1ull, alln),
                                                          100.0 * clk[k] / std::max(1ull, allc), (double)clk[k] / cnt[k]);
       fprintf(stderr, "  all              rows %llu  %7.0f clocks/row\n", alln, (double)allc / std::max(1ull, alln));
-      static unsigned long long sp[256][16]; HIP_TRY(hipMemcpyFromSymbol(sp, HIP_SYMBOL(rcn::g_secprof), sizeof(sp)));
-      static const char* secs[5] = {"window shift: certificate + register window re-based", "window shift: cold state, columns, tables", "general row: cold state read", "general row: predecessors combined", "general / medium row: tail"};
-      for (int k = 0; k < 5; ++k) { unsigned long long c_ = 0, n_ = 0; for (int b = 0; b < 256; ++b) { c_ += sp[b][k]; n_ += sp[b][8 + k]; }
+      static unsigned long long sp[256][40]; HIP_TRY(hipMemcpyFromSymbol(sp, HIP_SYMBOL(rcn::g_secprof), sizeof(sp)));
+      static const char* secs[15] = {"shift: edge flush + certificate of the dropped cells", "shift: register window re-based (bpermutes)", "shift: cold state updated", "shift: columns (bases, thresholds)",
+                                     "shift: profile tables", "shift: rest", "general row: cold state, descriptor", "general row: first predecessor", "general row: further predecessors", "general row: rest of the in-edge list",
+                                     "general / medium tail: candidates + scan", "general / medium tail: codes + store", "general / medium tail: ring + window", "general / medium tail: sink part + end", "general row in one round trip (round 6)"};
+      for (int k = 0; k < 15; ++k) { unsigned long long c_ = 0, n_ = 0; for (int b = 0; b < 256; ++b) { c_ += sp[b][k]; n_ += sp[b][20 + k]; }
         if (n_) fprintf(stderr, "  section %-56s %9llu times  %7.0f clocks each\n", secs[k], n_, (double)c_ / n_); } }
 #endif
 #ifdef RCN_PROF_WIN

@@ -32,7 +32,10 @@
 
 namespace rcn {
 
-constexpr int kBandG = 32;            // window offsets are multiples of this many columns
+#ifndef RCN_BAND_G
+#define RCN_BAND_G 32
+#endif
+constexpr int kBandG = RCN_BAND_G;    // window offsets are multiples of this many columns (64: half as many window shifts, a worse-centred window -- A/B in profiles/r03/r_band_granularity.txt and r06/z_)
 constexpr int kBandSeq = 1088;        // LDS copy of the layer's bases (window shifts re-read their columns from it) + the cold window state
 constexpr int kBandRing = 32;         // rows of the LDS ring of the banded DP (a power of two and a multiple of the octet: see dp2_rows_band_body)
 
@@ -131,10 +134,14 @@ __device__ __forceinline__ void band_row_offsets(const Ctx& c, Win& g, RCN_G con
 // profiling build: clocks and counts of the banded DP's rows by class (0 chain, 1 / 2 / 3 = fast rows with one / two /
 // three or four predecessors, 4 medium, 5 general, 6 rows where the window moved, 7 sink rows, 8 rows inside octets), spread over 256 copies
 __device__ unsigned long long g_rowprof[256][20];
-// sections of the rare rows: 0 window shift up to the re-based register window, 1 the rest of it (cold state, columns, tables), 2 general row: cold
-// state, 3 general row: predecessors combined, 4 general / medium row: the tail, 5 medium row: predecessors; 8 + k = how often
-__device__ unsigned long long g_secprof[256][16];
-#define RCN_SEC(k, dt) do { if (CODE && lane == 0) { atomicAdd(&g_secprof[blockIdx.x & 255][(k)], static_cast<unsigned long long>(dt)); atomicAdd(&g_secprof[blockIdx.x & 255][8 + (k)], 1ull); } } while (0)
+// sections of the rare rows (window shifts, general rows, their tail): clocks [k] and counts [20 + k] of section k, see engine.hip for the names
+__device__ unsigned long long g_secprof[256][40];
+#define RCN_SEC(k, dt) do { if (CODE && lane == 0) { atomicAdd(&g_secprof[blockIdx.x & 255][(k)], static_cast<unsigned long long>(dt)); atomicAdd(&g_secprof[blockIdx.x & 255][20 + (k)], 1ull); } } while (0)
+#define RCN_LAP0() do { sec_last = clock64(); } while (0)
+#define RCN_LAP(k, dep) do { const long long n__ = clock64() + (static_cast<int>(dep) & 0); RCN_SEC(k, n__ - sec_last); sec_last = clock64(); } while (0)
+#else
+#define RCN_LAP0() do {} while (0)
+#define RCN_LAP(k, dep) do {} while (0)
 #endif
 // ---- the banded one-wave DP (wave 0 of the work-group) ----
 // CODE: instead of the row of scores the wave stores, per cell, what the traceback would find out from the scores (one
@@ -199,6 +206,9 @@ __device__ __forceinline__ void dp2_rows_band_body() {
     { BandCold z = {0, 0, 0, 0, 0, 0}; *cold = z; }
     auto cold_get = [&](const int* p_) { return __builtin_amdgcn_readfirstlane(*p_); };
     int bfail = 0;
+#ifdef RCN_PROF_ROWS
+    long long sec_last = clock64();
+#endif
     uint32_t sqx[NP], thrv[NP];                 // bases / alive thresholds (m - g) * column of this lane's columns
     int own_lane = 0, own_q = 0, own_in = 0;    // where column len lives (own_in: inside the window)
     const int own_hi = len & 1;
@@ -215,6 +225,7 @@ __device__ __forceinline__ void dp2_rows_band_body() {
             sqx[q] = pack2(s0, s1);
             thrv[q] = pack2(mg * j0, mg * j1);
         }
+        RCN_LAP(3, sqx[0] + sqx[NP - 1]);
         if (TAB) {
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
@@ -223,12 +234,14 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                 for (int q = 0; q < NP; ++q) ptab[(sl * NTH + t) * NP + q] = pk_profile(sqx[q], symsym, ONE, XM, MG);
             }
         }
+        RCN_LAP(4, 0);
         const int rel = len - woff;
         own_in = rel < WB;
         own_lane = (rel / LPC) & 63; own_q = (rel % LPC) >> 1;
     };
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);              // lseq written by this wave, read right below
+    RCN_LAP0();
     set_columns();
 
     constexpr int R = dp2_window(NP);
@@ -267,18 +280,13 @@ __device__ __forceinline__ void dp2_rows_band_body() {
     asm volatile("" : "+v"(coff));
     RCN_G int32_t* sinkz = g.path_node.ptr();   // CODE: end score (column len) of the sink rows, for phase_sink_tie_full
     int dl_p0 = 0, dl_p1 = 0, dl_p2 = 0, dl_p3 = 0, dl_p4 = 0, dl_p5 = 0, dl_er = -1, dl_meta = 1 << 9, dl_off = 0;
-#ifdef RCN_PROF_ROWS
-    long long sec_t = 0;
-#endif
     unsigned int fast8 = 0u;                    // octets of the current descriptor block that consist of ordinary chain / fast rows
 
     // the window moves to new_off before row i is computed
     auto shift_to = [&](int i_in, int new_off) {
         int i = i_in, Vs = V;
         asm volatile("; window shift (rare): nothing of it is carried in the row loop" : "+s"(i), "+s"(Vs));
-#ifdef RCN_PROF_ROWS
-        const long long sh_t0 = clock64();
-#endif
+        RCN_LAP0();
         flush_edge();
         const int woff = cold_get(&cold->woff);
         const int delta = new_off - woff, dl = delta / LPC;
@@ -292,6 +300,7 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                 emaxV = lane < dl ? cand : emaxV;
             }
         }
+        RCN_LAP(0, emaxV);
         {   // re-base the register window: lane l <- lane l + dl
             const int srcl = ((lane + dl) & 63) * 4;
             const bool keep = lane + dl < 64;
@@ -306,10 +315,7 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                 prev[q] = keep ? v : NEGP;
             }
         }
-#ifdef RCN_PROF_ROWS
-        const long long sh_t1 = clock64() + (static_cast<int>(prev[0]) & 0);
-        RCN_SEC(0, sh_t1 - sh_t0);
-#endif
+        RCN_LAP(1, prev[0]);
         // guards in HBM (score matrix only): the cell left of the window for every row still to come ...
         if (!CODE) for (int r = i + lane; r <= Vs; r += NTH) H16w[static_cast<int64_t>(r) * hs + new_off - 1] = static_cast<int16_t>(kNeg16);
         if (!CODE) {   // ... and the columns this shift adds, for the rows later rows can still name as predecessors
@@ -324,12 +330,11 @@ __device__ __forceinline__ void dp2_rows_band_body() {
             n_.off2 = cold_get(&cold->off1); n_.s_row3 = cold_get(&cold->s_row2); n_.off1 = woff; n_.s_row2 = cold_get(&cold->s_row1); n_.s_row1 = i; n_.woff = new_off;
             *cold = n_;
         }
+        RCN_LAP(2, 0);
         hrow = H + static_cast<int64_t>(i) * hs2 + (new_off >> 1);
         coff = static_cast<uint32_t>(i) * static_cast<uint32_t>(hs) + static_cast<uint32_t>(new_off) + 4u * static_cast<uint32_t>(t);
         set_columns();
-#ifdef RCN_PROF_ROWS
-        RCN_SEC(1, clock64() + (static_cast<int>(sqx[0]) & 0) - sh_t1);
-#endif
+        RCN_LAP(5, own_lane);
     };
 
 #pragma unroll 1
@@ -550,18 +555,69 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                     } else {
                         // ---- general row: any number of predecessors from the LDS ring, each in the coordinates it was
                         //      written in (window offsets of the last two shifts are kept) ----
-#ifdef RCN_PROF_ROWS
-                        const long long gn_t0 = clock64();
-#endif
+                        RCN_LAP0();
                         const int p0 = __builtin_amdgcn_readlane(dl_p0, k);
                         const int er = __builtin_amdgcn_readlane(dl_er, k);
+                        // The common general row -- a sink, or a node with five or six in-edges: every predecessor is one of the six
+                        // in the descriptor, a real row, still in the ring, written under this row's window offset (bit 12 clear: phase_desc2
+                        // looked) -- takes its ring rows in ONE round trip, like a medium row: in situ the predecessor-by-predecessor
+                        // loop below costs ~450 clocks per predecessor (a dependent LDS round trip and half a dozen scalar branches
+                        // each: profiles/r06/z_rare_row_sections.txt), 1 % of the rows were 9-12 % of the DP's clocks.
+                        bool wide_done = false;
+                        if (!(meta & (1 << 12)) && er < 0 && ((meta >> 9) & 7) <= kInlinePreds) {
+                            const int npw = (meta >> 9) & 7;
+                            const int q1 = __builtin_amdgcn_readlane(dl_p1, k), q2 = __builtin_amdgcn_readlane(dl_p2, k);
+                            const int q3 = __builtin_amdgcn_readlane(dl_p3, k), q4 = __builtin_amdgcn_readlane(dl_p4, k);
+                            const int q5 = __builtin_amdgcn_readlane(dl_p5, k);
+                            // unused slots repeat predecessor 0: never strictly greater, the first-argmax does not see them
+                            const int pw[kInlinePreds] = {p0, npw > 1 ? q1 : p0, npw > 2 ? q2 : p0, npw > 3 ? q3 : p0, npw > 4 ? q4 : p0, npw > 5 ? q5 : p0};
+                            const int pmin = min(min(min(pw[0], pw[1]), min(pw[2], pw[3])), min(pw[4], pw[5]));
+                            if (pmin >= 1 && i - pmin < K - 1) {
+                                auto ring_row = [&](int p_, uint32_t (&hq)[NP]) {
+                                    int sp = slot - (i - p_); if (sp < 0) sp += K;
+                                    const uint32_t* src = ring + (sp * NTH + t) * NP;
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) hq[q] = src[q];
+                                };
+                                uint32_t h0[NP], h1[NP];
+                                ring_row(pw[0], h0); ring_row(pw[1], h1);
+                                if (npw > 2) {
+                                    uint32_t h2[NP], h3[NP], h4[NP], h5[NP];
+                                    ring_row(pw[2], h2); ring_row(pw[3], h3); ring_row(pw[4], h4); ring_row(pw[5], h5);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = h0[q];
+                                    if (CODE) arg_step(h1, 1);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], h1[q]);
+                                    if (CODE) arg_step(h2, 2);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], h2[q]);
+                                    if (CODE) arg_step(h3, 3);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], h3[q]);
+                                    if (CODE) arg_step(h4, 4);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], h4[q]);
+                                    if (CODE) arg_step(h5, 5);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], h5[q]);
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = h0[q];
+                                    if (CODE) arg_step(h1, 1);
+#pragma unroll
+                                    for (int q = 0; q < NP; ++q) M[q] = pk_max(M[q], h1[q]);
+                                }
+                                pred_rows += npw;
+                                wide_done = true;
+                                RCN_LAP(14, M[0]);
+                            }
+                        }
+                        if (!wide_done) {
                         const int woff = cold_get(&cold->woff), s_row1 = cold_get(&cold->s_row1), s_row2 = cold_get(&cold->s_row2), s_row3 = cold_get(&cold->s_row3);
                         const int off1 = cold_get(&cold->off1), off2 = cold_get(&cold->off2);
                         const int np = (meta >> 9) & 7;
-#ifdef RCN_PROF_ROWS
-                        const long long gn_t1 = clock64() + ((woff + s_row1 + s_row2 + s_row3 + off1 + off2) & 0);
-                        RCN_SEC(2, gn_t1 - gn_t0);
-#endif
+                        RCN_LAP(6, woff + s_row1 + s_row2 + s_row3 + off1 + off2 + p0 + er);
                         bool first = true;
                         int nq = 0;                          // ordinal of the predecessor being combined (= its index in the descriptor)
                         auto combine = [&](int p) {
@@ -622,6 +678,7 @@ __device__ __forceinline__ void dp2_rows_band_body() {
                             ++pred_rows; ++nq;
                         };
                         combine(p0);
+                        RCN_LAP(7, M[0]);
                         if (np > 1) {
                             const int q1 = __builtin_amdgcn_readlane(dl_p1, k), q2 = __builtin_amdgcn_readlane(dl_p2, k);
                             const int q3 = __builtin_amdgcn_readlane(dl_p3, k), q4 = __builtin_amdgcn_readlane(dl_p4, k);
@@ -629,22 +686,20 @@ __device__ __forceinline__ void dp2_rows_band_body() {
 #pragma unroll 1
                             for (int q = 1; q < np; ++q) combine(q == 1 ? q1 : q == 2 ? q2 : q == 3 ? q3 : q == 4 ? q4 : q5);
                         }
+                        RCN_LAP(8, M[0]);
                         for (int e = er; e >= 0; e = e_nin[e]) {          // more than six in-edges: the rest of the list
                             const int tl = e_tail[e];
                             if (sub && !inc[tl]) continue;
                             combine(nr[tl] + 1);
                         }
                         if (CODE && nq > 8) bfail |= 8;                   // move codes name predecessors 0..7 (three bits)
+                        RCN_LAP(9, M[0]);
+                        }
 #pragma unroll
                         for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(M[q]));
-#ifdef RCN_PROF_ROWS
-                        RCN_SEC(3, clock64() + (static_cast<int>(M[0]) & 0) - gn_t1);
-#endif
                     }
 
-#ifdef RCN_PROF_ROWS
-                    sec_t = clock64() + (static_cast<int>(M[0]) & 0);
-#endif
+                    RCN_LAP0();
                     {
 #define RCN_TAIL_MULTI 2
 #define RCN_TAIL_SINK 1
