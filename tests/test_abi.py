@@ -55,6 +55,15 @@ def test_product_does_not_link_the_oracle():
     assert "oracle_lib" not in src and "liboracle" not in src and "poa_oracle" not in src
 
 
+def test_product_libraries_are_not_sanitizer_builds():
+    """A sanitizer build of the host layer (CPU-side checks: make CXXFLAGS=-fsanitize=address) left in the tree travels to
+    the GPU box like any built .so, and every process that dlopens it dies in the sanitizer's start-up check -- silently under
+    pytest's capture.  __graft_entry__.build() rebuilds such a library; this test names it."""
+    import __graft_entry__ as ge
+    for rel in ("racon_amd/host/libracon_host.so", "racon_amd/host/racon_hip", "racon_amd/csrc/libracon_hip.so", "oracle/liboracle.so"):
+        assert not ge._instrumented(os.path.join(ROOT, rel)), f"{rel} is a sanitizer build: make -C {os.path.dirname(rel)} clean all"
+
+
 def test_library_holds_both_instances_of_the_consensus_kernel():
     """The consensus kernel is built twice, in two translation units (racon_amd/csrc/poa_kernel2.hpp): the instance for eight
     work-groups per CU and the one for a work-group that has a CU to itself (engine_deep.hip); and the int32 fallback kernel."""

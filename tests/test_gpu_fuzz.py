@@ -113,3 +113,21 @@ def test_fuzz_windows_forced_slow_traceback(oracle, seed, scores, monkeypatch):
     assert_same(HipEngine(*scores, True).consensus(b), oracle.consensus(b, *scores, True, 0), f"slow traceback, fuzz seed {seed}")
     b2 = simulate_windows(6000, 500, 12.0, 3000, seed=600 + seed)
     assert_same(HipEngine(*scores, True).consensus(b2), oracle.consensus(b2, *scores, True, 0), f"slow traceback, synthetic seed {seed}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,scores", [(dict(window_len=500, coverage=30.0, read_len=8000, low_complexity=0.9, n_rate=0.002), (3, -5, -4)),
+                                        (dict(window_len=200, coverage=60.0, read_len=150, sub=0.003, ins=0.002, dele=0.002, low_complexity=0.6, n_rate=0.02), (5, -4, -8)),
+                                        (dict(window_len=300, coverage=100.0, read_len=3000, sub=0.08, ins=0.06, dele=0.08, low_complexity=1.0), (1, -1, -1))])
+def test_low_complexity_contigs(oracle, kw, scores):
+    """Homopolymer runs, short tandem repeats, two-letter stretches, N bases (synth._low_complexity): alignments with many
+    co-optimal paths -- ties in the predecessor choice, the move priority and between sinks -- through both kernels
+    (tools/soak_vs_oracle.py --lowcomplexity is the same at size: profiles/r06/y_soak_low_complexity_vs_oracle.json)."""
+    from racon_amd.engine import HipEngine
+    from racon_amd.synth import simulate_windows
+    b = simulate_windows(150_000, seed=31, **kw)
+    for trim in (True, False):
+        ref = oracle.consensus(b, *scores, trim, 0)
+        got = HipEngine(*scores, trim).consensus(b)
+        assert_same(got, ref, f"low-complexity {kw} scores {scores} trim {trim}")
+

@@ -34,6 +34,24 @@ def test_oracle_matches_spec_on_synthetic(oracle):
         assert p == bool(r.polished[w])
 
 
+def test_low_complexity_contigs(oracle):
+    """Homopolymer runs, short tandem repeats, two-letter stretches and N bases (synth._low_complexity): many co-optimal
+    alignments, i.e. ties at every level.  The option leaves the seeded workloads without it unchanged; oracle = spec,
+    and the oracle's AVX2 variant = its scalar one."""
+    plain, again = simulate_windows(3000, 500, 12, 2000, seed=5), simulate_windows(3000, 500, 12, 2000, seed=5, low_complexity=0.0)
+    assert plain.bases.tobytes() == again.bases.tobytes() and plain.seq_off.tobytes() == again.seq_off.tobytes()
+    b = simulate_windows(2500, 250, 10, 1500, seed=11, low_complexity=0.9, n_rate=0.01)
+    assert b.bases.tobytes() != simulate_windows(2500, 250, 10, 1500, seed=11).bases.tobytes() and ord("N") in b.bases
+    r = oracle.consensus(b, 3, -5, -4, True, 2)
+    for w in range(b.n_windows):
+        c, p = spec_consensus(b.window(w), 3, -5, -4)
+        assert c == r.consensus[w], f"window {w}"
+        assert p == bool(r.polished[w])
+    big = simulate_windows(40000, 500, 30, 8000, seed=12, low_complexity=0.8, n_rate=0.002)
+    a, v = oracle.consensus(big, 3, -5, -4, True, 0, simd=False), oracle.consensus(big, 3, -5, -4, True, 0, simd=True)
+    assert a.consensus == v.consensus
+
+
 def test_oracle_trim_and_type_semantics(oracle):
     b = edge_case_batch()
     r_trim = oracle.consensus(b, 3, -5, -4, True, 1)
