@@ -354,7 +354,7 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
             (*polished)[w] = r.polished[w]; (*chimeric)[w] = r.chimeric[w];
         }
     });
-    if (want_stats && r.n_windows >= 32768)
+    if (want_stats)
         fprintf(stderr, "[racon::HipEngine::run] timing: engine run %.1f ms (kernel %.1f), result + stats %.1f ms, %u strings %.1f ms\n", 1e3 * t_run, last_kernel_ms_,
                 1e3 * (t_stats - t_run), r.n_windows, 1e3 * (seconds_since(f0) - t_stats));
 }

@@ -652,6 +652,8 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
     if (device_windows_) {
         // windows built in HBM (device_job): by initialize() already where every shard has an engine of its own -- polish() is then
         // the consensus of resident windows --, otherwise built and polished here, shard after shard
+        const bool timing_d = getenv("RACON_HIP_TIMING") != nullptr;
+        if (timing_d) fprintf(stderr, "[racon::Polisher::polish] timing: engines ready, result arrays made at %.2f ms\n", 1e3 * seconds_since(polish_begin));
         if (device_built_) device_job(2, &cons, &pol, &chim);
         else {
             // shard after shard inside polish(); a shard the device has no room for cuts the job finer (twice, four times ... the shards)
@@ -670,8 +672,10 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         for (uint64_t i = 0; i < nw; ++i)
             if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
                                  static_cast<unsigned long>(windows_[i]->id()), windows_[i]->rank());
+        if (timing_d) fprintf(stderr, "[racon::Polisher::polish] timing: windows polished at %.2f ms\n", 1e3 * seconds_since(polish_begin));
         assemble([&](uint64_t i) -> const std::string& { return cons[i]; }, [&](uint64_t i) { return pol[i] != 0; },
                  dst, drop_unpolished_sequences);
+        if (timing_d) fprintf(stderr, "[racon::Polisher::polish] timing: assembled at %.2f ms\n", 1e3 * seconds_since(polish_begin));
         logger_->log("[racon::Polisher::polish] generated consensus");
         return;
     }
