@@ -221,14 +221,25 @@ void Polisher::build_shard(HipEngine& engine, const ShardInput& in) {
 }
 
 // ---------------------------------------------------------------- run (the consensus of the resident windows) + results
-void Polisher::run_shard(HipEngine& engine, uint64_t window_base, uint64_t n_local, uint64_t wa, uint64_t wb,
+void Polisher::run_shard(bool views, HipEngine& engine, uint64_t window_base, uint64_t n_local, uint64_t wa, uint64_t wb,
                          std::vector<std::string>& cons, std::vector<uint8_t>& pol, std::vector<uint8_t>& chim) {
-    engine.set_fetch_range(wa - window_base, wb - window_base);                 // the strings of its own windows only
+    // `views`: no string per window -- the caller concatenates the windows straight from the engine's result block (cons_views_), which
+    // stays as it is until the engine's next run
+    if (views) engine.set_fetch_range(0, 0); else engine.set_fetch_range(wa - window_base, wb - window_base);   // the strings of its own windows only
     engine.set_verify_ids([window_base](uint32_t w) { return window_base + w; });
     struct Reset { HipEngine& e; ~Reset() { e.set_fetch_range(0, ~uint64_t(0)); e.set_verify_ids(nullptr); } } reset{engine};   // (also when run() throws)
     std::vector<std::string> c; std::vector<uint8_t> pl, ch;
     engine.run(trim_, &c, &pl, &ch);
     if (c.size() != n_local) throw std::runtime_error("[racon::Polisher::polish] error: window count mismatch between host and device!");
+    if (views) {
+        const rcn_result& r = engine.last_result();
+        for (uint64_t w = wa; w < wb; ++w) {
+            const uint64_t l = w - window_base;
+            cons_views_[w] = ConsensusView(reinterpret_cast<const char*>(r.cons + r.cons_off[l]), static_cast<size_t>(r.cons_off[l + 1] - r.cons_off[l]));
+            pol[w] = pl[l]; chim[w] = ch[l];
+        }
+        return;
+    }
     for (uint64_t w = wa; w < wb; ++w) { const uint64_t l = w - window_base; cons[w].swap(c[l]); pol[w] = pl[l]; chim[w] = ch[l]; }
 }
 
@@ -281,7 +292,7 @@ void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::ve
         try {
             if (phase == 2) {
                 for (uint32_t s : mine)
-                    run_shard(*eng[0], plan.first_window[plan.target_lo[s]], plan.n_shards == 1 ? nw : plan.first_window[plan.target_hi[s]] - plan.first_window[plan.target_lo[s]],
+                    run_shard(mine.size() == 1, *eng[0], plan.first_window[plan.target_lo[s]], plan.n_shards == 1 ? nw : plan.first_window[plan.target_hi[s]] - plan.first_window[plan.target_lo[s]],
                               plan.cut[s], plan.cut[s + 1], cons, pol, chim);
                 return;
             }
@@ -311,7 +322,7 @@ void Polisher::device_job(int phase, std::vector<std::string>* cons_out, std::ve
                 running = std::async(std::launch::async, [&, in, engine, t0, t_built, used_built, device]() {
                     FatalThrowsScope scope2;
                     const double t_run = seconds_since(job_begin);
-                    run_shard(*engine, in->window_base, in->n_local, in->wa, in->wb, cons, pol, chim);
+                    run_shard(false, *engine, in->window_base, in->n_local, in->wa, in->wb, cons, pol, chim);
                     if (timing) {
                         const uint64_t used = std::max(used_built, used_hbm(device));
                         fprintf(stderr, "[racon::Polisher::polish] timing: shard %u (windows %lu..%lu, %lu overlaps, %lu reads) on device %d: sliced in %.1f ms, built in %.1f ms (from %.1f), consensus + results in %.1f ms (from %.1f, kernel %.1f), %.2f GB of HBM in use\n",

@@ -343,6 +343,7 @@ void HipEngine::fetch(int rc, std::vector<std::string>* consensus, std::vector<u
         static const bool say = getenv("RACON_HIP_TIMING") != nullptr;
         if (say) fprintf(stderr, "[racon_hip] self-check: %u windows re-polished on the exact paths in %.1f ms (%u through the int32 kernel), none differs\n", rep.n_checked, rep.ms, rep.n_int32);
     }
+    last_result_ = r;
     consensus->resize(r.n_windows); polished->resize(r.n_windows); chimeric->resize(r.n_windows);
     // (a shard of cfg5 hands back 250 000 strings: on one thread that is 60-100 ms between two shards with the device idle)
     const uint32_t blocks = (r.n_windows + 4095) / 4096;

@@ -104,6 +104,10 @@ public:
     // Only windows [first, last) of the next consensus() calls are copied into strings (the others come back empty):
     // a shard of a device-built job owns a range of the windows its engine returns.  (0, ~0) = all.
     void set_fetch_range(uint64_t first, uint64_t last) { fetch_first_ = first; fetch_last_ = last; }
+    // The result block of the last run (consensus bytes at prefix-summed offsets in pinned host memory, written by the kernel): valid
+    // until this engine's next build / run / reset.  A caller that concatenates the windows anyway reads them from here instead of
+    // having every window copied into a string first (set_fetch_range(0, 0)).
+    const rcn_result& last_result() const { return last_result_; }
     // RACON_HIP_VERIFY (rcn_engine_verify, run behind every batch when set): the Polisher's ids of the next batch's windows, so that a
     // failed self-check names the window as the Polisher numbers it (empty: the index within the batch); windows checked so far
     void set_verify_ids(std::function<uint64_t(uint32_t)> ids) { verify_ids_ = std::move(ids); }
@@ -117,6 +121,7 @@ private:
     rcn_engine* handle_ = nullptr;
     double last_kernel_ms_ = 0;
     int last_rc_ = 0;
+    rcn_result last_result_{};
     uint64_t fetch_first_ = 0, fetch_last_ = ~uint64_t(0);
     std::function<uint64_t(uint32_t)> verify_ids_;
     uint64_t verified_windows_ = 0;

@@ -592,17 +592,22 @@ void Polisher::pack_windows(PackedBatch* out) const {
 
 void Polisher::assemble(const std::function<const std::string&(uint64_t)>& consensus, const std::function<bool(uint64_t)>& polished,
                         std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {
+    assemble_views([&](uint64_t i) { const std::string& c = consensus(i); return ConsensusView(c.data(), c.size()); }, polished, dst, drop_unpolished_sequences);
+}
+
+void Polisher::assemble_views(const std::function<ConsensusView(uint64_t)>& consensus, const std::function<bool(uint64_t)>& polished,
+                              std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences) {
     std::string polished_data;
     uint32_t num_polished_windows = 0;
     for (uint64_t i = 0; i < windows_.size(); ++i) {
         if (windows_[i]->rank() == 0) {
             // (one allocation per target, moved into the Sequence: a megabase grown by doubling and then copied is its pages touched twice)
             uint64_t total = 0;
-            for (uint64_t k = i; k < windows_.size() && (k == i || windows_[k]->rank() != 0); ++k) total += consensus(k).size();
+            for (uint64_t k = i; k < windows_.size() && (k == i || windows_[k]->rank() != 0); ++k) total += consensus(k).second;
             polished_data.reserve(total);
         }
         num_polished_windows += polished(i) ? 1 : 0;
-        polished_data += consensus(i);
+        { const ConsensusView c = consensus(i); polished_data.append(c.first, c.second); }
         if (i == windows_.size() - 1 || windows_[i + 1]->rank() == 0) {       // last window of this target
             const double polished_ratio = num_polished_windows / static_cast<double>(windows_[i]->rank() + 1);
             if (!drop_unpolished_sequences || polished_ratio > 0) {
@@ -654,7 +659,8 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
         // the consensus of resident windows --, otherwise built and polished here, shard after shard
         const bool timing_d = getenv("RACON_HIP_TIMING") != nullptr;
         if (timing_d) fprintf(stderr, "[racon::Polisher::polish] timing: engines ready, result arrays made at %.2f ms\n", 1e3 * seconds_since(polish_begin));
-        if (device_built_) device_job(2, &cons, &pol, &chim);
+        // (resident windows, one shard per engine: no string per window, the targets are assembled from the engines' result blocks)
+        if (device_built_) { cons_views_.assign(nw, ConsensusView(nullptr, 0)); device_job(2, &cons, &pol, &chim); }
         else {
             // shard after shard inside polish(); a shard the device has no room for cuts the job finer (twice, four times ... the shards)
             for (;;) {
@@ -673,8 +679,10 @@ void Polisher::polish(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unp
             if (chim[i]) fprintf(stderr, "[racon::Window::generate_consensus] warning: contig %lu might be chimeric in window %u!\n",
                                  static_cast<unsigned long>(windows_[i]->id()), windows_[i]->rank());
         if (timing_d) fprintf(stderr, "[racon::Polisher::polish] timing: windows polished at %.2f ms\n", 1e3 * seconds_since(polish_begin));
-        assemble([&](uint64_t i) -> const std::string& { return cons[i]; }, [&](uint64_t i) { return pol[i] != 0; },
-                 dst, drop_unpolished_sequences);
+        // (a window with a view has no string and the other way round: a lane with several shards on its engine keeps strings)
+        assemble_views([&](uint64_t i) { return (i < cons_views_.size() && cons_views_[i].first) ? cons_views_[i] : ConsensusView(cons[i].data(), cons[i].size()); },
+                       [&](uint64_t i) { return pol[i] != 0; }, dst, drop_unpolished_sequences);
+        cons_views_.clear();
         if (timing_d) fprintf(stderr, "[racon::Polisher::polish] timing: assembled at %.2f ms\n", 1e3 * seconds_since(polish_begin));
         logger_->log("[racon::Polisher::polish] generated consensus");
         return;

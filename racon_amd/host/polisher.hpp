@@ -145,6 +145,12 @@ public:
     void assemble(const std::function<const std::string&(uint64_t)>& consensus,
                   const std::function<bool(uint64_t)>& polished,
                   std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences);
+    // the same over (pointer, length) views: windows polished on resident device windows are concatenated straight from their engines'
+    // result blocks (HipEngine::last_result), without a string per window in between
+    typedef std::pair<const char*, size_t> ConsensusView;
+    void assemble_views(const std::function<ConsensusView(uint64_t)>& consensus,
+                        const std::function<bool(uint64_t)>& polished,
+                        std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unpolished_sequences);
     uint64_t num_windows() const { return windows_.size(); }
     const std::vector<std::shared_ptr<Window>>& windows() const { return windows_; }
 
@@ -196,8 +202,10 @@ protected:
     // windows built on the device (device_windows_): phase 1 at the end of initialize(), phase 2 in polish(); phase 0 = both in polish()
     void build_device_windows();
     void device_job(int phase, std::vector<std::string>* cons, std::vector<uint8_t>* pol, std::vector<uint8_t>* chim);
+    // phase 2 (every shard resident on an engine of its own): the windows' consensus as views into the engines' result blocks
+    std::vector<ConsensusView> cons_views_;
     void build_shard(HipEngine& engine, const ShardInput& in);           // rcn_engine_build_windows* by mode, host aligner as the way out
-    void run_shard(HipEngine& engine, uint64_t window_base, uint64_t n_local, uint64_t wa, uint64_t wb,
+    void run_shard(bool views, HipEngine& engine, uint64_t window_base, uint64_t n_local, uint64_t wa, uint64_t wb,
                    std::vector<std::string>& cons, std::vector<uint8_t>& pol, std::vector<uint8_t>& chim);
     uint32_t device_shards() const;         // devices, RACON_HIP_DEVICE_SHARDS, or what a failed build raised it to
     bool device_built_ = false;             // initialize() left the windows resident on the engines
