@@ -11,6 +11,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 export RCN_EXPERIMENT=1
 has() { [[ " $WHAT " == *" $1 "* ]]; }
+# the libraries travel with the tree as they were built: refuse to measure a library that is older than its sources (a closing set of this round
+# once ran a small-window kernel that had been reverted in the sources but not rebuilt: the stamped source hash then says nothing)
+for d in racon_amd/csrc racon_amd/host; do make -q -C $d all 2>/dev/null || { echo "$d: the built library is older than its sources -- make -C $d first" | tee "$OUT/STALE_LIBRARY.txt"; exit 1; }; done
 (nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocm-smi --showproductname 2>/dev/null | head -12) > "$OUT/box.txt" 2>&1
 benchline() { python -c "
 import json,sys
